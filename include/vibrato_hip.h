@@ -1,0 +1,184 @@
+/*
+ * vibrato_hip.h -- C ABI of libvibrato_hip.so: an MI355X (gfx950) drop-in for the
+ * tokenize() hot path of daac-tools/vibrato 0.5.2.
+ *
+ * The reference has no FFI layer; its boundary is the public Rust API of crate
+ * `vibrato` (vibrato/src/lib.rs:52-78).  Each entry point below names the Rust item
+ * it replaces (paths relative to /root/reference/vibrato/src).  INTEGRATION.md shows
+ * the Rust shim (`extern "C"` block + safe wrappers) a maintainer would add.
+ *
+ * Conventions
+ *   - every fallible call returns a vbt_status; vbt_last_error() returns the
+ *     thread-local message of the last failure (mirrors VibratoError, errors.rs:7-42)
+ *   - handles are opaque; strings are {ptr,len} UTF-8, never NUL-terminated
+ *   - tokenization never silently falls back to a CPU path: without a usable
+ *     gfx950 device every vbt_tokenizer_* / vbt_*tokenize* call fails with VBT_ERR_DEVICE
+ */
+#ifndef VIBRATO_HIP_H
+#define VIBRATO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VBT_API __attribute__((visibility("default")))
+
+typedef enum vbt_status {
+    VBT_OK = 0,
+    VBT_ERR_INVALID_ARGUMENT = 1, /* VibratoError::InvalidArgument, errors.rs:13 */
+    VBT_ERR_INVALID_FORMAT = 2,   /* VibratoError::InvalidFormat,   errors.rs:16 */
+    VBT_ERR_INVALID_STATE = 3,    /* VibratoError::InvalidState,    errors.rs:19 */
+    VBT_ERR_PARSE_INT = 4,        /* VibratoError::ParseInt,        errors.rs:25 */
+    VBT_ERR_UTF8 = 5,             /* VibratoError::Utf8,            errors.rs:37 */
+    VBT_ERR_DEVICE = 100,         /* HIP runtime / no gfx950 device (new: the reference is CPU-only) */
+    VBT_ERR_UNSUPPORTED = 101     /* input outside what the device image can represent */
+} vbt_status;
+
+/* LexType, dictionary.rs:30-40 */
+typedef enum vbt_lex_type { VBT_LEX_SYSTEM = 0, VBT_LEX_USER = 1, VBT_LEX_UNKNOWN = 2 } vbt_lex_type;
+
+/* Output modes of the `tokenize` CLI, tokenize/src/main.rs:83-127 */
+typedef enum vbt_format_mode { VBT_FORMAT_MECAB = 0, VBT_FORMAT_WAKATI = 1, VBT_FORMAT_DETAIL = 2 } vbt_format_mode;
+
+typedef struct vbt_dict vbt_dict;
+typedef struct vbt_tokenizer vbt_tokenizer;
+typedef struct vbt_worker vbt_worker;
+typedef struct vbt_batch vbt_batch;
+typedef struct vbt_workspace vbt_workspace;
+
+/* Fixed 24-byte token record written by the device (one per best-path node).
+ * Fields are what Token::{range_char, range_byte, word_idx, total_cost} return
+ * (token.rs:21-92); positions are relative to the sentence. */
+typedef struct vbt_token_rec {
+    uint32_t start_char, end_char; /* Token::range_char, token.rs:21-24 */
+    uint32_t start_byte, end_byte; /* Token::range_byte, token.rs:28-32 */
+    uint32_t word_idx;             /* WordIdx: lex_type << 30 | word_id (word_idx.rs:5-11) */
+    int32_t total_cost;            /* Token::total_cost, token.rs:89-92 */
+} vbt_token_rec;
+
+/* Full token view (Token accessors, token.rs:21-92). surface points into the
+ * caller's sentence bytes / batch copy, feature into dictionary memory. */
+typedef struct vbt_token {
+    const char* surface; size_t surface_len; /* Token::surface, token.rs:36-39 */
+    const char* feature; size_t feature_len; /* Token::feature, token.rs:49-54 */
+    uint32_t start_char, end_char, start_byte, end_byte;
+    uint32_t lex_type, word_id;              /* Token::lex_type / word_idx */
+    uint16_t left_id, right_id;              /* Token::left_id / right_id, token.rs:64-75 */
+    int16_t word_cost;                       /* Token::word_cost, token.rs:78-87 */
+    int32_t total_cost;
+} vbt_token;
+
+VBT_API const char* vbt_last_error(void);
+
+/* ---- Dictionary ------------------------------------------------------------ */
+
+/* SystemDictionaryBuilder::from_readers(lex.csv, matrix.def, char.def, unk.def), builder.rs:64-89 */
+VBT_API int vbt_dict_from_sources(const char* lex, size_t lex_len, const char* matrix_def, size_t matrix_len,
+                                  const char* char_def, size_t char_len, const char* unk_def, size_t unk_len,
+                                  vbt_dict** out);
+/* Same, with the connection matrix given in binary: data[left*num_right+right] (the layout of
+ * MatrixConnector, connector/matrix_connector.rs:11-15,47). A 459 MiB matrix has no sane text form. */
+VBT_API int vbt_dict_from_sources_binmatrix(const char* lex, size_t lex_len, const int16_t* matrix,
+                                            uint32_t num_right, uint32_t num_left, const char* char_def,
+                                            size_t char_len, const char* unk_def, size_t unk_len, vbt_dict** out);
+/* Dictionary::reset_user_lexicon_from_reader(Some(csv) | None), dictionary.rs:209-229 */
+VBT_API int vbt_dict_set_user_lexicon(vbt_dict* dict, const char* csv, size_t len);
+VBT_API void vbt_dict_free(vbt_dict* dict);
+
+VBT_API uint32_t vbt_dict_num_words(const vbt_dict* dict, uint32_t lex_type);
+VBT_API uint32_t vbt_dict_num_left(const vbt_dict* dict);  /* Connector::num_left,  connector.rs:14 */
+VBT_API uint32_t vbt_dict_num_right(const vbt_dict* dict); /* Connector::num_right, connector.rs:17 */
+/* Dictionary::word_feature, dictionary.rs:108-114 */
+VBT_API int vbt_dict_word_feature(const vbt_dict* dict, uint32_t lex_type, uint32_t word_id, const char** ptr, size_t* len);
+/* Dictionary::word_param, dictionary.rs:98-104: out = {left_id, right_id, word_cost} */
+VBT_API int vbt_dict_word_param(const vbt_dict* dict, uint32_t lex_type, uint32_t word_id, int32_t out[3]);
+/* ConnectorCost::cost(right_id, left_id), connector.rs:25-28 */
+VBT_API int vbt_dict_conn_cost(const vbt_dict* dict, uint32_t right_id, uint32_t left_id, int32_t* out);
+/* CharProperty::char_info, character.rs:112-116 (packed CharInfo u32, character.rs:10-24) */
+VBT_API uint32_t vbt_dict_char_info(const vbt_dict* dict, uint32_t code_point);
+/* CharProperty::cate_id, character.rs:119-124; -1 when undefined */
+VBT_API int vbt_dict_cate_id(const vbt_dict* dict, const char* name, size_t len);
+/* Lexicon::common_prefix_iterator, lexicon.rs:33-46 (host walk of the device trie image).
+ * out rows = {word_id, end_char}; returns the number of matches (may exceed cap). */
+VBT_API uint32_t vbt_dict_common_prefix(const vbt_dict* dict, uint32_t lex_type, const uint32_t* code_points,
+                                        uint32_t n, uint32_t* out, uint32_t cap);
+
+/* ---- Tokenizer ------------------------------------------------------------- */
+
+/* Tokenizer::new(dict).ignore_space(b)?.max_grouping_len(n), tokenizer.rs:26-74.
+ * Consumes `dict` on success (Tokenizer::new moves it). Uploads the device image to
+ * HIP device `device` (-1 = current device). max_grouping_len 0 = unlimited. */
+VBT_API int vbt_tokenizer_new(vbt_dict* dict, int ignore_space, uint32_t max_grouping_len, int device,
+                              vbt_tokenizer** out);
+VBT_API void vbt_tokenizer_free(vbt_tokenizer* tok);
+VBT_API const vbt_dict* vbt_tokenizer_dictionary(const vbt_tokenizer* tok); /* Tokenizer::dictionary, tokenizer.rs:77 */
+
+/* ---- Worker (per-sentence API, worker.rs:34-75) --------------------------------- */
+
+VBT_API int vbt_worker_new(const vbt_tokenizer* tok, vbt_worker** out);          /* Tokenizer::new_worker */
+VBT_API void vbt_worker_free(vbt_worker* w);
+VBT_API int vbt_worker_reset_sentence(vbt_worker* w, const char* utf8, size_t len); /* Worker::reset_sentence */
+VBT_API int vbt_worker_tokenize(vbt_worker* w);                                   /* Worker::tokenize */
+VBT_API uint32_t vbt_worker_num_tokens(const vbt_worker* w);                      /* Worker::num_tokens */
+VBT_API int vbt_worker_token(const vbt_worker* w, uint32_t i, vbt_token* out);    /* Worker::token(i) */
+
+/* ---- Batched host API (new: many sentences per call) ---------------------------- */
+
+/* The 3-call loop of tokenize/src/main.rs:78-82 over n sentences: sentence s is
+ * text[offsets[s] .. offsets[s+1]). Copies text to the device, runs the kernels,
+ * copies token records back. The batch keeps its own copy of the text. */
+VBT_API int vbt_tokenize_batch(const vbt_tokenizer* tok, const uint8_t* text, const uint64_t* offsets, uint64_t n,
+                               vbt_batch** out);
+VBT_API void vbt_batch_free(vbt_batch* b);
+VBT_API uint64_t vbt_batch_num_sentences(const vbt_batch* b);
+VBT_API uint64_t vbt_batch_total_tokens(const vbt_batch* b);
+VBT_API uint32_t vbt_batch_num_tokens(const vbt_batch* b, uint64_t sentence);
+VBT_API int vbt_batch_token(const vbt_batch* b, uint64_t sentence, uint32_t i, vbt_token* out);
+/* Raw records of one sentence (num_tokens of them, in sentence order). */
+VBT_API const vbt_token_rec* vbt_batch_records(const vbt_batch* b, uint64_t sentence);
+/* Whole-batch views: sentence s owns tokens[tok_off[s] .. tok_off[s] + tok_cnt[s]). */
+VBT_API int vbt_batch_arrays(const vbt_batch* b, const vbt_token_rec** tokens, const uint32_t** tok_off,
+                             const uint32_t** tok_cnt);
+/* Byte-identical output of the `tokenize` CLI for the whole batch (tokenize/src/main.rs:83-127).
+ * *out is malloc'ed; release with vbt_free. */
+VBT_API int vbt_batch_format(const vbt_batch* b, int mode, char** out, size_t* len);
+VBT_API void vbt_free(void* p);
+
+/* ---- Device-resident API (zero-copy; what bench.py times) ------------------------ */
+
+/* A workspace owns the device scratch + output buffers for batches of up to
+ * max_sentences sentences / max_bytes bytes of text, and is reused across calls. */
+VBT_API int vbt_workspace_new(const vbt_tokenizer* tok, uint64_t max_sentences, uint64_t max_bytes, vbt_workspace** out);
+VBT_API void vbt_workspace_free(vbt_workspace* ws);
+/* Enqueue the tokenization of n sentences on `hip_stream` (a hipStream_t, NULL = default
+ * stream). d_text / d_offsets are DEVICE pointers (offsets: n+1 x u64, bytes into d_text).
+ * Asynchronous; results are valid once the stream has been synchronized. */
+VBT_API int vbt_tokenize_batch_device(vbt_workspace* ws, const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n,
+                                      uint64_t total_bytes, void* hip_stream);
+/* Device pointers to the results of the last call:
+ *   tokens   : vbt_token_rec[], sentence s occupies [tok_off[s], tok_off[s] + tok_cnt[s])
+ *   tok_off  : u32[n]  (allocation order is unspecified; content is deterministic)
+ *   tok_cnt  : u32[n]
+ *   total    : u32[1]  total tokens written */
+VBT_API int vbt_workspace_results(const vbt_workspace* ws, const vbt_token_rec** d_tokens, const uint32_t** d_tok_off,
+                                  const uint32_t** d_tok_cnt, const uint32_t** d_total);
+/* Per-call statistics (synchronizes the stream of the last call): number of sentences that
+ * took each tier (0 = small LDS budget, 1 = large LDS budget, 2 = global-memory scratch),
+ * tokens written, device error flags (1 = token buffer full, 2 = scratch exhausted,
+ * 4 = sentence too long) and, with timing enabled, the hipEvent-measured duration (ms) of
+ * the tier-0 kernel and of the tier-1+2 kernels of the last call. */
+typedef struct vbt_call_stats {
+    uint64_t n_sentences, n_tier0, n_tier1, n_tier2, n_tokens;
+    uint32_t error_flags;
+    float ms_tier0, ms_tier12;
+} vbt_call_stats;
+VBT_API int vbt_workspace_set_timing(vbt_workspace* ws, int enabled);
+VBT_API int vbt_workspace_stats(vbt_workspace* ws, vbt_call_stats* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VIBRATO_HIP_H */

@@ -1,0 +1,151 @@
+"""Host-side tests of libvibrato_hip.so that need no GPU: the library loads, exports every
+symbol include/vibrato_hip.h declares, builds dictionaries exactly like the reference's
+builder (golden vectors) and agrees with the oracle's lexicon lookups.  No compute calls."""
+import os
+import random
+import re
+
+import numpy as np
+import pytest
+
+import vibrato_amd as V
+from vibrato_amd import _native as N
+from oracle import oracle as ora
+from tools import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _fixture_dict(src):
+    return V.SystemDictionaryBuilder.from_readers(src["lex.csv"], src["matrix.def"], src["char.def"], src["unk.def"])
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "vibrato_hip.h")).read()
+    declared = set(re.findall(r"VBT_API[^;(]*?\b(vbt_\w+)\s*\(", header))
+    assert len(declared) >= 35
+    assert declared == set(N.SIGNATURES), declared ^ set(N.SIGNATURES)
+    L = N.lib()
+    for name in declared:
+        assert getattr(L, name) is not None
+
+
+def test_lexicon_golden(unit_golden, fixture_sources):
+    for c in unit_golden["lexicon_common_prefix"]:
+        if c.get("dict") == "fixture":
+            d = _fixture_dict(fixture_sources)
+        else:
+            d = V.SystemDictionaryBuilder.from_readers(c["lex"], "12 12\n", "DEFAULT 0 1 0", "DEFAULT,0,0,0,*")
+        assert d.common_prefix(c["input"]) == c["expect"], c["source"]
+    d = _fixture_dict(fixture_sources)
+    assert d.num_words(0) == 46
+    for c in unit_golden["word_feature"]:
+        assert d.word_feature(0, c["word_id"]) == c["feature"]
+
+
+def test_connector_golden(unit_golden, fixture_sources):
+    for c in unit_golden["connector"]:
+        m = fixture_sources["matrix.def"] if c["matrix"] == "fixture" else c["matrix"]
+        d = V.SystemDictionaryBuilder.from_readers("a,0,0,0,x", m, "DEFAULT 0 1 0", "DEFAULT,0,0,0,*")
+        assert (d.num_left, d.num_right) == (c["num_left"], c["num_right"])
+        for r, l, cost in c["costs"]:
+            assert d.conn_cost(r, l) == cost
+    for c in unit_golden["connector_errors"]:
+        with pytest.raises(V.VibratoError):
+            V.SystemDictionaryBuilder.from_readers("a,0,0,0,x", c["matrix"], "DEFAULT 0 1 0", "DEFAULT,0,0,0,*")
+
+
+def test_char_def_golden(unit_golden):
+    for c in unit_golden["char_info"]:
+        d = V.SystemDictionaryBuilder.from_readers("a,0,0,0,x", "1 1\n0 0 0", c["char_def"], "DEFAULT,0,0,0,*")
+        ci = d.char_info(c["cp"])
+        for k in ["cate_idset", "base_id", "invoke", "group", "length"]:
+            assert ci[k] == c[k]
+    for c in unit_golden["char_def_errors"]:
+        with pytest.raises(V.VibratoError):
+            V.SystemDictionaryBuilder.from_readers("a,0,0,0,x", "1 1\n0 0 0", c["char_def"], "DEFAULT,0,0,0,*")
+    for c in unit_golden["char_def_ok"]:
+        V.SystemDictionaryBuilder.from_readers("a,0,0,0,x", "1 1\n0 0 0", c["char_def"], "DEFAULT,0,0,0,*")
+
+
+def test_error_behaviour(fixture_sources):
+    s = fixture_sources
+    with pytest.raises(V.VibratoError) as e:  # builder.rs:24-29
+        V.SystemDictionaryBuilder.from_readers("a,10,0,0,x", s["matrix.def"], s["char.def"], s["unk.def"])
+    assert e.value.code == 1
+    with pytest.raises(V.VibratoError) as e:  # lexicon.rs:170-176
+        V.SystemDictionaryBuilder.from_readers("a,0,0,0", s["matrix.def"], s["char.def"], s["unk.def"])
+    assert e.value.code == 2
+    with pytest.raises(V.VibratoError) as e:
+        V.SystemDictionaryBuilder.from_readers("a,x,0,0,f", s["matrix.def"], s["char.def"], s["unk.def"])
+    assert e.value.code == 4
+    with pytest.raises(V.VibratoError):  # unknown.rs:240-244
+        V.SystemDictionaryBuilder.from_readers(s["lex.csv"], s["matrix.def"], s["char.def"], "NOPE,0,0,0,*")
+    d = _fixture_dict(s)
+    with pytest.raises(V.VibratoError):  # dictionary.rs:218-223
+        d.reset_user_lexicon_from_reader("a,0,10,0,x")
+    d.reset_user_lexicon_from_reader(s["user.csv"])
+    assert d.num_words(1) == 3
+    d.reset_user_lexicon_from_reader(None)
+    assert d.num_words(1) == 0
+    d2 = V.SystemDictionaryBuilder.from_readers("a,0,0,0,x", "1 1\n0 0 0", "DEFAULT 0 1 0", "DEFAULT,0,0,0,*")
+    with pytest.raises(V.VibratoError):  # tokenizer.rs:44-49
+        V.Tokenizer(d2).ignore_space(True)
+
+
+def test_csv_dialect():
+    """csv_core defaults used by Lexicon::parse_csv (lexicon.rs:111-200)."""
+    lex = '"a,b",1,2,3,"x,y",z\r\n\r\n,0,0,0,skipped\n"q""r",0,0,-5,f1\nlast,0,0,7,tail'
+    for mk in (lambda: V.SystemDictionaryBuilder.from_readers(lex, "3 3\n", "DEFAULT 0 1 0", "DEFAULT,0,0,0,*"),
+               lambda: ora.Dictionary.from_sources(lex, "3 3\n", "DEFAULT 0 1 0", "DEFAULT,0,0,0,*")):
+        d = mk()
+        assert d.num_words(0) == 3
+        assert d.word_feature(0, 0) == '"x,y",z'
+        assert d.word_param(0, 0) == (1, 2, 3)
+        assert d.word_feature(0, 1) == "f1"
+        assert d.word_param(0, 1) == (0, 0, -5)
+        assert d.word_feature(0, 2) == "tail"
+        assert [m[:2] for m in d.common_prefix("a,b")] == [[0, 3]]
+        assert [m[:2] for m in d.common_prefix('q"r')] == [[1, 3]]
+
+
+def test_host_trie_matches_oracle_on_synthetic_lexicon():
+    sd = synth.SynthDict("small")
+    dv = V.SystemDictionaryBuilder.from_readers_binmatrix(sd.lex, sd.matrix, sd.num_right, sd.num_left, sd.char_def, sd.unk)
+    do = ora.Dictionary.from_sources_binmatrix(sd.lex, sd.matrix, sd.num_right, sd.num_left, sd.char_def, sd.unk)
+    assert dv.num_words(0) == do.num_words(0) == sd.n_words
+    assert dv.num_words(2) == do.num_words(2) == 40
+    text, offs = sd.sentences(300)
+    rng = random.Random(7)
+    n_match = 0
+    for s in range(300):
+        sent = bytes(text[offs[s]:offs[s + 1]]).decode("utf-8")
+        for _ in range(4):
+            i = rng.randrange(len(sent))
+            a, b = dv.common_prefix(sent[i:i + 16]), do.common_prefix(sent[i:i + 16])
+            assert a == b
+            n_match += len(a)
+    assert n_match > 1000
+    for wid in rng.sample(range(sd.n_words), 200):
+        assert dv.word_feature(0, wid) == do.word_feature(0, wid)
+        assert dv.word_param(0, wid) == do.word_param(0, wid)
+    for u in range(40):
+        assert dv.word_feature(2, u) == do.word_feature(2, u)
+        assert dv.word_param(2, u) == do.word_param(2, u)
+    for cp in [0x20, 0x41, 0x3042, 0x30A2, 0x4E00, 0x4E8C, 0x9FA5, 0x3002, 0x1F600]:
+        assert dv.char_info(cp) == do.char_info(cp)
+    m = sd.matrix
+    for _ in range(100):
+        r, l = rng.randrange(sd.num_right), rng.randrange(sd.num_left)
+        assert dv.conn_cost(r, l) == do.conn_cost(r, l) == int(m[l, r])
+
+
+def test_tokenizer_fails_loudly_without_gpu(fixture_sources):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    d = _fixture_dict(fixture_sources)
+    with pytest.raises(V.VibratoError) as e:
+        V.Tokenizer(d).new_worker()
+    assert e.value.code == 100  # VBT_ERR_DEVICE: no silent CPU fallback
+    assert d.num_words(0) == 46  # the dictionary handle survives a failed Tokenizer::new

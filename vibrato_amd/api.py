@@ -1,0 +1,339 @@
+"""Host-side mirror of vibrato's public API for the tokenize() path
+(vibrato/src/lib.rs:52-78): Dictionary / SystemDictionaryBuilder, Tokenizer, Worker,
+Token, plus the batched entry points this project adds.  Everything computes on the
+MI355X through libvibrato_hip.so; Python only moves handles and bytes."""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+from ._native import VibratoError  # noqa: F401
+
+LEX_NAMES = ("System", "User", "Unknown")  # LexType, dictionary.rs:30-40
+TOKEN_DTYPE = np.dtype([("start_char", "<u4"), ("end_char", "<u4"), ("start_byte", "<u4"),
+                        ("end_byte", "<u4"), ("word_idx", "<u4"), ("total_cost", "<i4")])
+
+
+def _b(x):
+    return x.encode("utf-8") if isinstance(x, str) else bytes(x)
+
+
+class Dictionary:
+    """vibrato::Dictionary (dictionary.rs:53-259)."""
+
+    def __init__(self, handle, owned=True):
+        self._h = handle
+        self._owned = owned
+
+    def __del__(self):
+        if getattr(self, "_h", None) and self._owned:
+            N.lib().vbt_dict_free(self._h)
+        self._h = None
+
+    def _handle(self):
+        if not self._h:
+            raise VibratoError(3, "dictionary was moved into a Tokenizer")
+        return self._h
+
+    def reset_user_lexicon_from_reader(self, csv):
+        """Dictionary::reset_user_lexicon_from_reader (dictionary.rs:209-229); csv=None clears."""
+        if csv is None:
+            N.check(N.lib().vbt_dict_set_user_lexicon(self._handle(), None, 0))
+        else:
+            csv = _b(csv)
+            N.check(N.lib().vbt_dict_set_user_lexicon(self._handle(), csv, len(csv)))
+        return self
+
+    def num_words(self, lex_type=0):
+        return N.lib().vbt_dict_num_words(self._handle(), lex_type)
+
+    @property
+    def num_left(self):
+        return N.lib().vbt_dict_num_left(self._handle())
+
+    @property
+    def num_right(self):
+        return N.lib().vbt_dict_num_right(self._handle())
+
+    def word_feature(self, lex_type, word_id):
+        """Dictionary::word_feature (dictionary.rs:108-114)."""
+        p, n = C.c_void_p(), C.c_size_t()
+        N.check(N.lib().vbt_dict_word_feature(self._handle(), lex_type, word_id, C.byref(p), C.byref(n)))
+        return C.string_at(p, n.value).decode("utf-8")
+
+    def word_param(self, lex_type, word_id):
+        out = (C.c_int32 * 3)()
+        N.check(N.lib().vbt_dict_word_param(self._handle(), lex_type, word_id, out))
+        return tuple(out)
+
+    def conn_cost(self, right_id, left_id):
+        """ConnectorCost::cost(right_id, left_id) (connector.rs:25-28)."""
+        out = C.c_int32()
+        N.check(N.lib().vbt_dict_conn_cost(self._handle(), right_id, left_id, C.byref(out)))
+        return out.value
+
+    def char_info(self, cp):
+        x = N.lib().vbt_dict_char_info(self._handle(), cp)
+        return {"cate_idset": x & 0x3FFFF, "base_id": (x >> 18) & 0xFF, "invoke": (x >> 26) & 1,
+                "group": (x >> 27) & 1, "length": x >> 28}
+
+    def cate_id(self, name):
+        name = _b(name)
+        return N.lib().vbt_dict_cate_id(self._handle(), name, len(name))
+
+    def common_prefix(self, text, lex_type=0):
+        """Lexicon::common_prefix_iterator (lexicon.rs:33-46): [(word_id, end_char, left, right, cost)]."""
+        cps = np.array([ord(c) for c in text], dtype=np.uint32)
+        out = np.zeros((1024, 2), dtype=np.uint32)
+        n = N.lib().vbt_dict_common_prefix(self._handle(), lex_type, cps.ctypes.data, len(cps), out.ctypes.data, 1024)
+        return [[int(w), int(e), *self.word_param(lex_type, int(w))] for w, e in out[:n]]
+
+
+class SystemDictionaryBuilder:
+    """vibrato::SystemDictionaryBuilder (dictionary/builder.rs:12-89)."""
+
+    @staticmethod
+    def from_readers(lex, matrix, char_def, unk):
+        lex, matrix, char_def, unk = _b(lex), _b(matrix), _b(char_def), _b(unk)
+        h = C.c_void_p()
+        N.check(N.lib().vbt_dict_from_sources(lex, len(lex), matrix, len(matrix), char_def, len(char_def), unk, len(unk), C.byref(h)))
+        return Dictionary(h)
+
+    @staticmethod
+    def from_readers_binmatrix(lex, matrix_i16, num_right, num_left, char_def, unk):
+        """Same with a binary connection matrix laid out data[left*num_right+right]."""
+        lex, char_def, unk = _b(lex), _b(char_def), _b(unk)
+        m = np.ascontiguousarray(matrix_i16, dtype=np.int16)
+        if m.size != num_right * num_left:
+            raise VibratoError(1, "matrix: size must be num_right*num_left")
+        h = C.c_void_p()
+        N.check(N.lib().vbt_dict_from_sources_binmatrix(lex, len(lex), m.ctypes.data, num_right, num_left, char_def,
+                                                        len(char_def), unk, len(unk), C.byref(h)))
+        return Dictionary(h)
+
+
+class Token:
+    """vibrato::token::Token (token.rs:8-92)."""
+
+    __slots__ = ("surface", "feature", "range_char", "range_byte", "lex_type", "word_id", "left_id", "right_id",
+                 "word_cost", "total_cost")
+
+    def __init__(self, t):
+        self.surface = C.string_at(t.surface, t.surface_len).decode("utf-8")
+        self.feature = C.string_at(t.feature, t.feature_len).decode("utf-8")
+        self.range_char = (t.start_char, t.end_char)
+        self.range_byte = (t.start_byte, t.end_byte)
+        self.lex_type = t.lex_type
+        self.word_id = t.word_id
+        self.left_id = t.left_id
+        self.right_id = t.right_id
+        self.word_cost = t.word_cost
+        self.total_cost = t.total_cost
+
+    def __repr__(self):
+        return (f"Token(surface={self.surface!r}, range_char={self.range_char}, feature={self.feature!r}, "
+                f"lex_type={LEX_NAMES[self.lex_type]}, total_cost={self.total_cost})")
+
+
+class Tokenizer:
+    """vibrato::Tokenizer (tokenizer.rs:13-84). Creating one uploads the dictionary image to the GPU."""
+
+    def __init__(self, dictionary, device=-1):
+        self._dict_in = dictionary
+        self._ignore_space = False
+        self._max_grouping_len = 0
+        self._device = device
+        self._h = None
+        self._dict = None
+
+    @classmethod
+    def new(cls, dictionary, device=-1):
+        return cls(dictionary, device)
+
+    def ignore_space(self, yes):
+        """Tokenizer::ignore_space (tokenizer.rs:42-55)."""
+        self._require_unbuilt()
+        self._ignore_space = bool(yes)
+        if yes and self._dict_in.cate_id("SPACE") < 0:
+            raise VibratoError(1, "dict: SPACE is not defined in the input dictionary (i.e., char.def).")
+        return self
+
+    def max_grouping_len(self, n):
+        """Tokenizer::max_grouping_len (tokenizer.rs:67-74); 0 = unlimited."""
+        self._require_unbuilt()
+        self._max_grouping_len = int(n)
+        return self
+
+    def _require_unbuilt(self):
+        if self._h:
+            raise VibratoError(3, "tokenizer options must be set before the first use")
+
+    def _handle(self):
+        if not self._h:
+            h = C.c_void_p()
+            N.check(N.lib().vbt_tokenizer_new(self._dict_in._handle(), int(self._ignore_space), self._max_grouping_len,
+                                              self._device, C.byref(h)))
+            self._h = h
+            self._dict_in._h = None  # moved (Tokenizer::new consumes the dictionary)
+            self._dict = Dictionary(C.c_void_p(N.lib().vbt_tokenizer_dictionary(h)), owned=False)
+        return self._h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            N.lib().vbt_tokenizer_free(self._h)
+            self._h = None
+
+    def dictionary(self):
+        """Tokenizer::dictionary (tokenizer.rs:77-79)."""
+        self._handle()
+        return self._dict
+
+    def new_worker(self):
+        """Tokenizer::new_worker (tokenizer.rs:82-84)."""
+        return Worker(self)
+
+    def tokenize_batch(self, sentences=None, text=None, offsets=None):
+        """Batched tokenization of host data: a list of str, or (uint8 text, uint64 offsets[n+1])."""
+        if sentences is not None:
+            enc = [_b(s) for s in sentences]
+            offsets = np.zeros(len(enc) + 1, dtype=np.uint64)
+            if enc:
+                offsets[1:] = np.cumsum([len(e) for e in enc])
+            text = np.frombuffer(b"".join(enc), dtype=np.uint8)
+        text = np.ascontiguousarray(text, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        h = C.c_void_p()
+        N.check(N.lib().vbt_tokenize_batch(self._handle(), text.ctypes.data if text.size else None, offsets.ctypes.data,
+                                           len(offsets) - 1, C.byref(h)))
+        return Batch(self, h)
+
+    def workspace(self, max_sentences, max_bytes):
+        return Workspace(self, max_sentences, max_bytes)
+
+
+class Worker:
+    """vibrato::tokenizer::worker::Worker (worker.rs:13-75): per-sentence API (one launch per sentence)."""
+
+    def __init__(self, tokenizer):
+        self.tokenizer = tokenizer
+        h = C.c_void_p()
+        N.check(N.lib().vbt_worker_new(tokenizer._handle(), C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            N.lib().vbt_worker_free(self._h)
+            self._h = None
+
+    def reset_sentence(self, text):
+        text = _b(text)
+        N.check(N.lib().vbt_worker_reset_sentence(self._h, text, len(text)))
+
+    def tokenize(self):
+        N.check(N.lib().vbt_worker_tokenize(self._h))
+
+    def num_tokens(self):
+        return N.lib().vbt_worker_num_tokens(self._h)
+
+    def token(self, i):
+        t = N.Token()
+        N.check(N.lib().vbt_worker_token(self._h, i, C.byref(t)))
+        return Token(t)
+
+    def token_iter(self):
+        return (self.token(i) for i in range(self.num_tokens()))
+
+
+class Batch:
+    """Results of Tokenizer.tokenize_batch (host copy)."""
+
+    def __init__(self, tokenizer, handle):
+        self.tokenizer = tokenizer
+        self._h = handle
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            N.lib().vbt_batch_free(self._h)
+            self._h = None
+
+    def __len__(self):
+        return N.lib().vbt_batch_num_sentences(self._h)
+
+    def total_tokens(self):
+        return N.lib().vbt_batch_total_tokens(self._h)
+
+    def num_tokens(self, s):
+        return N.lib().vbt_batch_num_tokens(self._h, s)
+
+    def token(self, s, i):
+        t = N.Token()
+        N.check(N.lib().vbt_batch_token(self._h, s, i, C.byref(t)))
+        return Token(t)
+
+    def records(self, s):
+        """Token records of sentence s as a structured numpy array (copy)."""
+        n = self.num_tokens(s)
+        if n == 0:
+            return np.zeros(0, dtype=TOKEN_DTYPE)
+        p = N.lib().vbt_batch_records(self._h, s)
+        return np.frombuffer(C.string_at(p, n * TOKEN_DTYPE.itemsize), dtype=TOKEN_DTYPE).copy()
+
+    def arrays(self):
+        """(tokens[TOKEN_DTYPE], tok_off[u32], tok_cnt[u32]) copies for the whole batch."""
+        pt, po, pc = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        N.check(N.lib().vbt_batch_arrays(self._h, C.byref(pt), C.byref(po), C.byref(pc)))
+        n, t = len(self), self.total_tokens()
+        toks = np.frombuffer(C.string_at(pt, t * TOKEN_DTYPE.itemsize), dtype=TOKEN_DTYPE).copy() if t else np.zeros(0, TOKEN_DTYPE)
+        off = np.frombuffer(C.string_at(po, n * 4), dtype=np.uint32).copy() if n else np.zeros(0, np.uint32)
+        cnt = np.frombuffer(C.string_at(pc, n * 4), dtype=np.uint32).copy() if n else np.zeros(0, np.uint32)
+        return toks, off, cnt
+
+    def tokens_in_order(self):
+        """All token records concatenated in sentence order + exclusive offsets (n+1)."""
+        toks, off, cnt = self.arrays()
+        ends = np.zeros(len(cnt) + 1, dtype=np.uint64)
+        ends[1:] = np.cumsum(cnt, dtype=np.uint64)
+        idx = np.repeat(off.astype(np.int64) - ends[:-1].astype(np.int64), cnt) + np.arange(int(ends[-1]), dtype=np.int64)
+        return toks[idx], ends
+
+    def format(self, mode="mecab"):
+        """Byte-identical `tokenize` CLI output (tokenize/src/main.rs:83-127)."""
+        m = {"mecab": 0, "wakati": 1, "detail": 2}[mode]
+        p, n = C.c_void_p(), C.c_size_t()
+        N.check(N.lib().vbt_batch_format(self._h, m, C.byref(p), C.byref(n)))
+        try:
+            return C.string_at(p, n.value).decode("utf-8")
+        finally:
+            N.lib().vbt_free(p)
+
+
+class Workspace:
+    """Device-resident batch interface (zero host copies): what bench.py times."""
+
+    def __init__(self, tokenizer, max_sentences, max_bytes):
+        self.tokenizer = tokenizer
+        h = C.c_void_p()
+        N.check(N.lib().vbt_workspace_new(tokenizer._handle(), max_sentences, max_bytes, C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            N.lib().vbt_workspace_free(self._h)
+            self._h = None
+
+    def set_timing(self, on=True):
+        N.check(N.lib().vbt_workspace_set_timing(self._h, int(on)))
+
+    def run(self, d_text_ptr, d_offsets_ptr, n, total_bytes, stream=0):
+        """Enqueue on `stream` (raw hipStream_t as int). Pointers are raw device addresses."""
+        N.check(N.lib().vbt_tokenize_batch_device(self._h, d_text_ptr, d_offsets_ptr, n, total_bytes, stream or None))
+
+    def result_ptrs(self):
+        p = [C.c_void_p() for _ in range(4)]
+        N.check(N.lib().vbt_workspace_results(self._h, *[C.byref(x) for x in p]))
+        return {"tokens": p[0].value, "tok_off": p[1].value, "tok_cnt": p[2].value, "total": p[3].value}
+
+    def stats(self):
+        st = N.CallStats()
+        N.check(N.lib().vbt_workspace_stats(self._h, C.byref(st)))
+        return {f: getattr(st, f) for f, _ in N.CallStats._fields_}

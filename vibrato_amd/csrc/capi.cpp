@@ -1,0 +1,413 @@
+// extern "C" boundary of libvibrato_hip.so (see include/vibrato_hip.h).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "engine.hpp"
+
+using namespace vbt;
+
+struct vbt_dict {
+    Dictionary* d = nullptr;
+    bool owned = true;
+    ~vbt_dict() { if (owned) delete d; }
+};
+struct vbt_tokenizer {
+    std::unique_ptr<Tokenizer> t;
+    vbt_dict dict_view;  // borrowed view handed out by vbt_tokenizer_dictionary
+};
+struct vbt_workspace { std::unique_ptr<Workspace> w; };
+
+struct vbt_batch {
+    const vbt_tokenizer* tok;
+    std::vector<uint8_t> text;
+    std::vector<uint64_t> offsets;
+    std::vector<uint32_t> tok_off, tok_cnt;
+    std::vector<vbt_token_rec> tokens;
+};
+
+struct vbt_worker {
+    const vbt_tokenizer* tok;
+    std::string text;
+    std::unique_ptr<Workspace> ws;
+    void* d_text = nullptr;
+    uint64_t* d_offsets = nullptr;
+    size_t d_text_cap = 0;
+    std::vector<vbt_token_rec> tokens;
+    ~vbt_worker() { (void)hipFree(d_text); (void)hipFree(d_offsets); }
+};
+
+namespace {
+
+thread_local std::string g_last_error;
+
+template <typename F>
+int guarded(F&& f) {
+    try {
+        f();
+        return VBT_OK;
+    } catch (const Error& e) {
+        g_last_error = e.what();
+        return e.code;
+    } catch (const std::bad_alloc&) {
+        g_last_error = "out of host memory";
+        return VBT_ERR_INVALID_STATE;
+    } catch (const std::exception& e) {
+        g_last_error = e.what();
+        return VBT_ERR_INVALID_STATE;
+    }
+}
+
+#define HIPX(expr)                                                                                  \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess) throw Error(VBT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+const Lexicon& lexicon_of(const Dictionary& d, uint32_t lex_type) {
+    if (lex_type == VBT_LEX_SYSTEM) return d.system;
+    if (lex_type == VBT_LEX_USER && d.has_user) return d.user;
+    throw Error(VBT_ERR_INVALID_ARGUMENT, "lex_type: no such lexicon");
+}
+
+void check_device_errors(uint32_t flags) {
+    if (flags & kErrTokCap) throw Error(VBT_ERR_INVALID_STATE, "device token buffer overflow");
+    if (flags & kErrScratch) throw Error(VBT_ERR_UNSUPPORTED, "device scratch arena exhausted (raise VBT_SCRATCH_MB)");
+    if (flags & kErrTooLong) throw Error(VBT_ERR_UNSUPPORTED, "sentence too long for the device image (>= 4 GiB or >= 2^32 lattice nodes)");
+}
+
+// Token accessors (token.rs:21-92) from a raw record.
+void fill_token(const Dictionary& d, const uint8_t* sentence, const vbt_token_rec& r, vbt_token* out) {
+    const uint32_t lex = r.word_idx >> 30, wid = r.word_idx & 0x3FFFFFFFu;
+    out->surface = reinterpret_cast<const char*>(sentence) + r.start_byte;
+    out->surface_len = r.end_byte - r.start_byte;
+    out->start_char = r.start_char; out->end_char = r.end_char;
+    out->start_byte = r.start_byte; out->end_byte = r.end_byte;
+    out->lex_type = lex; out->word_id = wid;
+    out->total_cost = r.total_cost;
+    if (lex == VBT_LEX_UNKNOWN) {
+        const Entry& e = d.unk_entries.at(wid);
+        out->left_id = (uint16_t)(e.left_right & 0xFFFF); out->right_id = (uint16_t)(e.left_right >> 16);
+        out->word_cost = (int16_t)(uint16_t)e.cost;
+        out->feature = d.unk_features[wid].data(); out->feature_len = d.unk_features[wid].size();
+    } else {
+        const Lexicon& lx = lex == VBT_LEX_SYSTEM ? d.system : d.user;
+        const WordParam& p = lx.params.at(wid);
+        out->left_id = p.left_id; out->right_id = p.right_id; out->word_cost = p.word_cost;
+        out->feature = lx.features[wid].data(); out->feature_len = lx.features[wid].size();
+    }
+}
+
+// Runs one batch through a workspace and copies the compact results to the host.
+void run_and_fetch(Workspace& ws, const uint8_t* d_text, const uint64_t* d_off, uint64_t n, uint64_t bytes,
+                   std::vector<uint32_t>& tok_off, std::vector<uint32_t>& tok_cnt, std::vector<vbt_token_rec>& tokens) {
+    ws.run(d_text, d_off, n, bytes, nullptr);
+    vbt_call_stats st;
+    ws.stats(&st);
+    check_device_errors(st.error_flags);
+    tok_off.resize(n); tok_cnt.resize(n); tokens.resize(st.n_tokens);
+    if (n) {
+        HIPX(hipMemcpy(tok_off.data(), ws.d_tok_off, n * 4, hipMemcpyDeviceToHost));
+        HIPX(hipMemcpy(tok_cnt.data(), ws.d_tok_cnt, n * 4, hipMemcpyDeviceToHost));
+    }
+    if (st.n_tokens) HIPX(hipMemcpy(tokens.data(), ws.d_tokens, st.n_tokens * sizeof(vbt_token_rec), hipMemcpyDeviceToHost));
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* vbt_last_error(void) { return g_last_error.c_str(); }
+
+int vbt_dict_from_sources(const char* lex, size_t lex_len, const char* matrix_def, size_t matrix_len, const char* char_def,
+                          size_t char_len, const char* unk_def, size_t unk_len, vbt_dict** out) {
+    return guarded([&] {
+        if (!out || !lex || !matrix_def || !char_def || !unk_def) throw Error(VBT_ERR_INVALID_ARGUMENT, "null argument");
+        Dictionary* d = build_dictionary({lex, lex_len}, {matrix_def, matrix_len}, nullptr, 0, 0, {char_def, char_len}, {unk_def, unk_len});
+        *out = new vbt_dict{d, true};
+    });
+}
+
+int vbt_dict_from_sources_binmatrix(const char* lex, size_t lex_len, const int16_t* matrix, uint32_t num_right, uint32_t num_left,
+                                    const char* char_def, size_t char_len, const char* unk_def, size_t unk_len, vbt_dict** out) {
+    return guarded([&] {
+        if (!out || !lex || !matrix || !char_def || !unk_def) throw Error(VBT_ERR_INVALID_ARGUMENT, "null argument");
+        Dictionary* d = build_dictionary({lex, lex_len}, {}, matrix, num_right, num_left, {char_def, char_len}, {unk_def, unk_len});
+        *out = new vbt_dict{d, true};
+    });
+}
+
+int vbt_dict_set_user_lexicon(vbt_dict* dict, const char* csv, size_t len) {
+    return guarded([&] {
+        if (!dict || !dict->d) throw Error(VBT_ERR_INVALID_ARGUMENT, "dict: null or consumed");
+        set_user_lexicon(*dict->d, csv, len);
+    });
+}
+
+void vbt_dict_free(vbt_dict* dict) { delete dict; }
+
+uint32_t vbt_dict_num_words(const vbt_dict* dict, uint32_t lex_type) {
+    const Dictionary& d = *dict->d;
+    if (lex_type == VBT_LEX_SYSTEM) return (uint32_t)d.system.params.size();
+    if (lex_type == VBT_LEX_USER) return d.has_user ? (uint32_t)d.user.params.size() : 0;
+    return (uint32_t)d.unk_entries.size();
+}
+uint32_t vbt_dict_num_left(const vbt_dict* dict) { return dict->d->num_left; }
+uint32_t vbt_dict_num_right(const vbt_dict* dict) { return dict->d->num_right; }
+
+int vbt_dict_word_feature(const vbt_dict* dict, uint32_t lex_type, uint32_t word_id, const char** ptr, size_t* len) {
+    return guarded([&] {
+        const Dictionary& d = *dict->d;
+        const std::string* s;
+        if (lex_type == VBT_LEX_UNKNOWN) {
+            if (word_id >= d.unk_features.size()) throw Error(VBT_ERR_INVALID_ARGUMENT, "word_id out of range");
+            s = &d.unk_features[word_id];
+        } else {
+            const Lexicon& lx = lexicon_of(d, lex_type);
+            if (word_id >= lx.features.size()) throw Error(VBT_ERR_INVALID_ARGUMENT, "word_id out of range");
+            s = &lx.features[word_id];
+        }
+        *ptr = s->data();
+        *len = s->size();
+    });
+}
+
+int vbt_dict_word_param(const vbt_dict* dict, uint32_t lex_type, uint32_t word_id, int32_t out[3]) {
+    return guarded([&] {
+        const Dictionary& d = *dict->d;
+        if (lex_type == VBT_LEX_UNKNOWN) {
+            if (word_id >= d.unk_entries.size()) throw Error(VBT_ERR_INVALID_ARGUMENT, "word_id out of range");
+            const Entry& e = d.unk_entries[word_id];
+            out[0] = e.left_right & 0xFFFF; out[1] = e.left_right >> 16; out[2] = (int16_t)(uint16_t)e.cost;
+        } else {
+            const Lexicon& lx = lexicon_of(d, lex_type);
+            if (word_id >= lx.params.size()) throw Error(VBT_ERR_INVALID_ARGUMENT, "word_id out of range");
+            out[0] = lx.params[word_id].left_id; out[1] = lx.params[word_id].right_id; out[2] = lx.params[word_id].word_cost;
+        }
+    });
+}
+
+int vbt_dict_conn_cost(const vbt_dict* dict, uint32_t right_id, uint32_t left_id, int32_t* out) {
+    return guarded([&] {
+        const Dictionary& d = *dict->d;
+        if (right_id >= d.num_right || left_id >= d.num_left) throw Error(VBT_ERR_INVALID_ARGUMENT, "connection id out of range");
+        *out = d.matrix[(size_t)left_id * d.num_right + right_id];
+    });
+}
+
+uint32_t vbt_dict_char_info(const vbt_dict* dict, uint32_t cp) { return dict->d->chr2inf[cp < 65536 ? cp : 0]; }
+
+int vbt_dict_cate_id(const vbt_dict* dict, const char* name, size_t len) { return dict->d->cate_id({name, len}); }
+
+uint32_t vbt_dict_common_prefix(const vbt_dict* dict, uint32_t lex_type, const uint32_t* cps, uint32_t n, uint32_t* out, uint32_t cap) {
+    const Dictionary& d = *dict->d;
+    if (lex_type == VBT_LEX_USER && !d.has_user) return 0;
+    const Lexicon& lx = lex_type == VBT_LEX_USER ? d.user : d.system;
+    std::vector<std::pair<uint32_t, uint32_t>> m;
+    lx.common_prefix(cps, n, m);
+    for (uint32_t i = 0; i < m.size() && i < cap; ++i) { out[2 * i] = m[i].first; out[2 * i + 1] = m[i].second; }
+    return (uint32_t)m.size();
+}
+
+int vbt_tokenizer_new(vbt_dict* dict, int ignore_space, uint32_t max_grouping_len, int device, vbt_tokenizer** out) {
+    return guarded([&] {
+        if (!dict || !dict->d || !dict->owned || !out) throw Error(VBT_ERR_INVALID_ARGUMENT, "dict: null or already consumed");
+        // Tokenizer::new moves the dictionary in (tokenizer.rs:26). On failure the caller keeps the handle.
+        auto t = std::make_unique<Tokenizer>(dict->d, ignore_space != 0, max_grouping_len, device);
+        t->adopt(std::unique_ptr<Dictionary>(dict->d));
+        dict->d = nullptr;
+        auto* h = new vbt_tokenizer{std::move(t), {}};
+        h->dict_view.d = const_cast<Dictionary*>(&h->t->dict());
+        h->dict_view.owned = false;
+        *out = h;
+        delete dict;
+    });
+}
+
+void vbt_tokenizer_free(vbt_tokenizer* tok) { delete tok; }
+
+const vbt_dict* vbt_tokenizer_dictionary(const vbt_tokenizer* tok) { return &tok->dict_view; }  // borrowed: do not free
+
+int vbt_worker_new(const vbt_tokenizer* tok, vbt_worker** out) {
+    return guarded([&] {
+        if (!tok || !out) throw Error(VBT_ERR_INVALID_ARGUMENT, "null argument");
+        auto w = std::make_unique<vbt_worker>();
+        w->tok = tok;
+        *out = w.release();
+    });
+}
+
+void vbt_worker_free(vbt_worker* w) { delete w; }
+
+int vbt_worker_reset_sentence(vbt_worker* w, const char* utf8, size_t len) {
+    return guarded([&] {
+        w->tokens.clear();
+        w->text.assign(utf8 ? utf8 : "", utf8 ? len : 0);
+    });
+}
+
+int vbt_worker_tokenize(vbt_worker* w) {
+    return guarded([&] {
+        w->tokens.clear();
+        if (w->text.empty()) return;  // worker.rs:50-52
+        const size_t len = w->text.size();
+        HIPX(hipSetDevice(w->tok->t->device()));
+        if (!w->ws || w->ws->max_bytes < len) {
+            const size_t cap = std::max<size_t>(len * 2, 4096);
+            w->ws = std::make_unique<Workspace>(*w->tok->t, 1, cap);
+            (void)hipFree(w->d_text); (void)hipFree(w->d_offsets);
+            w->d_text = nullptr; w->d_offsets = nullptr;
+            HIPX(hipMalloc(&w->d_text, cap));
+            HIPX(hipMalloc(reinterpret_cast<void**>(&w->d_offsets), 16));
+        }
+        const uint64_t offs[2] = {0, len};
+        HIPX(hipMemcpy(w->d_text, w->text.data(), len, hipMemcpyHostToDevice));
+        HIPX(hipMemcpy(w->d_offsets, offs, 16, hipMemcpyHostToDevice));
+        std::vector<uint32_t> off, cnt;
+        run_and_fetch(*w->ws, static_cast<const uint8_t*>(w->d_text), w->d_offsets, 1, len, off, cnt, w->tokens);
+    });
+}
+
+uint32_t vbt_worker_num_tokens(const vbt_worker* w) { return (uint32_t)w->tokens.size(); }
+
+int vbt_worker_token(const vbt_worker* w, uint32_t i, vbt_token* out) {
+    return guarded([&] {
+        if (i >= w->tokens.size()) throw Error(VBT_ERR_INVALID_ARGUMENT, "token index out of range");
+        fill_token(w->tok->t->dict(), reinterpret_cast<const uint8_t*>(w->text.data()), w->tokens[i], out);
+    });
+}
+
+int vbt_tokenize_batch(const vbt_tokenizer* tok, const uint8_t* text, const uint64_t* offsets, uint64_t n, vbt_batch** out) {
+    return guarded([&] {
+        if (!tok || !offsets || !out || (!text && n && offsets[n] != offsets[0])) throw Error(VBT_ERR_INVALID_ARGUMENT, "null argument");
+        auto b = std::make_unique<vbt_batch>();
+        b->tok = tok;
+        const uint64_t lo = offsets[0], bytes = offsets[n] - lo;
+        b->text.assign(text + lo, text + lo + bytes);
+        b->offsets.resize(n + 1);
+        for (uint64_t i = 0; i <= n; ++i) {
+            if (offsets[i] < lo || (i && offsets[i] < offsets[i - 1])) throw Error(VBT_ERR_INVALID_ARGUMENT, "offsets must be non-decreasing");
+            b->offsets[i] = offsets[i] - lo;
+        }
+        HIPX(hipSetDevice(tok->t->device()));
+        Workspace ws(*tok->t, n, bytes);
+        void* d_text = nullptr;
+        uint64_t* d_off = nullptr;
+        HIPX(hipMalloc(&d_text, std::max<uint64_t>(bytes, 16)));
+        if (hipMalloc(reinterpret_cast<void**>(&d_off), (n + 1) * 8) != hipSuccess) { (void)hipFree(d_text); throw Error(VBT_ERR_DEVICE, "hipMalloc failed"); }
+        try {
+            if (bytes) HIPX(hipMemcpy(d_text, b->text.data(), bytes, hipMemcpyHostToDevice));
+            HIPX(hipMemcpy(d_off, b->offsets.data(), (n + 1) * 8, hipMemcpyHostToDevice));
+            run_and_fetch(ws, static_cast<const uint8_t*>(d_text), d_off, n, bytes, b->tok_off, b->tok_cnt, b->tokens);
+        } catch (...) {
+            (void)hipFree(d_text); (void)hipFree(d_off);
+            throw;
+        }
+        (void)hipFree(d_text); (void)hipFree(d_off);
+        *out = b.release();
+    });
+}
+
+void vbt_batch_free(vbt_batch* b) { delete b; }
+uint64_t vbt_batch_num_sentences(const vbt_batch* b) { return b->tok_cnt.size(); }
+uint64_t vbt_batch_total_tokens(const vbt_batch* b) { return b->tokens.size(); }
+uint32_t vbt_batch_num_tokens(const vbt_batch* b, uint64_t s) { return s < b->tok_cnt.size() ? b->tok_cnt[s] : 0; }
+const vbt_token_rec* vbt_batch_records(const vbt_batch* b, uint64_t s) {
+    return s < b->tok_cnt.size() && b->tok_cnt[s] ? &b->tokens[b->tok_off[s]] : nullptr;
+}
+
+int vbt_batch_arrays(const vbt_batch* b, const vbt_token_rec** tokens, const uint32_t** tok_off, const uint32_t** tok_cnt) {
+    if (tokens) *tokens = b->tokens.data();
+    if (tok_off) *tok_off = b->tok_off.data();
+    if (tok_cnt) *tok_cnt = b->tok_cnt.data();
+    return VBT_OK;
+}
+
+int vbt_batch_token(const vbt_batch* b, uint64_t s, uint32_t i, vbt_token* out) {
+    return guarded([&] {
+        if (s >= b->tok_cnt.size() || i >= b->tok_cnt[s]) throw Error(VBT_ERR_INVALID_ARGUMENT, "token index out of range");
+        fill_token(b->tok->t->dict(), b->text.data() + b->offsets[s], b->tokens[b->tok_off[s] + i], out);
+    });
+}
+
+int vbt_batch_format(const vbt_batch* b, int mode, char** out, size_t* len) {
+    return guarded([&] {
+        if (mode < VBT_FORMAT_MECAB || mode > VBT_FORMAT_DETAIL) throw Error(VBT_ERR_INVALID_ARGUMENT, "mode: unknown output mode");
+        static const char* kLexNames[3] = {"System", "User", "Unknown"};  // {:?} of LexType
+        std::string s;
+        s.reserve(b->tokens.size() * 64 + b->tok_cnt.size() * 4);
+        const Dictionary& d = b->tok->t->dict();
+        char num[96];
+        for (size_t si = 0; si < b->tok_cnt.size(); ++si) {
+            const uint8_t* sent = b->text.data() + b->offsets[si];
+            for (uint32_t i = 0; i < b->tok_cnt[si]; ++i) {
+                vbt_token t;
+                fill_token(d, sent, b->tokens[b->tok_off[si] + i], &t);
+                if (mode == VBT_FORMAT_WAKATI) {  // tokenize/src/main.rs:96-103
+                    if (i) s.push_back(' ');
+                    s.append(t.surface, t.surface_len);
+                    continue;
+                }
+                s.append(t.surface, t.surface_len);
+                s.push_back('\t');
+                s.append(t.feature, t.feature_len);
+                if (mode == VBT_FORMAT_DETAIL) {  // tokenize/src/main.rs:108-123
+                    int k = std::snprintf(num, sizeof(num), "\tlex_type=%s\tleft_id=%u\tright_id=%u\tword_cost=%d\ttotal_cost=%d",
+                                          kLexNames[t.lex_type], (unsigned)t.left_id, (unsigned)t.right_id, (int)t.word_cost, (int)t.total_cost);
+                    s.append(num, (size_t)k);
+                }
+                s.push_back('\n');
+            }
+            if (mode == VBT_FORMAT_WAKATI) s.push_back('\n');
+            else s.append("EOS\n");  // tokenize/src/main.rs:91
+        }
+        char* p = static_cast<char*>(std::malloc(s.size() + 1));
+        if (!p) throw std::bad_alloc();
+        std::memcpy(p, s.data(), s.size());
+        p[s.size()] = 0;
+        *out = p;
+        *len = s.size();
+    });
+}
+
+void vbt_free(void* p) { std::free(p); }
+
+int vbt_workspace_new(const vbt_tokenizer* tok, uint64_t max_sentences, uint64_t max_bytes, vbt_workspace** out) {
+    return guarded([&] {
+        if (!tok || !out) throw Error(VBT_ERR_INVALID_ARGUMENT, "null argument");
+        *out = new vbt_workspace{std::make_unique<Workspace>(*tok->t, max_sentences, max_bytes)};
+    });
+}
+
+void vbt_workspace_free(vbt_workspace* ws) { delete ws; }
+
+int vbt_tokenize_batch_device(vbt_workspace* ws, const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n, uint64_t total_bytes,
+                              void* hip_stream) {
+    return guarded([&] { ws->w->run(d_text, d_offsets, n, total_bytes, hip_stream); });
+}
+
+int vbt_workspace_results(const vbt_workspace* ws, const vbt_token_rec** d_tokens, const uint32_t** d_tok_off, const uint32_t** d_tok_cnt,
+                          const uint32_t** d_total) {
+    return guarded([&] {
+        if (d_tokens) *d_tokens = ws->w->d_tokens;
+        if (d_tok_off) *d_tok_off = ws->w->d_tok_off;
+        if (d_tok_cnt) *d_tok_cnt = ws->w->d_tok_cnt;
+        if (d_total) *d_total = ws->w->d_ctrl;
+    });
+}
+
+int vbt_workspace_set_timing(vbt_workspace* ws, int enabled) {
+    ws->w->timing = enabled != 0;
+    return VBT_OK;
+}
+
+int vbt_workspace_stats(vbt_workspace* ws, vbt_call_stats* out) {
+    return guarded([&] { ws->w->stats(out); });
+}
+
+}  // extern "C"

@@ -1,0 +1,87 @@
+// Host-side dictionary model of the MI355X tokenizer (product code).
+//
+// Parses MeCab-format sources exactly as vibrato's SystemDictionaryBuilder does
+// (reference: vibrato/src/dictionary/builder.rs:64-89) and lays the result out in
+// the flat arrays the HIP kernels read ("device image").
+#pragma once
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <string_view>
+#include <vector>
+
+#include "../../include/vibrato_hip.h"
+
+namespace vbt {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+// One double-array node as the GPU reads it: a single 16-byte load per transition.
+//   child(n, c) = nodes[n].base ^ c, valid iff nodes[child].check == n
+//   nodes[n].cnt > 0  <=> some word ends at n; its entries are entries[val .. val+cnt)
+struct alignas(16) TrieNode {
+    uint32_t base;
+    uint32_t check;
+    uint32_t val;
+    uint32_t cnt;
+};
+static_assert(sizeof(TrieNode) == 16, "TrieNode must be 16 bytes");
+
+// One lexicon / unknown-word entry: what Lattice::insert_node needs, 12 bytes.
+//   w0 = word_id, w1 = left_id | right_id << 16, w2 = (uint16) word_cost
+struct Entry {
+    uint32_t word_id;
+    uint32_t left_right;
+    uint32_t cost;
+};
+static_assert(sizeof(Entry) == 12, "Entry must be 12 bytes");
+
+struct WordParam {
+    uint16_t left_id, right_id;
+    int16_t word_cost;
+};
+
+// A lexicon (system or user): trie + entries + per-word parameters and features.
+// Mirrors vibrato::dictionary::lexicon::Lexicon (lexicon.rs:23-29).
+struct Lexicon {
+    std::vector<uint16_t> mapper;   // code point -> trie code (0 = not in any key)
+    uint32_t alphabet = 0;          // codes are 1..alphabet
+    std::vector<TrieNode> nodes;    // double array, root = 0
+    std::vector<Entry> entries;     // grouped by surface, word ids ascending
+    std::vector<WordParam> params;  // indexed by word id
+    std::vector<std::string> features;
+    uint32_t max_word_chars = 0;
+
+    // Host mirror of the device walk; used by tests (Lexicon::common_prefix_iterator,
+    // lexicon.rs:33-46). Appends (word_id, end_char) pairs in enumeration order.
+    void common_prefix(const uint32_t* cps, size_t n, std::vector<std::pair<uint32_t, uint32_t>>& out) const;
+};
+
+struct Dictionary {
+    Lexicon system;
+    bool has_user = false;
+    Lexicon user;
+    std::vector<int16_t> matrix;  // data[left * num_right + right], matrix_connector.rs:47
+    uint32_t num_right = 0, num_left = 0;
+    std::vector<uint32_t> chr2inf;  // 65536 packed CharInfo, character.rs:10-24
+    std::vector<std::string> categories;
+    std::vector<uint32_t> unk_offsets;  // per category, unknown.rs:63-66
+    std::vector<Entry> unk_entries;     // word_id = row index
+    std::vector<std::string> unk_features;
+
+    int cate_id(std::string_view name) const;
+};
+
+// SystemDictionaryBuilder::from_readers (builder.rs:64-89). If matrix_bin != nullptr the
+// connection matrix comes from a binary i16 array (data[left*num_right+right]).
+Dictionary* build_dictionary(std::string_view lex, std::string_view matrix_def, const int16_t* matrix_bin,
+                             uint32_t num_right, uint32_t num_left, std::string_view char_def,
+                             std::string_view unk_def);
+
+// Dictionary::reset_user_lexicon_from_reader (dictionary.rs:209-229).
+void set_user_lexicon(Dictionary& d, const char* csv, size_t len);
+
+}  // namespace vbt
