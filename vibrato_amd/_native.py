@@ -90,6 +90,13 @@ def lib():
     """Loads (building first if sources are newer) the HIP shared library. Never falls back."""
     global _lib
     if _lib is None:
+        # torch bundles its own libamdhip64.so.7 / libhsa-runtime64; two HIP runtimes in one process
+        # cannot both own the GPU.  Importing torch first makes the loader resolve our NEEDED
+        # libamdhip64.so.7 to the copy torch already mapped (plumbing only: no torch compute here).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         so = _build.SO
         if _build.needs_build():
             if os.path.exists(_build.HIPCC):

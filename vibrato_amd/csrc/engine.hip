@@ -390,7 +390,7 @@ __device__ __forceinline__ uint64_t process_sentence(const DevDict& D, const Bat
     uint32_t T = 0;
     if (ln == 0) {
         uint32_t cur = eos_pred;
-        while (cur != 0) {
+        while (cur != 0 && T < n) {  // tokens <= chars; the bound also keeps a corrupted chain finite
             path[T++] = (IdxT)cur;
             cur = e_back[cur];
         }
