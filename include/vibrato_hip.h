@@ -176,6 +176,10 @@ typedef struct vbt_call_stats {
     float ms_tier0, ms_tier12;
 } vbt_call_stats;
 VBT_API int vbt_workspace_set_timing(vbt_workspace* ws, int enabled);
+/* Developer aid: per-phase shader-clock cycles summed over all sentences since the last reset
+ * (enabled by VBT_PROFILE=1 in the environment when the workspace is created). out[0..7] =
+ * decode, count, fill, end lists, pre-pass, gather, recurrence, emit; out[8] = sentences. */
+VBT_API int vbt_workspace_profile(vbt_workspace* ws, uint64_t out[9], int reset);
 VBT_API int vbt_workspace_stats(vbt_workspace* ws, vbt_call_stats* out);
 
 #ifdef __cplusplus

@@ -105,11 +105,11 @@ def test_differential_spaces_without_ignore_space():
     _assert_batch_equal(to, tv, text, offs)
 
 
-@pytest.mark.parametrize("lds0,lds1", [("2048", "8192"), ("1024", "1024")])
-def test_all_tiers_agree(lds0, lds1, monkeypatch):
-    """Force sentences through tier 1 (large LDS) and tier 2 (global scratch)."""
-    monkeypatch.setenv("VBT_LDS0", lds0)
-    monkeypatch.setenv("VBT_LDS1", lds1)
+@pytest.mark.parametrize("tiers", ["2048,8192", "1024", "4096,6144,8192,12288,16384,65536"])
+def test_all_tiers_agree(tiers, monkeypatch):
+    """Force sentences through the larger LDS tiers and the global-scratch tier
+    (and through multi-block connection-cost staging when LDS is tight)."""
+    monkeypatch.setenv("VBT_TIERS", tiers)
     sd = synth.SynthDict("small")
     to, tv = _oracle_and_product(sd, ignore_space=True)
     text, offs = sd.sentences(3000, "mixed", space_p=0.05)

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Developer aid: per-phase cycle breakdown of the fused tokenize kernel (VBT_PROFILE=1)."""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["VBT_PROFILE"] = "1"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dict", default="unidic")
+    ap.add_argument("--sentences", type=int, default=100000)
+    ap.add_argument("--steps", type=int, default=5)
+    args = ap.parse_args()
+    import torch
+    import vibrato_amd as V
+    from tools import synth
+    sd = synth.SynthDict(args.dict)
+    dv = V.SystemDictionaryBuilder.from_readers_binmatrix(sd.lex, sd.matrix, sd.num_right, sd.num_left, sd.char_def, sd.unk)
+    tok = V.Tokenizer(dv, device=0)
+    text, offs = sd.sentences(args.sentences, "lognormal_40")
+    d_text = torch.from_numpy(text).cuda()
+    d_offs = torch.from_numpy(offs.astype(np.int64)).cuda()
+    ws = tok.workspace(args.sentences, len(text))
+    ws.set_timing(True)
+    for i in range(args.steps + 1):
+        ws.run(d_text.data_ptr(), d_offs.data_ptr(), args.sentences, len(text), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        if i == 0:
+            ws.profile(reset=True)
+    st = ws.stats()
+    pr = ws.profile()
+    ns = pr.pop("sentences")
+    tot = sum(pr.values())
+    print(f"tiers={os.environ.get('VBT_TIERS', 'default')} stats={st}")
+    print(f"sentences profiled: {ns}; mean cycles/sentence {tot / max(ns, 1):.0f} (~{tot / max(ns, 1) / 2.4e3:.1f} us @2.4GHz)")
+    for k, v in pr.items():
+        print(f"  {k:11s} {v / max(ns, 1):9.0f} cyc/sentence  {100.0 * v / max(tot, 1):5.1f}%")
+
+
+if __name__ == "__main__":
+    main()

@@ -82,6 +82,7 @@ SIGNATURES = {
     "vbt_tokenize_batch_device": (_int, [_vp, _vp, _vp, _u64, _u64, _vp]),
     "vbt_workspace_results": (_int, [_vp, _PP, _PP, _PP, _PP]),
     "vbt_workspace_set_timing": (_int, [_vp, _int]),
+    "vbt_workspace_profile": (_int, [_vp, C.POINTER(C.c_uint64), _int]),
     "vbt_workspace_stats": (_int, [_vp, C.POINTER(CallStats)]),
 }
 

@@ -333,6 +333,16 @@ class Workspace:
         N.check(N.lib().vbt_workspace_results(self._h, *[C.byref(x) for x in p]))
         return {"tokens": p[0].value, "tok_off": p[1].value, "tok_cnt": p[2].value, "total": p[3].value}
 
+    PHASES = ("decode", "count", "fill", "end_lists", "prepass", "gather", "recurrence", "emit")
+
+    def profile(self, reset=True):
+        """Per-phase cycle totals (needs VBT_PROFILE=1 at workspace creation)."""
+        out = (C.c_uint64 * 9)()
+        N.check(N.lib().vbt_workspace_profile(self._h, out, int(reset)))
+        d = dict(zip(self.PHASES, [int(x) for x in out[:8]]))
+        d["sentences"] = int(out[8])
+        return d
+
     def stats(self):
         st = N.CallStats()
         N.check(N.lib().vbt_workspace_stats(self._h, C.byref(st)))

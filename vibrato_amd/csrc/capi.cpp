@@ -406,6 +406,10 @@ int vbt_workspace_set_timing(vbt_workspace* ws, int enabled) {
     return VBT_OK;
 }
 
+int vbt_workspace_profile(vbt_workspace* ws, uint64_t out[9], int reset) {
+    return guarded([&] { ws->w->read_profile(out, reset != 0); });
+}
+
 int vbt_workspace_stats(vbt_workspace* ws, vbt_call_stats* out) {
     return guarded([&] { ws->w->stats(out); });
 }

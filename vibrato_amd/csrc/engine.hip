@@ -28,7 +28,6 @@
 namespace vbt {
 namespace {
 
-constexpr int32_t kInvalidCost = 0x7FFFFFFF;  // MAX_COST, lattice.rs:9
 constexpr uint64_t kNoFit = ~0ull;
 
 #define HIP_CHECK(expr)                                                                               \
@@ -51,15 +50,36 @@ __device__ __forceinline__ uint32_t wave_exscan(uint32_t v, uint32_t& total) {
     return x - v;
 }
 
-__device__ __forceinline__ uint64_t wave_min_u64(uint64_t k) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        uint32_t lo = __shfl_xor((uint32_t)k, d), hi = __shfl_xor((uint32_t)(k >> 32), d);
-        uint64_t o = ((uint64_t)hi << 32) | lo;
-        k = o < k ? o : k;
-    }
-    return k;
+// Packed lattice key: high word = min_cost biased to unsigned order (cost ^ 0x80000000), low word =
+// 0xFFFFFFFE - insertion sequence number.  Unsigned-minimum over keys = minimum cost with ties broken
+// towards the LAST inserted node, the `<=` rule of search_min_node (lattice.rs:141-146).  Adding a
+// connection cost is a wrapping add on the high word.  Low word 0xFFFFFFFF marks "never inserted".
+constexpr uint64_t kDeadKey = ~0ull;
+__device__ __forceinline__ uint64_t make_key(uint32_t cost, uint32_t seq) {
+    return ((uint64_t)(cost ^ 0x80000000u) << 32) | (0xFFFFFFFEu - seq);
 }
+__device__ __forceinline__ uint32_t key_cost(uint64_t k) { return (uint32_t)(k >> 32) ^ 0x80000000u; }
+__device__ __forceinline__ uint32_t key_seq(uint64_t k) { return 0xFFFFFFFEu - (uint32_t)k; }
+
+// 128-bit window helpers (shift distances 0..64), by value so everything stays in registers
+struct U128 { uint64_t lo, hi; };
+__device__ __forceinline__ U128 shr128(U128 w, uint32_t d) {
+    const uint64_t lo_s = d >= 64 ? w.hi : (d ? (w.lo >> d) | (w.hi << (64 - d)) : w.lo);
+    const uint64_t hi_s = d >= 64 ? 0ull : (w.hi >> d);
+    return U128{lo_s, hi_s};
+}
+__device__ __forceinline__ U128 or_shl128(U128 w, uint64_t m, uint32_t d) {
+    const uint64_t lo_m = d >= 64 ? 0ull : (m << d);
+    const uint64_t hi_m = d >= 64 ? m : (d ? m >> (64 - d) : 0ull);
+    return U128{w.lo | lo_m, w.hi | hi_m};
+}
+__device__ __forceinline__ uint64_t uniform64(uint64_t v) {
+    return ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)v);
+}
+
+// One step of the position sweep: candidates [cbeg, cbeg+nc) connect to end-list slots [pbeg, pbeg+np).
+template <typename IdxT>
+struct StepRec { IdxT cbeg, nc, pbeg, np; };
 
 // Bump allocator over the per-sentence arena (LDS or a global slab).
 struct Arena {
@@ -133,6 +153,16 @@ __device__ __forceinline__ uint64_t process_sentence(const DevDict& D, const Bat
                                                      uint64_t acap) {
     const uint32_t ln = threadIdx.x;
     const uint64_t lt_mask = (1ull << ln) - 1ull;
+    // optional per-phase cycle accounting (A.prof != nullptr): s_memtime deltas summed per launch
+    uint64_t prof_t = A.prof ? clock64() : 0, prof_acc[kProfPhases] = {};
+#define PROF_MARK(i)                                  \
+    do {                                              \
+        if (A.prof) {                                 \
+            const uint64_t t_ = clock64();            \
+            prof_acc[i] += t_ - prof_t;               \
+            prof_t = t_;                              \
+        }                                             \
+    } while (0)
     constexpr uint64_t kIdxMax = (uint64_t)(IdxT) ~(IdxT)0;
     const uint64_t b0 = A.offsets[sid], nb64 = A.offsets[sid + 1] - b0;
     if (nb64 == 0) {
@@ -211,6 +241,7 @@ __device__ __forceinline__ uint64_t process_sentence(const DevDict& D, const Bat
         }
     }
     __syncthreads();
+    PROF_MARK(0);
 
     // ---- P1a: count candidates per start position --------------------------------------
     uint32_t C = 0;
@@ -230,19 +261,23 @@ __device__ __forceinline__ uint64_t process_sentence(const DevDict& D, const Bat
         if (i < n) cand_off[i] = (IdxT)(C + ex);
         C += tot;
     }
-    if ((uint64_t)C + 2 >= kIdxMax) return kNoFit;
+    if ((uint64_t)C + 3 >= kIdxMax) return kNoFit;
     if (ln == 0) cand_off[n] = (IdxT)C;
+    PROF_MARK(1);
 
-    // start-major node arrays
+    // start-major node arrays; index C is the EOS pseudo node (left_id 0), C+1 stands for BOS
+    uint64_t* e_key = ar.take<uint64_t>(C + 2);  // end-major: packed (cost, sequence) key, see make_key
+    uint64_t* lens = ar.take<uint64_t>(n + 1);   // per start position: bit L-1 set <=> a candidate of length L
+    StepRec<IdxT>* st;                           // sweep steps (one per visited start position, + EOS)
+    if constexpr (sizeof(StepRec<IdxT>) == 8) st = reinterpret_cast<StepRec<IdxT>*>(lens);  // step S <= its start_word: safe alias
+    else st = ar.take<StepRec<IdxT>>(n + 1);
     uint32_t* nd_word = ar.take<uint32_t>(C);
-    int32_t* e_mc = ar.take<int32_t>(C + 1);  // end-major: min cost (kInvalidCost = never inserted)
-    uint16_t* nd_left = ar.take<uint16_t>(C);
-    int16_t* nd_wcost = ar.take<int16_t>(C);
-    uint16_t* e_right = ar.take<uint16_t>(C + 1);
+    uint16_t* nd_left = ar.take<uint16_t>(C + 1);
+    int16_t* nd_wcost = ar.take<int16_t>(C + 1);
+    uint16_t* e_right = ar.take<uint16_t>(C + 2);
     IdxT* nd_end = ar.take<IdxT>(C);
-    IdxT* nd_eslot = ar.take<IdxT>(C);
-    IdxT* e_seq = ar.take<IdxT>(C + 1);
-    IdxT* e_back = ar.take<IdxT>(C + 1);
+    IdxT* nd_eslot = ar.take<IdxT>(C + 2);
+    IdxT* e_back = ar.take<IdxT>(C + 2);  // end-major: sequence number of the best predecessor
     if (!ar.ok) return ar.used;
     uint16_t* tmp_right = reinterpret_cast<uint16_t*>(e_back);  // right ids until the end lists exist
 
@@ -252,12 +287,17 @@ __device__ __forceinline__ uint64_t process_sentence(const DevDict& D, const Bat
     __syncthreads();
 
     // ---- P1b: fill candidates in reference insertion order (tokenizer.rs:155-198) --------
+    bool any_long = false;  // a word longer than 64 chars: the windowed pre-pass cannot represent it
     for (uint32_t c0 = 0; c0 < n; c0 += 64) {
         const uint32_t i = c0 + ln;
+        bool is_long = false;
         if (i < n) {
             uint32_t k = cand_off[i];
+            uint64_t lmask = 0;
             bool matched = false;
             auto put = [&](const Entry* ent, uint32_t v, uint32_t c, uint32_t end, uint32_t lex) {
+                const uint32_t len = end - i;
+                if (len <= 64) lmask |= 1ull << (len - 1); else is_long = true;
                 for (uint32_t t = 0; t < c; ++t, ++k) {
                     const Entry e = ent[v + t];
                     nd_word[k] = (lex << 30) | e.word_id;
@@ -275,9 +315,12 @@ __device__ __forceinline__ uint64_t process_sentence(const DevDict& D, const Bat
             const uint32_t cinfo = ci[i], cate = (cinfo >> 18) & 0xFFu;
             const uint32_t u0 = D.unk_off[cate], nunk = D.unk_off[cate + 1] - u0;
             unk_spans(cinfo, grp[i], i, matched, D.max_grouping_len, [&](uint32_t e) { put(D.unk_entries, u0, nunk, e, 2u); });
+            lens[i] = lmask;
         }
+        any_long |= __ballot(is_long) != 0;
     }
     __syncthreads();
+    PROF_MARK(2);
 
     // ---- P2: end lists: exclusive scan of per-end counts; slot 0 is BOS --------------------
     {
@@ -299,100 +342,251 @@ __device__ __forceinline__ uint64_t process_sentence(const DevDict& D, const Bat
         const uint16_t r = tmp_right[c];
         nd_eslot[c] = (IdxT)es;
         e_right[es] = r;
-        e_seq[es] = (IdxT)c;
-        e_mc[es] = kInvalidCost;
+        e_key[es] = kDeadKey;  // never inserted until a sweep step reaches its start position
     }
     __syncthreads();  // all tmp_right reads done before e_back is written
+    const uint32_t kBosSeq = C + 1;
     if (ln == 0) {
         e_right[0] = 0;  // BOS: right_id = BOS_EOS_CONNECTION_ID, min_cost = 0 (lattice.rs:72-83)
-        e_seq[0] = 0;
-        e_mc[0] = 0;
-        e_back[0] = 0;
-        reach[0] = 1;
+        e_key[0] = make_key(0u, kBosSeq);
+        nd_eslot[kBosSeq] = 0;
+        e_back[0] = (IdxT)kBosSeq;
+        nd_left[C] = 0;  // EOS: left_id = BOS_EOS_CONNECTION_ID (lattice.rs:85-101), no word cost
+        nd_wcost[C] = 0;
+        nd_eslot[C] = (IdxT)(C + 1);
+        e_key[C + 1] = kDeadKey;
     }
     __syncthreads();
+    PROF_MARK(3);
 
-    // ---- P4: position sweep (build_lattice_inner tokenizer.rs:106-138) ------------------------
-    const int16_t* __restrict__ matrix = D.matrix;
-    const uint32_t NR = D.num_right;
-    uint32_t sn = 0, sw = 0;
-    while (sw < n) {
-        if (!__builtin_amdgcn_readfirstlane(reach[sn])) {  // has_previous_node, lattice.rs:155-157
+    // ---- P3a: structural pre-pass of build_lattice_inner (tokenizer.rs:106-138): which
+    // (start_node, start_word) steps the sweep takes depends only on which positions have a
+    // word ending there, never on costs.  Records one step per visited start position + EOS.
+    uint32_t S = 0, sn_eos = 0;
+    uint64_t total_pairs = 0, max_pairs = 0;
+    bool windowed = !any_long;
+    if (windowed) {
+        // Reachability as a 128-bit sliding window: bit b <=> a word ends at position p + b.
+        U128 w{1, 0};  // BOS ends at position 0
+        uint32_t p = 0;
+        while (p < n) {
+            w.lo = uniform64(w.lo);  // wave-uniform by construction: keep the state machine on the scalar unit
+            w.hi = uniform64(w.hi);
+            p = __builtin_amdgcn_readfirstlane(p);
+            if (!(w.lo & 1)) {  // has_previous_node(p) is false: skip to the next reachable position
+                uint32_t z = w.lo ? (uint32_t)__builtin_ctzll(w.lo) : 64u;
+                if (z > n - p) z = n - p;
+                w = shr128(w, z);
+                p += z;
+                continue;
+            }
+            uint32_t sw = p;
+            if (D.space_cateset) {  // tokenizer.rs:117-125
+                const uint32_t cs = __builtin_amdgcn_readfirstlane(ci[p]);
+                if (cs & D.space_cateset) sw += __builtin_amdgcn_readfirstlane((uint32_t)grp[p]);
+            }
+            if (sw >= n) break;  // input ends with spaces, tokenizer.rs:128-130
+            const uint32_t d = sw - p + 1;
+            if (d > 64) { windowed = false; break; }  // a space run too long for the window: generic path
+            const uint64_t lm = uniform64(lens[sw]);
+            const uint32_t c_beg = __builtin_amdgcn_readfirstlane((uint32_t)cand_off[sw]);
+            const uint32_t c_end = __builtin_amdgcn_readfirstlane((uint32_t)cand_off[sw + 1]);
+            const uint32_t p_beg = __builtin_amdgcn_readfirstlane(end_off[p]);
+            const uint32_t p_end = __builtin_amdgcn_readfirstlane(end_off[p + 1]);
+            if (ln == 0) st[S] = StepRec<IdxT>{(IdxT)c_beg, (IdxT)(c_end - c_beg), (IdxT)p_beg, (IdxT)(p_end - p_beg)};
+            const uint64_t pairs = (uint64_t)(c_end - c_beg) * (p_end - p_beg);
+            total_pairs += pairs;
+            max_pairs = pairs > max_pairs ? pairs : max_pairs;
+            ++S;
+            // words starting at sw end at sw + L: bit (L - 1) of lm -> window bit (L - 1) + d; then advance to sw + 1
+            w = shr128(or_shl128(w, lm, d), d);
+            p = sw + 1;
+        }
+        sn_eos = p < n ? p : n;
+        if (!windowed) { S = 0; total_pairs = 0; max_pairs = 0; }
+    }
+    if (!windowed) {  // generic path: byte-per-position reachability in LDS
+        __syncthreads();
+        if (ln == 0) reach[0] = 1;
+        __syncthreads();
+        uint32_t sn = 0, sw = 0;
+        while (sw < n) {
+            if (!__builtin_amdgcn_readfirstlane(reach[sn])) {  // has_previous_node, lattice.rs:155-157
+                sw += 1;
+                sn = sw;
+                continue;
+            }
+            if (D.space_cateset) {
+                const uint32_t cs = __builtin_amdgcn_readfirstlane(ci[sn]);
+                if (cs & D.space_cateset) sw += __builtin_amdgcn_readfirstlane((uint32_t)grp[sn]);
+            }
+            if (sw == n) break;
+            const uint32_t c_beg = __builtin_amdgcn_readfirstlane((uint32_t)cand_off[sw]);
+            const uint32_t c_end = __builtin_amdgcn_readfirstlane((uint32_t)cand_off[sw + 1]);
+            const uint32_t p_beg = __builtin_amdgcn_readfirstlane(end_off[sn]);
+            const uint32_t p_end = __builtin_amdgcn_readfirstlane(end_off[sn + 1]);
+            for (uint32_t c = c_beg + ln; c < c_end; c += 64) reach[nd_end[c]] = 1;
+            __syncthreads();  // (also orders the lens[] reads of other lanes before st[] overwrites them)
+            if (ln == 0) st[S] = StepRec<IdxT>{(IdxT)c_beg, (IdxT)(c_end - c_beg), (IdxT)p_beg, (IdxT)(p_end - p_beg)};
+            const uint64_t pairs = (uint64_t)(c_end - c_beg) * (p_end - p_beg);
+            total_pairs += pairs;
+            max_pairs = pairs > max_pairs ? pairs : max_pairs;
+            ++S;
             sw += 1;
             sn = sw;
-            continue;
         }
-        if (D.space_cateset) {  // tokenizer.rs:117-125
-            const uint32_t cs = __builtin_amdgcn_readfirstlane(ci[sn]);
-            if (cs & D.space_cateset) sw += __builtin_amdgcn_readfirstlane((uint32_t)grp[sn]);
+        sn_eos = sn;
+    }
+    {   // EOS step (insert_eos(start_node), tokenizer.rs:138): one candidate (node C), preds = ends[sn]
+        const uint32_t p_beg = __builtin_amdgcn_readfirstlane(end_off[sn_eos]);
+        const uint32_t p_end = __builtin_amdgcn_readfirstlane(end_off[sn_eos + 1]);
+        if (ln == 0) st[S] = StepRec<IdxT>{(IdxT)C, (IdxT)1, (IdxT)p_beg, (IdxT)(p_end - p_beg)};
+        total_pairs += p_end - p_beg;
+        max_pairs = (uint64_t)(p_end - p_beg) > max_pairs ? (uint64_t)(p_end - p_beg) : max_pairs;
+        ++S;
+    }
+    // connection-cost staging buffer: all pairs if they fit, else as many whole steps as fit
+    uint64_t q_cap;
+    int16_t* conn;
+    {
+        const uint64_t off = (ar.used + 1) & ~1ull;
+        const uint64_t room = ar.cap > off ? (ar.cap - off) / 2 : 0;
+        if (room < max_pairs) return off + 2 * max_pairs;
+        q_cap = room < total_pairs ? room : total_pairs;
+        conn = reinterpret_cast<int16_t*>(ar.base + off);
+    }
+    __syncthreads();
+    PROF_MARK(4);
+
+    // ---- P3b/P4: per block of steps: gather the connection costs of every (candidate,
+    // predecessor) pair into `conn` with many loads in flight (addresses depend on ids only),
+    // then run the cost recurrence of search_min_node/insert_node (lattice.rs:103-151) from LDS.
+    const int16_t* __restrict__ matrix = D.matrix;
+    const uint32_t NR = D.num_right;
+    for (uint32_t k = 0; k < S;) {
+        uint32_t kend = k;
+        {
+            uint64_t q = 0;
+            while (kend < S) {
+                const StepRec<IdxT> r = st[kend];
+                const uint64_t pairs = (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)r.nc) *
+                                       __builtin_amdgcn_readfirstlane((uint32_t)r.np);
+                if (q + pairs > q_cap) break;
+                q += pairs;
+                ++kend;
+            }
         }
-        if (sw == n) break;  // input ends with spaces, tokenizer.rs:128-130
-        const uint32_t c_beg = __builtin_amdgcn_readfirstlane((uint32_t)cand_off[sw]);
-        const uint32_t c_end = __builtin_amdgcn_readfirstlane((uint32_t)cand_off[sw + 1]);
-        const uint32_t p_beg = __builtin_amdgcn_readfirstlane(end_off[sn]);
-        const uint32_t p_end = __builtin_amdgcn_readfirstlane(end_off[sn + 1]);
-        for (uint32_t cb = c_beg; cb < c_end; cb += 64) {
-            const uint32_t c = cb + ln;
-            if (c < c_end) {
-                // search_min_node(start_node, left_id), lattice.rs:129-151
-                const int16_t* row = matrix + (size_t)nd_left[c] * NR;  // matrix_connector.rs:79-85
-                // Branch-free argmin over a packed key: (cost biased to unsigned) << 32 | ~seq, so the
-                // minimum key = minimum cost, ties -> largest insertion sequence number (`<=`, l.143).
-                uint64_t best = ~0ull;
-                for (uint32_t j = p_beg; j < p_end; j += 8) {
+        // gather: layout conn[soff + j * nc + ci] (pred-major: consecutive lanes = consecutive candidates).
+        // A slot is 64 consecutive pairs of one step; the (j, ci) of a lane advances incrementally by
+        // (64 / nc, 64 % nc) from slot to slot, so there is one division per step, none per pair.
+        {
+            constexpr int U = 32;
+            uint32_t kk = k, q0 = 0, soff = 0;
+            uint32_t c_beg = 0, nc = 1, p_beg = 0, pairs = 0, dq = 0, dr = 0;
+            uint32_t pj = 0, pr = 0;  // this lane's pred / candidate offset within the current slot
+            auto load_step = [&]() {
+                const StepRec<IdxT> r = st[kk];
+                c_beg = __builtin_amdgcn_readfirstlane((uint32_t)r.cbeg);
+                nc = __builtin_amdgcn_readfirstlane((uint32_t)r.nc);
+                p_beg = __builtin_amdgcn_readfirstlane((uint32_t)r.pbeg);
+                pairs = nc * __builtin_amdgcn_readfirstlane((uint32_t)r.np);
+                dq = 64u / nc;
+                dr = 64u - dq * nc;
+                pj = ln / nc;
+                pr = ln - pj * nc;
+            };
+            load_step();
+            while (kk < kend) {
+                // Issue U independent gathers before the first use: loads are unconditional (inactive
+                // slots re-read a valid cell) and kept in 32-bit registers, so the compiler places one
+                // counted s_waitcnt per consumer instead of one vmcnt(0) per load.
+                int32_t val[U];
+                uint32_t idx[U];
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const bool in = j + k < p_end;
-                        const uint32_t jj = in ? j + k : p_end - 1;
-                        const int32_t mc = e_mc[jj];
-                        const int32_t conn = row[e_right[jj]];
-                        const uint32_t v = (uint32_t)mc + (uint32_t)conn;  // wrapping add, as in release builds
-                        uint64_t key = ((uint64_t)(v ^ 0x80000000u) << 32) | (uint32_t)(~(uint32_t)e_seq[jj]);
-                        key = (in && mc != kInvalidCost) ? key : ~0ull;
-                        best = key < best ? key : best;
+                for (int u = 0; u < U; ++u) {
+                    kk = __builtin_amdgcn_readfirstlane(kk);
+                    q0 = __builtin_amdgcn_readfirstlane(q0);
+                    soff = __builtin_amdgcn_readfirstlane(soff);
+                    const bool live = kk < kend;
+                    const uint32_t ql = q0 + ln;
+                    const bool valid = live && ql < pairs;
+                    const uint32_t left = nd_left[c_beg + (valid ? pr : 0u)];
+                    const uint32_t right = e_right[p_beg + (valid ? pj : 0u)];
+                    val[u] = matrix[(size_t)left * NR + right];  // matrix_connector.rs:79-85
+                    idx[u] = valid ? soff + ql : 0xFFFFFFFFu;
+                    if (live) {
+                        q0 += 64;
+                        if (q0 >= pairs) {
+                            soff += pairs;
+                            q0 = 0;
+                            ++kk;
+                            if (kk < kend) load_step();
+                        } else {
+                            pj += dq;
+                            pr += dr;
+                            if (pr >= nc) { pr -= nc; ++pj; }
+                        }
                     }
                 }
-                const uint32_t bseq = ~(uint32_t)best;
-                const uint32_t bj = sn == 0 ? 0u : (uint32_t)nd_eslot[bseq];  // ends[0] holds only BOS (slot 0)
-                const uint32_t bcost = (uint32_t)(best >> 32) ^ 0x80000000u;
-                const uint32_t es = nd_eslot[c];
-                e_mc[es] = (int32_t)(bcost + (uint32_t)(int32_t)nd_wcost[c]);  // lattice.rs:125
-                e_back[es] = (IdxT)bj;
-                reach[nd_end[c]] = 1;
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (idx[u] != 0xFFFFFFFFu) conn[idx[u]] = (int16_t)val[u];
             }
         }
         __syncthreads();
-        sw += 1;
-        sn = sw;
-    }
-
-    // ---- EOS (insert_eos lattice.rs:85-101): left_id = 0 --------------------------------------
-    uint32_t eos_pred;
-    {
-        const uint32_t p_beg = end_off[sn], p_end = end_off[sn + 1];
-        uint64_t key = ~0ull;
-        for (uint32_t j = p_beg + ln; j < p_end; j += 64) {
-            const int32_t mc = e_mc[j];
-            if (mc != kInvalidCost) {
-                const int32_t v = (int32_t)((uint32_t)mc + (uint32_t)(int32_t)matrix[e_right[j]]);
-                // min cost, ties -> largest sequence number; low word also identifies the slot
-                const uint64_t k2 = ((uint64_t)((uint32_t)v ^ 0x80000000u) << 32) | (uint32_t)(~(uint32_t)e_seq[j]);
-                key = k2 < key ? k2 : key;
+        PROF_MARK(5);
+        // cost recurrence, one step per visited start position
+        {
+            uint32_t soff = 0;
+            for (uint32_t kk = k; kk < kend; ++kk) {
+                const StepRec<IdxT> sr = st[kk];
+                const uint32_t c_beg = __builtin_amdgcn_readfirstlane((uint32_t)sr.cbeg);
+                const uint32_t nc = __builtin_amdgcn_readfirstlane((uint32_t)sr.nc);
+                const uint32_t p_beg = __builtin_amdgcn_readfirstlane((uint32_t)sr.pbeg);
+                const uint32_t np = __builtin_amdgcn_readfirstlane((uint32_t)sr.np);
+                for (uint32_t cb = 0; cb < nc; cb += 64) {
+                    const uint32_t ci_ = cb + ln;
+                    if (ci_ < nc) {
+                        const uint32_t c = c_beg + ci_;
+                        const uint32_t es = nd_eslot[c];
+                        const uint32_t wcost = (uint32_t)(int32_t)nd_wcost[c];
+                        // argmin over packed keys: minimum key = minimum cost, ties -> largest insertion
+                        // sequence number, i.e. the `<=` of search_min_node (lattice.rs:141-146)
+                        uint64_t best = kDeadKey;
+                        const int16_t* col = conn + soff + ci_;
+                        const uint64_t* pk = e_key + p_beg;
+                        for (uint32_t j = 0; j < np; j += 8) {
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) {
+                                const uint32_t jj = j + u < np ? j + u : np - 1;  // tail re-reads the last pred (idempotent)
+                                const uint64_t kb = pk[jj];
+                                const uint32_t cv = (uint32_t)(int32_t)col[(size_t)jj * nc];
+                                uint64_t key = kb + ((uint64_t)cv << 32);  // wrapping i32 add of the connection cost
+                                key = (uint32_t)kb == 0xFFFFFFFFu ? kDeadKey : key;
+                                best = key < best ? key : best;
+                            }
+                        }
+                        const uint32_t bseq = key_seq(best);
+                        e_key[es] = make_key(key_cost(best) + wcost, c);  // lattice.rs:125
+                        e_back[es] = (IdxT)bseq;
+                    }
+                }
+                soff += nc * np;
+                __syncthreads();
             }
         }
-        key = wave_min_u64(key);
-        const uint32_t seq = ~(uint32_t)key;
-        eos_pred = sn == 0 ? 0u : (uint32_t)nd_eslot[seq];
+        PROF_MARK(6);
+        k = kend;
     }
 
     // ---- P5: back-trace (append_top_nodes lattice.rs:159-168) + token records ------------------
     IdxT* path = grp;  // groupable is dead after the sweep; tokens <= chars
     uint32_t T = 0;
     if (ln == 0) {
-        uint32_t cur = eos_pred;
-        while (cur != 0 && T < n) {  // tokens <= chars; the bound also keeps a corrupted chain finite
-            path[T++] = (IdxT)cur;
-            cur = e_back[cur];
+        uint32_t seq = e_back[C + 1];
+        while (seq != kBosSeq && T < n) {  // tokens <= chars; the bound also keeps a corrupted chain finite
+            path[T++] = (IdxT)seq;
+            seq = e_back[nd_eslot[seq]];
         }
     }
     T = __shfl(T, 0);
@@ -406,22 +600,28 @@ __device__ __forceinline__ uint64_t process_sentence(const DevDict& D, const Bat
     }
     if (ln == 0) { A.tok_off[sid] = out_base; A.tok_cnt[sid] = T; }
     for (uint32_t t = ln; t < T; t += 64) {
-        const uint32_t es = path[T - 1 - t];  // Worker::token: index = n-1-i (worker.rs:65-68)
-        const uint32_t c = e_seq[es];
+        const uint32_t c = path[T - 1 - t];  // Worker::token: index = n-1-i (worker.rs:65-68)
         // start_word = the position whose candidate range contains c: upper_bound(cand_off, c) - 1
         uint32_t lo = 0, hi = n;
         while (lo < hi) {
             const uint32_t mid = (lo + hi) >> 1;
             if ((uint32_t)cand_off[mid + 1] <= c) lo = mid + 1; else hi = mid;
         }
-        const uint32_t st = lo, en = nd_end[c];
+        const uint32_t stp = lo, en = nd_end[c];
         vbt_token_rec r;
-        r.start_char = st; r.end_char = en;
-        r.start_byte = c2b[st]; r.end_byte = c2b[en];
+        r.start_char = stp; r.end_char = en;
+        r.start_byte = c2b[stp]; r.end_byte = c2b[en];
         r.word_idx = nd_word[c];
-        r.total_cost = e_mc[es];
+        r.total_cost = (int32_t)key_cost(e_key[nd_eslot[c]]);
         A.tokens[out_base + t] = r;
     }
+    PROF_MARK(7);
+    if (A.prof && ln == 0) {
+#pragma unroll
+        for (int i = 0; i < kProfPhases; ++i) atomicAdd(&A.prof[i], (unsigned long long)prof_acc[i]);
+        atomicAdd(&A.prof[kProfPhases], 1ull);
+    }
+#undef PROF_MARK
     return 0;
 }
 
@@ -431,42 +631,46 @@ __device__ __forceinline__ void push_overflow(uint32_t* list, uint32_t* counter,
     if (threadIdx.x == 0) list[atomicAdd(counter, 1u)] = sid;
 }
 
-// Tier 0: one single-wave workgroup per sentence, lattice in `lds_bytes` of LDS.
-__global__ void __launch_bounds__(64) tokenize_tier0(DevDict D, BatchArgs A, uint32_t lds_bytes) {
-    const uint32_t sid = blockIdx.x;
-    if (process_sentence<uint16_t, false>(D, A, sid, g_smem, lds_bytes) != 0) push_overflow(A.overflow0, &A.ctrl[kOver0], sid);
-}
-
-// Tier 1: persistent waves with a large LDS budget drain the tier-0 overflow list.
-__global__ void __launch_bounds__(64) tokenize_tier1(DevDict D, BatchArgs A, uint32_t lds_bytes) {
-    const uint32_t count = A.ctrl[kOver0];
+// LDS tiers: one wavefront per sentence, lattice in `lds_bytes` of LDS.  in_list == nullptr: the
+// grid covers all sentences (block b = sentence b); otherwise persistent waves drain in_list.
+// Sentences that do not fit go to out_list for the next (larger) tier.
+__global__ void __launch_bounds__(64) tokenize_lds(DevDict D, BatchArgs A, uint32_t lds_bytes, const uint32_t* in_list,
+                                                   const uint32_t* in_count, uint32_t* cursor, uint32_t* out_list,
+                                                   uint32_t* out_count) {
+    if (in_list == nullptr) {
+        const uint32_t sid = blockIdx.x;
+        if (process_sentence<uint16_t, false>(D, A, sid, g_smem, lds_bytes) != 0) push_overflow(out_list, out_count, sid);
+        return;
+    }
+    const uint32_t count = *in_count;
     for (;;) {
         uint32_t k = 0;
-        if (threadIdx.x == 0) k = atomicAdd(&A.ctrl[kCursor1], 1u);
+        if (threadIdx.x == 0) k = atomicAdd(cursor, 1u);
         k = __shfl(k, 0);
         if (k >= count) break;
-        const uint32_t sid = A.overflow0[k];
-        if (process_sentence<uint16_t, false>(D, A, sid, g_smem, lds_bytes) != 0) push_overflow(A.overflow1, &A.ctrl[kOver1], sid);
+        const uint32_t sid = in_list[k];
+        if (process_sentence<uint16_t, false>(D, A, sid, g_smem, lds_bytes) != 0) push_overflow(out_list, out_count, sid);
         __syncthreads();
     }
 }
 
-// Tier 2: persistent waves, lattice in a private global-memory slab (any sentence length).
-__global__ void __launch_bounds__(64) tokenize_tier2(DevDict D, BatchArgs A) {
-    const uint32_t count = A.ctrl[kOver1];
+// Last tier: persistent waves, lattice in a private global-memory slab (any sentence length).
+__global__ void __launch_bounds__(64) tokenize_global(DevDict D, BatchArgs A, const uint32_t* in_list, const uint32_t* in_count,
+                                                      uint32_t* cursor) {
+    const uint32_t count = *in_count;
     char* slab = nullptr;
     uint64_t slab_bytes = 0;
     unsigned long long* bump = reinterpret_cast<unsigned long long*>(&A.ctrl[kBump]);
     for (;;) {
         uint32_t k = 0;
-        if (threadIdx.x == 0) k = atomicAdd(&A.ctrl[kCursor2], 1u);
+        if (threadIdx.x == 0) k = atomicAdd(cursor, 1u);
         k = __shfl(k, 0);
         if (k >= count) break;
-        const uint32_t sid = A.overflow1[k];
-        for (int attempt = 0; attempt < 4; ++attempt) {
+        const uint32_t sid = in_list[k];
+        for (int attempt = 0; attempt < 5; ++attempt) {
             const uint64_t need = process_sentence<uint32_t, true>(D, A, sid, slab, slab_bytes);
             if (need == 0) break;
-            bool failed = need == kNoFit || attempt == 3;
+            bool failed = need == kNoFit || attempt == 4;
             if (!failed) {  // grow: take a fresh slab from the bump arena
                 uint64_t want = need + need / 4 + 4096;
                 want = (want + 255) & ~255ull;
@@ -564,25 +768,39 @@ Tokenizer::~Tokenizer() {
 Workspace::Workspace(const Tokenizer& t, uint64_t max_s, uint64_t max_b) : tok(t), max_sentences(max_s), max_bytes(max_b) {
     HIP_CHECK(hipSetDevice(tok.device()));
     if (max_b >= 0xFFFFFFFFull || max_s >= 0xFFFFFFFFull) throw Error(VBT_ERR_INVALID_ARGUMENT, "workspace: batch too large (split it)");
+    // LDS tiers (bytes per wave), ascending; the global-memory tier always follows
+    {
+        const char* e = std::getenv("VBT_TIERS");
+        std::string spec = e && *e ? e : "16384,32768,65536";
+        size_t pos = 0;
+        while (pos < spec.size()) {
+            size_t c = spec.find(',', pos);
+            if (c == std::string::npos) c = spec.size();
+            uint32_t v = (uint32_t)std::strtoul(spec.substr(pos, c - pos).c_str(), nullptr, 10);
+            if (v < 256 || v > 65536 || (!tiers.empty() && v <= tiers.back()) || tiers.size() >= kMaxTiers)
+                throw Error(VBT_ERR_INVALID_ARGUMENT, "VBT_TIERS: expected up to 6 ascending LDS sizes in [256, 65536]");
+            tiers.push_back(v);
+            pos = c + 1;
+        }
+    }
     const size_t ns = std::max<uint64_t>(max_s, 1), nbts = std::max<uint64_t>(max_b, 1);
     HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_tokens), nbts * sizeof(vbt_token_rec)));  // tokens <= chars <= bytes
     HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_tok_off), ns * 4));
     HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_tok_cnt), ns * 4));
-    HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_over0), ns * 4));
-    HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_over1), ns * 4));
+    HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_over), ns * 4 * tiers.size()));
     HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_ctrl), kCtrlWords * 4));
+    HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_prof), (kProfPhases + 1) * 8));
+    HIP_CHECK(hipMemset(d_prof, 0, (kProfPhases + 1) * 8));
     const uint64_t mb = env_u32("VBT_SCRATCH_MB", 0);
-    scratch_bytes = mb ? mb << 20 : std::max<uint64_t>(256ull << 20, 128 * nbts);
+    scratch_bytes = mb ? mb << 20 : std::max<uint64_t>(256ull << 20, 256 * nbts);
     HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_scratch), scratch_bytes));
-    lds0 = env_u32("VBT_LDS0", 12288);
-    lds1 = env_u32("VBT_LDS1", 65536);
-    if (lds0 > 65536 || lds1 > 65536) throw Error(VBT_ERR_INVALID_ARGUMENT, "VBT_LDS0/VBT_LDS1 must be <= 65536");
+    profile = env_u32("VBT_PROFILE", 0) != 0;
     for (auto& e : ev) HIP_CHECK(hipEventCreate(reinterpret_cast<hipEvent_t*>(&e)));
 }
 
 Workspace::~Workspace() {
-    (void)hipFree(d_tokens); (void)hipFree(d_tok_off); (void)hipFree(d_tok_cnt); (void)hipFree(d_over0);
-    (void)hipFree(d_over1); (void)hipFree(d_ctrl); (void)hipFree(d_scratch);
+    (void)hipFree(d_tokens); (void)hipFree(d_tok_off); (void)hipFree(d_tok_cnt); (void)hipFree(d_over);
+    (void)hipFree(d_ctrl); (void)hipFree(d_scratch); (void)hipFree(d_prof);
     for (auto& e : ev) if (e) (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(e));
 }
 
@@ -597,16 +815,26 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
     BatchArgs a;
     a.text = d_text; a.offsets = d_offsets; a.n = (uint32_t)n;
     a.tokens = d_tokens; a.tok_cap = (uint32_t)std::max<uint64_t>(max_bytes, 1);
-    a.tok_off = d_tok_off; a.tok_cnt = d_tok_cnt; a.ctrl = d_ctrl; a.overflow0 = d_over0; a.overflow1 = d_over1;
+    a.tok_off = d_tok_off; a.tok_cnt = d_tok_cnt; a.ctrl = d_ctrl;
     a.scratch = d_scratch; a.scratch_bytes = scratch_bytes;
+    a.prof = profile ? d_prof : nullptr;
     const DevDict& D = tok.dev();
     auto rec = [&](int i) { if (timing) HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(ev[i]), stream)); };
+    const size_t T = tiers.size();
+    auto over = [&](size_t t) { return d_over + t * std::max<uint64_t>(max_sentences, 1); };
+    auto count = [&](size_t t) { return d_ctrl + kTierCtrl + 2 * t; };
+    auto cursor = [&](size_t t) { return d_ctrl + kTierCtrl + 2 * t + 1; };
     rec(0);
-    hipLaunchKernelGGL(tokenize_tier0, dim3((uint32_t)n), dim3(64), lds0, stream, D, a, lds0);
+    hipLaunchKernelGGL(tokenize_lds, dim3((uint32_t)n), dim3(64), tiers[0], stream, D, a, tiers[0], (const uint32_t*)nullptr,
+                       (const uint32_t*)nullptr, (uint32_t*)nullptr, over(0), count(0));
     rec(1);
-    const uint32_t g1 = (uint32_t)std::min<uint64_t>(n, 512), g2 = (uint32_t)std::min<uint64_t>(n, 512);
-    hipLaunchKernelGGL(tokenize_tier1, dim3(g1), dim3(64), lds1, stream, D, a, lds1);
-    hipLaunchKernelGGL(tokenize_tier2, dim3(g2), dim3(64), 0, stream, D, a);
+    for (size_t t = 1; t < T; ++t) {
+        const uint32_t waves = (uint32_t)std::min<uint64_t>(n, (uint64_t)std::max<uint32_t>(1, 163840 / tiers[t]) * 256);
+        hipLaunchKernelGGL(tokenize_lds, dim3(waves), dim3(64), tiers[t], stream, D, a, tiers[t], (const uint32_t*)over(t - 1),
+                           (const uint32_t*)count(t - 1), cursor(t), over(t), count(t));
+    }
+    hipLaunchKernelGGL(tokenize_global, dim3((uint32_t)std::min<uint64_t>(n, 1024)), dim3(64), 0, stream, D, a,
+                       (const uint32_t*)over(T - 1), (const uint32_t*)count(T - 1), cursor(T));
     rec(2);
     HIP_CHECK(hipGetLastError());
 }
@@ -617,16 +845,24 @@ void Workspace::stats(vbt_call_stats* out) {
     uint32_t ctrl[kCtrlWords];
     HIP_CHECK(hipMemcpy(ctrl, d_ctrl, sizeof(ctrl), hipMemcpyDeviceToHost));
     std::memset(out, 0, sizeof(*out));
+    const size_t T = tiers.size();
     out->n_sentences = last_n;
-    out->n_tier0 = last_n - ctrl[kOver0];
-    out->n_tier1 = ctrl[kOver0] - ctrl[kOver1];
-    out->n_tier2 = ctrl[kOver1];
+    out->n_tier0 = last_n - ctrl[kTierCtrl];
+    out->n_tier2 = ctrl[kTierCtrl + 2 * (T - 1)];
+    out->n_tier1 = last_n - out->n_tier0 - out->n_tier2;
     out->n_tokens = ctrl[kTotal];
     out->error_flags = ctrl[kError];
     if (timing && last_n) {
         HIP_CHECK(hipEventElapsedTime(&out->ms_tier0, reinterpret_cast<hipEvent_t>(ev[0]), reinterpret_cast<hipEvent_t>(ev[1])));
         HIP_CHECK(hipEventElapsedTime(&out->ms_tier12, reinterpret_cast<hipEvent_t>(ev[1]), reinterpret_cast<hipEvent_t>(ev[2])));
     }
+}
+
+void Workspace::read_profile(uint64_t* out, bool reset) {
+    HIP_CHECK(hipSetDevice(tok.device()));
+    HIP_CHECK(hipStreamSynchronize(reinterpret_cast<hipStream_t>(last_stream)));
+    HIP_CHECK(hipMemcpy(out, d_prof, (kProfPhases + 1) * 8, hipMemcpyDeviceToHost));
+    if (reset) HIP_CHECK(hipMemset(d_prof, 0, (kProfPhases + 1) * 8));
 }
 
 }  // namespace vbt

@@ -41,17 +41,20 @@ struct BatchArgs {
     uint32_t tok_cap;
     uint32_t* tok_off;
     uint32_t* tok_cnt;
-    // control block (device): [0]=total tokens [1]=overflow0 count [2]=overflow1 count
-    // [3]=cursor tier1 [4]=cursor tier2 [5]=error flags [6..7]=scratch bump (u64)
+    // control block (device, kCtrlWords u32): see CtrlSlot
     uint32_t* ctrl;
-    uint32_t* overflow0;  // sentences that did not fit tier 0
-    uint32_t* overflow1;  // sentences that did not fit tier 1
-    // global scratch arena for tier 2
+    // global scratch arena for the last tier
     char* scratch;
     uint64_t scratch_bytes;
+    // optional per-phase cycle counters (kProfPhases + 1 u64), nullptr = off
+    unsigned long long* prof;
 };
 
-enum CtrlSlot { kTotal = 0, kOver0 = 1, kOver1 = 2, kCursor1 = 3, kCursor2 = 4, kError = 5, kBump = 6, kCtrlWords = 8 };
+// ctrl[kTotal] total tokens; ctrl[kError] DevError flags; ctrl[kBump..+1] u64 scratch bump pointer;
+// ctrl[kTierCtrl + 2t] = number of sentences tier t passed on, ctrl[kTierCtrl + 2t + 1] = work cursor of tier t
+enum CtrlSlot { kTotal = 0, kError = 1, kBump = 2, kTierCtrl = 4, kCtrlWords = 32 };
+constexpr int kMaxTiers = 6;
+constexpr int kProfPhases = 8;  // decode, count, fill, end lists, pre-pass, gather, recurrence, emit
 enum DevError { kErrTokCap = 1, kErrScratch = 2, kErrTooLong = 4 };
 
 class Tokenizer {
@@ -83,11 +86,13 @@ class Workspace {
     const Tokenizer& tok;
     uint64_t max_sentences, max_bytes;
     vbt_token_rec* d_tokens = nullptr;
-    uint32_t *d_tok_off = nullptr, *d_tok_cnt = nullptr, *d_ctrl = nullptr, *d_over0 = nullptr, *d_over1 = nullptr;
+    uint32_t *d_tok_off = nullptr, *d_tok_cnt = nullptr, *d_ctrl = nullptr, *d_over = nullptr;
+    unsigned long long* d_prof = nullptr;
     char* d_scratch = nullptr;
     uint64_t scratch_bytes = 0;
-    uint32_t lds0 = 0, lds1 = 0;
-    bool timing = false;
+    std::vector<uint32_t> tiers;  // LDS bytes per wave of each LDS tier
+    bool timing = false, profile = false;
+    void read_profile(uint64_t* out, bool reset);  // kProfPhases + 1 values (last = sentences counted)
     uint64_t last_n = 0;
     void* last_stream = nullptr;
     void* ev[4] = {nullptr, nullptr, nullptr, nullptr};
