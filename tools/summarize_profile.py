@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Distils gpurun_out/prof_<tag>/ (tools/profile_round.sh) into profiles/<tag>_*.{csv,md,json}."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = f"gpurun_out/prof_{tag}"
+os.makedirs("profiles", exist_ok=True)
+lines = [f"# rocprofv3 summary, round {tag}\n"]
+if os.path.exists(f"{src}/bench_line.json") and os.path.getsize(f"{src}/bench_line.json"):
+    bench = json.load(open(f"{src}/bench_line.json"))
+    lines += ["## bench line of the profiled command\n", "```json", json.dumps(bench, ensure_ascii=False), "```\n"]
+stats = glob.glob(f"{src}/stats/**/*kernel_stats.csv", recursive=True)
+if stats:
+    shutil.copyfile(stats[0], f"profiles/{tag}_kernel_stats.csv")
+    lines += [f"## `rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline` (profiles/{tag}_kernel_stats.csv)\n",
+              "| kernel | calls | total ms | avg us | min us | max us | % |", "|---|---|---|---|---|---|---|"]
+    for r in csv.DictReader(open(stats[0])):
+        lines.append(f"| `{r['Name'][:70]}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.3f} | {float(r['AverageNs']) / 1e3:.1f} | "
+                     f"{float(r['MinNs']) / 1e3:.1f} | {float(r['MaxNs']) / 1e3:.1f} | {float(r['Percentage']):.1f} |")
+    lines.append("")
+pm = collections.OrderedDict()
+for f in sorted(glob.glob(f"{src}/pmc*/**/*counter_collection.csv", recursive=True)):
+    rows = collections.OrderedDict()
+    for r in csv.DictReader(open(f)):
+        if "tokenize" not in r["Kernel_Name"] and "lattice" not in r["Kernel_Name"] and "candidates" not in r["Kernel_Name"]:
+            continue
+        d = rows.setdefault(int(r["Dispatch_Id"]), {"kernel": r["Kernel_Name"].split("(")[0].split("::")[-1], "grid": int(r["Grid_Size"]),
+                                                      "vgpr": r["VGPR_Count"], "agpr": r["Accum_VGPR_Count"], "sgpr": r["SGPR_Count"]})
+        d[r["Counter_Name"]] = float(r["Counter_Value"])
+        d["dur_us"] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    ks = sorted(rows)
+    if not ks:
+        continue
+    big = max(rows[k]["grid"] for k in ks)
+    first = rows[[k for k in ks if rows[k]["grid"] == big][0]]["kernel"]
+    starts = [i for i, k in enumerate(ks) if rows[k]["grid"] == big and rows[k]["kernel"] == first]
+    idx = starts[-1]
+    j = idx
+    while j < len(ks) and (j == idx or j not in starts):
+        d = rows[ks[j]]
+        pm.setdefault((j - idx, d["kernel"], d["grid"]), {}).update(d)
+        j += 1
+if pm:
+    lines += ["## PMC counters, one full-batch step (separate `--pmc` passes; per dispatch)\n"]
+    for (i, k, g), d in pm.items():
+        lines.append(f"### launch {i}: `{k}` grid={g} ({g // 64} waves), {d.get('dur_us', 0):.1f} us, VGPR {d['vgpr']} AGPR {d['agpr']} SGPR {d['sgpr']}\n")
+        lines.append("| counter | value |\n|---|---|")
+        for c, v in d.items():
+            if c not in ("kernel", "grid", "vgpr", "agpr", "sgpr", "dur_us"):
+                lines.append(f"| {c} | {v:,.0f} |")
+        if "FETCH_SIZE" in d:
+            fb, wb = d["FETCH_SIZE"] * 1024, d.get("WRITE_SIZE", 0) * 1024
+            lines.append(f"\nHBM traffic (guide: bytes = (FETCH_SIZE + WRITE_SIZE) * 1024; narrow gathers, not the 2x wide-read case): "
+                         f"fetch {fb / 1e6:.1f} MB + write {wb / 1e6:.1f} MB = {(fb + wb) / 1e6:.1f} MB")
+        if "TCC_HIT_sum" in d and "TCC_MISS_sum" in d:
+            lines.append(f"L2 hit rate: {d['TCC_HIT_sum'] / (d['TCC_HIT_sum'] + d['TCC_MISS_sum']):.3f}")
+        lines.append("")
+    json.dump({f"{i}:{k}:{g}": d for (i, k, g), d in pm.items()}, open(f"profiles/{tag}_pmc.json", "w"), indent=1)
+open(f"profiles/{tag}_summary.md", "w").write("\n".join(lines) + "\n")
+print("\n".join(lines[:70]))
