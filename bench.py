@@ -28,6 +28,21 @@ def algorithmic_bytes(c):
             + 8 * c["n_lex_matches"] + 8 * c["n_unk_nodes"] + 2 * c["n_pairs_dedup"] + 24 * c["n_tokens"])
 
 
+def measured_traffic(workload):
+    """HBM bytes per step from the newest committed PMC summary of the same workload
+    (profiles/*_traffic.json, written by tools/summarize_profile.py from separate --pmc passes)."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))):
+        try:
+            t = json.load(open(f))
+        except Exception:
+            continue
+        if t.get("workload") == workload:
+            best = t
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -132,9 +147,14 @@ def main():
         cnt = w.counters()
         b_alg = algorithmic_bytes(cnt)
         achieved = b_alg / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0
-        roofline = {"bound": "hbm", "kernel": "tokenize_tier0(+tier1/2 tail)", "achieved": round(achieved / 1e9, 3),
+        workload = (f"{sd.name} ({sd.n_words} words, {sd.num_right}x{sd.num_left} i16 matrix = "
+                    f"{sd.num_right * sd.num_left * 2 / 2**20:.1f} MiB), {n} sentences/GPU lognormal(40,0.6) chars, "
+                    f"{nbytes} bytes/GPU, seed {synth.SEED}")
+        tr = measured_traffic(workload)
+        roofline = {"bound": "hbm", "kernel": "tokenize_lds (all tiers of one step)", "achieved": round(achieved / 1e9, 3),
                     "peak": HBM_PEAK_BPS / 1e9, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_BPS, 6),
-                    "traffic": None, "algorithmic_bytes_per_launch": int(b_alg),
+                    "traffic": tr["hbm_bytes_per_step"] if tr else None, "traffic_source": tr["source"] if tr else None,
+                    "algorithmic_bytes_per_launch": int(b_alg),
                     "connector_GBps": round(2 * cnt["n_pairs_dedup"] / (kernel_ms * 1e-3) / 1e9, 3) if kernel_ms > 0 else 0.0,
                     "kernel_ms": round(kernel_ms, 4), "tiers": [st["n_tier0"], st["n_tier1"], st["n_tier2"]]}
         cpu = None
@@ -157,9 +177,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i32 costs / i16 matrix / u32 ids",
             "data": "synthetic", "input_MB_per_s": round(total_bytes * args.steps / elapsed / 1e6, 2),
-            "config": {"workload": f"{sd.name} ({sd.n_words} words, {sd.num_right}x{sd.num_left} i16 matrix = "
-                                   f"{sd.num_right * sd.num_left * 2 / 2**20:.1f} MiB), {n} sentences/GPU lognormal(40,0.6) chars, "
-                                   f"{nbytes} bytes/GPU, seed {synth.SEED}",
+            "config": {"workload": workload,
                        "ignore_space": args.ignore_space, "max_grouping_len": args.max_grouping_len,
                        "parallelism": f"dp{world} (independent sentence shards, final RCCL gather of totals)"},
             "parity_vs_oracle_sample": parity, "tokens_per_step": int(st["n_tokens"]) if world == 1 else int(totals[:, 1].sum().item()),

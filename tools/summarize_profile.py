@@ -5,6 +5,7 @@ import csv
 import glob
 import json
 import os
+import re
 import shutil
 import sys
 
@@ -30,7 +31,7 @@ for f in sorted(glob.glob(f"{src}/pmc*/**/*counter_collection.csv", recursive=Tr
     for r in csv.DictReader(open(f)):
         if "tokenize" not in r["Kernel_Name"] and "lattice" not in r["Kernel_Name"] and "candidates" not in r["Kernel_Name"]:
             continue
-        d = rows.setdefault(int(r["Dispatch_Id"]), {"kernel": r["Kernel_Name"].split("(")[0].split("::")[-1], "grid": int(r["Grid_Size"]),
+        d = rows.setdefault(int(r["Dispatch_Id"]), {"kernel": (re.findall(r"(\w+)\(vbt::", r["Kernel_Name"]) or [r["Kernel_Name"][:40]])[0], "grid": int(r["Grid_Size"]),
                                                       "vgpr": r["VGPR_Count"], "agpr": r["Accum_VGPR_Count"], "sgpr": r["SGPR_Count"]})
         d[r["Counter_Name"]] = float(r["Counter_Value"])
         d["dur_us"] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
@@ -41,11 +42,10 @@ for f in sorted(glob.glob(f"{src}/pmc*/**/*counter_collection.csv", recursive=Tr
     first = rows[[k for k in ks if rows[k]["grid"] == big][0]]["kernel"]
     starts = [i for i, k in enumerate(ks) if rows[k]["grid"] == big and rows[k]["kernel"] == first]
     idx = starts[-1]
-    j = idx
-    while j < len(ks) and (j == idx or j not in starts):
+    per_step = starts[-1] - starts[-2] if len(starts) > 1 else len(ks) - idx
+    for j in range(idx, min(idx + per_step, len(ks))):
         d = rows[ks[j]]
         pm.setdefault((j - idx, d["kernel"], d["grid"]), {}).update(d)
-        j += 1
 if pm:
     lines += ["## PMC counters, one full-batch step (separate `--pmc` passes; per dispatch)\n"]
     for (i, k, g), d in pm.items():
@@ -62,5 +62,12 @@ if pm:
             lines.append(f"L2 hit rate: {d['TCC_HIT_sum'] / (d['TCC_HIT_sum'] + d['TCC_MISS_sum']):.3f}")
         lines.append("")
     json.dump({f"{i}:{k}:{g}": d for (i, k, g), d in pm.items()}, open(f"profiles/{tag}_pmc.json", "w"), indent=1)
+    if all("FETCH_SIZE" in d for d in pm.values()):
+        total = sum((d["FETCH_SIZE"] + d.get("WRITE_SIZE", 0)) * 1024 for d in pm.values())
+        bench_cfg = json.load(open(f"{src}/bench_line.json"))["config"]["workload"] if os.path.getsize(f"{src}/bench_line.json") else ""
+        json.dump({"workload": bench_cfg, "hbm_bytes_per_step": int(total), "source": f"profiles/{tag}_pmc.json",
+                   "method": "sum over the step's kernels of (FETCH_SIZE + WRITE_SIZE) * 1024, separate rocprofv3 --pmc passes"},
+                  open(f"profiles/{tag}_traffic.json", "w"), indent=1)
+        lines.append(f"## HBM traffic of one step (all kernels): {total / 1e6:.1f} MB\n")
 open(f"profiles/{tag}_summary.md", "w").write("\n".join(lines) + "\n")
 print("\n".join(lines[:70]))
