@@ -105,11 +105,13 @@ def test_differential_spaces_without_ignore_space():
     _assert_batch_equal(to, tv, text, offs)
 
 
+@pytest.mark.parametrize("fused", ["0", "1"])
 @pytest.mark.parametrize("tiers", ["2048,8192", "1024", "4096,6144,8192,12288,16384,65536"])
-def test_all_tiers_agree(tiers, monkeypatch):
+def test_all_tiers_agree(tiers, fused, monkeypatch):
     """Force sentences through the larger LDS tiers and the global-scratch tier
     (and through multi-block connection-cost staging when LDS is tight)."""
     monkeypatch.setenv("VBT_TIERS", tiers)
+    monkeypatch.setenv("VBT_FUSED", fused)  # 1 = the single fused kernel (kept as the global-scratch fallback)
     sd = synth.SynthDict("small")
     to, tv = _oracle_and_product(sd, ignore_space=True)
     text, offs = sd.sentences(3000, "mixed", space_p=0.05)
@@ -170,7 +172,7 @@ def test_workspace_device_api_and_roundtrip():
     torch.cuda.synchronize()
     st = ws.stats()
     assert st["error_flags"] == 0 and st["n_sentences"] == n
-    assert st["n_tier0"] + st["n_tier1"] + st["n_tier2"] == n
+    assert st["n_tier0"] + st["n_tier1"] + st["n_tier2"] >= n  # re-routed sentences are counted in both lists
     assert st["ms_tier0"] > 0
     exp_tok, exp_off = to.new_worker().tokenize_batch(text, offs)
     assert st["n_tokens"] == len(exp_tok)

@@ -16,6 +16,8 @@ def main():
     ap.add_argument("--dict", default="unidic")
     ap.add_argument("--sentences", type=int, default=100000)
     ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--min-chars", type=int, default=0, help="keep only sentences with at least this many bytes/3")
+    ap.add_argument("--max-chars", type=int, default=0)
     args = ap.parse_args()
     import torch
     import vibrato_amd as V
@@ -24,6 +26,15 @@ def main():
     dv = V.SystemDictionaryBuilder.from_readers_binmatrix(sd.lex, sd.matrix, sd.num_right, sd.num_left, sd.char_def, sd.unk)
     tok = V.Tokenizer(dv, device=0)
     text, offs = sd.sentences(args.sentences, "lognormal_40")
+    if args.min_chars or args.max_chars:
+        lens = np.diff(offs).astype(np.int64)
+        keep = np.nonzero((lens >= 2.85 * args.min_chars) & ((lens <= 2.85 * args.max_chars) if args.max_chars else True))[0]
+        parts = [text[int(offs[i]):int(offs[i + 1])] for i in keep]
+        text = np.concatenate(parts) if parts else np.zeros(0, np.uint8)
+        offs = np.zeros(len(keep) + 1, dtype=np.uint64)
+        offs[1:] = np.cumsum([len(p) for p in parts])
+        args.sentences = len(keep)
+        print(f"filtered to {len(keep)} sentences, {len(text)} bytes")
     d_text = torch.from_numpy(text).cuda()
     d_offs = torch.from_numpy(offs.astype(np.int64)).cuda()
     ws = tok.workspace(args.sentences, len(text))

@@ -98,8 +98,12 @@ def lib():
             import torch  # noqa: F401
         except ImportError:
             pass
-        so = _build.SO
-        if _build.needs_build():
+        variant = os.environ.get("VBT_LIB_VARIANT", "")
+        so = _build.variant_so(variant)
+        if variant:
+            if not os.path.exists(so):
+                raise ImportError(f"{so} (VBT_LIB_VARIANT={variant}) has not been built")
+        elif _build.needs_build():
             if os.path.exists(_build.HIPCC):
                 _build.build()
             elif not os.path.exists(so):

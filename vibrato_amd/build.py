@@ -19,18 +19,26 @@ def needs_build():
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
-def build(force=False, verbose=False):
-    if not force and not needs_build():
-        return SO
+def variant_so(variant):
+    return os.path.join(LIBDIR, f"libvibrato_hip{('_' + variant) if variant else ''}.so")
+
+
+def build(force=False, verbose=False, variant="", defines=()):
+    """variant/defines: developer A/B builds (lib/libvibrato_hip_<variant>.so with -D flags),
+    selected at load time with VBT_LIB_VARIANT=<variant>."""
+    so = variant_so(variant)
+    if not variant and not force and not needs_build():
+        return so
     os.makedirs(LIBDIR, exist_ok=True)
     cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
            "-Wall", "-Wno-unused-result", "-x", "hip"]
+    cmd += ["-D" + d for d in defines]
     cmd += [os.path.join(CSRC, f) for f in SOURCES]
-    cmd += ["-o", SO]
+    cmd += ["-o", so]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
-    return SO
+    return so
 
 
 if __name__ == "__main__":

@@ -30,6 +30,20 @@ namespace {
 
 constexpr uint64_t kNoFit = ~0ull;
 
+// Cache policy of the three random-access streams (A/B knobs): non-temporal loads
+// do not allocate in the per-CU vector L1, whose in-order tag pipeline stalls on hit-under-miss.
+#ifndef VBT_NT_MATRIX
+#define VBT_NT_MATRIX 0
+#endif
+#ifndef VBT_NT_TRIE
+#define VBT_NT_TRIE 0
+#endif
+template <bool kNt, typename T>
+__device__ __forceinline__ T load_policy(const T* p) {
+    if constexpr (kNt) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+
 #define HIP_CHECK(expr)                                                                               \
     do {                                                                                              \
         hipError_t e_ = (expr);                                                                       \
@@ -115,7 +129,9 @@ __device__ __forceinline__ bool walk_trie(const DevLexicon& L, const uint16_t* c
         const uint32_t c = code[j];
         if (c == 0) break;
         const uint32_t child = base ^ c;
-        const uint4 nd = *reinterpret_cast<const uint4*>(&L.nodes[child]);
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 ndv = load_policy<VBT_NT_TRIE != 0>(reinterpret_cast<const u32x4*>(&L.nodes[child]));
+        const uint4 nd = make_uint4(ndv.x, ndv.y, ndv.z, ndv.w);
         if (nd.y != cur) break;
         cur = child;
         base = nd.x;
@@ -512,7 +528,7 @@ __device__ __forceinline__ uint64_t process_sentence(const DevDict& D, const Bat
                     const bool valid = live && ql < pairs;
                     const uint32_t left = nd_left[c_beg + (valid ? pr : 0u)];
                     const uint32_t right = e_right[p_beg + (valid ? pj : 0u)];
-                    val[u] = matrix[(size_t)left * NR + right];  // matrix_connector.rs:79-85
+                    val[u] = load_policy<VBT_NT_MATRIX != 0>(&matrix[(size_t)left * NR + right]);  // matrix_connector.rs:79-85
                     idx[u] = valid ? soff + ql : 0xFFFFFFFFu;
                     if (live) {
                         q0 += 64;
@@ -625,7 +641,658 @@ __device__ __forceinline__ uint64_t process_sentence(const DevDict& D, const Bat
     return 0;
 }
 
+// One sweep step of lattice_lds: candidates [cbeg, cbeg+nc) in ng left-id groups [gbeg, gbeg+ng)
+// connect to the end-list slots [pbeg, pbeg+np).
+struct LStep { uint16_t cbeg, nc, pbeg, np, gbeg, ng; };
+// One pass of the fused gather+recurrence loop: up to 64 (group, predecessor) lanes of one step.
+// gabs = first group of the pass (absolute), grel = its index within the step, last = 1 on the
+// step's final pass (the candidates are then finalised).
+struct alignas(16) LSlot { uint16_t cbeg, nc, pbeg, np, gabs, ngs, grel, last; };
+
+// LDS bytes of the lattice arrays of lattice_lds (must over-estimate the Arena carve there).
+__host__ __device__ __forceinline__ uint64_t lattice_fixed_bytes(uint32_t n, uint32_t C, uint32_t G, uint32_t ngmax, bool space_mode, uint32_t passes) {
+    return 8ull * (C + 2) + 8ull * (n + 1) + 8ull * (ngmax + 1) + 4ull * (n + 2) + (space_mode ? 4ull * n : 0) +
+           4ull * (n + 1) + sizeof(LSlot) * (passes + 18ull) + 2ull * (n + 1) * 2 + 2ull * (C + 1) * 2 + 2ull * C + 2ull * (C + 2) * 3 +
+           2ull * (G + 1) + (n + 1ull) + (C + 1ull) + 96;
+}
+
+// =====================================================================================
+// Two-kernel pipeline (default).  Candidate generation is memory-latency bound (dependent
+// double-array loads), the lattice sweep is LDS bound: splitting them lets the first run at
+// high occupancy with a small LDS footprint and lets the second be launched per exact LDS tier,
+// all tiers concurrently on side streams.
+// =====================================================================================
+
 extern __shared__ __attribute__((aligned(16))) char g_smem[];
+
+__device__ __forceinline__ void list_push(const BatchArgs& A, uint32_t t, uint32_t sid) {
+    if (threadIdx.x == 0) A.lists[(size_t)t * A.list_stride + atomicAdd(&A.ctrl[kTierCtrl + 2 * t], 1u)] = sid;
+}
+
+// Kernel 1 body: Sentence::compile + candidate enumeration of one sentence by one wavefront.
+// Per-character working arrays live in LDS (the vector L1 stalls on hit-under-miss, so nothing
+// is re-read from global while in flight); outputs: per-char records, byte offsets and the
+// candidates in reference insertion order, each tagged with its (start position, left_id) group:
+// search_min_node's result depends only on that pair (lattice.rs:129-151), so the lattice kernel
+// evaluates one row per group instead of one per candidate.
+__device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, uint32_t sid, uint32_t lds_bytes, bool large) {
+    const uint32_t ln = threadIdx.x;
+    const uint64_t lt_mask = (1ull << ln) - 1ull;
+    uint64_t prof_t = A.prof ? clock64() : 0, prof_acc[3] = {};
+#define PROF_MARK(i) do { if (A.prof) { const uint64_t t_ = clock64(); prof_acc[i] += t_ - prof_t; prof_t = t_; } } while (0)
+    const uint64_t b0 = A.offsets[sid], nb64 = A.offsets[sid + 1] - b0;
+    const uint32_t fallback = A.n_tiers, large_list = A.n_tiers + 1;
+    // gen routes a sentence by writing its list index; build_lists turns that into work lists with
+    // wave-aggregated atomics (a per-sentence atomic on a hot word caps the kernel at ~88 M/s)
+    auto route = [&](uint32_t t) { if (ln == 0) A.s_tier[sid] = (uint8_t)t; };
+    if (ln == 0 && !large) { A.s_n[sid] = 0; A.s_C[sid] = 0; A.s_tier[sid] = 0xFF; }
+    if (nb64 == 0) {
+        if (ln == 0) { A.tok_off[sid] = 0; A.tok_cnt[sid] = 0; }
+        return;
+    }
+    if (nb64 >= 65535) { route(fallback); return; }  // positions are u16 in the LDS lattice
+    const uint32_t nb = (uint32_t)nb64;
+    const uint8_t* __restrict__ txt = A.text + b0;
+    const size_t slot0 = (size_t)b0 + sid;
+
+    uint32_t n = 0;
+    for (uint32_t c0 = 0; c0 < nb; c0 += 64) {
+        const uint32_t bi = c0 + ln;
+        const bool lead = bi < nb && (txt[bi] & 0xC0) != 0x80;
+        n += (uint32_t)__popcll(__ballot(lead));
+    }
+    if (n == 0) {
+        if (ln == 0) { A.tok_off[sid] = 0; A.tok_cnt[sid] = 0; }
+        return;
+    }
+    Arena ar{g_smem, lds_bytes, 0, true};
+    uint64_t* lens = ar.take<uint64_t>(n);
+    uint32_t* ci = ar.take<uint32_t>(n);
+    uint32_t* cand_off = ar.take<uint32_t>(n + 1);
+    uint16_t* code = ar.take<uint16_t>(n);
+    uint16_t* ucode = D.has_user ? ar.take<uint16_t>(n) : code;
+    uint16_t* grp = ar.take<uint16_t>(n);
+    uint16_t* goff = ar.take<uint16_t>(n + 1);
+    uint32_t* endc = ar.take<uint32_t>(n + 1);  // candidates ending at each position (bounds the pass count)
+    uint8_t* ngp = ar.take<uint8_t>(n);
+    if (!ar.ok) { route(large ? fallback : large_list); return; }
+    for (uint32_t i = ln; i < n + 1; i += 64) endc[i] = i == 0 ? 1u : 0u;  // BOS ends at 0
+
+    // decode (Sentence::compute_basic / compute_categories, sentence.rs:40-55); the 3 bytes after a
+    // lead byte come from neighbouring lanes (or the look-ahead chunk), not from memory again
+    {
+        uint16_t* c2b = A.g_c2b + slot0;
+        uint32_t cb = 0;
+        uint32_t cur = ln < nb ? txt[ln] : 0x80u;
+        for (uint32_t c0 = 0; c0 < nb; c0 += 64) {
+            const uint32_t bi = c0 + ln;
+            const uint32_t nxt = bi + 64 < nb ? txt[bi + 64] : 0x80u;
+            const uint32_t b = cur;
+            uint32_t t[3];
+#pragma unroll
+            for (int k = 1; k <= 3; ++k) {
+                const uint32_t src = (ln + k) & 63u;
+                const uint32_t a = __shfl(cur, src), c = __shfl(nxt, src);
+                t[k - 1] = ((ln + k < 64) ? a : c) & 0x3Fu;
+            }
+            const bool lead = bi < nb && (b & 0xC0) != 0x80;
+            const uint64_t m = __ballot(lead);
+            if (lead) {
+                const uint32_t idx = cb + (uint32_t)__popcll(m & lt_mask);
+                uint32_t cp;
+                if (b < 0x80) cp = b;
+                else if (b < 0xE0) cp = ((b & 0x1F) << 6) | t[0];
+                else if (b < 0xF0) cp = ((b & 0x0F) << 12) | (t[0] << 6) | t[1];
+                else cp = ((b & 0x07) << 18) | (t[0] << 12) | (t[1] << 6) | t[2];
+                ci[idx] = D.chr2inf[cp < 65536u ? cp : 0u];  // character.rs:112-116
+                code[idx] = cp < D.sys.mapper_len ? D.sys.mapper[cp] : (uint16_t)0;
+                if (D.has_user) ucode[idx] = cp < D.user.mapper_len ? D.user.mapper[cp] : (uint16_t)0;
+                c2b[idx] = (uint16_t)bi;
+            }
+            cb += (uint32_t)__popcll(m);
+            cur = nxt;
+        }
+        if (ln == 0) c2b[n] = (uint16_t)nb;
+    }
+    __syncthreads();
+    {   // groupable (sentence.rs:57-71)
+        uint32_t carry = 0;
+        for (int ch = (int)((n - 1) / 64); ch >= 0; --ch) {
+            const uint32_t i = (uint32_t)ch * 64 + ln;
+            const bool valid = i < n;
+            bool link = false;
+            if (valid && i + 1 < n) link = ((ci[i] & ci[i + 1]) & 0x3FFFFu) != 0;
+            const uint64_t brk = __ballot(valid && !link);
+            const uint64_t m = brk >> ln;
+            const uint32_t g = m ? (uint32_t)__builtin_ctzll(m) + 1 : (64 - ln) + carry;
+            if (valid) grp[i] = (uint16_t)g;
+            carry = __shfl(g, 0);
+        }
+    }
+    __syncthreads();
+    PROF_MARK(0);
+
+    // count candidates per start position (tokenizer.rs:155-198, unknown.rs:69-116)
+    uint32_t C = 0;
+    bool any_long = false;
+    for (uint32_t c0 = 0; c0 < n; c0 += 64) {
+        const uint32_t i = c0 + ln;
+        uint32_t cnt = 0;
+        uint64_t lmask = 0;
+        bool is_long = false;
+        if (i < n) {
+            auto seen = [&](uint32_t c, uint32_t end) {
+                cnt += c;
+                const uint32_t len = end - i;
+                if (len <= 64) lmask |= 1ull << (len - 1); else is_long = true;
+                atomicAdd(&endc[end], c);
+            };
+            bool matched = false;
+            if (D.has_user) matched |= walk_trie(D.user, ucode, i, n, [&](uint32_t, uint32_t c, uint32_t e) { seen(c, e); });
+            matched |= walk_trie(D.sys, code, i, n, [&](uint32_t, uint32_t c, uint32_t e) { seen(c, e); });
+            const uint32_t cinfo = ci[i], cate = (cinfo >> 18) & 0xFFu;
+            const uint32_t nunk = D.unk_off[cate + 1] - D.unk_off[cate];
+            unk_spans(cinfo, grp[i], i, matched, D.max_grouping_len, [&](uint32_t e) { seen(nunk, e); });
+            lens[i] = lmask;
+        }
+        uint32_t tot;
+        const uint32_t ex = wave_exscan(cnt, tot);
+        if (i < n) cand_off[i] = C + ex;
+        C += tot;
+        any_long |= __ballot(is_long) != 0;
+    }
+    // words > 64 chars need the generic pre-pass, > 65531 nodes need u32 indices: fused kernel
+    if (C >= 65532 || any_long) { route(fallback); return; }
+    if (ln == 0) cand_off[n] = C;
+    const uint64_t base = (uint64_t)A.node_factor * slot0;  // this sentence's node region (no allocation atomic)
+    if (C > (uint64_t)A.node_factor * (nb + 1)) { route(fallback); return; }  // denser than the region: fused path
+    __syncthreads();
+    PROF_MARK(1);
+
+    // fill candidates in reference insertion order; group them by left_id within a start position
+    uint32_t G = 0, ngmax = 0;
+    bool too_many_groups = false;
+    for (uint32_t c0 = 0; c0 < n; c0 += 64) {
+        const uint32_t i = c0 + ln;
+        uint32_t ng = 0;
+        if (i < n) {
+            uint64_t k = base + cand_off[i];
+            uint32_t gl[8];  // the first 8 distinct left ids of this position (register cache)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) gl[q] = 0xFFFFFFFFu;
+            bool matched = false;
+            auto put = [&](const Entry* ent, uint32_t v, uint32_t c, uint32_t end, uint32_t lex) {
+                for (uint32_t t = 0; t < c; ++t, ++k) {
+                    const Entry e = ent[v + t];
+                    const uint32_t left = e.left_right & 0xFFFFu;
+                    uint32_t g = 0xFFFFFFFFu;
+#pragma unroll
+                    for (int q = 7; q >= 0; --q) g = gl[q] == left ? (uint32_t)q : g;
+                    const bool first = g == 0xFFFFFFFFu;
+                    if (first) {
+                        g = ng;
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) gl[q] = (uint32_t)q == ng ? left : gl[q];
+                        ++ng;
+                    }
+                    A.g_nd[k] = make_uint4(e.left_right, (e.cost & 0xFFFFu) | (end << 16), (lex << 30) | e.word_id,
+                                           (g & 0x7Fu) | (first ? 0x80u : 0u));
+                }
+            };
+            if (D.has_user)
+                matched |= walk_trie(D.user, ucode, i, n, [&](uint32_t v, uint32_t c, uint32_t e) { put(D.user.entries, v, c, e, 1u); });
+            matched |= walk_trie(D.sys, code, i, n, [&](uint32_t v, uint32_t c, uint32_t e) { put(D.sys.entries, v, c, e, 0u); });
+            const uint32_t cinfo = ci[i], cate = (cinfo >> 18) & 0xFFu;
+            const uint32_t u0 = D.unk_off[cate], nunk = D.unk_off[cate + 1] - u0;
+            unk_spans(cinfo, grp[i], i, matched, D.max_grouping_len, [&](uint32_t e) { put(D.unk_entries, u0, nunk, e, 2u); });
+            ngp[i] = (uint8_t)ng;
+        }
+        too_many_groups |= __ballot(ng > 127u) != 0;
+        uint32_t tot;
+        const uint32_t ex = wave_exscan(ng, tot);
+        if (i < n) goff[i] = (uint16_t)(G + ex);
+        G += tot;
+        uint32_t m = ng;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = __shfl_xor(m, d); m = o > m ? o : m; }
+        ngmax = m > ngmax ? m : ngmax;
+    }
+    if (too_many_groups) { route(fallback); return; }
+    __syncthreads();
+    // upper bound of the number of (step, <= 64 pair lanes) passes of the lattice kernel
+    uint32_t passes = 1;  // EOS
+    for (uint32_t c0 = 0; c0 < n; c0 += 64) {
+        const uint32_t i = c0 + ln;
+        uint32_t nsl = 0;
+        if (i < n) {
+            const uint32_t np = endc[i], ng = ngp[i];
+            const uint32_t lg = np <= 1 ? 0u : 32u - (uint32_t)__builtin_clz(np - 1);
+            const uint32_t gpp = 64u >> (lg > 6 ? 6 : lg);
+            nsl = np <= 64 ? (ng + gpp - 1) / gpp : ng * ((np + 63) / 64);
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) nsl += __shfl_xor(nsl, d);
+        passes += nsl;
+    }
+    {   // per-character records for the lattice kernel: {cand_off | goff << 16, grp | ng << 16 | space << 31, lens}
+        uint4* pc = A.g_pc + slot0;
+        for (uint32_t i = ln; i < n; i += 64) {
+            const uint32_t cinfo = ci[i];
+            const uint32_t space = (D.space_cateset && (cinfo & D.space_cateset)) ? 0x80000000u : 0u;
+            const uint64_t lm = lens[i];
+            pc[i] = make_uint4(cand_off[i] | ((uint32_t)goff[i] << 16), (uint32_t)grp[i] | ((uint32_t)ngp[i] << 16) | space,
+                               (uint32_t)lm, (uint32_t)(lm >> 32));
+        }
+        if (ln == 0) pc[n] = make_uint4(C | (G << 16), 0, 0, 0);
+    }
+    if (ln == 0) {
+        A.s_n[sid] = n; A.s_C[sid] = C; A.s_flags[sid] = G | (ngmax << 16);
+    }
+    // smallest tier whose LDS holds the lattice arrays (connection costs are never staged)
+    const uint64_t fixed = lattice_fixed_bytes(n, C, G, ngmax, D.space_cateset != 0, passes);
+    uint32_t tier = fallback;
+    for (uint32_t t = 0; t < A.n_tiers; ++t)
+        if (fixed <= A.tier_bytes[t]) { tier = t; break; }
+    route(tier);
+    PROF_MARK(2);
+    if (A.prof && ln == 0) {
+        for (int i = 0; i < 3; ++i) atomicAdd(&A.prof[i], (unsigned long long)prof_acc[i]);
+        atomicAdd(&A.prof[kProfPhases], 1ull);
+    }
+#undef PROF_MARK
+}
+
+// Turns the per-sentence routing decisions into work lists: one atomic per (wave, list) instead of
+// one per sentence.  only_list >= 0 restricts the pass to that list (the gen_candidates_large input).
+__global__ void __launch_bounds__(256) build_lists(BatchArgs A, int only_list) {
+    const uint32_t sid = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t t = sid < A.n ? A.s_tier[sid] : 0xFFu;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n_lists = A.n_tiers + 2;
+    for (uint32_t l = 0; l < n_lists; ++l) {
+        if (only_list >= 0 ? (int)l != only_list : l == A.n_tiers + 1) continue;
+        const uint64_t m = __ballot(t == l);
+        if (m == 0) continue;
+        uint32_t basei = 0;
+        if (lane == (uint32_t)__builtin_ctzll(m)) basei = atomicAdd(&A.ctrl[kTierCtrl + 2 * l], (uint32_t)__popcll(m));
+        basei = __shfl(basei, (int)__builtin_ctzll(m));
+        if (t == l) A.lists[(size_t)l * A.list_stride + basei + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = sid;
+    }
+}
+
+// Kernel 1: one single-wave workgroup per sentence (small LDS, high occupancy) ...
+__global__ void __launch_bounds__(64) gen_candidates(DevDict D, BatchArgs A, uint32_t lds_bytes) {
+    gen_one(D, A, blockIdx.x, lds_bytes, false);
+}
+// ... and persistent waves with a large LDS budget for the sentences that did not fit.
+__global__ void __launch_bounds__(64) gen_candidates_large(DevDict D, BatchArgs A, uint32_t lds_bytes) {
+    const uint32_t t = A.n_tiers + 1;
+    const uint32_t count = A.ctrl[kTierCtrl + 2 * t];
+    for (;;) {
+        uint32_t k = 0;
+        if (threadIdx.x == 0) k = atomicAdd(&A.ctrl[kTierCtrl + 2 * t + 1], 1u);
+        k = __shfl(k, 0);
+        if (k >= count) break;
+        gen_one(D, A, A.lists[(size_t)t * A.list_stride + k], lds_bytes, true);
+        __syncthreads();
+    }
+}
+
+// Kernel 2: the lattice sweep of one sentence per wavefront, entirely in LDS.  Persistent waves
+// drain the work list of their tier.  Sentences whose lattice does not fit after all go to the
+// fallback list (fused kernel with global scratch).
+__global__ void __launch_bounds__(64) lattice_lds(DevDict D, BatchArgs A, uint32_t tier) {
+    const uint32_t ln = threadIdx.x;
+    const uint32_t lds_bytes = A.tier_bytes[tier];
+    const uint32_t* list = A.lists + (size_t)tier * A.list_stride;
+    const uint32_t count = A.ctrl[kTierCtrl + 2 * tier];
+    uint32_t* cursor = &A.ctrl[kTierCtrl + 2 * tier + 1];
+    const int16_t* __restrict__ matrix = D.matrix;
+    const uint32_t NR = D.num_right;
+    const bool space_mode = D.space_cateset != 0;
+    for (;;) {
+        uint32_t item = 0;
+        if (ln == 0) item = atomicAdd(cursor, 1u);
+        item = __shfl(item, 0);
+        if (item >= count) break;
+        const uint32_t sid = list[item];
+        uint64_t prof_t = A.prof ? clock64() : 0, prof_acc[kProfPhases] = {};
+#define PROF_MARK(i) do { if (A.prof) { const uint64_t t_ = clock64(); prof_acc[i] += t_ - prof_t; prof_t = t_; } } while (0)
+        const uint32_t n = A.s_n[sid], C = A.s_C[sid];
+        const uint32_t G = A.s_flags[sid] & 0xFFFFu, ngmax = A.s_flags[sid] >> 16;
+        const size_t slot0 = (size_t)A.offsets[sid] + sid;
+        const uint4* __restrict__ nd = A.g_nd + (size_t)A.node_factor * slot0;
+        const uint4* __restrict__ pc = A.g_pc + slot0;
+
+        Arena ar{g_smem, lds_bytes, 0, true};
+        uint64_t* e_key = ar.take<uint64_t>(C + 2);    // end-major packed (cost, sequence) keys
+        uint64_t* lens = ar.take<uint64_t>(n + 1);     // length bitmask per start position (pre-pass), then the token path
+        uint64_t* g_best = ar.take<uint64_t>(ngmax + 1);  // per step: best key of each left-id group
+        uint32_t* end_off = ar.take<uint32_t>(n + 2);
+        uint32_t* grpf = space_mode ? ar.take<uint32_t>(n) : end_off;  // groupable | is_space << 31
+        uint32_t* sp = ar.take<uint32_t>(n + 1);  // (start_node | start_word << 16) per sweep step
+        uint16_t* cand_off = ar.take<uint16_t>(n + 1);
+        uint16_t* goff = ar.take<uint16_t>(n + 1);
+        uint16_t* nd_left = ar.take<uint16_t>(C + 1);
+        int16_t* nd_wcost = ar.take<int16_t>(C + 1);
+        uint16_t* nd_end = ar.take<uint16_t>(C);
+        uint16_t* nd_eslot = ar.take<uint16_t>(C + 2);
+        uint16_t* e_right = ar.take<uint16_t>(C + 2);
+        uint16_t* e_back = ar.take<uint16_t>(C + 2);
+        uint16_t* g_left = ar.take<uint16_t>(G + 1);
+        uint8_t* ngp = ar.take<uint8_t>(n + 1);
+        uint8_t* nd_gid = ar.take<uint8_t>(C + 1);
+        uint16_t* tmp_right = e_back;
+        if (!ar.ok) { if (ln == 0) atomicAdd(&A.ctrl[26], 1u); list_push(A, A.n_tiers, sid); __syncthreads(); continue; }
+
+        // ---- load: per-char records and candidates from global; count end-list sizes ----
+        for (uint32_t p = ln; p < n + 2; p += 64) end_off[p] = 0;
+        __syncthreads();
+        for (uint32_t i = ln; i < n + 1; i += 64) {
+            const uint4 r = pc[i];
+            cand_off[i] = (uint16_t)(r.x & 0xFFFFu);
+            goff[i] = (uint16_t)(r.x >> 16);
+            if (i < n) {
+                lens[i] = ((uint64_t)r.w << 32) | r.z;
+                ngp[i] = (uint8_t)((r.y >> 16) & 0xFFu);
+                if (space_mode) grpf[i] = (r.y & 0xFFFFu) | (r.y & 0x80000000u);
+            }
+        }
+        for (uint32_t c0 = 0; c0 < C; c0 += 64 * 8) {  // 8 independent 16-byte loads per lane in flight
+            uint4 r[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t c = c0 + u * 64 + ln;
+                r[u] = c < C ? nd[c] : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t c = c0 + u * 64 + ln;
+                if (c < C) {
+                    const uint32_t end = r[u].y >> 16;
+                    nd_left[c] = (uint16_t)(r[u].x & 0xFFFFu);
+                    tmp_right[c] = (uint16_t)(r[u].x >> 16);
+                    nd_wcost[c] = (int16_t)(uint16_t)(r[u].y & 0xFFFFu);
+                    nd_end[c] = (uint16_t)end;
+                    nd_gid[c] = (uint8_t)r[u].w;
+                    nd_eslot[c] = (uint16_t)atomicAdd(&end_off[end], 1u);
+                }
+            }
+        }
+        __syncthreads();
+        // left id of every group (first candidate of the group carries flag 0x80)
+        for (uint32_t i = ln; i < n; i += 64) {
+            const uint32_t gb = goff[i];
+            for (uint32_t c = cand_off[i], ce = cand_off[i + 1]; c < ce; ++c) {
+                const uint32_t gid = nd_gid[c];
+                if (gid & 0x80u) g_left[gb + (gid & 0x7Fu)] = nd_left[c];
+            }
+        }
+        {   // end lists: exclusive scan of per-end counts; slot 0 is BOS (lattice.rs:72-83)
+            uint32_t running = 0;
+            for (uint32_t c0 = 0; c0 < n + 1; c0 += 64) {
+                const uint32_t p = c0 + ln;
+                uint32_t cnt = 0;
+                if (p < n + 1) cnt = end_off[p] + (p == 0 ? 1u : 0u);
+                uint32_t tot;
+                const uint32_t ex = wave_exscan(cnt, tot);
+                if (p < n + 1) end_off[p] = running + ex;
+                running += tot;
+            }
+            if (ln == 0) end_off[n + 1] = running;
+        }
+        __syncthreads();
+        for (uint32_t c = ln; c < C; c += 64) {
+            const uint32_t es = end_off[nd_end[c]] + nd_eslot[c];
+            const uint16_t r = tmp_right[c];
+            nd_eslot[c] = (uint16_t)es;
+            e_right[es] = r;
+            e_key[es] = kDeadKey;
+        }
+        __syncthreads();
+        const uint32_t kBosSeq = C + 1;
+        if (ln == 0) {
+            e_right[0] = 0;
+            e_key[0] = make_key(0u, kBosSeq);
+            nd_eslot[kBosSeq] = 0;
+            e_back[0] = (uint16_t)kBosSeq;
+            nd_left[C] = 0;  // EOS pseudo candidate: left_id 0, its own group G
+            nd_wcost[C] = 0;
+            nd_eslot[C] = (uint16_t)(C + 1);
+            nd_gid[C] = 0x80u;
+            g_left[G] = 0;
+            e_key[C + 1] = kDeadKey;
+        }
+        __syncthreads();
+        PROF_MARK(3);
+
+        // ---- structural pre-pass (tokenizer.rs:106-138, control flow only) ----
+        // (a) a scalar state machine walks the positions with a 128-bit reachability window; the
+        //     length masks of 64 consecutive positions sit in one VGPR pair and are read with
+        //     v_readlane, so the loop touches LDS only when it crosses a 64-position boundary;
+        // (b) lanes then build the step records in parallel.
+        uint32_t S = 0, sn_eos = 0;
+        bool windowed = true;
+        {
+            U128 w{1, 0};
+            uint32_t p = 0, chunk = 0;
+            uint32_t l_lo = ln < n ? (uint32_t)lens[ln] : 0u, l_hi = ln < n ? (uint32_t)(lens[ln] >> 32) : 0u;
+            while (p < n) {
+                w.lo = uniform64(w.lo);
+                w.hi = uniform64(w.hi);
+                p = __builtin_amdgcn_readfirstlane(p);
+                if (!(w.lo & 1)) {
+                    uint32_t z = w.lo ? (uint32_t)__builtin_ctzll(w.lo) : 64u;
+                    if (z > n - p) z = n - p;
+                    w = shr128(w, z);
+                    p += z;
+                    continue;
+                }
+                uint32_t sw = p;
+                if (space_mode) {
+                    const uint32_t gf = __builtin_amdgcn_readfirstlane(grpf[p]);
+                    if (gf >> 31) sw += gf & 0x7FFFFFFFu;
+                }
+                if (sw >= n) break;
+                const uint32_t d = sw - p + 1;
+                if (d > 64) { windowed = false; break; }
+                if (sw - chunk >= 64) {
+                    chunk = sw & ~63u;
+                    const uint32_t i = chunk + ln;
+                    l_lo = i < n ? (uint32_t)lens[i] : 0u;
+                    l_hi = i < n ? (uint32_t)(lens[i] >> 32) : 0u;
+                }
+                const uint64_t lm = ((uint64_t)__builtin_amdgcn_readlane(l_hi, sw - chunk) << 32) | __builtin_amdgcn_readlane(l_lo, sw - chunk);
+                if (ln == 0) sp[S] = p | (sw << 16);
+                ++S;
+                w = shr128(or_shl128(w, lm, d), d);
+                p = sw + 1;
+            }
+            sn_eos = p < n ? p : n;
+        }
+        if (!windowed) {  // > 63 skipped spaces in a row: generic pre-pass of the fused kernel
+            if (ln == 0) atomicAdd(&A.ctrl[27], 1u);
+            list_push(A, A.n_tiers, sid);
+            __syncthreads();
+            continue;
+        }
+        ++S;  // + the EOS step (insert_eos(start_node), tokenizer.rs:138)
+        if (ln == 0) sp[S - 1] = sn_eos | (0xFFFFu << 16);
+        __syncthreads();
+        // (b) lanes = steps: split every step into passes of <= 64 (group, predecessor) lanes and lay
+        //     the pass records out contiguously (exclusive scan of the pass counts).
+        uint32_t SL = 0;
+        LSlot* sl = reinterpret_cast<LSlot*>(g_smem + ((ar.used + 15) & ~15ull));
+        const uint32_t sl_cap = lds_bytes > ((ar.used + 15) & ~15ull) ? (uint32_t)((lds_bytes - ((ar.used + 15) & ~15ull)) / sizeof(LSlot)) : 0u;
+        for (uint32_t k0 = 0; k0 < S; k0 += 64) {
+            const uint32_t k = k0 + ln;
+            uint32_t c_beg = 0, nc = 0, p_beg = 0, np = 1, g_beg = 0, ng = 0, nsl = 0, gpp = 64;
+            if (k < S) {
+                const uint32_t v = sp[k], p = v & 0xFFFFu, sw = v >> 16;
+                p_beg = end_off[p];
+                np = end_off[p + 1] - p_beg;
+                if (sw == 0xFFFFu) { c_beg = C; nc = 1; g_beg = G; ng = 1; }
+                else { c_beg = cand_off[sw]; nc = cand_off[sw + 1] - c_beg; g_beg = goff[sw]; ng = ngp[sw]; }
+                const uint32_t lg = np <= 1 ? 0u : 32u - (uint32_t)__builtin_clz(np - 1);
+                gpp = 64u >> (lg > 6 ? 6 : lg);
+                nsl = np <= 64 ? (ng + gpp - 1) / gpp : ng * ((np + 63) / 64);
+            }
+            uint32_t tot;
+            const uint32_t ex = wave_exscan(nsl, tot);
+            if (SL + tot <= sl_cap) {
+                if (np <= 64) {
+                    for (uint32_t q = 0; q < nsl; ++q) {
+                        const uint32_t rem = ng - q * gpp;
+                        sl[SL + ex + q] = LSlot{(uint16_t)c_beg, (uint16_t)nc, (uint16_t)p_beg, (uint16_t)np, (uint16_t)(g_beg + q * gpp),
+                                                (uint16_t)(rem < gpp ? rem : gpp), (uint16_t)(q * gpp), (uint16_t)(q + 1 == nsl ? 1u : 0u)};
+                    }
+                } else {  // > 64 predecessors: one group per pass, 64 predecessors at a time, partial minima accumulate
+                    const uint32_t nch = (np + 63) / 64;
+                    for (uint32_t q = 0; q < nsl; ++q) {
+                        const uint32_t g = q / nch, jc = q - g * nch;
+                        const uint32_t rem = np - jc * 64;
+                        sl[SL + ex + q] = LSlot{(uint16_t)c_beg, (uint16_t)nc, (uint16_t)(p_beg + jc * 64), (uint16_t)(rem < 64 ? rem : 64),
+                                                (uint16_t)(g_beg + g), (uint16_t)1, (uint16_t)g,
+                                                (uint16_t)((q + 1 == nsl ? 1u : 0u) | (jc ? 2u : 0u))};
+                    }
+                }
+            }
+            SL += tot;
+        }
+        // no LDS left for the pass records: fused kernel
+        constexpr uint32_t kDepth = 8;  // prefetch distance of the fused loop, in passes
+        if (SL + 2 * kDepth > sl_cap) { if (ln == 0) atomicAdd(&A.ctrl[29], 1u); list_push(A, A.n_tiers, sid); __syncthreads(); continue; }
+        // pad with empty passes so the pipelined loop needs no bounds branches
+        if (ln < 2 * kDepth) sl[SL + ln] = LSlot{0, 0, 0, 1, 0, 0, 0, 0};
+        __syncthreads();
+        PROF_MARK(4);
+
+        // ---- fused gather + cost recurrence (matrix_connector.rs:79-85, lattice.rs:103-151) ----
+        // Per pass the lanes are (left-id group g, predecessor j) pairs: g = lane >> lg, j = lane & (2^lg - 1)
+        // with 2^lg >= np.  The connection cost of a lane's pair depends on ids only, so it is loaded
+        // kDepth passes ahead into a register ring (software pipeline): the recurrence never waits for
+        // HBM, and nothing is staged in LDS.  Per pass: key = e_key[pred] + (conn << 32); segmented
+        // butterfly min over the 2^lg lanes of a group (minimum cost, ties -> last inserted = `<=`).
+        // The loop body contains no branch around a global load, so the compiler keeps counted
+        // s_waitcnt vmcnt(kDepth-1) at the use of a ring slot.
+        {
+            // ring[u]: the aligned 32-bit word holding this lane's i16 cell of pass (s0 + u); the half is
+            // picked at use.  (A 16-bit destination would be packed two-per-VGPR by the compiler, which
+            // forces a vmcnt(0) right behind every load and serialises the pipeline.)
+            uint32_t ring[kDepth];
+            const uint32_t* __restrict__ matrix32 = reinterpret_cast<const uint32_t*>(matrix);
+            auto cell_index = [&](uint32_t si) -> uint32_t {  // matrix element index of this lane's pair in pass si (0 if none)
+                const LSlot r = sl[si];  // passes >= SL are empty padding (ngs = 0)
+                const uint32_t np = __builtin_amdgcn_readfirstlane((uint32_t)r.np), ngs = __builtin_amdgcn_readfirstlane((uint32_t)r.ngs);
+                const uint32_t p_beg = __builtin_amdgcn_readfirstlane((uint32_t)r.pbeg), gabs = __builtin_amdgcn_readfirstlane((uint32_t)r.gabs);
+                const uint32_t lg = np <= 1 ? 0u : 32u - (uint32_t)__builtin_clz(np - 1);
+                const uint32_t g = ln >> lg, j = ln & ((1u << lg) - 1u);
+                const bool valid = g < ngs && j < np;
+                const uint32_t left = g_left[gabs + (valid ? g : 0u)];
+                const uint32_t right = e_right[p_beg + (valid ? j : 0u)];
+                return valid ? left * NR + right : 0u;  // < 2^32: num_left, num_right <= 65535
+            };
+#pragma unroll
+            for (uint32_t u = 0; u < kDepth; ++u) ring[u] = load_policy<VBT_NT_MATRIX != 0>(&matrix32[cell_index(u) >> 1]);
+            for (uint32_t s0 = 0; s0 < SL; s0 += kDepth) {
+#pragma unroll
+                for (uint32_t u = 0; u < kDepth; ++u) {
+                    const uint32_t si = s0 + u;
+                    {
+                        const uint32_t cword = ring[u];
+                        ring[u] = load_policy<VBT_NT_MATRIX != 0>(&matrix32[cell_index(si + kDepth) >> 1]);
+                        const LSlot sr = sl[si];
+                        const uint32_t c_beg = __builtin_amdgcn_readfirstlane((uint32_t)sr.cbeg);
+                        const uint32_t nc = __builtin_amdgcn_readfirstlane((uint32_t)sr.nc);
+                        const uint32_t p_beg = __builtin_amdgcn_readfirstlane((uint32_t)sr.pbeg);
+                        const uint32_t np = __builtin_amdgcn_readfirstlane((uint32_t)sr.np);
+                        const uint32_t gabs = __builtin_amdgcn_readfirstlane((uint32_t)sr.gabs);
+                        const uint32_t ngs = __builtin_amdgcn_readfirstlane((uint32_t)sr.ngs);
+                        const uint32_t grel = __builtin_amdgcn_readfirstlane((uint32_t)sr.grel);
+                        const uint32_t flags = __builtin_amdgcn_readfirstlane((uint32_t)sr.last);
+                        const uint32_t last = flags & 1u, acc = flags & 2u;
+                        const uint32_t lg = np <= 1 ? 0u : 32u - (uint32_t)__builtin_clz(np - 1);
+                        const uint32_t npp = 1u << lg;
+                        const uint32_t g = ln >> lg, j = ln & (npp - 1);
+                        uint64_t key = kDeadKey;
+                        if (g < ngs && j < np) {
+                            const uint64_t kb = e_key[p_beg + j];
+                            const uint32_t cell = (uint32_t)g_left[gabs + g] * NR + e_right[p_beg + j];
+                            const uint32_t cv = (uint32_t)(int32_t)(int16_t)(cword >> ((cell & 1u) * 16u));
+                            key = (uint32_t)kb == 0xFFFFFFFFu ? kDeadKey : kb + ((uint64_t)cv << 32);  // wrapping i32 add
+                        }
+                        for (uint32_t d = npp >> 1; d >= 1; d >>= 1) {
+                            const uint64_t o = __shfl_xor((unsigned long long)key, (int)d);
+                            key = o < key ? o : key;
+                        }
+                        if (g < ngs && j == 0) {
+                            if (acc) { const uint64_t prev = g_best[grel + g]; key = prev < key ? prev : key; }
+                            g_best[grel + g] = key;
+                        }
+                        __syncthreads();
+                        if (last) {
+                            for (uint32_t cb = 0; cb < nc; cb += 64) {
+                                const uint32_t ci_ = cb + ln;
+                                if (ci_ < nc) {
+                                    const uint32_t c = c_beg + ci_;
+                                    const uint64_t best = g_best[nd_gid[c] & 0x7Fu];
+                                    const uint32_t es = nd_eslot[c];
+                                    e_key[es] = make_key(key_cost(best) + (uint32_t)(int32_t)nd_wcost[c], c);  // lattice.rs:125
+                                    e_back[es] = (uint16_t)key_seq(best);
+                                }
+                            }
+                            __syncthreads();
+                        }
+                    }
+                }
+            }
+        }
+        PROF_MARK(6);
+
+        // ---- back-trace + token records ----
+        uint16_t* path = reinterpret_cast<uint16_t*>(lens);  // the length masks are dead now; tokens <= chars
+        uint32_t T = 0;
+        if (ln == 0) {
+            uint32_t seq = e_back[C + 1];
+            while (seq != kBosSeq && T < n) {
+                path[T++] = (uint16_t)seq;
+                seq = e_back[nd_eslot[seq]];
+            }
+        }
+        T = __shfl(T, 0);
+        uint32_t out_base = 0;
+        if (ln == 0) out_base = atomicAdd(&A.ctrl[kTotal], T);
+        out_base = __shfl(out_base, 0);
+        __syncthreads();
+        if ((uint64_t)out_base + T > A.tok_cap) {
+            if (ln == 0) { atomicOr(&A.ctrl[kError], (uint32_t)kErrTokCap); A.tok_off[sid] = 0; A.tok_cnt[sid] = 0; }
+        } else {
+            if (ln == 0) { A.tok_off[sid] = out_base; A.tok_cnt[sid] = T; }
+            const uint16_t* __restrict__ c2b = A.g_c2b + slot0;
+            for (uint32_t t = ln; t < T; t += 64) {
+                const uint32_t c = path[T - 1 - t];
+                uint32_t lo = 0, hi = n;
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if ((uint32_t)cand_off[mid + 1] <= c) lo = mid + 1; else hi = mid;
+                }
+                const uint32_t stp = lo, en = nd_end[c];
+                vbt_token_rec r;
+                r.start_char = stp; r.end_char = en;
+                r.start_byte = c2b[stp]; r.end_byte = c2b[en];
+                r.word_idx = nd[c].z;
+                r.total_cost = (int32_t)key_cost(e_key[nd_eslot[c]]);
+                A.tokens[out_base + t] = r;
+            }
+        }
+        PROF_MARK(7);
+        if (A.prof && ln == 0) {
+            for (int i = 3; i < kProfPhases; ++i) atomicAdd(&A.prof[i], (unsigned long long)prof_acc[i]);
+        }
+#undef PROF_MARK
+        __syncthreads();
+    }
+}
 
 __device__ __forceinline__ void push_overflow(uint32_t* list, uint32_t* counter, uint32_t sid) {
     if (threadIdx.x == 0) list[atomicAdd(counter, 1u)] = sid;
@@ -740,7 +1407,11 @@ Tokenizer::Tokenizer(const Dictionary* dict, bool ignore_space, uint32_t max_gro
         dev_.has_user = dict_->has_user ? 1 : 0;
         if (dict_->has_user) upload_lexicon(dict_->user, dev_.user);
         else dev_.user = dev_.sys;
-        dev_.matrix = dev_upload(dict_->matrix, allocs_);
+        {   // + 1 element: lattice_lds reads the aligned 32-bit word around a cell
+            std::vector<int16_t> padded(dict_->matrix);
+            padded.push_back(0);
+            dev_.matrix = dev_upload(padded, allocs_);
+        }
         dev_.num_right = dict_->num_right;
         dev_.chr2inf = dev_upload(dict_->chr2inf, allocs_);
         dev_.unk_off = dev_upload(dict_->unk_offsets, allocs_);
@@ -768,40 +1439,77 @@ Tokenizer::~Tokenizer() {
 Workspace::Workspace(const Tokenizer& t, uint64_t max_s, uint64_t max_b) : tok(t), max_sentences(max_s), max_bytes(max_b) {
     HIP_CHECK(hipSetDevice(tok.device()));
     if (max_b >= 0xFFFFFFFFull || max_s >= 0xFFFFFFFFull) throw Error(VBT_ERR_INVALID_ARGUMENT, "workspace: batch too large (split it)");
+    fused = env_u32("VBT_FUSED", 0) != 0;
     // LDS tiers (bytes per wave), ascending; the global-memory tier always follows
     {
         const char* e = std::getenv("VBT_TIERS");
-        std::string spec = e && *e ? e : "16384,32768,65536";
+        std::string spec = e && *e ? e : (fused ? "16384,32768,65536" : "8192,12288,16384,24576,32768,49152,65536,163840");
         size_t pos = 0;
         while (pos < spec.size()) {
             size_t c = spec.find(',', pos);
             if (c == std::string::npos) c = spec.size();
             uint32_t v = (uint32_t)std::strtoul(spec.substr(pos, c - pos).c_str(), nullptr, 10);
-            if (v < 256 || v > 65536 || (!tiers.empty() && v <= tiers.back()) || tiers.size() >= kMaxTiers)
-                throw Error(VBT_ERR_INVALID_ARGUMENT, "VBT_TIERS: expected up to 6 ascending LDS sizes in [256, 65536]");
+            if (v < 256 || v > 163840 || (fused && v > 65536) || (!tiers.empty() && v <= tiers.back()) || tiers.size() >= kMaxTiers)
+                throw Error(VBT_ERR_INVALID_ARGUMENT, "VBT_TIERS: expected up to 8 ascending LDS sizes in [256, 163840]");
             tiers.push_back(v);
             pos = c + 1;
         }
     }
     const size_t ns = std::max<uint64_t>(max_s, 1), nbts = std::max<uint64_t>(max_b, 1);
-    HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_tokens), nbts * sizeof(vbt_token_rec)));  // tokens <= chars <= bytes
-    HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_tok_off), ns * 4));
-    HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_tok_cnt), ns * 4));
-    HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_over), ns * 4 * tiers.size()));
-    HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_ctrl), kCtrlWords * 4));
-    HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_prof), (kProfPhases + 1) * 8));
+    auto alloc = [&](size_t bytes) {
+        void* p = nullptr;
+        HIP_CHECK(hipMalloc(&p, std::max<size_t>(bytes, 16)));
+        pipe_allocs.push_back(p);
+        return p;
+    };
+    d_tokens = static_cast<vbt_token_rec*>(alloc(nbts * sizeof(vbt_token_rec)));  // tokens <= chars <= bytes
+    d_tok_off = static_cast<uint32_t*>(alloc(ns * 4));
+    d_tok_cnt = static_cast<uint32_t*>(alloc(ns * 4));
+    d_over = static_cast<uint32_t*>(alloc(ns * 4 * (tiers.size() + 2)));
+    d_ctrl = static_cast<uint32_t*>(alloc(kCtrlWords * 4));
+    d_prof = static_cast<unsigned long long*>(alloc((kProfPhases + 1) * 8));
     HIP_CHECK(hipMemset(d_prof, 0, (kProfPhases + 1) * 8));
     const uint64_t mb = env_u32("VBT_SCRATCH_MB", 0);
     scratch_bytes = mb ? mb << 20 : std::max<uint64_t>(256ull << 20, 256 * nbts);
-    HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_scratch), scratch_bytes));
+    d_scratch = static_cast<char*>(alloc(scratch_bytes));
     profile = env_u32("VBT_PROFILE", 0) != 0;
     for (auto& e : ev) HIP_CHECK(hipEventCreate(reinterpret_cast<hipEvent_t*>(&e)));
+    // two-kernel pipeline buffers
+    const size_t slots = nbts + ns + 1;
+    pipe.s_n = static_cast<uint32_t*>(alloc(ns * 4));
+    pipe.s_C = static_cast<uint32_t*>(alloc(ns * 4));
+    pipe.s_base = static_cast<uint32_t*>(alloc(ns * 4));
+    pipe.s_flags = static_cast<uint32_t*>(alloc(ns * 4));
+    if (!fused) {
+        pipe.g_code = static_cast<uint16_t*>(alloc(slots * 2));
+        pipe.g_ucode = static_cast<uint16_t*>(alloc(slots * 2));
+        pipe.g_ci = static_cast<uint32_t*>(alloc(slots * 4));
+        pipe.g_grp = static_cast<uint16_t*>(alloc(slots * 2));
+        pipe.g_c2b = static_cast<uint16_t*>(alloc(slots * 2));
+        pipe.g_pc = static_cast<uint4*>(alloc(slots * 16));
+        pipe.node_factor = std::max<uint32_t>(1, env_u32("VBT_NODE_FACTOR", 8));  // candidate slots per input byte
+        pipe.g_nd = static_cast<uint4*>(alloc((size_t)pipe.node_factor * slots * 16));
+        pipe.s_tier = static_cast<uint8_t*>(alloc(ns));
+        for (size_t t = 0; t < tiers.size(); ++t) {
+            hipStream_t st;
+            HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+            streams.push_back(st);
+            hipEvent_t e;
+            HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            tier_events.push_back(e);
+        }
+        HIP_CHECK(hipEventCreateWithFlags(reinterpret_cast<hipEvent_t*>(&ev_fork), hipEventDisableTiming));
+        if (tiers.back() > 65536)  // a single workgroup may use the CU's whole 160 KiB
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lattice_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tiers.back()));
+    }
 }
 
 Workspace::~Workspace() {
-    (void)hipFree(d_tokens); (void)hipFree(d_tok_off); (void)hipFree(d_tok_cnt); (void)hipFree(d_over);
-    (void)hipFree(d_ctrl); (void)hipFree(d_scratch); (void)hipFree(d_prof);
+    for (void* p : pipe_allocs) (void)hipFree(p);
     for (auto& e : ev) if (e) (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(e));
+    for (void* e : tier_events) (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(e));
+    if (ev_fork) (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(ev_fork));
+    for (void* st : streams) (void)hipStreamDestroy(reinterpret_cast<hipStream_t>(st));
 }
 
 void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n, uint64_t total_bytes, void* stream_) {
@@ -812,29 +1520,56 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
     last_stream = stream_;
     HIP_CHECK(hipMemsetAsync(d_ctrl, 0, kCtrlWords * 4, stream));
     if (n == 0) return;
-    BatchArgs a;
+    const size_t T = tiers.size();
+    const size_t stride = std::max<uint64_t>(max_sentences, 1);
+    BatchArgs a = pipe;
     a.text = d_text; a.offsets = d_offsets; a.n = (uint32_t)n;
     a.tokens = d_tokens; a.tok_cap = (uint32_t)std::max<uint64_t>(max_bytes, 1);
     a.tok_off = d_tok_off; a.tok_cnt = d_tok_cnt; a.ctrl = d_ctrl;
     a.scratch = d_scratch; a.scratch_bytes = scratch_bytes;
     a.prof = profile ? d_prof : nullptr;
+    a.lists = d_over; a.list_stride = (uint32_t)stride; a.n_tiers = (uint32_t)T;
+    for (size_t t = 0; t < T; ++t) a.tier_bytes[t] = tiers[t];
     const DevDict& D = tok.dev();
     auto rec = [&](int i) { if (timing) HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(ev[i]), stream)); };
-    const size_t T = tiers.size();
-    auto over = [&](size_t t) { return d_over + t * std::max<uint64_t>(max_sentences, 1); };
+    auto over = [&](size_t t) { return d_over + t * stride; };
     auto count = [&](size_t t) { return d_ctrl + kTierCtrl + 2 * t; };
     auto cursor = [&](size_t t) { return d_ctrl + kTierCtrl + 2 * t + 1; };
+    auto waves_for = [&](uint32_t lds) {
+        const uint32_t per_cu = std::min<uint32_t>(32, std::max<uint32_t>(1, 163840 / lds));
+        return (uint32_t)std::min<uint64_t>(n, (uint64_t)per_cu * 256);
+    };
     rec(0);
-    hipLaunchKernelGGL(tokenize_lds, dim3((uint32_t)n), dim3(64), tiers[0], stream, D, a, tiers[0], (const uint32_t*)nullptr,
-                       (const uint32_t*)nullptr, (uint32_t*)nullptr, over(0), count(0));
-    rec(1);
-    for (size_t t = 1; t < T; ++t) {
-        const uint32_t waves = (uint32_t)std::min<uint64_t>(n, (uint64_t)std::max<uint32_t>(1, 163840 / tiers[t]) * 256);
-        hipLaunchKernelGGL(tokenize_lds, dim3(waves), dim3(64), tiers[t], stream, D, a, tiers[t], (const uint32_t*)over(t - 1),
-                           (const uint32_t*)count(t - 1), cursor(t), over(t), count(t));
+    if (fused) {
+        hipLaunchKernelGGL(tokenize_lds, dim3((uint32_t)n), dim3(64), tiers[0], stream, D, a, tiers[0], (const uint32_t*)nullptr,
+                           (const uint32_t*)nullptr, (uint32_t*)nullptr, over(0), count(0));
+        rec(1);
+        for (size_t t = 1; t < T; ++t)
+            hipLaunchKernelGGL(tokenize_lds, dim3(waves_for(tiers[t])), dim3(64), tiers[t], stream, D, a, tiers[t],
+                               (const uint32_t*)over(t - 1), (const uint32_t*)count(t - 1), cursor(t), over(t), count(t));
+        hipLaunchKernelGGL(tokenize_global, dim3((uint32_t)std::min<uint64_t>(n, 1024)), dim3(64), 0, stream, D, a,
+                           (const uint32_t*)over(T - 1), (const uint32_t*)count(T - 1), cursor(T));
+    } else {
+        const uint32_t gen_lds = env_u32("VBT_GEN_LDS", 4096), gen_lds_large = 65536;
+        const uint32_t lb = (uint32_t)((n + 255) / 256);
+        hipLaunchKernelGGL(gen_candidates, dim3((uint32_t)n), dim3(64), gen_lds, stream, D, a, gen_lds);
+        hipLaunchKernelGGL(build_lists, dim3(lb), dim3(256), 0, stream, a, (int)(T + 1));  // sentences for the large instance
+        hipLaunchKernelGGL(gen_candidates_large, dim3(waves_for(gen_lds_large)), dim3(64), gen_lds_large, stream, D, a, gen_lds_large);
+        hipLaunchKernelGGL(build_lists, dim3(lb), dim3(256), 0, stream, a, -1);
+        rec(1);
+        // every LDS tier on its own stream, largest (slowest per sentence) first
+        HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_fork), stream));
+        for (size_t i = 0; i < T; ++i) {
+            const size_t t = T - 1 - i;
+            hipStream_t side = reinterpret_cast<hipStream_t>(streams[t]);
+            HIP_CHECK(hipStreamWaitEvent(side, reinterpret_cast<hipEvent_t>(ev_fork), 0));
+            hipLaunchKernelGGL(lattice_lds, dim3(waves_for(tiers[t])), dim3(64), tiers[t], side, D, a, (uint32_t)t);
+            HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(tier_events[t]), side));
+        }
+        for (size_t t = 0; t < T; ++t) HIP_CHECK(hipStreamWaitEvent(stream, reinterpret_cast<hipEvent_t>(tier_events[t]), 0));
+        hipLaunchKernelGGL(tokenize_global, dim3((uint32_t)std::min<uint64_t>(n, 1024)), dim3(64), 0, stream, D, a,
+                           (const uint32_t*)over(T), (const uint32_t*)count(T), cursor(T));
     }
-    hipLaunchKernelGGL(tokenize_global, dim3((uint32_t)std::min<uint64_t>(n, 1024)), dim3(64), 0, stream, D, a,
-                       (const uint32_t*)over(T - 1), (const uint32_t*)count(T - 1), cursor(T));
     rec(2);
     HIP_CHECK(hipGetLastError());
 }
@@ -847,11 +1582,18 @@ void Workspace::stats(vbt_call_stats* out) {
     std::memset(out, 0, sizeof(*out));
     const size_t T = tiers.size();
     out->n_sentences = last_n;
-    out->n_tier0 = last_n - ctrl[kTierCtrl];
-    out->n_tier2 = ctrl[kTierCtrl + 2 * (T - 1)];
-    out->n_tier1 = last_n - out->n_tier0 - out->n_tier2;
+    if (fused) {
+        out->n_tier0 = last_n - ctrl[kTierCtrl];
+        out->n_tier2 = ctrl[kTierCtrl + 2 * (T - 1)];
+        out->n_tier1 = last_n - out->n_tier0 - out->n_tier2;
+    } else {
+        out->n_tier0 = ctrl[kTierCtrl];
+        out->n_tier2 = ctrl[kTierCtrl + 2 * T];
+        for (size_t t = 1; t < T; ++t) out->n_tier1 += ctrl[kTierCtrl + 2 * t];
+    }
     out->n_tokens = ctrl[kTotal];
     out->error_flags = ctrl[kError];
+    if (std::getenv("VBT_DEBUG")) std::fprintf(stderr, "[vbt] lattice fallbacks: arena=%u window=%u wide=%u passes=%u; lists:", ctrl[26], ctrl[27], ctrl[28], ctrl[29]), [&]{ for (size_t t = 0; t < T + 2; ++t) std::fprintf(stderr, " %u", ctrl[kTierCtrl + 2 * t]); std::fprintf(stderr, "\n"); }();
     if (timing && last_n) {
         HIP_CHECK(hipEventElapsedTime(&out->ms_tier0, reinterpret_cast<hipEvent_t>(ev[0]), reinterpret_cast<hipEvent_t>(ev[1])));
         HIP_CHECK(hipEventElapsedTime(&out->ms_tier12, reinterpret_cast<hipEvent_t>(ev[1]), reinterpret_cast<hipEvent_t>(ev[2])));

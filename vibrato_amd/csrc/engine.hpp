@@ -48,12 +48,39 @@ struct BatchArgs {
     uint64_t scratch_bytes;
     // optional per-phase cycle counters (kProfPhases + 1 u64), nullptr = off
     unsigned long long* prof;
+    // ---- two-kernel pipeline: gen_candidates -> lattice_lds (per LDS tier) ----
+    // per sentence
+    uint32_t* s_n;      // characters
+    uint32_t* s_C;      // lattice candidates
+    uint32_t* s_base;   // first node index in the node arrays
+    uint32_t* s_flags;  // bit0: a candidate longer than 64 chars exists
+    // per character slot (sentence s, char i -> slot offsets[s] + s + i; nb + 1 slots per sentence)
+    uint16_t* g_code;
+    uint16_t* g_ucode;
+    uint32_t* g_ci;
+    uint16_t* g_grp;
+    uint16_t* g_c2b;
+    uint4* g_pc;        // {cand_off, groupable | is_space << 31, lens lo, lens hi}
+    // per candidate (insertion order, contiguous per sentence; sentence s owns the node slots
+    // [node_factor * (offsets[s] + s), node_factor * (offsets[s+1] + s + 1)): no allocation atomics).
+    // One 16-byte record: {left_id | right_id << 16, (u16) word_cost | end_char << 16, word_idx,
+    //                      left-id group within the start position | 0x80 on the group's first candidate}
+    uint4* g_nd;
+    uint32_t node_factor;
+    uint8_t* s_tier;    // LDS tier chosen by gen_candidates (0xFF = none / empty sentence)
+    // work lists: list t (t < n_tiers) feeds LDS tier t, list n_tiers the global-memory fallback (fused kernel),
+    // list n_tiers + 1 the large-LDS instance of gen_candidates
+    uint32_t* lists;
+    uint32_t list_stride;
+    uint32_t n_tiers;
+    uint32_t tier_bytes[8];
 };
 
 // ctrl[kTotal] total tokens; ctrl[kError] DevError flags; ctrl[kBump..+1] u64 scratch bump pointer;
 // ctrl[kTierCtrl + 2t] = number of sentences tier t passed on, ctrl[kTierCtrl + 2t + 1] = work cursor of tier t
-enum CtrlSlot { kTotal = 0, kError = 1, kBump = 2, kTierCtrl = 4, kCtrlWords = 32 };
-constexpr int kMaxTiers = 6;
+// ctrl[kNodeCursor] bump pointer of the candidate arrays
+enum CtrlSlot { kTotal = 0, kError = 1, kBump = 2, kNodeCursor = 4, kTierCtrl = 6, kCtrlWords = 32 };
+constexpr int kMaxTiers = 8;
 constexpr int kProfPhases = 8;  // decode, count, fill, end lists, pre-pass, gather, recurrence, emit
 enum DevError { kErrTokCap = 1, kErrScratch = 2, kErrTooLong = 4 };
 
@@ -87,6 +114,12 @@ class Workspace {
     uint64_t max_sentences, max_bytes;
     vbt_token_rec* d_tokens = nullptr;
     uint32_t *d_tok_off = nullptr, *d_tok_cnt = nullptr, *d_ctrl = nullptr, *d_over = nullptr;
+    std::vector<void*> pipe_allocs;  // buffers of the two-kernel pipeline
+    BatchArgs pipe{};                // device pointers of those buffers
+    std::vector<void*> streams;      // one side stream per LDS tier
+    std::vector<void*> tier_events;
+    void* ev_fork = nullptr;
+    bool fused = false;              // VBT_FUSED=1: the single fused kernel per sentence (A/B reference)
     unsigned long long* d_prof = nullptr;
     char* d_scratch = nullptr;
     uint64_t scratch_bytes = 0;
