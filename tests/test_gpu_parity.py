@@ -118,6 +118,24 @@ def test_all_tiers_agree(tiers, fused, monkeypatch):
     _assert_batch_equal(to, tv, text, offs)
 
 
+@pytest.mark.parametrize("shape", ["ipadic", "unidic"])
+def test_full_size_batch_bit_exact(shape):
+    """BASELINE configs 2 and 3 at full size: 100k sentences over the ipadic- / unidic-shaped
+    synthetic dictionary (458.6 MiB matrix), every token record compared with the oracle."""
+    sd = synth.SynthDict(shape)
+    to, tv = _oracle_and_product(sd)
+    text, offs = sd.sentences(100000, "lognormal_40")
+    batch, ntok = _assert_batch_equal(to, tv, text, offs)
+    assert ntok > 2_000_000
+    # size-independent property: tokens tile every sentence (no spaces are skipped in this mode)
+    toks, off, cnt = batch.arrays()
+    first = off[cnt > 0]
+    last = (off + cnt - 1)[cnt > 0]
+    lens = np.diff(offs).astype(np.uint32)
+    assert np.all(toks["start_byte"][first] == 0)
+    assert np.array_equal(toks["end_byte"][last], lens[cnt > 0])
+
+
 def test_edge_cases(fixture_sources):
     s = fixture_sources
     d = V.SystemDictionaryBuilder.from_readers(s["lex.csv"], s["matrix.def"], s["char.def"], s["unk.def"])

@@ -1,7 +1,11 @@
 #!/bin/bash
-# A/B of build variants on the GPU box: tools/ab_variants.sh "<variant> <variant> ..." [bench args]
+# A/B of build variants / env settings on the GPU box: tools/ab_variants.sh "<variant>[:ENV=VAL[:ENV=VAL]] ..." [bench args]
 VARS=$1; shift
-for v in $VARS; do
-  if [ "$v" = "base" ]; then export VBT_LIB_VARIANT=; else export VBT_LIB_VARIANT=$v; fi
-  echo "== $v"; timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline "$@" 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['parity_vs_oracle_sample'], d['roofline']['tiers'])"
+export GPU_MAX_HW_QUEUES=10
+for spec in $VARS; do
+  v=${spec%%:*}
+  ( IFS=':' read -ra parts <<< "$spec"
+    for kv in "${parts[@]:1}"; do export "$kv"; done
+    if [ "$v" = "base" ]; then export VBT_LIB_VARIANT=; else export VBT_LIB_VARIANT=$v; fi
+    echo -n "== $spec : "; timeout 200 python bench.py --steps 10 --warmup 3 --no-cpu-baseline "$@" 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['parity_vs_oracle_sample'], d['roofline']['tiers'])" )
 done

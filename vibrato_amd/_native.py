@@ -91,6 +91,10 @@ def lib():
     """Loads (building first if sources are newer) the HIP shared library. Never falls back."""
     global _lib
     if _lib is None:
+        # The lattice kernel is launched once per LDS tier on its own stream; the ROCm runtime maps
+        # streams onto 4 hardware queues by default, which serialises half of them.  Must be set
+        # before the HIP runtime initialises (harmless if it already has).
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "10")
         # torch bundles its own libamdhip64.so.7 / libhsa-runtime64; two HIP runtimes in one process
         # cannot both own the GPU.  Importing torch first makes the loader resolve our NEEDED
         # libamdhip64.so.7 to the copy torch already mapped (plumbing only: no torch compute here).

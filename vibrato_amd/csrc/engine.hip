@@ -75,6 +75,26 @@ __device__ __forceinline__ uint64_t make_key(uint32_t cost, uint32_t seq) {
 __device__ __forceinline__ uint32_t key_cost(uint64_t k) { return (uint32_t)(k >> 32) ^ 0x80000000u; }
 __device__ __forceinline__ uint32_t key_seq(uint64_t k) { return 0xFFFFFFFEu - (uint32_t)k; }
 
+// Segmented butterfly minimum of 64-bit keys over aligned groups of 2^lg lanes.  Levels inside a
+// 16-lane row are DPP moves (quad_perm / row_half_mirror / row_mirror: a few cycles each); only the
+// 32- and 64-lane levels go through the LDS crossbar.  Every lane of a group ends with the group min.
+template <int kCtrl>
+__device__ __forceinline__ uint64_t dpp_min_u64(uint64_t k) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)k, kCtrl, 0xF, 0xF, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(k >> 32), kCtrl, 0xF, 0xF, false);
+    const uint64_t o = ((uint64_t)hi << 32) | lo;
+    return o < k ? o : k;
+}
+__device__ __forceinline__ uint64_t group_min_u64(uint64_t key, uint32_t lg) {  // lg is wave-uniform
+    if (lg >= 1) key = dpp_min_u64<0xB1>(key);   // quad_perm [1,0,3,2]
+    if (lg >= 2) key = dpp_min_u64<0x4E>(key);   // quad_perm [2,3,0,1]
+    if (lg >= 3) key = dpp_min_u64<0x141>(key);  // row_half_mirror
+    if (lg >= 4) key = dpp_min_u64<0x140>(key);  // row_mirror
+    if (lg >= 5) { const uint64_t o = __shfl_xor((unsigned long long)key, 16); key = o < key ? o : key; }
+    if (lg >= 6) { const uint64_t o = __shfl_xor((unsigned long long)key, 32); key = o < key ? o : key; }
+    return key;
+}
+
 // 128-bit window helpers (shift distances 0..64), by value so everything stays in registers
 struct U128 { uint64_t lo, hi; };
 __device__ __forceinline__ U128 shr128(U128 w, uint32_t d) {
@@ -941,7 +961,10 @@ __global__ void __launch_bounds__(64) gen_candidates_large(DevDict D, BatchArgs 
 // Kernel 2: the lattice sweep of one sentence per wavefront, entirely in LDS.  Persistent waves
 // drain the work list of their tier.  Sentences whose lattice does not fit after all go to the
 // fallback list (fused kernel with global scratch).
-__global__ void __launch_bounds__(64) lattice_lds(DevDict D, BatchArgs A, uint32_t tier) {
+#ifndef VBT_LAT_WAVES
+#define VBT_LAT_WAVES 4
+#endif
+__global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, BatchArgs A, uint32_t tier) {
     const uint32_t ln = threadIdx.x;
     const uint32_t lds_bytes = A.tier_bytes[tier];
     const uint32_t* list = A.lists + (size_t)tier * A.list_stride;
@@ -1179,7 +1202,7 @@ __global__ void __launch_bounds__(64) lattice_lds(DevDict D, BatchArgs A, uint32
             // ring[u]: the aligned 32-bit word holding this lane's i16 cell of pass (s0 + u); the half is
             // picked at use.  (A 16-bit destination would be packed two-per-VGPR by the compiler, which
             // forces a vmcnt(0) right behind every load and serialises the pipeline.)
-            uint32_t ring[kDepth];
+            uint32_t ring[kDepth], par[kDepth];  // par[u]: which half of ring[u] is this lane's cell (0 / 16)
             const uint32_t* __restrict__ matrix32 = reinterpret_cast<const uint32_t*>(matrix);
             auto cell_index = [&](uint32_t si) -> uint32_t {  // matrix element index of this lane's pair in pass si (0 if none)
                 const LSlot r = sl[si];  // passes >= SL are empty padding (ngs = 0)
@@ -1193,56 +1216,67 @@ __global__ void __launch_bounds__(64) lattice_lds(DevDict D, BatchArgs A, uint32
                 return valid ? left * NR + right : 0u;  // < 2^32: num_left, num_right <= 65535
             };
 #pragma unroll
-            for (uint32_t u = 0; u < kDepth; ++u) ring[u] = load_policy<VBT_NT_MATRIX != 0>(&matrix32[cell_index(u) >> 1]);
+            for (uint32_t u = 0; u < kDepth; ++u) {
+                const uint32_t cell = cell_index(u);
+                ring[u] = load_policy<VBT_NT_MATRIX != 0>(&matrix32[cell >> 1]);
+                par[u] = (cell & 1u) * 16u;
+            }
+            LSlot nx = sl[0];
             for (uint32_t s0 = 0; s0 < SL; s0 += kDepth) {
 #pragma unroll
                 for (uint32_t u = 0; u < kDepth; ++u) {
                     const uint32_t si = s0 + u;
-                    {
-                        const uint32_t cword = ring[u];
-                        ring[u] = load_policy<VBT_NT_MATRIX != 0>(&matrix32[cell_index(si + kDepth) >> 1]);
-                        const LSlot sr = sl[si];
-                        const uint32_t c_beg = __builtin_amdgcn_readfirstlane((uint32_t)sr.cbeg);
-                        const uint32_t nc = __builtin_amdgcn_readfirstlane((uint32_t)sr.nc);
-                        const uint32_t p_beg = __builtin_amdgcn_readfirstlane((uint32_t)sr.pbeg);
-                        const uint32_t np = __builtin_amdgcn_readfirstlane((uint32_t)sr.np);
-                        const uint32_t gabs = __builtin_amdgcn_readfirstlane((uint32_t)sr.gabs);
-                        const uint32_t ngs = __builtin_amdgcn_readfirstlane((uint32_t)sr.ngs);
-                        const uint32_t grel = __builtin_amdgcn_readfirstlane((uint32_t)sr.grel);
-                        const uint32_t flags = __builtin_amdgcn_readfirstlane((uint32_t)sr.last);
-                        const uint32_t last = flags & 1u, acc = flags & 2u;
-                        const uint32_t lg = np <= 1 ? 0u : 32u - (uint32_t)__builtin_clz(np - 1);
-                        const uint32_t npp = 1u << lg;
-                        const uint32_t g = ln >> lg, j = ln & (npp - 1);
-                        uint64_t key = kDeadKey;
-                        if (g < ngs && j < np) {
-                            const uint64_t kb = e_key[p_beg + j];
-                            const uint32_t cell = (uint32_t)g_left[gabs + g] * NR + e_right[p_beg + j];
-                            const uint32_t cv = (uint32_t)(int32_t)(int16_t)(cword >> ((cell & 1u) * 16u));
-                            key = (uint32_t)kb == 0xFFFFFFFFu ? kDeadKey : kb + ((uint64_t)cv << 32);  // wrapping i32 add
+                    const uint32_t cword = ring[u], cpar = par[u];
+                    {   // prefetch the cell of pass si + kDepth into the slot just consumed
+                        const uint32_t cell = cell_index(si + kDepth);
+                        ring[u] = load_policy<VBT_NT_MATRIX != 0>(&matrix32[cell >> 1]);
+                        par[u] = (cell & 1u) * 16u;
+                    }
+                    const LSlot sr = nx;
+                    nx = sl[si + 1];  // record of the next pass (padding makes si + 1 always readable)
+                    const uint32_t c_beg = __builtin_amdgcn_readfirstlane((uint32_t)sr.cbeg);
+                    const uint32_t nc = __builtin_amdgcn_readfirstlane((uint32_t)sr.nc);
+                    const uint32_t p_beg = __builtin_amdgcn_readfirstlane((uint32_t)sr.pbeg);
+                    const uint32_t np = __builtin_amdgcn_readfirstlane((uint32_t)sr.np);
+                    const uint32_t ngs = __builtin_amdgcn_readfirstlane((uint32_t)sr.ngs);
+                    const uint32_t grel = __builtin_amdgcn_readfirstlane((uint32_t)sr.grel);
+                    const uint32_t flags = __builtin_amdgcn_readfirstlane((uint32_t)sr.last);
+                    const uint32_t last = flags & 1u, acc = flags & 2u;
+                    const uint32_t lg = np <= 1 ? 0u : 32u - (uint32_t)__builtin_clz(np - 1);
+                    const uint32_t g = ln >> lg, j = ln & ((1u << lg) - 1u);
+                    // candidate-side operands of the step's final pass (independent of the reduction)
+                    const uint32_t c = c_beg + (ln < nc ? ln : 0u);
+                    const uint32_t gid = nd_gid[c] & 0x7Fu, es = nd_eslot[c];
+                    const uint32_t wcost = (uint32_t)(int32_t)nd_wcost[c];
+                    uint64_t key = kDeadKey;
+                    if (g < ngs && j < np) {
+                        const uint64_t kb = e_key[p_beg + j];
+                        const uint32_t cv = (uint32_t)(int32_t)(int16_t)(cword >> cpar);
+                        key = (uint32_t)kb == 0xFFFFFFFFu ? kDeadKey : kb + ((uint64_t)cv << 32);  // wrapping i32 add
+                    }
+                    key = group_min_u64(key, lg);
+                    if (g < ngs && j == 0) {
+                        if (acc) { const uint64_t prev = g_best[grel + g]; key = prev < key ? prev : key; }
+                        g_best[grel + g] = key;
+                    }
+                    __syncthreads();
+                    if (last) {
+                        if (ln < nc) {
+                            const uint64_t best = g_best[gid];
+                            e_key[es] = make_key(key_cost(best) + wcost, c);  // lattice.rs:125
+                            e_back[es] = (uint16_t)key_seq(best);
                         }
-                        for (uint32_t d = npp >> 1; d >= 1; d >>= 1) {
-                            const uint64_t o = __shfl_xor((unsigned long long)key, (int)d);
-                            key = o < key ? o : key;
-                        }
-                        if (g < ngs && j == 0) {
-                            if (acc) { const uint64_t prev = g_best[grel + g]; key = prev < key ? prev : key; }
-                            g_best[grel + g] = key;
+                        for (uint32_t cb = 64; cb < nc; cb += 64) {  // > 64 candidates at one start position (rare)
+                            const uint32_t ci_ = cb + ln;
+                            if (ci_ < nc) {
+                                const uint32_t c2 = c_beg + ci_;
+                                const uint64_t best = g_best[nd_gid[c2] & 0x7Fu];
+                                const uint32_t es2 = nd_eslot[c2];
+                                e_key[es2] = make_key(key_cost(best) + (uint32_t)(int32_t)nd_wcost[c2], c2);
+                                e_back[es2] = (uint16_t)key_seq(best);
+                            }
                         }
                         __syncthreads();
-                        if (last) {
-                            for (uint32_t cb = 0; cb < nc; cb += 64) {
-                                const uint32_t ci_ = cb + ln;
-                                if (ci_ < nc) {
-                                    const uint32_t c = c_beg + ci_;
-                                    const uint64_t best = g_best[nd_gid[c] & 0x7Fu];
-                                    const uint32_t es = nd_eslot[c];
-                                    e_key[es] = make_key(key_cost(best) + (uint32_t)(int32_t)nd_wcost[c], c);  // lattice.rs:125
-                                    e_back[es] = (uint16_t)key_seq(best);
-                                }
-                            }
-                            __syncthreads();
-                        }
                     }
                 }
             }
@@ -1381,6 +1415,7 @@ uint32_t env_u32(const char* name, uint32_t dflt) {
 // ------------------------------------------------------------------ Tokenizer
 
 Tokenizer::Tokenizer(const Dictionary* dict, bool ignore_space, uint32_t max_grouping_len, int device) : dict_(dict) {
+    setenv("GPU_MAX_HW_QUEUES", "10", 0);  // one stream per LDS tier (no effect once HIP is initialised)
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count == 0)
