@@ -165,11 +165,12 @@ VBT_API int vbt_tokenize_batch_device(vbt_workspace* ws, const uint8_t* d_text, 
  *   total    : u32[1]  total tokens written */
 VBT_API int vbt_workspace_results(const vbt_workspace* ws, const vbt_token_rec** d_tokens, const uint32_t** d_tok_off,
                                   const uint32_t** d_tok_cnt, const uint32_t** d_total);
-/* Per-call statistics (synchronizes the stream of the last call): number of sentences that
- * took each tier (0 = small LDS budget, 1 = large LDS budget, 2 = global-memory scratch),
- * tokens written, device error flags (1 = token buffer full, 2 = scratch exhausted,
- * 4 = sentence too long) and, with timing enabled, the hipEvent-measured duration (ms) of
- * the tier-0 kernel and of the tier-1+2 kernels of the last call. */
+/* Per-call statistics (synchronizes the stream of the last call): how many sentences were routed
+ * to the smallest LDS tier of the lattice kernel (n_tier0), to the larger LDS tiers (n_tier1) and to
+ * the global-memory fallback kernel (n_tier2; a re-routed sentence is counted twice), tokens
+ * written, device error flags (1 = token buffer full, 2 = scratch exhausted, 4 = sentence too
+ * long) and, with timing enabled, the hipEvent-measured duration (ms, on the launch stream) of the
+ * candidate-generation kernels (ms_tier0) and of everything after them (ms_tier12). */
 typedef struct vbt_call_stats {
     uint64_t n_sentences, n_tier0, n_tier1, n_tier2, n_tokens;
     uint32_t error_flags;
