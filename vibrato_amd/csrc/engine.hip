@@ -29,6 +29,7 @@ namespace vbt {
 namespace {
 
 constexpr uint64_t kNoFit = ~0ull;
+constexpr uint8_t kRouteDone = 0xFC;  // s_tier value of a sentence that already sits in a work list
 
 // Cache policy of the three random-access streams (A/B knobs): non-temporal loads
 // do not allocate in the per-CU vector L1, whose in-order tag pipeline stalls on hit-under-miss.
@@ -686,7 +687,7 @@ __host__ __device__ __forceinline__ uint64_t lattice_fixed_bytes(uint32_t n, uin
 extern __shared__ __attribute__((aligned(16))) char g_smem[];
 
 __device__ __forceinline__ void list_push(const BatchArgs& A, uint32_t t, uint32_t sid) {
-    if (threadIdx.x == 0) A.lists[(size_t)t * A.list_stride + atomicAdd(&A.ctrl[kTierCtrl + 2 * t], 1u)] = sid;
+    if (threadIdx.x == 0) A.lists[(size_t)t * A.list_stride + A.list_off + atomicAdd(&A.cctrl[2 * t], 1u)] = sid;
 }
 
 // Kernel 1 body: Sentence::compile + candidate enumeration of one sentence by one wavefront.
@@ -705,6 +706,7 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
     // gen routes a sentence by writing its list index; build_lists turns that into work lists with
     // wave-aggregated atomics (a per-sentence atomic on a hot word caps the kernel at ~88 M/s)
     auto route = [&](uint32_t t) { if (ln == 0) A.s_tier[sid] = (uint8_t)t; };
+    if (!large && A.s_tier[sid] == kRouteDone) return;  // a long sentence: generated and filed by the early pass
     if (ln == 0 && !large) { A.s_n[sid] = 0; A.s_C[sid] = 0; A.s_tier[sid] = 0xFF; }
     if (nb64 == 0) {
         if (ln == 0) { A.tok_off[sid] = 0; A.tok_cnt[sid] = 0; }
@@ -922,11 +924,22 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
 #undef PROF_MARK
 }
 
+// Long-first scheduling: sentences of >= long_bytes bytes are generated and swept before the bulk so
+// that the few slow ones overlap it instead of forming a tail.  Marks them for the large generator.
+__global__ void __launch_bounds__(256) classify_long(BatchArgs A, uint32_t long_bytes) {
+    const uint32_t rel = blockIdx.x * 256 + threadIdx.x;
+    if (rel >= A.n) return;
+    const uint32_t sid = A.sid0 + rel;
+    const uint64_t nb = A.offsets[sid + 1] - A.offsets[sid];
+    A.s_tier[sid] = nb >= long_bytes ? (uint8_t)(A.n_tiers + 1) : (uint8_t)0xFF;
+    if (nb >= long_bytes) { A.s_n[sid] = 0; A.s_C[sid] = 0; }
+}
+
 // Turns the per-sentence routing decisions into work lists: one atomic per (wave, list) instead of
 // one per sentence.  only_list >= 0 restricts the pass to that list (the gen_candidates_large input).
 __global__ void __launch_bounds__(256) build_lists(BatchArgs A, int only_list) {
-    const uint32_t sid = blockIdx.x * 256 + threadIdx.x;
-    const uint32_t t = sid < A.n ? A.s_tier[sid] : 0xFFu;
+    const uint32_t rel = blockIdx.x * 256 + threadIdx.x, sid = A.sid0 + rel;
+    const uint32_t t = rel < A.n ? A.s_tier[sid] : 0xFFu;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_lists = A.n_tiers + 2;
     for (uint32_t l = 0; l < n_lists; ++l) {
@@ -934,26 +947,29 @@ __global__ void __launch_bounds__(256) build_lists(BatchArgs A, int only_list) {
         const uint64_t m = __ballot(t == l);
         if (m == 0) continue;
         uint32_t basei = 0;
-        if (lane == (uint32_t)__builtin_ctzll(m)) basei = atomicAdd(&A.ctrl[kTierCtrl + 2 * l], (uint32_t)__popcll(m));
+        if (lane == (uint32_t)__builtin_ctzll(m)) basei = atomicAdd(&A.cctrl[2 * l], (uint32_t)__popcll(m));
         basei = __shfl(basei, (int)__builtin_ctzll(m));
-        if (t == l) A.lists[(size_t)l * A.list_stride + basei + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = sid;
+        if (t == l) {
+            A.lists[(size_t)l * A.list_stride + A.list_off + basei + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = sid;
+            if (only_list < 0) A.s_tier[sid] = kRouteDone;  // filed: a later pass must not file it again
+        }
     }
 }
 
 // Kernel 1: one single-wave workgroup per sentence (small LDS, high occupancy) ...
 __global__ void __launch_bounds__(64) gen_candidates(DevDict D, BatchArgs A, uint32_t lds_bytes) {
-    gen_one(D, A, blockIdx.x, lds_bytes, false);
+    gen_one(D, A, A.sid0 + blockIdx.x, lds_bytes, false);
 }
 // ... and persistent waves with a large LDS budget for the sentences that did not fit.
 __global__ void __launch_bounds__(64) gen_candidates_large(DevDict D, BatchArgs A, uint32_t lds_bytes) {
     const uint32_t t = A.n_tiers + 1;
-    const uint32_t count = A.ctrl[kTierCtrl + 2 * t];
+    const uint32_t count = A.cctrl[2 * t];
     for (;;) {
         uint32_t k = 0;
-        if (threadIdx.x == 0) k = atomicAdd(&A.ctrl[kTierCtrl + 2 * t + 1], 1u);
+        if (threadIdx.x == 0) k = atomicAdd(&A.cctrl[2 * t + 1], 1u);
         k = __shfl(k, 0);
         if (k >= count) break;
-        gen_one(D, A, A.lists[(size_t)t * A.list_stride + k], lds_bytes, true);
+        gen_one(D, A, A.lists[(size_t)t * A.list_stride + A.list_off + k], lds_bytes, true);
         __syncthreads();
     }
 }
@@ -967,12 +983,14 @@ __global__ void __launch_bounds__(64) gen_candidates_large(DevDict D, BatchArgs 
 __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, BatchArgs A, uint32_t tier) {
     const uint32_t ln = threadIdx.x;
     const uint32_t lds_bytes = A.tier_bytes[tier];
-    const uint32_t* list = A.lists + (size_t)tier * A.list_stride;
-    const uint32_t count = A.ctrl[kTierCtrl + 2 * tier];
-    uint32_t* cursor = &A.ctrl[kTierCtrl + 2 * tier + 1];
+    const uint32_t* list = A.lists + (size_t)tier * A.list_stride + A.list_off;
+    const uint32_t count = A.cctrl[2 * tier];
+    uint32_t* cursor = &A.cctrl[2 * tier + 1];
     const int16_t* __restrict__ matrix = D.matrix;
     const uint32_t NR = D.num_right;
     const bool space_mode = D.space_cateset != 0;
+    // long sentences are the critical path of a batch: let their waves win issue arbitration
+    if (A.tier_prio && tier + A.tier_prio >= A.n_tiers) __builtin_amdgcn_s_setprio(2);
     for (;;) {
         uint32_t item = 0;
         if (ln == 0) item = atomicAdd(cursor, 1u);
@@ -997,9 +1015,8 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
         uint16_t* cand_off = ar.take<uint16_t>(n + 1);
         uint16_t* goff = ar.take<uint16_t>(n + 1);
         uint16_t* nd_left = ar.take<uint16_t>(C + 1);
-        int16_t* nd_wcost = ar.take<int16_t>(C + 1);
         uint16_t* nd_end = ar.take<uint16_t>(C);
-        uint16_t* nd_eslot = ar.take<uint16_t>(C + 2);
+        uint32_t* nd_ew = ar.take<uint32_t>(C + 2);  // per candidate: end-list slot | (u16) word_cost << 16
         uint16_t* e_right = ar.take<uint16_t>(C + 2);
         uint16_t* e_back = ar.take<uint16_t>(C + 2);
         uint16_t* g_left = ar.take<uint16_t>(G + 1);
@@ -1035,10 +1052,9 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
                     const uint32_t end = r[u].y >> 16;
                     nd_left[c] = (uint16_t)(r[u].x & 0xFFFFu);
                     tmp_right[c] = (uint16_t)(r[u].x >> 16);
-                    nd_wcost[c] = (int16_t)(uint16_t)(r[u].y & 0xFFFFu);
                     nd_end[c] = (uint16_t)end;
                     nd_gid[c] = (uint8_t)r[u].w;
-                    nd_eslot[c] = (uint16_t)atomicAdd(&end_off[end], 1u);
+                    nd_ew[c] = atomicAdd(&end_off[end], 1u) | (r[u].y << 16);
                 }
             }
         }
@@ -1066,9 +1082,10 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
         }
         __syncthreads();
         for (uint32_t c = ln; c < C; c += 64) {
-            const uint32_t es = end_off[nd_end[c]] + nd_eslot[c];
+            const uint32_t ew = nd_ew[c];
+            const uint32_t es = end_off[nd_end[c]] + (ew & 0xFFFFu);
             const uint16_t r = tmp_right[c];
-            nd_eslot[c] = (uint16_t)es;
+            nd_ew[c] = (ew & 0xFFFF0000u) | es;
             e_right[es] = r;
             e_key[es] = kDeadKey;
         }
@@ -1077,11 +1094,10 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
         if (ln == 0) {
             e_right[0] = 0;
             e_key[0] = make_key(0u, kBosSeq);
-            nd_eslot[kBosSeq] = 0;
+            nd_ew[kBosSeq] = 0;
             e_back[0] = (uint16_t)kBosSeq;
             nd_left[C] = 0;  // EOS pseudo candidate: left_id 0, its own group G
-            nd_wcost[C] = 0;
-            nd_eslot[C] = (uint16_t)(C + 1);
+            nd_ew[C] = C + 1;  // word cost 0
             nd_gid[C] = 0x80u;
             g_left[G] = 0;
             e_key[C + 1] = kDeadKey;
@@ -1149,7 +1165,7 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
         const uint32_t sl_cap = lds_bytes > ((ar.used + 15) & ~15ull) ? (uint32_t)((lds_bytes - ((ar.used + 15) & ~15ull)) / sizeof(LSlot)) : 0u;
         for (uint32_t k0 = 0; k0 < S; k0 += 64) {
             const uint32_t k = k0 + ln;
-            uint32_t c_beg = 0, nc = 0, p_beg = 0, np = 1, g_beg = 0, ng = 0, nsl = 0, gpp = 64;
+            uint32_t c_beg = 0, nc = 0, p_beg = 0, np = 1, g_beg = 0, ng = 0, nsl = 0, gpp = 64, lgp = 0;
             if (k < S) {
                 const uint32_t v = sp[k], p = v & 0xFFFFu, sw = v >> 16;
                 p_beg = end_off[p];
@@ -1157,7 +1173,8 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
                 if (sw == 0xFFFFu) { c_beg = C; nc = 1; g_beg = G; ng = 1; }
                 else { c_beg = cand_off[sw]; nc = cand_off[sw + 1] - c_beg; g_beg = goff[sw]; ng = ngp[sw]; }
                 const uint32_t lg = np <= 1 ? 0u : 32u - (uint32_t)__builtin_clz(np - 1);
-                gpp = 64u >> (lg > 6 ? 6 : lg);
+                lgp = lg > 6 ? 6 : lg;
+                gpp = 64u >> lgp;
                 nsl = np <= 64 ? (ng + gpp - 1) / gpp : ng * ((np + 63) / 64);
             }
             uint32_t tot;
@@ -1166,17 +1183,20 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
                 if (np <= 64) {
                     for (uint32_t q = 0; q < nsl; ++q) {
                         const uint32_t rem = ng - q * gpp;
+                        const uint32_t fl = (q + 1 == nsl ? 1u : 0u) | ((nsl == 1 && nc <= 64) ? 8u : 0u) | (lgp << 4);
                         sl[SL + ex + q] = LSlot{(uint16_t)c_beg, (uint16_t)nc, (uint16_t)p_beg, (uint16_t)np, (uint16_t)(g_beg + q * gpp),
-                                                (uint16_t)(rem < gpp ? rem : gpp), (uint16_t)(q * gpp), (uint16_t)(q + 1 == nsl ? 1u : 0u)};
+                                                (uint16_t)(rem < gpp ? rem : gpp), (uint16_t)(q * gpp), (uint16_t)fl};
                     }
                 } else {  // > 64 predecessors: one group per pass, 64 predecessors at a time, partial minima accumulate
                     const uint32_t nch = (np + 63) / 64;
                     for (uint32_t q = 0; q < nsl; ++q) {
                         const uint32_t g = q / nch, jc = q - g * nch;
                         const uint32_t rem = np - jc * 64;
-                        sl[SL + ex + q] = LSlot{(uint16_t)c_beg, (uint16_t)nc, (uint16_t)(p_beg + jc * 64), (uint16_t)(rem < 64 ? rem : 64),
+                        const uint32_t npc = rem < 64 ? rem : 64;
+                        const uint32_t lgc = npc <= 1 ? 0u : 32u - (uint32_t)__builtin_clz(npc - 1);
+                        sl[SL + ex + q] = LSlot{(uint16_t)c_beg, (uint16_t)nc, (uint16_t)(p_beg + jc * 64), (uint16_t)npc,
                                                 (uint16_t)(g_beg + g), (uint16_t)1, (uint16_t)g,
-                                                (uint16_t)((q + 1 == nsl ? 1u : 0u) | (jc ? 2u : 0u))};
+                                                (uint16_t)((q + 1 == nsl ? 1u : 0u) | (jc ? 2u : 0u) | (lgc << 4))};
                     }
                 }
             }
@@ -1186,7 +1206,7 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
         constexpr uint32_t kDepth = 8;  // prefetch distance of the fused loop, in passes
         if (SL + 2 * kDepth > sl_cap) { if (ln == 0) atomicAdd(&A.ctrl[29], 1u); list_push(A, A.n_tiers, sid); __syncthreads(); continue; }
         // pad with empty passes so the pipelined loop needs no bounds branches
-        if (ln < 2 * kDepth) sl[SL + ln] = LSlot{0, 0, 0, 1, 0, 0, 0, 0};
+        if (ln < 2 * kDepth) sl[SL + ln] = LSlot{0, 0, 0, 1, 0, 0, 0, 0};  // np = 1, ngs = 0, lg = 0: nothing to do
         __syncthreads();
         PROF_MARK(4);
 
@@ -1203,51 +1223,35 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
             // picked at use.  (A 16-bit destination would be packed two-per-VGPR by the compiler, which
             // forces a vmcnt(0) right behind every load and serialises the pipeline.)
             uint32_t ring[kDepth], par[kDepth];  // par[u]: which half of ring[u] is this lane's cell (0 / 16)
+            uint4 rw[kDepth];                     // the (wave-uniform) pass record of ring slot u, unpacked once
             const uint32_t* __restrict__ matrix32 = reinterpret_cast<const uint32_t*>(matrix);
-            auto cell_index = [&](uint32_t si) -> uint32_t {  // matrix element index of this lane's pair in pass si (0 if none)
-                const LSlot r = sl[si];  // passes >= SL are empty padding (ngs = 0)
-                const uint32_t np = __builtin_amdgcn_readfirstlane((uint32_t)r.np), ngs = __builtin_amdgcn_readfirstlane((uint32_t)r.ngs);
-                const uint32_t p_beg = __builtin_amdgcn_readfirstlane((uint32_t)r.pbeg), gabs = __builtin_amdgcn_readfirstlane((uint32_t)r.gabs);
-                const uint32_t lg = np <= 1 ? 0u : 32u - (uint32_t)__builtin_clz(np - 1);
+            auto fetch = [&](uint32_t si, uint32_t u) {  // issue the gather of pass si into ring slot u
+                const uint4 q = *reinterpret_cast<const uint4*>(&sl[si]);  // passes >= SL are empty padding
+                const uint4 r = make_uint4(__builtin_amdgcn_readfirstlane(q.x), __builtin_amdgcn_readfirstlane(q.y),
+                                           __builtin_amdgcn_readfirstlane(q.z), __builtin_amdgcn_readfirstlane(q.w));
+                rw[u] = r;
+                const uint32_t p_beg = r.y & 0xFFFFu, np = r.y >> 16, gabs = r.z & 0xFFFFu, ngs = r.z >> 16, lg = (r.w >> 20) & 7u;
                 const uint32_t g = ln >> lg, j = ln & ((1u << lg) - 1u);
                 const bool valid = g < ngs && j < np;
                 const uint32_t left = g_left[gabs + (valid ? g : 0u)];
                 const uint32_t right = e_right[p_beg + (valid ? j : 0u)];
-                return valid ? left * NR + right : 0u;  // < 2^32: num_left, num_right <= 65535
-            };
-#pragma unroll
-            for (uint32_t u = 0; u < kDepth; ++u) {
-                const uint32_t cell = cell_index(u);
+                const uint32_t cell = valid ? left * NR + right : 0u;  // < 2^32: num_left, num_right <= 65535
                 ring[u] = load_policy<VBT_NT_MATRIX != 0>(&matrix32[cell >> 1]);
                 par[u] = (cell & 1u) * 16u;
-            }
-            LSlot nx = sl[0];
+            };
+#pragma unroll
+            for (uint32_t u = 0; u < kDepth; ++u) fetch(u, u);
             for (uint32_t s0 = 0; s0 < SL; s0 += kDepth) {
 #pragma unroll
                 for (uint32_t u = 0; u < kDepth; ++u) {
                     const uint32_t si = s0 + u;
                     const uint32_t cword = ring[u], cpar = par[u];
-                    {   // prefetch the cell of pass si + kDepth into the slot just consumed
-                        const uint32_t cell = cell_index(si + kDepth);
-                        ring[u] = load_policy<VBT_NT_MATRIX != 0>(&matrix32[cell >> 1]);
-                        par[u] = (cell & 1u) * 16u;
-                    }
-                    const LSlot sr = nx;
-                    nx = sl[si + 1];  // record of the next pass (padding makes si + 1 always readable)
-                    const uint32_t c_beg = __builtin_amdgcn_readfirstlane((uint32_t)sr.cbeg);
-                    const uint32_t nc = __builtin_amdgcn_readfirstlane((uint32_t)sr.nc);
-                    const uint32_t p_beg = __builtin_amdgcn_readfirstlane((uint32_t)sr.pbeg);
-                    const uint32_t np = __builtin_amdgcn_readfirstlane((uint32_t)sr.np);
-                    const uint32_t ngs = __builtin_amdgcn_readfirstlane((uint32_t)sr.ngs);
-                    const uint32_t grel = __builtin_amdgcn_readfirstlane((uint32_t)sr.grel);
-                    const uint32_t flags = __builtin_amdgcn_readfirstlane((uint32_t)sr.last);
-                    const uint32_t last = flags & 1u, acc = flags & 2u;
-                    const uint32_t lg = np <= 1 ? 0u : 32u - (uint32_t)__builtin_clz(np - 1);
+                    const uint4 r = rw[u];
+                    fetch(si + kDepth, u);  // prefetch into the slot just consumed
+                    const uint32_t c_beg = r.x & 0xFFFFu, nc = r.x >> 16, p_beg = r.y & 0xFFFFu, np = r.y >> 16;
+                    const uint32_t ngs = r.z >> 16, grel = r.w & 0xFFFFu, fl = r.w >> 16;
+                    const uint32_t last = fl & 1u, acc = fl & 2u, single = fl & 8u, lg = (fl >> 4) & 7u;
                     const uint32_t g = ln >> lg, j = ln & ((1u << lg) - 1u);
-                    // candidate-side operands of the step's final pass (independent of the reduction)
-                    const uint32_t c = c_beg + (ln < nc ? ln : 0u);
-                    const uint32_t gid = nd_gid[c] & 0x7Fu, es = nd_eslot[c];
-                    const uint32_t wcost = (uint32_t)(int32_t)nd_wcost[c];
                     uint64_t key = kDeadKey;
                     if (g < ngs && j < np) {
                         const uint64_t kb = e_key[p_beg + j];
@@ -1255,28 +1259,35 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
                         key = (uint32_t)kb == 0xFFFFFFFFu ? kDeadKey : kb + ((uint64_t)cv << 32);  // wrapping i32 add
                     }
                     key = group_min_u64(key, lg);
-                    if (g < ngs && j == 0) {
-                        if (acc) { const uint64_t prev = g_best[grel + g]; key = prev < key ? prev : key; }
-                        g_best[grel + g] = key;
-                    }
-                    __syncthreads();
-                    if (last) {
+                    if (single) {
+                        // the whole step is this pass: group minima go straight to the candidate lanes
+                        const uint32_t c = c_beg + (ln < nc ? ln : 0u);
+                        const uint32_t ew = nd_ew[c];
+                        const uint64_t best = __shfl((unsigned long long)key, (int)((nd_gid[c] & 0x7Fu) << lg));
                         if (ln < nc) {
-                            const uint64_t best = g_best[gid];
-                            e_key[es] = make_key(key_cost(best) + wcost, c);  // lattice.rs:125
-                            e_back[es] = (uint16_t)key_seq(best);
-                        }
-                        for (uint32_t cb = 64; cb < nc; cb += 64) {  // > 64 candidates at one start position (rare)
-                            const uint32_t ci_ = cb + ln;
-                            if (ci_ < nc) {
-                                const uint32_t c2 = c_beg + ci_;
-                                const uint64_t best = g_best[nd_gid[c2] & 0x7Fu];
-                                const uint32_t es2 = nd_eslot[c2];
-                                e_key[es2] = make_key(key_cost(best) + (uint32_t)(int32_t)nd_wcost[c2], c2);
-                                e_back[es2] = (uint16_t)key_seq(best);
-                            }
+                            e_key[ew & 0xFFFFu] = make_key(key_cost(best) + (uint32_t)(int32_t)(int16_t)(ew >> 16), c);  // lattice.rs:125
+                            e_back[ew & 0xFFFFu] = (uint16_t)key_seq(best);
                         }
                         __syncthreads();
+                    } else {
+                        if (g < ngs && j == 0) {
+                            if (acc) { const uint64_t prev = g_best[grel + g]; key = prev < key ? prev : key; }
+                            g_best[grel + g] = key;
+                        }
+                        __syncthreads();
+                        if (last) {
+                            for (uint32_t cb = 0; cb < nc; cb += 64) {
+                                const uint32_t ci_ = cb + ln;
+                                if (ci_ < nc) {
+                                    const uint32_t c = c_beg + ci_;
+                                    const uint64_t best = g_best[nd_gid[c] & 0x7Fu];
+                                    const uint32_t ew = nd_ew[c];
+                                    e_key[ew & 0xFFFFu] = make_key(key_cost(best) + (uint32_t)(int32_t)(int16_t)(ew >> 16), c);
+                                    e_back[ew & 0xFFFFu] = (uint16_t)key_seq(best);
+                                }
+                            }
+                            __syncthreads();
+                        }
                     }
                 }
             }
@@ -1290,7 +1301,7 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
             uint32_t seq = e_back[C + 1];
             while (seq != kBosSeq && T < n) {
                 path[T++] = (uint16_t)seq;
-                seq = e_back[nd_eslot[seq]];
+                seq = e_back[nd_ew[seq] & 0xFFFFu];
             }
         }
         T = __shfl(T, 0);
@@ -1315,7 +1326,7 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
                 r.start_char = stp; r.end_char = en;
                 r.start_byte = c2b[stp]; r.end_byte = c2b[en];
                 r.word_idx = nd[c].z;
-                r.total_cost = (int32_t)key_cost(e_key[nd_eslot[c]]);
+                r.total_cost = (int32_t)key_cost(e_key[nd_ew[c] & 0xFFFFu]);
                 A.tokens[out_base + t] = r;
             }
         }
@@ -1500,8 +1511,10 @@ Workspace::Workspace(const Tokenizer& t, uint64_t max_s, uint64_t max_b) : tok(t
     d_tokens = static_cast<vbt_token_rec*>(alloc(nbts * sizeof(vbt_token_rec)));  // tokens <= chars <= bytes
     d_tok_off = static_cast<uint32_t*>(alloc(ns * 4));
     d_tok_cnt = static_cast<uint32_t*>(alloc(ns * 4));
-    d_over = static_cast<uint32_t*>(alloc(ns * 4 * (tiers.size() + 2)));
+    d_over = static_cast<uint32_t*>(alloc(2 * ns * 4 * (tiers.size() + 2)));  // two regions per list: long-first pass + bulk
     d_ctrl = static_cast<uint32_t*>(alloc(kCtrlWords * 4));
+    d_cctrl = static_cast<uint32_t*>(alloc((size_t)kMaxChunks * kChunkCtrlWords * 4));
+    n_chunks = std::min<uint32_t>(kMaxChunks / 2, std::max<uint32_t>(1, env_u32("VBT_CHUNKS", 1)));  // > 1 measured slower (launch overhead)
     d_prof = static_cast<unsigned long long*>(alloc((kProfPhases + 1) * 8));
     HIP_CHECK(hipMemset(d_prof, 0, (kProfPhases + 1) * 8));
     const uint64_t mb = env_u32("VBT_SCRATCH_MB", 0);
@@ -1554,9 +1567,10 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
     last_n = n;
     last_stream = stream_;
     HIP_CHECK(hipMemsetAsync(d_ctrl, 0, kCtrlWords * 4, stream));
+    HIP_CHECK(hipMemsetAsync(d_cctrl, 0, kMaxChunks * kChunkCtrlWords * 4, stream));
     if (n == 0) return;
     const size_t T = tiers.size();
-    const size_t stride = std::max<uint64_t>(max_sentences, 1);
+    const size_t half = std::max<uint64_t>(max_sentences, 1), stride = 2 * half;
     BatchArgs a = pipe;
     a.text = d_text; a.offsets = d_offsets; a.n = (uint32_t)n;
     a.tokens = d_tokens; a.tok_cap = (uint32_t)std::max<uint64_t>(max_bytes, 1);
@@ -1564,46 +1578,90 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
     a.scratch = d_scratch; a.scratch_bytes = scratch_bytes;
     a.prof = profile ? d_prof : nullptr;
     a.lists = d_over; a.list_stride = (uint32_t)stride; a.n_tiers = (uint32_t)T;
+    a.tier_prio = env_u32("VBT_TIER_PRIO", 3);
+    a.sid0 = 0; a.cctrl = d_cctrl; a.list_off = 0;
     for (size_t t = 0; t < T; ++t) a.tier_bytes[t] = tiers[t];
     const DevDict& D = tok.dev();
     auto rec = [&](int i) { if (timing) HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(ev[i]), stream)); };
     auto over = [&](size_t t) { return d_over + t * stride; };
-    auto count = [&](size_t t) { return d_ctrl + kTierCtrl + 2 * t; };
-    auto cursor = [&](size_t t) { return d_ctrl + kTierCtrl + 2 * t + 1; };
-    auto waves_for = [&](uint32_t lds) {
+    auto waves_for = [&](uint32_t lds, uint64_t items) {
         const uint32_t per_cu = std::min<uint32_t>(32, std::max<uint32_t>(1, 163840 / lds));
-        return (uint32_t)std::min<uint64_t>(n, (uint64_t)per_cu * 256);
+        return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(items, (uint64_t)per_cu * 256));
     };
     rec(0);
     if (fused) {
+        last_chunks = 1;
+        auto count = [&](size_t t) { return d_cctrl + 2 * t; };
+        auto cursor = [&](size_t t) { return d_cctrl + 2 * t + 1; };
         hipLaunchKernelGGL(tokenize_lds, dim3((uint32_t)n), dim3(64), tiers[0], stream, D, a, tiers[0], (const uint32_t*)nullptr,
                            (const uint32_t*)nullptr, (uint32_t*)nullptr, over(0), count(0));
         rec(1);
         for (size_t t = 1; t < T; ++t)
-            hipLaunchKernelGGL(tokenize_lds, dim3(waves_for(tiers[t])), dim3(64), tiers[t], stream, D, a, tiers[t],
+            hipLaunchKernelGGL(tokenize_lds, dim3(waves_for(tiers[t], n)), dim3(64), tiers[t], stream, D, a, tiers[t],
                                (const uint32_t*)over(t - 1), (const uint32_t*)count(t - 1), cursor(t), over(t), count(t));
         hipLaunchKernelGGL(tokenize_global, dim3((uint32_t)std::min<uint64_t>(n, 1024)), dim3(64), 0, stream, D, a,
                            (const uint32_t*)over(T - 1), (const uint32_t*)count(T - 1), cursor(T));
     } else {
-        const uint32_t gen_lds = env_u32("VBT_GEN_LDS", 4096), gen_lds_large = 65536;
-        const uint32_t lb = (uint32_t)((n + 255) / 256);
-        hipLaunchKernelGGL(gen_candidates, dim3((uint32_t)n), dim3(64), gen_lds, stream, D, a, gen_lds);
-        hipLaunchKernelGGL(build_lists, dim3(lb), dim3(256), 0, stream, a, (int)(T + 1));  // sentences for the large instance
-        hipLaunchKernelGGL(gen_candidates_large, dim3(waves_for(gen_lds_large)), dim3(64), gen_lds_large, stream, D, a, gen_lds_large);
-        hipLaunchKernelGGL(build_lists, dim3(lb), dim3(256), 0, stream, a, -1);
-        rec(1);
-        // every LDS tier on its own stream, largest (slowest per sentence) first
-        HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_fork), stream));
-        for (size_t i = 0; i < T; ++i) {
-            const size_t t = T - 1 - i;
-            hipStream_t side = reinterpret_cast<hipStream_t>(streams[t]);
-            HIP_CHECK(hipStreamWaitEvent(side, reinterpret_cast<hipEvent_t>(ev_fork), 0));
-            hipLaunchKernelGGL(lattice_lds, dim3(waves_for(tiers[t])), dim3(64), tiers[t], side, D, a, (uint32_t)t);
-            HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(tier_events[t]), side));
+        // The batch is cut into chunks of sentences so that candidate generation of chunk c + 1
+        // (memory-latency bound, no LDS) overlaps the lattice sweep of chunk c (LDS / issue bound).
+        // Every LDS tier has its own stream (largest = slowest sentences first); the launch stream
+        // only forks and joins.
+        const uint32_t gen_lds = env_u32("VBT_GEN_LDS", 6144), gen_lds_large = 65536;
+        uint32_t K = n_chunks;
+        if (K > kMaxChunks / 2) K = kMaxChunks / 2;
+        while (K > 1 && n / K < 8192) --K;
+        last_chunks = K;
+        const uint32_t long_bytes = env_u32("VBT_LONG_BYTES", 0);
+        auto fork_tiers = [&](uint32_t cn) {
+            HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_fork), stream));
+            for (size_t i = 0; i < T; ++i) {
+                const size_t t = T - 1 - i;
+                hipStream_t side = reinterpret_cast<hipStream_t>(streams[t]);
+                HIP_CHECK(hipStreamWaitEvent(side, reinterpret_cast<hipEvent_t>(ev_fork), 0));
+                hipLaunchKernelGGL(lattice_lds, dim3(waves_for(tiers[t], cn)), dim3(64), tiers[t], side, D, a, (uint32_t)t);
+            }
+        };
+        for (uint32_t c = 0; c < K; ++c) {
+            const uint32_t lo = (uint32_t)(n * c / K), hi = (uint32_t)(n * (c + 1) / K), cn = hi - lo;
+            a.sid0 = lo; a.n = cn;
+            const uint32_t lb = (cn + 255) / 256;
+            a.cctrl = d_cctrl + (size_t)c * kChunkCtrlWords; a.list_off = lo;
+            if (long_bytes) {
+                // optional long-first pass (VBT_LONG_BYTES > 0): sentences of >= long_bytes bytes are generated,
+                // filed and swept before the bulk.  Off by default: on MI355X the 12 extra launches cost more
+                // than the tail they remove (measured 5.67 ms vs 5.22 ms per 100k sentences).
+                a.cctrl = d_cctrl + (size_t)(K + c) * kChunkCtrlWords; a.list_off = (uint32_t)half + lo;
+                hipLaunchKernelGGL(classify_long, dim3(lb), dim3(256), 0, stream, a, long_bytes);
+                hipLaunchKernelGGL(build_lists, dim3(lb), dim3(256), 0, stream, a, (int)(T + 1));
+                hipLaunchKernelGGL(gen_candidates_large, dim3(waves_for(gen_lds_large, cn)), dim3(64), gen_lds_large, stream, D, a, gen_lds_large);
+                hipLaunchKernelGGL(build_lists, dim3(lb), dim3(256), 0, stream, a, -1);
+                fork_tiers(std::min<uint32_t>(cn, 4096));
+                a.cctrl = d_cctrl + (size_t)c * kChunkCtrlWords; a.list_off = lo;
+            } else {
+                HIP_CHECK(hipMemsetAsync(pipe.s_tier + lo, 0xFF, cn, stream));  // nothing filed yet
+            }
+            // 2. the bulk (the small generator skips what step 1 filed); stragglers that outgrow its LDS
+            //    go through the large generator again
+            hipLaunchKernelGGL(gen_candidates, dim3(cn), dim3(64), gen_lds, stream, D, a, gen_lds);
+            hipLaunchKernelGGL(build_lists, dim3(lb), dim3(256), 0, stream, a, (int)(T + 1));
+            hipLaunchKernelGGL(gen_candidates_large, dim3(waves_for(gen_lds_large, cn)), dim3(64), gen_lds_large, stream, D, a, gen_lds_large);
+            hipLaunchKernelGGL(build_lists, dim3(lb), dim3(256), 0, stream, a, -1);
+            if (c == 0) rec(1);
+            fork_tiers(cn);
         }
-        for (size_t t = 0; t < T; ++t) HIP_CHECK(hipStreamWaitEvent(stream, reinterpret_cast<hipEvent_t>(tier_events[t]), 0));
-        hipLaunchKernelGGL(tokenize_global, dim3((uint32_t)std::min<uint64_t>(n, 1024)), dim3(64), 0, stream, D, a,
-                           (const uint32_t*)over(T), (const uint32_t*)count(T), cursor(T));
+        for (size_t t = 0; t < T; ++t) {
+            hipStream_t side = reinterpret_cast<hipStream_t>(streams[t]);
+            HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(tier_events[t]), side));
+            HIP_CHECK(hipStreamWaitEvent(stream, reinterpret_cast<hipEvent_t>(tier_events[t]), 0));
+        }
+        for (uint32_t c = 0; c < (long_bytes ? 2 * K : K); ++c) {  // whatever the pipeline could not take: fused kernel, global-memory lattice
+            const uint32_t cc_i = c % K, phase1 = c / K;
+            const uint32_t lo = (uint32_t)(n * cc_i / K), hi = (uint32_t)(n * (cc_i + 1) / K);
+            uint32_t* cc = d_cctrl + (size_t)(phase1 ? K + cc_i : cc_i) * kChunkCtrlWords;
+            a.sid0 = lo; a.n = hi - lo; a.cctrl = cc; a.list_off = (phase1 ? (uint32_t)half : 0u) + lo;
+            hipLaunchKernelGGL(tokenize_global, dim3((uint32_t)std::min<uint64_t>(hi - lo, phase1 ? 256 : 1024)), dim3(64), 0, stream, D, a,
+                               (const uint32_t*)(over(T) + a.list_off), (const uint32_t*)(cc + 2 * T), cc + 2 * T + 1);
+        }
     }
     rec(2);
     HIP_CHECK(hipGetLastError());
@@ -1613,22 +1671,31 @@ void Workspace::stats(vbt_call_stats* out) {
     HIP_CHECK(hipSetDevice(tok.device()));
     HIP_CHECK(hipStreamSynchronize(reinterpret_cast<hipStream_t>(last_stream)));
     uint32_t ctrl[kCtrlWords];
+    std::vector<uint32_t> cc((size_t)kMaxChunks * kChunkCtrlWords);
     HIP_CHECK(hipMemcpy(ctrl, d_ctrl, sizeof(ctrl), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(cc.data(), d_cctrl, cc.size() * 4, hipMemcpyDeviceToHost));
     std::memset(out, 0, sizeof(*out));
     const size_t T = tiers.size();
     out->n_sentences = last_n;
     if (fused) {
-        out->n_tier0 = last_n - ctrl[kTierCtrl];
-        out->n_tier2 = ctrl[kTierCtrl + 2 * (T - 1)];
+        out->n_tier0 = last_n - cc[0];
+        out->n_tier2 = cc[2 * (T - 1)];
         out->n_tier1 = last_n - out->n_tier0 - out->n_tier2;
     } else {
-        out->n_tier0 = ctrl[kTierCtrl];
-        out->n_tier2 = ctrl[kTierCtrl + 2 * T];
-        for (size_t t = 1; t < T; ++t) out->n_tier1 += ctrl[kTierCtrl + 2 * t];
+        for (uint32_t c = 0; c < 2 * last_chunks; ++c) {  // bulk blocks, then the long-first blocks
+            const uint32_t* k = cc.data() + (size_t)c * kChunkCtrlWords;
+            out->n_tier0 += k[0];
+            out->n_tier2 += k[2 * T];
+            for (size_t t = 1; t < T; ++t) out->n_tier1 += k[2 * t];
+        }
     }
     out->n_tokens = ctrl[kTotal];
     out->error_flags = ctrl[kError];
-    if (std::getenv("VBT_DEBUG")) std::fprintf(stderr, "[vbt] lattice fallbacks: arena=%u window=%u wide=%u passes=%u; lists:", ctrl[26], ctrl[27], ctrl[28], ctrl[29]), [&]{ for (size_t t = 0; t < T + 2; ++t) std::fprintf(stderr, " %u", ctrl[kTierCtrl + 2 * t]); std::fprintf(stderr, "\n"); }();
+    if (std::getenv("VBT_DEBUG")) {
+        std::fprintf(stderr, "[vbt] chunks=%u lattice fallbacks: arena=%u window=%u passes=%u; chunk-0 lists:", last_chunks, ctrl[26], ctrl[27], ctrl[29]);
+        for (size_t t = 0; t < T + 2; ++t) std::fprintf(stderr, " %u", cc[2 * t]);
+        std::fprintf(stderr, "\n");
+    }
     if (timing && last_n) {
         HIP_CHECK(hipEventElapsedTime(&out->ms_tier0, reinterpret_cast<hipEvent_t>(ev[0]), reinterpret_cast<hipEvent_t>(ev[1])));
         HIP_CHECK(hipEventElapsedTime(&out->ms_tier12, reinterpret_cast<hipEvent_t>(ev[1]), reinterpret_cast<hipEvent_t>(ev[2])));

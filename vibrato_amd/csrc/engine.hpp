@@ -73,6 +73,13 @@ struct BatchArgs {
     uint32_t* lists;
     uint32_t list_stride;
     uint32_t n_tiers;
+    uint32_t tier_prio;  // the top `tier_prio` LDS tiers run at raised wave priority (0 = off)
+    // chunked pipeline: a launch covers sentences [sid0, sid0 + n); cctrl = this chunk's list counters
+    // (cctrl[2t] = entries of list t, cctrl[2t+1] = its work cursor); list t of the chunk starts at
+    // lists[t * list_stride + sid0]
+    uint32_t sid0;
+    uint32_t* cctrl;
+    uint32_t list_off;  // offset of this launch's entries inside every list region
     uint32_t tier_bytes[8];
 };
 
@@ -81,6 +88,8 @@ struct BatchArgs {
 // ctrl[kNodeCursor] bump pointer of the candidate arrays
 enum CtrlSlot { kTotal = 0, kError = 1, kBump = 2, kNodeCursor = 4, kTierCtrl = 6, kCtrlWords = 32 };
 constexpr int kMaxTiers = 8;
+constexpr int kMaxChunks = 16;
+constexpr int kChunkCtrlWords = 2 * (kMaxTiers + 2);
 constexpr int kProfPhases = 8;  // decode, count, fill, end lists, pre-pass, gather, recurrence, emit
 enum DevError { kErrTokCap = 1, kErrScratch = 2, kErrTooLong = 4 };
 
@@ -113,7 +122,8 @@ class Workspace {
     const Tokenizer& tok;
     uint64_t max_sentences, max_bytes;
     vbt_token_rec* d_tokens = nullptr;
-    uint32_t *d_tok_off = nullptr, *d_tok_cnt = nullptr, *d_ctrl = nullptr, *d_over = nullptr;
+    uint32_t *d_tok_off = nullptr, *d_tok_cnt = nullptr, *d_ctrl = nullptr, *d_over = nullptr, *d_cctrl = nullptr;
+    uint32_t n_chunks = 1, last_chunks = 1;
     std::vector<void*> pipe_allocs;  // buffers of the two-kernel pipeline
     BatchArgs pipe{};                // device pointers of those buffers
     std::vector<void*> streams;      // one side stream per LDS tier
