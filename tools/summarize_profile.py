@@ -25,6 +25,33 @@ if stats:
         lines.append(f"| `{r['Name'][:70]}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.3f} | {float(r['AverageNs']) / 1e3:.1f} | "
                      f"{float(r['MinNs']) / 1e3:.1f} | {float(r['MaxNs']) / 1e3:.1f} | {float(r['Percentage']):.1f} |")
     lines.append("")
+trace = glob.glob(f"{src}/stats/**/*kernel_trace.csv", recursive=True)
+if trace:
+    rows = [r for r in csv.DictReader(open(trace[0])) if "vbt::" in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    name = lambda r: (re.findall(r"(\w+)\(vbt::", r["Kernel_Name"]) or ["?"])[0]
+    big = max(int(r["Grid_Size_X"]) for r in rows)
+    first = name(next(r for r in rows if int(r["Grid_Size_X"]) == big))
+    starts = [i for i, r in enumerate(rows) if int(r["Grid_Size_X"]) == big and name(r) == first]
+    spans = []
+    for a, b in zip(starts, starts[1:] + [len(rows)]):
+        step = [r for r in rows[a:b] if int(r["Grid_Size_X"]) > 0]
+        lat = [r for r in step if name(r) == "lattice_lds"]
+        if len(step) < 3 or not lat:
+            continue
+        t0 = int(step[0]["Start_Timestamp"])
+        spans.append({"step_us": (max(int(r["End_Timestamp"]) for r in step) - t0) / 1e3,
+                      "gen_us": sum((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in step if name(r).startswith("gen_candidates")) / 1e3,
+                      "lattice_span_us": (max(int(r["End_Timestamp"]) for r in lat) - min(int(r["Start_Timestamp"]) for r in lat)) / 1e3,
+                      "lattice_launches": len(lat)})
+    per = sorted(x["lattice_launches"] for x in spans)[len(spans) // 2]  # the last step also holds the parity-sample batch
+    spans = [s_ for s_ in spans if s_["lattice_launches"] == per] or spans
+    if spans:
+        avg = lambda k: sum(s_[k] for s_ in spans) / len(spans)
+        lines += ["## Per-step wall spans from the same kernel trace (the per-tier `lattice_lds` launches of a step run concurrently, so the",
+                  "   per-launch average above is not a wall time; bench.py times the same span with hipEvents on the launch stream)\n",
+                  f"| steps | whole step us | gen_candidates(+large) us | lattice_lds span (first start -> last end) us |\n|---|---|---|---|",
+                  f"| {len(spans)} full-batch steps | {avg('step_us'):.1f} | {avg('gen_us'):.1f} | {avg('lattice_span_us'):.1f} |\n"]
 pm = collections.OrderedDict()
 for f in sorted(glob.glob(f"{src}/pmc*/**/*counter_collection.csv", recursive=True)):
     rows = collections.OrderedDict()
@@ -64,8 +91,11 @@ if pm:
     json.dump({f"{i}:{k}:{g}": d for (i, k, g), d in pm.items()}, open(f"profiles/{tag}_pmc.json", "w"), indent=1)
     if all("FETCH_SIZE" in d for d in pm.values()):
         total = sum((d["FETCH_SIZE"] + d.get("WRITE_SIZE", 0)) * 1024 for d in pm.values())
+        by_kernel = collections.OrderedDict()
+        for (i, k, g), d in pm.items():
+            by_kernel[k] = by_kernel.get(k, 0) + int((d["FETCH_SIZE"] + d.get("WRITE_SIZE", 0)) * 1024)
         bench_cfg = json.load(open(f"{src}/bench_line.json"))["config"]["workload"] if os.path.getsize(f"{src}/bench_line.json") else ""
-        json.dump({"workload": bench_cfg, "hbm_bytes_per_step": int(total), "source": f"profiles/{tag}_pmc.json",
+        json.dump({"workload": bench_cfg, "hbm_bytes_per_step": int(total), "hbm_bytes_by_kernel": by_kernel, "source": f"profiles/{tag}_pmc.json",
                    "method": "sum over the step's kernels of (FETCH_SIZE + WRITE_SIZE) * 1024, separate rocprofv3 --pmc passes"},
                   open(f"profiles/{tag}_traffic.json", "w"), indent=1)
         lines.append(f"## HBM traffic of one step (all kernels): {total / 1e6:.1f} MB\n")
