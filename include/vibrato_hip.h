@@ -86,6 +86,9 @@ VBT_API int vbt_dict_from_sources_binmatrix(const char* lex, size_t lex_len, con
                                             size_t char_len, const char* unk_def, size_t unk_len, vbt_dict** out);
 /* Dictionary::reset_user_lexicon_from_reader(Some(csv) | None), dictionary.rs:209-229 */
 VBT_API int vbt_dict_set_user_lexicon(vbt_dict* dict, const char* csv, size_t len);
+/* Dictionary::map_connection_ids_from_iter(lmap, rmap), dictionary.rs:245-259: the i-th item (1-origin) is the
+ * old id mapped to new id i; id 0 (BOS/EOS) is fixed. Permutes lexicon params, unknown entries and the matrix. */
+VBT_API int vbt_dict_map_connection_ids(vbt_dict* dict, const uint16_t* lmap, size_t n_lmap, const uint16_t* rmap, size_t n_rmap);
 VBT_API void vbt_dict_free(vbt_dict* dict);
 
 VBT_API uint32_t vbt_dict_num_words(const vbt_dict* dict, uint32_t lex_type);
@@ -177,6 +180,12 @@ typedef struct vbt_call_stats {
     float ms_tier0, ms_tier12;
 } vbt_call_stats;
 VBT_API int vbt_workspace_set_timing(vbt_workspace* ws, int enabled);
+/* Worker::init_connid_counter / update_connid_counts (worker.rs:77-93, Lattice::add_connid_counts lattice.rs:170-183):
+ * while enabled, every batch adds, for each adjacent (left node, right node) pair of each lattice, 1 to
+ * lid[right_node.left_id] and rid[left_node.right_id] (sentences that take the fused fallback kernel are not counted:
+ * check vbt_call_stats.n_tier2).  vbt_workspace_connid_counts copies the totals (num_left / num_right u64). */
+VBT_API int vbt_workspace_count_connids(vbt_workspace* ws, int enabled);
+VBT_API int vbt_workspace_connid_counts(vbt_workspace* ws, uint64_t* lid, uint64_t* rid, int reset);
 /* Developer aid: per-phase shader-clock cycles summed over all sentences since the last reset
  * (enabled by VBT_PROFILE=1 in the environment when the workspace is created). out[0..7] =
  * decode, count, fill, end lists, pre-pass, gather, recurrence, emit; out[8] = sentences. */

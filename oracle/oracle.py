@@ -42,6 +42,8 @@ def lib():
         L.ora_dict_from_sources_binmatrix.argtypes = [u8p, sz, vp, u32, u32, u8p, sz, u8p, sz, u8p, sz]
         L.ora_dict_set_user_lexicon.restype = C.c_int
         L.ora_dict_set_user_lexicon.argtypes = [vp, u8p, sz, u8p, sz]
+        L.ora_dict_map_connection_ids.restype = C.c_int
+        L.ora_dict_map_connection_ids.argtypes = [vp, vp, sz, vp, sz, u8p, sz]
         L.ora_dict_free.argtypes = [vp]
         for f in ["ora_dict_num_left", "ora_dict_num_right", "ora_dict_num_categories"]:
             getattr(L, f).restype = u32
@@ -69,6 +71,7 @@ def lib():
         L.ora_worker_free.argtypes = [vp]
         L.ora_worker_reset_sentence.restype = C.c_int
         L.ora_worker_reset_sentence.argtypes = [vp, u8p, sz]
+        L.ora_worker_add_connid_counts.argtypes = [vp, vp, vp]
         L.ora_worker_tokenize.argtypes = [vp]
         L.ora_worker_tokenize_counted.argtypes = [vp]
         L.ora_worker_num_tokens.restype = u32
@@ -130,6 +133,14 @@ class Dictionary:
             csv = _b(csv)
             ok = lib().ora_dict_set_user_lexicon(self._h, csv, len(csv), err, 512)
         if not ok:
+            raise OracleError(err.value.decode("utf-8", "replace"))
+        return self
+
+    def map_connection_ids_from_iter(self, lmap, rmap):
+        l = np.ascontiguousarray(list(lmap), dtype=np.uint16)
+        r = np.ascontiguousarray(list(rmap), dtype=np.uint16)
+        err = C.create_string_buffer(512)
+        if not lib().ora_dict_map_connection_ids(self._h, l.ctypes.data, len(l), r.ctypes.data, len(r), err, 512):
             raise OracleError(err.value.decode("utf-8", "replace"))
         return self
 
@@ -241,6 +252,10 @@ class Worker:
             "word_cost": d.word_param(lex_type, word_id)[2],
             "total_cost": int(r["total_cost"]),
         }
+
+    def add_connid_counts(self, lid, rid):
+        """Worker::update_connid_counts for the sentence just tokenized; lid/rid are np.uint64 arrays."""
+        lib().ora_worker_add_connid_counts(self._h, lid.ctypes.data, rid.ctypes.data)
 
     def counters(self):
         buf = (C.c_uint64 * len(COUNTER_FIELDS))()

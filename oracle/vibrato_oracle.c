@@ -436,6 +436,7 @@ typedef struct ora_dict {
     uint32_t *unk_offsets;   /* unknown.rs:63-66 */
     unk_entry *unk_entries;
     uint32_t n_unk;
+    uint16_t *map_left, *map_right; /* ConnIdMapper, mapper.rs:9-12 (NULL = None) */
 } ora_dict;
 
 /* CharInfo bit layout, character.rs:10-24,56-95 */
@@ -821,6 +822,7 @@ ORA_API void ora_dict_free(ora_dict *d) {
         for (uint32_t i = 0; i < d->n_categories; i++) free(d->categories[i]);
         free(d->categories);
     }
+    free(d->map_left); free(d->map_right);
     free(d->unk_offsets);
     if (d->unk_entries) {
         for (uint32_t i = 0; i < d->n_unk; i++) free(d->unk_entries[i].feature);
@@ -891,6 +893,17 @@ ORA_API int ora_dict_set_user_lexicon(ora_dict *d, const char *csv, size_t len, 
     lexicon lx;
     lexicon_build(&lx, &ev, 1);
     entry_vec_free(&ev);
+    if (d->map_left) { /* dictionary.rs:214-217 */
+        for (uint32_t i = 0; i < lx.n_words; i++) {
+            if (lx.params[i].left_id >= d->num_left || lx.params[i].right_id >= d->num_right) {
+                lexicon_free(&lx);
+                set_err(err, errcap, "user_lexicon_rdr: includes invalid connection ids.");
+                return 0;
+            }
+            lx.params[i].left_id = d->map_left[lx.params[i].left_id];
+            lx.params[i].right_id = d->map_right[lx.params[i].right_id];
+        }
+    }
     if (!lexicon_verify(&lx, d->num_left, d->num_right)) {
         lexicon_free(&lx);
         set_err(err, errcap, "user_lexicon_rdr: includes invalid connection ids.");
@@ -898,6 +911,62 @@ ORA_API int ora_dict_set_user_lexicon(ora_dict *d, const char *csv, size_t len, 
     }
     d->user = lx;
     d->has_user = 1;
+    return 1;
+}
+
+/* ConnIdMapper::parse, mapper.rs:49-80 */
+static uint16_t *parse_id_map(const uint16_t *map, size_t n, size_t *out_len, char *err, size_t errcap) {
+    size_t len = n + 1;
+    if (len > 0x10000) { set_err(err, errcap, "map: too many ids"); return NULL; }
+    uint16_t *new_ids = (uint16_t *)malloc(2 * len);
+    for (size_t i = 0; i < len; i++) new_ids[i] = 0xFFFF;
+    new_ids[0] = 0;
+    for (size_t new_id = 1; new_id < len; new_id++) {
+        uint32_t old_id = map[new_id - 1];
+        if (old_id == 0) { set_err(err, errcap, "map: Id 0 is reserved."); free(new_ids); return NULL; }
+        if (old_id >= len) { set_err(err, errcap, "map: ids are out of range."); free(new_ids); return NULL; }
+        if (new_ids[old_id] != 0xFFFF) { set_err(err, errcap, "map: ids are duplicate."); free(new_ids); return NULL; }
+        new_ids[old_id] = (uint16_t)new_id;
+    }
+    *out_len = len;
+    return new_ids;
+}
+
+/* Dictionary::map_connection_ids_from_iter, dictionary.rs:245-259 (lexicon/param.rs:48-53,
+ * matrix_connector.rs:99-116, unknown.rs:206-211) */
+ORA_API int ora_dict_map_connection_ids(ora_dict *d, const uint16_t *lmap, size_t nl, const uint16_t *rmap, size_t nr,
+                                        char *err, size_t errcap) {
+    size_t ll, rl;
+    uint16_t *ml = parse_id_map(lmap, nl, &ll, err, errcap);
+    if (!ml) return 0;
+    uint16_t *mr = parse_id_map(rmap, nr, &rl, err, errcap);
+    if (!mr) { free(ml); return 0; }
+    if (ll != d->num_left || rl != d->num_right) {
+        set_err(err, errcap, "map: the mappings must cover every connection id except 0");
+        free(ml); free(mr);
+        return 0;
+    }
+    lexicon *lxs[2] = {&d->sys, d->has_user ? &d->user : NULL};
+    for (int k = 0; k < 2; k++) {
+        if (!lxs[k]) continue;
+        for (uint32_t i = 0; i < lxs[k]->n_words; i++) {
+            lxs[k]->params[i].left_id = ml[lxs[k]->params[i].left_id];
+            lxs[k]->params[i].right_id = mr[lxs[k]->params[i].right_id];
+        }
+    }
+    size_t n = (size_t)d->num_left * d->num_right;
+    int16_t *mapped = (int16_t *)malloc(n ? n * 2 : 2);
+    for (uint32_t r = 0; r < d->num_right; r++)
+        for (uint32_t l = 0; l < d->num_left; l++)
+            mapped[(size_t)ml[l] * d->num_right + mr[r]] = d->matrix[(size_t)l * d->num_right + r];
+    free(d->matrix);
+    d->matrix = mapped;
+    for (uint32_t i = 0; i < d->n_unk; i++) {
+        d->unk_entries[i].left_id = ml[d->unk_entries[i].left_id];
+        d->unk_entries[i].right_id = mr[d->unk_entries[i].right_id];
+    }
+    free(d->map_left); free(d->map_right);
+    d->map_left = ml; d->map_right = mr;
     return 1;
 }
 
@@ -1238,6 +1307,22 @@ static inline void tokenize_impl(ora_worker *w, int count) {
         min_idx = nd->min_idx;
     }
     if (count) { w->cnt.n_sentences++; w->cnt.n_bytes += w->input_len; w->cnt.n_chars += len; w->cnt.n_tokens += w->n_top; }
+}
+
+/* Lattice::add_connid_counts, lattice.rs:170-183 (Worker::update_connid_counts, worker.rs:86-93).
+ * lid / rid: caller-owned counters of num_left / num_right entries, incremented in place. */
+ORA_API void ora_worker_add_connid_counts(const ora_worker *w, uint64_t *lid, uint64_t *rid) {
+    if (w->len_char == 0) return;
+    for (uint32_t end_char = 1; end_char <= w->len_char; end_char++) {
+        const node_vec *e = &w->ends[end_char];
+        for (uint32_t a = 0; a < e->n; a++) {
+            const node *r = &e->v[a];
+            const node_vec *le = &w->ends[r->start_node];
+            for (uint32_t b = 0; b < le->n; b++) { lid[r->left_id] += 1; rid[le->v[b].right_id] += 1; }
+        }
+    }
+    const node_vec *le = &w->ends[w->len_char];
+    for (uint32_t b = 0; b < le->n; b++) { lid[0] += 1; rid[le->v[b].right_id] += 1; }
 }
 
 ORA_API void ora_worker_tokenize(ora_worker *w) { tokenize_impl(w, 0); }

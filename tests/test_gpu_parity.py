@@ -173,6 +173,30 @@ def test_cli_output_formats(fixture_sources):
     assert batch.format("mecab").startswith("京都東京都\tカスタム名詞\n京都\t京都,名詞,固有名詞,地名,一般,*,*,キョウト,京都,*,A,*,*,*,1/5\nEOS\n")
 
 
+def test_tokenize_cli_matches_reference_cli_format(tmp_path):
+    """python -m vibrato_amd.cli mirrors tokenize/src/main.rs (-i -u -O -S -M), incl. \\r\\n and empty lines."""
+    import io
+    import shutil
+    from conftest import GOLDEN
+    from vibrato_amd import cli
+    res = os.path.join(GOLDEN, "resources")
+    lines = ["京都東京都京都", "kampersanda", "", "東京 都  ", "一橋大学大学院"]
+    stdin = ("\n".join(lines[:2]) + "\r\n" + "\n".join(lines[2:]) + "\n").encode()
+    src = {k: open(os.path.join(res, k), "rb").read() for k in ["lex.csv", "matrix.def", "char.def", "unk.def", "user.csv"]}
+    for mode, S, M in [("mecab", False, None), ("wakati", True, 24), ("detail", True, 9)]:
+        do = ora.Dictionary.from_sources(src["lex.csv"], src["matrix.def"], src["char.def"], src["unk.def"]).reset_user_lexicon(src["user.csv"])
+        w = ora.Tokenizer(do, S, M or 0).new_worker()
+        exp = ""
+        for x in lines:
+            w.reset_sentence(x)
+            w.tokenize()
+            exp += ora.format_tokens(w, mode)
+        out = io.BytesIO()
+        argv = ["-i", res, "-u", os.path.join(res, "user.csv"), "-O", mode, "--block", "2"] + (["-S"] if S else []) + (["-M", str(M)] if M else [])
+        assert cli.main(argv, stdin=io.BytesIO(stdin), stdout=out) == 0
+        assert out.getvalue().decode() == exp, mode
+
+
 def test_workspace_device_api_and_roundtrip():
     """Device-resident API: tokens reproduce the input exactly when ignore_space is off
     (concatenated surfaces == sentence), a size-independent property usable at full size."""

@@ -48,6 +48,7 @@ SIGNATURES = {
     "vbt_dict_from_sources": (_int, [_cp, _sz, _cp, _sz, _cp, _sz, _cp, _sz, _PP]),
     "vbt_dict_from_sources_binmatrix": (_int, [_cp, _sz, _vp, _u32, _u32, _cp, _sz, _cp, _sz, _PP]),
     "vbt_dict_set_user_lexicon": (_int, [_vp, _cp, _sz]),
+    "vbt_dict_map_connection_ids": (_int, [_vp, _vp, _sz, _vp, _sz]),
     "vbt_dict_free": (None, [_vp]),
     "vbt_dict_num_words": (_u32, [_vp, _u32]),
     "vbt_dict_num_left": (_u32, [_vp]),
@@ -82,6 +83,8 @@ SIGNATURES = {
     "vbt_tokenize_batch_device": (_int, [_vp, _vp, _vp, _u64, _u64, _vp]),
     "vbt_workspace_results": (_int, [_vp, _PP, _PP, _PP, _PP]),
     "vbt_workspace_set_timing": (_int, [_vp, _int]),
+    "vbt_workspace_count_connids": (_int, [_vp, _int]),
+    "vbt_workspace_connid_counts": (_int, [_vp, _vp, _vp, _int]),
     "vbt_workspace_profile": (_int, [_vp, C.POINTER(C.c_uint64), _int]),
     "vbt_workspace_stats": (_int, [_vp, C.POINTER(CallStats)]),
 }

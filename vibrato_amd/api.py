@@ -44,6 +44,13 @@ class Dictionary:
             N.check(N.lib().vbt_dict_set_user_lexicon(self._handle(), csv, len(csv)))
         return self
 
+    def map_connection_ids_from_iter(self, lmap, rmap):
+        """Dictionary::map_connection_ids_from_iter (dictionary.rs:245-259)."""
+        l = np.ascontiguousarray(list(lmap), dtype=np.uint16)
+        r = np.ascontiguousarray(list(rmap), dtype=np.uint16)
+        N.check(N.lib().vbt_dict_map_connection_ids(self._handle(), l.ctypes.data, len(l), r.ctypes.data, len(r)))
+        return self
+
     def num_words(self, lex_type=0):
         return N.lib().vbt_dict_num_words(self._handle(), lex_type)
 
@@ -307,6 +314,18 @@ class Batch:
             N.lib().vbt_free(p)
 
 
+def compute_connid_probs(lid_count, rid_count):
+    """ConnIdCounter::compute_probs (mapper.rs:108-146): per side, (id, count / sum) without id 0, sorted by
+    probability descending then id ascending -- the content of the reference's *.lmap / *.rmap files."""
+    out = []
+    for cnt in (np.asarray(lid_count, dtype=np.float64), np.asarray(rid_count, dtype=np.float64)):
+        probs = cnt / cnt.sum()
+        items = [(i, float(probs[i])) for i in range(1, len(probs))]
+        items.sort(key=lambda t: (-t[1], t[0]))
+        out.append(items)
+    return out[0], out[1]
+
+
 class Workspace:
     """Device-resident batch interface (zero host copies): what bench.py times."""
 
@@ -332,6 +351,18 @@ class Workspace:
         p = [C.c_void_p() for _ in range(4)]
         N.check(N.lib().vbt_workspace_results(self._h, *[C.byref(x) for x in p]))
         return {"tokens": p[0].value, "tok_off": p[1].value, "tok_cnt": p[2].value, "total": p[3].value}
+
+    def count_connids(self, on=True):
+        """Worker::init_connid_counter (worker.rs:77-84): start accumulating connection-id usage."""
+        N.check(N.lib().vbt_workspace_count_connids(self._h, int(on)))
+
+    def connid_counts(self, reset=False):
+        """(lid_count[num_left], rid_count[num_right]) accumulated by Worker::update_connid_counts."""
+        d = self.tokenizer.dictionary()
+        lid = np.zeros(d.num_left, dtype=np.uint64)
+        rid = np.zeros(d.num_right, dtype=np.uint64)
+        N.check(N.lib().vbt_workspace_connid_counts(self._h, lid.ctypes.data, rid.ctypes.data, int(reset)))
+        return lid, rid
 
     PHASES = ("decode", "count", "fill", "end_lists", "prepass", "gather", "recurrence", "emit")
 

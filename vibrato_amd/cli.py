@@ -1,0 +1,67 @@
+"""`tokenize`-compatible command line (reference: tokenize/src/main.rs:31-132).
+
+    python -m vibrato_amd.cli -i DICT_DIR [-u user.csv] [-O mecab|wakati|detail] [-S] [-M N] < lines.txt
+
+DICT_DIR holds MeCab-format sources (lex.csv, matrix.def, char.def, unk.def): the compiled
+`system.dic.zst` container of the reference (zstd + bincode + crawdad blob) is not readable
+offline -- see DESIGN.md "next" rows.  Lines are read with the semantics of BufRead::lines()
+(`\\n` / `\\r\\n` stripped) and tokenized in blocks of --block lines per GPU batch; the bytes
+written are exactly those of the reference CLI for the same mode.
+"""
+import argparse
+import os
+import sys
+
+from . import api
+
+
+def read_sources(d):
+    out = []
+    for f in ("lex.csv", "matrix.def", "char.def", "unk.def"):
+        with open(os.path.join(d, f), "rb") as fh:
+            out.append(fh.read())
+    return out
+
+
+def main(argv=None, stdin=None, stdout=None):
+    ap = argparse.ArgumentParser(prog="tokenize", description="Predicts morphemes")
+    ap.add_argument("-i", "--sysdic", required=True, help="directory with lex.csv, matrix.def, char.def, unk.def")
+    ap.add_argument("-u", "--userlex-csv", default=None, help="User lexicon file.")
+    ap.add_argument("-O", "--output-mode", default="mecab", choices=["mecab", "wakati", "detail"])
+    ap.add_argument("-S", "--ignore-space", action="store_true", help="Ignores white spaces in input strings.")
+    ap.add_argument("-M", "--max-grouping-len", type=int, default=None, help="Maximum length of unknown words.")
+    ap.add_argument("--block", type=int, default=65536, help="lines per GPU batch")
+    ap.add_argument("--device", type=int, default=-1)
+    args = ap.parse_args(argv)
+    stdin = stdin or sys.stdin.buffer
+    stdout = stdout or sys.stdout.buffer
+
+    print("Loading the dictionary...", file=sys.stderr)
+    d = api.SystemDictionaryBuilder.from_readers(*read_sources(args.sysdic))
+    if args.userlex_csv:
+        with open(args.userlex_csv, "rb") as fh:
+            d.reset_user_lexicon_from_reader(fh.read())
+    tok = api.Tokenizer(d, device=args.device).ignore_space(args.ignore_space).max_grouping_len(args.max_grouping_len or 0)
+    print("Ready to tokenize", file=sys.stderr)
+
+    def flush(lines):
+        if lines:
+            stdout.write(tok.tokenize_batch(lines).format(args.output_mode).encode("utf-8"))
+
+    block = []
+    for raw in stdin:
+        if raw.endswith(b"\n"):
+            raw = raw[:-1]
+            if raw.endswith(b"\r"):
+                raw = raw[:-1]
+        block.append(raw)
+        if len(block) >= args.block:
+            flush(block)
+            block = []
+    flush(block)
+    stdout.flush()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -149,6 +149,14 @@ int vbt_dict_set_user_lexicon(vbt_dict* dict, const char* csv, size_t len) {
     });
 }
 
+int vbt_dict_map_connection_ids(vbt_dict* dict, const uint16_t* lmap, size_t n_lmap, const uint16_t* rmap, size_t n_rmap) {
+    return guarded([&] {
+        if (!dict || !dict->d || !dict->owned) throw Error(VBT_ERR_INVALID_ARGUMENT, "dict: null or consumed");
+        if ((!lmap && n_lmap) || (!rmap && n_rmap)) throw Error(VBT_ERR_INVALID_ARGUMENT, "null argument");
+        map_connection_ids(*dict->d, lmap, n_lmap, rmap, n_rmap);
+    });
+}
+
 void vbt_dict_free(vbt_dict* dict) { delete dict; }
 
 uint32_t vbt_dict_num_words(const vbt_dict* dict, uint32_t lex_type) {
@@ -404,6 +412,14 @@ int vbt_workspace_results(const vbt_workspace* ws, const vbt_token_rec** d_token
 int vbt_workspace_set_timing(vbt_workspace* ws, int enabled) {
     ws->w->timing = enabled != 0;
     return VBT_OK;
+}
+
+int vbt_workspace_count_connids(vbt_workspace* ws, int enabled) {
+    return guarded([&] { ws->w->enable_connid_counts(enabled != 0); });
+}
+
+int vbt_workspace_connid_counts(vbt_workspace* ws, uint64_t* lid, uint64_t* rid, int reset) {
+    return guarded([&] { ws->w->read_connid_counts(lid, rid, reset != 0); });
 }
 
 int vbt_workspace_profile(vbt_workspace* ws, uint64_t out[9], int reset) {

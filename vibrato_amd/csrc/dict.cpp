@@ -529,6 +529,53 @@ Dictionary* build_dictionary(std::string_view lex, std::string_view matrix_def, 
     return d.release();
 }
 
+namespace {
+
+// ConnIdMapper::parse (mapper.rs:49-80)
+std::vector<uint16_t> parse_id_map(const uint16_t* map, size_t n) {
+    std::vector<uint32_t> old_ids{0};
+    for (size_t i = 0; i < n; ++i) {
+        if (map[i] == 0) fail(VBT_ERR_INVALID_ARGUMENT, "map: Id 0 is reserved.");
+        old_ids.push_back(map[i]);
+    }
+    if (old_ids.size() > 0x10000) fail(VBT_ERR_INVALID_ARGUMENT, "map: too many ids");
+    std::vector<uint16_t> new_ids(old_ids.size(), 0xFFFF);
+    new_ids[0] = 0;
+    for (size_t new_id = 1; new_id < old_ids.size(); ++new_id) {
+        const uint32_t old_id = old_ids[new_id];
+        if (old_id >= new_ids.size()) fail(VBT_ERR_INVALID_ARGUMENT, "map: ids are out of range.");
+        if (new_ids[old_id] != 0xFFFF) fail(VBT_ERR_INVALID_ARGUMENT, "map: ids are duplicate.");
+        new_ids[old_id] = (uint16_t)new_id;
+    }
+    return new_ids;
+}
+
+void map_lexicon(Lexicon& lx, const std::vector<uint16_t>& ml, const std::vector<uint16_t>& mr) {  // param.rs:48-53
+    for (WordParam& p : lx.params) { p.left_id = ml[p.left_id]; p.right_id = mr[p.right_id]; }
+    for (Entry& e : lx.entries) e.left_right = (uint32_t)ml[e.left_right & 0xFFFF] | ((uint32_t)mr[e.left_right >> 16] << 16);
+}
+
+}  // namespace
+
+void map_connection_ids(Dictionary& d, const uint16_t* lmap, size_t n_lmap, const uint16_t* rmap, size_t n_rmap) {
+    std::vector<uint16_t> ml = parse_id_map(lmap, n_lmap), mr = parse_id_map(rmap, n_rmap);
+    if (ml.size() != d.num_left || mr.size() != d.num_right)  // assert_eq! in matrix_connector.rs:100-101
+        fail(VBT_ERR_INVALID_ARGUMENT, "map: the mappings must cover every connection id except 0");
+    map_lexicon(d.system, ml, mr);
+    if (d.has_user) map_lexicon(d.user, ml, mr);
+    std::vector<int16_t> mapped(d.matrix.size());  // matrix_connector.rs:99-116
+    for (uint32_t l = 0; l < d.num_left; ++l) {
+        const int16_t* src = d.matrix.data() + (size_t)l * d.num_right;
+        int16_t* dst = mapped.data() + (size_t)ml[l] * d.num_right;
+        for (uint32_t r = 0; r < d.num_right; ++r) dst[mr[r]] = src[r];
+    }
+    d.matrix.swap(mapped);
+    for (Entry& e : d.unk_entries)  // unknown.rs:206-211
+        e.left_right = (uint32_t)ml[e.left_right & 0xFFFF] | ((uint32_t)mr[e.left_right >> 16] << 16);
+    d.mapper_left = std::move(ml);
+    d.mapper_right = std::move(mr);
+}
+
 void set_user_lexicon(Dictionary& d, const char* csv, size_t len) {
     if (!csv) {
         d.has_user = false;
@@ -538,6 +585,12 @@ void set_user_lexicon(Dictionary& d, const char* csv, size_t len) {
     auto rows = parse_lexicon_csv(std::string_view(csv, len), "lex.csv");
     Lexicon lx;
     build_lexicon(lx, rows, "lex.csv");
+    if (!d.mapper_left.empty()) {  // dictionary.rs:214-217: the stored mapper is applied before verification
+        for (const WordParam& p : lx.params)
+            if (p.left_id >= d.mapper_left.size() || p.right_id >= d.mapper_right.size())
+                fail(VBT_ERR_INVALID_ARGUMENT, "user_lexicon_rdr: includes invalid connection ids.");
+        map_lexicon(lx, d.mapper_left, d.mapper_right);
+    }
     if (!verify_ids(lx.params, d.num_left, d.num_right))
         fail(VBT_ERR_INVALID_ARGUMENT, "user_lexicon_rdr: includes invalid connection ids.");
     d.user = std::move(lx);

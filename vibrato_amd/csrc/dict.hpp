@@ -71,6 +71,9 @@ struct Dictionary {
     std::vector<uint32_t> unk_offsets;  // per category, unknown.rs:63-66
     std::vector<Entry> unk_entries;     // word_id = row index
     std::vector<std::string> unk_features;
+    // ConnIdMapper of the last map_connection_ids call (mapper.rs:9-12); empty = none.
+    // new id = mapper_left[old id]; applied to user lexicons attached later (dictionary.rs:214-217).
+    std::vector<uint16_t> mapper_left, mapper_right;
 
     int cate_id(std::string_view name) const;
 };
@@ -80,6 +83,10 @@ struct Dictionary {
 Dictionary* build_dictionary(std::string_view lex, std::string_view matrix_def, const int16_t* matrix_bin,
                              uint32_t num_right, uint32_t num_left, std::string_view char_def,
                              std::string_view unk_def);
+
+// Dictionary::map_connection_ids_from_iter (dictionary.rs:245-259): the i-th item (1-origin) of lmap / rmap
+// is the OLD id that becomes new id i (ConnIdMapper::parse, mapper.rs:49-80).
+void map_connection_ids(Dictionary& d, const uint16_t* lmap, size_t n_lmap, const uint16_t* rmap, size_t n_rmap);
 
 // Dictionary::reset_user_lexicon_from_reader (dictionary.rs:209-229).
 void set_user_lexicon(Dictionary& d, const char* csv, size_t len);

@@ -1294,6 +1294,27 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
         }
         PROF_MARK(6);
 
+        if (A.lid_count) {
+            // Lattice::add_connid_counts (lattice.rs:170-183): for every inserted node r and every node l in
+            // ends[r.start_node]: lid_count[r.left_id] += 1, rid_count[l.right_id] += 1; then the same for EOS
+            // (left_id 0) against ends[len_char].  Only inserted ("live") nodes exist in the reference's lists.
+            for (uint32_t k = 0; k < S; ++k) {
+                const uint32_t v = __builtin_amdgcn_readfirstlane(sp[k]);
+                const uint32_t p = (k + 1 == S) ? n : (v & 0xFFFFu), sw = v >> 16;  // EOS pairs with ends[len_char]
+                const uint32_t p_beg = __builtin_amdgcn_readfirstlane(end_off[p]), p_end = __builtin_amdgcn_readfirstlane(end_off[p + 1]);
+                uint32_t c_beg = C, nc = 1;
+                if (k + 1 < S) { c_beg = __builtin_amdgcn_readfirstlane((uint32_t)cand_off[sw]); nc = __builtin_amdgcn_readfirstlane((uint32_t)cand_off[sw + 1]) - c_beg; }
+                uint32_t live = 0;
+                for (uint32_t j0 = p_beg; j0 < p_end; j0 += 64) {
+                    const uint32_t j = j0 + ln;
+                    const bool alive = j < p_end && (uint32_t)e_key[j] != 0xFFFFFFFFu;
+                    live += (uint32_t)__popcll(__ballot(alive));
+                    if (alive) atomicAdd(&A.rid_count[e_right[j]], (unsigned long long)nc);
+                }
+                for (uint32_t c = c_beg + ln; c < c_beg + nc; c += 64) atomicAdd(&A.lid_count[nd_left[c]], (unsigned long long)live);
+            }
+        }
+
         // ---- back-trace + token records ----
         uint16_t* path = reinterpret_cast<uint16_t*>(lens);  // the length masks are dead now; tokens <= chars
         uint32_t T = 0;
@@ -1580,6 +1601,8 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
     a.lists = d_over; a.list_stride = (uint32_t)stride; a.n_tiers = (uint32_t)T;
     a.tier_prio = env_u32("VBT_TIER_PRIO", 3);
     a.sid0 = 0; a.cctrl = d_cctrl; a.list_off = 0;
+    a.lid_count = count_connids ? d_connid : nullptr;
+    a.rid_count = count_connids ? d_connid + tok.dict().num_left : nullptr;
     for (size_t t = 0; t < T; ++t) a.tier_bytes[t] = tiers[t];
     const DevDict& D = tok.dev();
     auto rec = [&](int i) { if (timing) HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(ev[i]), stream)); };
@@ -1700,6 +1723,30 @@ void Workspace::stats(vbt_call_stats* out) {
         HIP_CHECK(hipEventElapsedTime(&out->ms_tier0, reinterpret_cast<hipEvent_t>(ev[0]), reinterpret_cast<hipEvent_t>(ev[1])));
         HIP_CHECK(hipEventElapsedTime(&out->ms_tier12, reinterpret_cast<hipEvent_t>(ev[1]), reinterpret_cast<hipEvent_t>(ev[2])));
     }
+}
+
+void Workspace::enable_connid_counts(bool on) {
+    HIP_CHECK(hipSetDevice(tok.device()));
+    if (on && fused) throw Error(VBT_ERR_UNSUPPORTED, "connection-id counting needs the two-kernel pipeline (unset VBT_FUSED)");
+    const size_t words = (size_t)tok.dict().num_left + tok.dict().num_right;
+    if (on && !d_connid) {
+        void* p = nullptr;
+        HIP_CHECK(hipMalloc(&p, std::max<size_t>(words * 8, 16)));
+        pipe_allocs.push_back(p);
+        d_connid = static_cast<unsigned long long*>(p);
+        HIP_CHECK(hipMemset(d_connid, 0, words * 8));
+    }
+    count_connids = on;
+}
+
+void Workspace::read_connid_counts(uint64_t* lid, uint64_t* rid, bool reset) {
+    HIP_CHECK(hipSetDevice(tok.device()));
+    if (!d_connid) throw Error(VBT_ERR_INVALID_STATE, "connection-id counting was never enabled");
+    HIP_CHECK(hipStreamSynchronize(reinterpret_cast<hipStream_t>(last_stream)));
+    const size_t nl = tok.dict().num_left, nr = tok.dict().num_right;
+    HIP_CHECK(hipMemcpy(lid, d_connid, nl * 8, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(rid, d_connid + nl, nr * 8, hipMemcpyDeviceToHost));
+    if (reset) HIP_CHECK(hipMemset(d_connid, 0, (nl + nr) * 8));
 }
 
 void Workspace::read_profile(uint64_t* out, bool reset) {

@@ -80,6 +80,9 @@ struct BatchArgs {
     uint32_t sid0;
     uint32_t* cctrl;
     uint32_t list_off;  // offset of this launch's entries inside every list region
+    // optional connection-id usage counters (Worker::update_connid_counts, worker.rs:77-93): nullptr = off
+    unsigned long long* lid_count;
+    unsigned long long* rid_count;
     uint32_t tier_bytes[8];
 };
 
@@ -130,6 +133,10 @@ class Workspace {
     std::vector<void*> tier_events;
     void* ev_fork = nullptr;
     bool fused = false;              // VBT_FUSED=1: the single fused kernel per sentence (A/B reference)
+    unsigned long long* d_connid = nullptr;  // [num_left + num_right] usage counters, allocated on first use
+    bool count_connids = false;
+    void enable_connid_counts(bool on);
+    void read_connid_counts(uint64_t* lid, uint64_t* rid, bool reset);
     unsigned long long* d_prof = nullptr;
     char* d_scratch = nullptr;
     uint64_t scratch_bytes = 0;
