@@ -153,6 +153,26 @@ def test_edge_cases(fixture_sources):
     assert empty.format("mecab") == ""
 
 
+@pytest.mark.parametrize("ignore_space", [False, True])
+def test_group_spans_at_length_mask_boundaries(fixture_sources, ignore_space):
+    """Grouped unknown words of exactly 32 / 33 / 63 / 64 / 65 characters (bits 31 and 63 of the per-position
+    length mask, and the > 64 overflow path) whose interior positions are unreachable, around skipped spaces."""
+    s = fixture_sources
+    d = V.SystemDictionaryBuilder.from_readers(s["lex.csv"], s["matrix.def"], s["char.def"], s["unk.def"])
+    tok = V.Tokenizer(d).ignore_space(ignore_space)
+    do = ora.Dictionary.from_sources(s["lex.csv"], s["matrix.def"], s["char.def"], s["unk.def"])
+    to = ora.Tokenizer(do, ignore_space, 0)
+    sents = []
+    for k in (31, 32, 33, 63, 64, 65, 127, 128):
+        sents += ["a" * k + "1" * 25 + "a" * k + "京都", "東京" + "a" * k, "a" * k + " " + "1" * k + "  " + "a" * k,
+                  " " * k + "a" * k + " " * k, "京都 " + " " * (k - 1) + "東京都" + "a" * k + " "]
+    enc = [x.encode() for x in sents]
+    offs = np.zeros(len(enc) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([len(e) for e in enc])
+    text = np.frombuffer(b"".join(enc), dtype=np.uint8)
+    _assert_batch_equal(to, tok, text, offs)
+
+
 def test_cli_output_formats(fixture_sources):
     """Byte-identical tokenize CLI output (tokenize/src/main.rs:83-127) vs the oracle's formatter."""
     s = fixture_sources

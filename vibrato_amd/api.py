@@ -364,7 +364,7 @@ class Workspace:
         N.check(N.lib().vbt_workspace_connid_counts(self._h, lid.ctypes.data, rid.ctypes.data, int(reset)))
         return lid, rid
 
-    PHASES = ("decode", "count", "fill", "end_lists", "prepass", "gather", "recurrence", "emit")
+    PHASES = ("decode", "count", "fill", "end_lists", "prepass", "pass_records", "recurrence", "emit")
 
     def profile(self, reset=True):
         """Per-phase cycle totals (needs VBT_PROFILE=1 at workspace creation)."""

@@ -16,6 +16,7 @@
 // search_min_node (lattice.rs:141-146).  Candidates of positions the sweep never visits
 // (unreachable or inside a skipped space run) keep cost = kInvalidCost and are ignored.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include <algorithm>
 #include <cstdio>
@@ -96,6 +97,30 @@ __device__ __forceinline__ uint64_t group_min_u64(uint64_t key, uint32_t lg) {  
     return key;
 }
 
+// The same reduction on split keys: minimum of the high words first, then the minimum low word among
+// the lanes that hold it (u64 order is lexicographic in (hi, lo)).  Each level is one v_min_u32 with a
+// DPP source operand; the 32- and 64-lane levels use the gfx950 row / half-wave swaps
+// (v_permlane16_swap / v_permlane32_swap) instead of the LDS crossbar.
+template <int kCtrl>
+__device__ __forceinline__ uint32_t dpp_min_u32(uint32_t x) {
+    const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, kCtrl, 0xF, 0xF, true);
+    return o < x ? o : x;
+}
+__device__ __forceinline__ uint32_t group_min_u32(uint32_t x, uint32_t lg) {  // lg is wave-uniform
+    if (lg >= 1) x = dpp_min_u32<0xB1>(x);
+    if (lg >= 2) x = dpp_min_u32<0x4E>(x);
+    if (lg >= 3) x = dpp_min_u32<0x141>(x);
+    if (lg >= 4) x = dpp_min_u32<0x140>(x);
+    if (lg >= 5) { const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false); x = r[0] < r[1] ? r[0] : r[1]; }
+    if (lg >= 6) { const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false); x = r[0] < r[1] ? r[0] : r[1]; }
+    return x;
+}
+__device__ __forceinline__ void group_min_split(uint32_t& hi, uint32_t& lo, uint32_t lg) {
+    const uint32_t m = group_min_u32(hi, lg);
+    lo = group_min_u32(hi == m ? lo : 0xFFFFFFFFu, lg);
+    hi = m;
+}
+
 // 128-bit window helpers (shift distances 0..64), by value so everything stays in registers
 struct U128 { uint64_t lo, hi; };
 __device__ __forceinline__ U128 shr128(U128 w, uint32_t d) {
@@ -109,7 +134,8 @@ __device__ __forceinline__ U128 or_shl128(U128 w, uint64_t m, uint32_t d) {
     return U128{w.lo | lo_m, w.hi | hi_m};
 }
 __device__ __forceinline__ uint64_t uniform64(uint64_t v) {
-    return ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)v);
+    // (the builtin returns int: without the casts the low half would sign-extend into the high half)
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v);
 }
 
 // One step of the position sweep: candidates [cbeg, cbeg+nc) connect to end-list slots [pbeg, pbeg+np).
@@ -654,9 +680,10 @@ __device__ __forceinline__ uint64_t process_sentence(const DevDict& D, const Bat
     }
     PROF_MARK(7);
     if (A.prof && ln == 0) {
+        unsigned long long* pr_ = A.prof + (size_t)(sid & (kProfSlots - 1)) * (kProfPhases + 1);
 #pragma unroll
-        for (int i = 0; i < kProfPhases; ++i) atomicAdd(&A.prof[i], (unsigned long long)prof_acc[i]);
-        atomicAdd(&A.prof[kProfPhases], 1ull);
+        for (int i = 0; i < kProfPhases; ++i) atomicAdd(&pr_[i], (unsigned long long)prof_acc[i]);
+        atomicAdd(&pr_[kProfPhases], 1ull);
     }
 #undef PROF_MARK
     return 0;
@@ -918,8 +945,9 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
     route(tier);
     PROF_MARK(2);
     if (A.prof && ln == 0) {
-        for (int i = 0; i < 3; ++i) atomicAdd(&A.prof[i], (unsigned long long)prof_acc[i]);
-        atomicAdd(&A.prof[kProfPhases], 1ull);
+        unsigned long long* pr_ = A.prof + (size_t)(sid & (kProfSlots - 1)) * (kProfPhases + 1);
+        for (int i = 0; i < 3; ++i) atomicAdd(&pr_[i], (unsigned long long)prof_acc[i]);
+        atomicAdd(&pr_[kProfPhases], 1ull);
     }
 #undef PROF_MARK
 }
@@ -994,14 +1022,15 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
     for (;;) {
         uint32_t item = 0;
         if (ln == 0) item = atomicAdd(cursor, 1u);
-        item = __shfl(item, 0);
+        item = __builtin_amdgcn_readfirstlane(item);  // lane 0 is always active here; keeps everything below scalar
         if (item >= count) break;
-        const uint32_t sid = list[item];
+        const uint32_t sid = __builtin_amdgcn_readfirstlane(list[item]);
         uint64_t prof_t = A.prof ? clock64() : 0, prof_acc[kProfPhases] = {};
 #define PROF_MARK(i) do { if (A.prof) { const uint64_t t_ = clock64(); prof_acc[i] += t_ - prof_t; prof_t = t_; } } while (0)
-        const uint32_t n = A.s_n[sid], C = A.s_C[sid];
-        const uint32_t G = A.s_flags[sid] & 0xFFFFu, ngmax = A.s_flags[sid] >> 16;
-        const size_t slot0 = (size_t)A.offsets[sid] + sid;
+        const uint32_t n = __builtin_amdgcn_readfirstlane(A.s_n[sid]), C = __builtin_amdgcn_readfirstlane(A.s_C[sid]);
+        const uint32_t sflags = __builtin_amdgcn_readfirstlane(A.s_flags[sid]);
+        const uint32_t G = sflags & 0xFFFFu, ngmax = sflags >> 16;
+        const size_t slot0 = (size_t)uniform64(A.offsets[sid]) + sid;
         const uint4* __restrict__ nd = A.g_nd + (size_t)A.node_factor * slot0;
         const uint4* __restrict__ pc = A.g_pc + slot0;
 
@@ -1110,44 +1139,65 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
         //     length masks of 64 consecutive positions sit in one VGPR pair and are read with
         //     v_readlane, so the loop touches LDS only when it crosses a 64-position boundary;
         // (b) lanes then build the step records in parallel.
-        uint32_t S = 0, sn_eos = 0;
+        uint32_t S = 0, sn_eos = n;
         bool windowed = true;
         {
-            U128 w{1, 0};
-            uint32_t p = 0, chunk = 0;
-            uint32_t l_lo = ln < n ? (uint32_t)lens[ln] : 0u, l_hi = ln < n ? (uint32_t)(lens[ln] >> 32) : 0u;
-            while (p < n) {
-                w.lo = uniform64(w.lo);
-                w.hi = uniform64(w.hi);
-                p = __builtin_amdgcn_readfirstlane(p);
-                if (!(w.lo & 1)) {
-                    uint32_t z = w.lo ? (uint32_t)__builtin_ctzll(w.lo) : 64u;
-                    if (z > n - p) z = n - p;
-                    w = shr128(w, z);
-                    p += z;
-                    continue;
-                }
-                uint32_t sw = p;
-                if (space_mode) {
-                    const uint32_t gf = __builtin_amdgcn_readfirstlane(grpf[p]);
-                    if (gf >> 31) sw += gf & 0x7FFFFFFFu;
-                }
-                if (sw >= n) break;
-                const uint32_t d = sw - p + 1;
-                if (d > 64) { windowed = false; break; }
-                if (sw - chunk >= 64) {
-                    chunk = sw & ~63u;
+            // Bit-serial sweep, all state in SGPRs.  w bit i <=> position p + 1 + i is the end of an inserted
+            // node; cur <=> position p is (has_previous_node, tokenizer.rs:108).  A visited position ORs its
+            // length mask into w; a visited space run of r characters (ignore_space, tokenizer.rs:113-125)
+            // hands its visit over to position p + r and drops the reachability of everything in between
+            // (the reference continues from start_word + 1).  The visited set of 64 positions is collected
+            // in a mask and turned into step records by the lanes afterwards.
+            auto sweep = [&](auto space_tag) {
+                constexpr bool kSpace = decltype(space_tag)::value;
+                uint64_t w = 0;
+                uint32_t cur = 1, pend = 0, stop = 0;
+                for (uint32_t chunk = 0; chunk < n && !stop; chunk += 64) {
                     const uint32_t i = chunk + ln;
-                    l_lo = i < n ? (uint32_t)lens[i] : 0u;
-                    l_hi = i < n ? (uint32_t)(lens[i] >> 32) : 0u;
+                    const uint64_t lm = i < n ? lens[i] : 0ull;
+                    const uint32_t l_lo = (uint32_t)lm, l_hi = (uint32_t)(lm >> 32);
+                    const uint32_t gf = (kSpace && i < n) ? grpf[i] : 0u;
+                    const uint64_t spm = kSpace ? __ballot((gf >> 31) != 0) : 0ull;
+                    const uint32_t cnt = n - chunk < 64 ? n - chunk : 64;
+                    uint64_t vis = 0, visp = 0;
+#pragma unroll
+                    for (uint32_t k = 0; k < 64; ++k) {
+                        if ((k & 7u) == 0 && k >= cnt) break;
+                        const uint64_t bit = 1ull << k;
+                        const uint64_t m = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(l_hi, k) << 32) | (uint32_t)__builtin_amdgcn_readlane(l_lo, k);
+                        if constexpr (kSpace) {
+                            if (cur && !pend && (spm & bit)) {  // rare: a reachable space run
+                                const uint32_t r = __builtin_amdgcn_readlane(gf, k) & 0x7FFFFFFFu;
+                                if (chunk + k + r >= n) { sn_eos = chunk + k; stop = 1; w = 0; }  // only spaces left: EOS connects here
+                                else if (r > 63) { windowed = false; stop = 1; w = 0; }
+                                else {
+                                    visp |= bit;
+                                    w = (w & ~((1ull << r) - 1ull)) | (1ull << (r - 1));
+                                    pend = 1;
+                                }
+                            } else {
+                                w |= cur ? m : 0ull;
+                                vis |= (cur && !pend) ? bit : 0ull;
+                                pend = cur ? 0u : pend;
+                            }
+                        } else {
+                            w |= cur ? m : 0ull;
+                            vis |= cur ? bit : 0ull;
+                        }
+                        cur = (uint32_t)w & 1u;
+                        w >>= 1;
+                    }
+                    if (cnt < 64) { vis &= (1ull << cnt) - 1ull; visp &= (1ull << cnt) - 1ull; }
+                    const uint64_t any = vis | visp;
+                    if ((any >> ln) & 1ull) {
+                        const uint32_t idx = S + (uint32_t)__popcll(any & ((1ull << ln) - 1ull));
+                        const uint32_t sw = ((visp >> ln) & 1ull) ? i + (gf & 0x7FFFFFFFu) : i;
+                        sp[idx] = i | (sw << 16);
+                    }
+                    S += (uint32_t)__popcll(any);
                 }
-                const uint64_t lm = ((uint64_t)__builtin_amdgcn_readlane(l_hi, sw - chunk) << 32) | __builtin_amdgcn_readlane(l_lo, sw - chunk);
-                if (ln == 0) sp[S] = p | (sw << 16);
-                ++S;
-                w = shr128(or_shl128(w, lm, d), d);
-                p = sw + 1;
-            }
-            sn_eos = p < n ? p : n;
+            };
+            if (space_mode) sweep(std::true_type{}); else sweep(std::false_type{});
         }
         if (!windowed) {  // > 63 skipped spaces in a row: generic pre-pass of the fused kernel
             if (ln == 0) atomicAdd(&A.ctrl[27], 1u);
@@ -1158,6 +1208,7 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
         ++S;  // + the EOS step (insert_eos(start_node), tokenizer.rs:138)
         if (ln == 0) sp[S - 1] = sn_eos | (0xFFFFu << 16);
         __syncthreads();
+        PROF_MARK(4);
         // (b) lanes = steps: split every step into passes of <= 64 (group, predecessor) lanes and lay
         //     the pass records out contiguously (exclusive scan of the pass counts).
         uint32_t SL = 0;
@@ -1204,11 +1255,11 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
         }
         // no LDS left for the pass records: fused kernel
         constexpr uint32_t kDepth = 8;  // prefetch distance of the fused loop, in passes
-        if (SL + 2 * kDepth > sl_cap) { if (ln == 0) atomicAdd(&A.ctrl[29], 1u); list_push(A, A.n_tiers, sid); __syncthreads(); continue; }
+        if (SL + 2 * kDepth + 1 > sl_cap) { if (ln == 0) atomicAdd(&A.ctrl[29], 1u); list_push(A, A.n_tiers, sid); __syncthreads(); continue; }
         // pad with empty passes so the pipelined loop needs no bounds branches
-        if (ln < 2 * kDepth) sl[SL + ln] = LSlot{0, 0, 0, 1, 0, 0, 0, 0};  // np = 1, ngs = 0, lg = 0: nothing to do
+        if (ln < 2 * kDepth + 1) sl[SL + ln] = LSlot{0, 0, 0, 1, 0, 0, 0, 0};  // np = 1, ngs = 0, lg = 0: nothing to do
         __syncthreads();
-        PROF_MARK(4);
+        PROF_MARK(5);
 
         // ---- fused gather + cost recurrence (matrix_connector.rs:79-85, lattice.rs:103-151) ----
         // Per pass the lanes are (left-id group g, predecessor j) pairs: g = lane >> lg, j = lane & (2^lg - 1)
@@ -1225,72 +1276,97 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
             uint32_t ring[kDepth], par[kDepth];  // par[u]: which half of ring[u] is this lane's cell (0 / 16)
             uint4 rw[kDepth];                     // the (wave-uniform) pass record of ring slot u, unpacked once
             const uint32_t* __restrict__ matrix32 = reinterpret_cast<const uint32_t*>(matrix);
-            auto fetch = [&](uint32_t si, uint32_t u) {  // issue the gather of pass si into ring slot u
-                const uint4 q = *reinterpret_cast<const uint4*>(&sl[si]);  // passes >= SL are empty padding
-                const uint4 r = make_uint4(__builtin_amdgcn_readfirstlane(q.x), __builtin_amdgcn_readfirstlane(q.y),
-                                           __builtin_amdgcn_readfirstlane(q.z), __builtin_amdgcn_readfirstlane(q.w));
-                rw[u] = r;
+            auto uniform4 = [](uint4 q) {
+                return make_uint4(__builtin_amdgcn_readfirstlane(q.x), __builtin_amdgcn_readfirstlane(q.y),
+                                  __builtin_amdgcn_readfirstlane(q.z), __builtin_amdgcn_readfirstlane(q.w));
+            };
+            // the LDS address pair (left id of the lane's group, right id of its predecessor) of a pass
+            auto id_slots = [&](const uint4& r, uint32_t& li, uint32_t& ri) {
                 const uint32_t p_beg = r.y & 0xFFFFu, np = r.y >> 16, gabs = r.z & 0xFFFFu, ngs = r.z >> 16, lg = (r.w >> 20) & 7u;
                 const uint32_t g = ln >> lg, j = ln & ((1u << lg) - 1u);
                 const bool valid = g < ngs && j < np;
-                const uint32_t left = g_left[gabs + (valid ? g : 0u)];
-                const uint32_t right = e_right[p_beg + (valid ? j : 0u)];
-                const uint32_t cell = valid ? left * NR + right : 0u;  // < 2^32: num_left, num_right <= 65535
+                li = gabs + (valid ? g : 0u);
+                ri = p_beg + (valid ? j : 0u);
+            };
+            auto gather = [&](uint32_t left, uint32_t right, uint32_t u) {
+                uint32_t cell = left * NR + right;  // < 2^32: num_left, num_right <= 65535
+#ifdef VBT_EXP_SMALL_GATHER  // timing experiment only (wrong results): all gathers hit one 16 KiB region
+                cell &= 0x1FFFu;
+#endif
                 ring[u] = load_policy<VBT_NT_MATRIX != 0>(&matrix32[cell >> 1]);
                 par[u] = (cell & 1u) * 16u;
             };
 #pragma unroll
-            for (uint32_t u = 0; u < kDepth; ++u) fetch(u, u);
+            for (uint32_t u = 0; u < kDepth; ++u) {  // passes >= SL are empty padding
+                rw[u] = uniform4(*reinterpret_cast<const uint4*>(&sl[u]));
+                uint32_t li, ri;
+                id_slots(rw[u], li, ri);
+                gather(g_left[li], e_right[ri], u);
+            }
+            uint4 qn = *reinterpret_cast<const uint4*>(&sl[kDepth]);  // record of the next pass to prefetch
             for (uint32_t s0 = 0; s0 < SL; s0 += kDepth) {
 #pragma unroll
                 for (uint32_t u = 0; u < kDepth; ++u) {
                     const uint32_t si = s0 + u;
                     const uint32_t cword = ring[u], cpar = par[u];
                     const uint4 r = rw[u];
-                    fetch(si + kDepth, u);  // prefetch into the slot just consumed
                     const uint32_t c_beg = r.x & 0xFFFFu, nc = r.x >> 16, p_beg = r.y & 0xFFFFu, np = r.y >> 16;
                     const uint32_t ngs = r.z >> 16, grel = r.w & 0xFFFFu, fl = r.w >> 16;
                     const uint32_t last = fl & 1u, acc = fl & 2u, single = fl & 8u, lg = (fl >> 4) & 7u;
                     const uint32_t g = ln >> lg, j = ln & ((1u << lg) - 1u);
-                    uint64_t key = kDeadKey;
-                    if (g < ngs && j < np) {
-                        const uint64_t kb = e_key[p_beg + j];
-                        const uint32_t cv = (uint32_t)(int32_t)(int16_t)(cword >> cpar);
-                        key = (uint32_t)kb == 0xFFFFFFFFu ? kDeadKey : kb + ((uint64_t)cv << 32);  // wrapping i32 add
-                    }
-                    key = group_min_u64(key, lg);
+                    const bool valid = g < ngs && j < np;
+                    // Every LDS read of the pass is issued here, branch-free, so one wait covers them all:
+                    // the record after next, the id pair of the pass to prefetch, and this pass's operands.
+                    const uint4 f = uniform4(qn);
+                    qn = *reinterpret_cast<const uint4*>(&sl[si + kDepth + 1]);
+                    uint32_t li, ri;
+                    id_slots(f, li, ri);
+                    const uint32_t f_left = g_left[li], f_right = e_right[ri];
+                    const uint64_t kb = e_key[p_beg + (valid ? j : 0u)];
+                    const uint32_t c = c_beg + (ln < nc ? ln : 0u);
+                    const uint32_t ew = nd_ew[c], gid = nd_gid[c];
+                    rw[u] = f;
+                    gather(f_left, f_right, u);  // prefetch into the ring slot just consumed
+                    const uint32_t cv = (uint32_t)(int32_t)(int16_t)(cword >> cpar);
+                    const bool live = valid && (uint32_t)kb != 0xFFFFFFFFu;
+                    uint32_t khi = live ? (uint32_t)(kb >> 32) + cv : 0xFFFFFFFFu;  // wrapping i32 add
+                    uint32_t klo = live ? (uint32_t)kb : 0xFFFFFFFFu;
+                    group_min_split(khi, klo, lg);
                     if (single) {
                         // the whole step is this pass: group minima go straight to the candidate lanes
-                        const uint32_t c = c_beg + (ln < nc ? ln : 0u);
-                        const uint32_t ew = nd_ew[c];
-                        const uint64_t best = __shfl((unsigned long long)key, (int)((nd_gid[c] & 0x7Fu) << lg));
+                        const int src = (int)((gid & 0x7Fu) << lg);
+                        const uint32_t bhi = __shfl(khi, src), blo = __shfl(klo, src);
                         if (ln < nc) {
-                            e_key[ew & 0xFFFFu] = make_key(key_cost(best) + (uint32_t)(int32_t)(int16_t)(ew >> 16), c);  // lattice.rs:125
-                            e_back[ew & 0xFFFFu] = (uint16_t)key_seq(best);
+                            // lattice.rs:125; the biased cost takes the (sign-extended) word cost by wrapping add
+                            e_key[ew & 0xFFFFu] = ((uint64_t)(bhi + (uint32_t)(int32_t)(int16_t)(ew >> 16)) << 32) | (0xFFFFFFFEu - c);
+                            e_back[ew & 0xFFFFu] = (uint16_t)(0xFFFFFFFEu - blo);
                         }
-                        __syncthreads();
                     } else {
+                        uint64_t key = ((uint64_t)khi << 32) | klo;
                         if (g < ngs && j == 0) {
                             if (acc) { const uint64_t prev = g_best[grel + g]; key = prev < key ? prev : key; }
                             g_best[grel + g] = key;
                         }
-                        __syncthreads();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                         if (last) {
                             for (uint32_t cb = 0; cb < nc; cb += 64) {
                                 const uint32_t ci_ = cb + ln;
                                 if (ci_ < nc) {
-                                    const uint32_t c = c_beg + ci_;
-                                    const uint64_t best = g_best[nd_gid[c] & 0x7Fu];
-                                    const uint32_t ew = nd_ew[c];
-                                    e_key[ew & 0xFFFFu] = make_key(key_cost(best) + (uint32_t)(int32_t)(int16_t)(ew >> 16), c);
-                                    e_back[ew & 0xFFFFu] = (uint16_t)key_seq(best);
+                                    const uint32_t c2 = c_beg + ci_;
+                                    const uint64_t best = g_best[nd_gid[c2] & 0x7Fu];
+                                    const uint32_t ew2 = nd_ew[c2];
+                                    e_key[ew2 & 0xFFFFu] = make_key(key_cost(best) + (uint32_t)(int32_t)(int16_t)(ew2 >> 16), c2);
+                                    e_back[ew2 & 0xFFFFu] = (uint16_t)key_seq(best);
                                 }
                             }
-                            __syncthreads();
                         }
                     }
+                    // LDS operations of one wave execute in order: a compiler-level fence is all the next pass needs
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
                 }
             }
+            __syncthreads();
         }
         PROF_MARK(6);
 
@@ -1353,7 +1429,8 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
         }
         PROF_MARK(7);
         if (A.prof && ln == 0) {
-            for (int i = 3; i < kProfPhases; ++i) atomicAdd(&A.prof[i], (unsigned long long)prof_acc[i]);
+            unsigned long long* pr_ = A.prof + (size_t)(sid & (kProfSlots - 1)) * (kProfPhases + 1);
+            for (int i = 3; i < kProfPhases; ++i) atomicAdd(&pr_[i], (unsigned long long)prof_acc[i]);
         }
 #undef PROF_MARK
         __syncthreads();
@@ -1536,8 +1613,8 @@ Workspace::Workspace(const Tokenizer& t, uint64_t max_s, uint64_t max_b) : tok(t
     d_ctrl = static_cast<uint32_t*>(alloc(kCtrlWords * 4));
     d_cctrl = static_cast<uint32_t*>(alloc((size_t)kMaxChunks * kChunkCtrlWords * 4));
     n_chunks = std::min<uint32_t>(kMaxChunks / 2, std::max<uint32_t>(1, env_u32("VBT_CHUNKS", 1)));  // > 1 measured slower (launch overhead)
-    d_prof = static_cast<unsigned long long*>(alloc((kProfPhases + 1) * 8));
-    HIP_CHECK(hipMemset(d_prof, 0, (kProfPhases + 1) * 8));
+    d_prof = static_cast<unsigned long long*>(alloc(kProfSlots * (kProfPhases + 1) * 8));
+    HIP_CHECK(hipMemset(d_prof, 0, kProfSlots * (kProfPhases + 1) * 8));
     const uint64_t mb = env_u32("VBT_SCRATCH_MB", 0);
     scratch_bytes = mb ? mb << 20 : std::max<uint64_t>(256ull << 20, 256 * nbts);
     d_scratch = static_cast<char*>(alloc(scratch_bytes));
@@ -1752,8 +1829,12 @@ void Workspace::read_connid_counts(uint64_t* lid, uint64_t* rid, bool reset) {
 void Workspace::read_profile(uint64_t* out, bool reset) {
     HIP_CHECK(hipSetDevice(tok.device()));
     HIP_CHECK(hipStreamSynchronize(reinterpret_cast<hipStream_t>(last_stream)));
-    HIP_CHECK(hipMemcpy(out, d_prof, (kProfPhases + 1) * 8, hipMemcpyDeviceToHost));
-    if (reset) HIP_CHECK(hipMemset(d_prof, 0, (kProfPhases + 1) * 8));
+    std::vector<uint64_t> h((size_t)kProfSlots * (kProfPhases + 1));
+    HIP_CHECK(hipMemcpy(h.data(), d_prof, h.size() * 8, hipMemcpyDeviceToHost));
+    for (int i = 0; i <= kProfPhases; ++i) out[i] = 0;
+    for (int k = 0; k < kProfSlots; ++k)
+        for (int i = 0; i <= kProfPhases; ++i) out[i] += h[(size_t)k * (kProfPhases + 1) + i];
+    if (reset) HIP_CHECK(hipMemset(d_prof, 0, h.size() * 8));
 }
 
 }  // namespace vbt

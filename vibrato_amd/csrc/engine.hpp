@@ -93,6 +93,7 @@ enum CtrlSlot { kTotal = 0, kError = 1, kBump = 2, kNodeCursor = 4, kTierCtrl = 
 constexpr int kMaxTiers = 8;
 constexpr int kMaxChunks = 16;
 constexpr int kChunkCtrlWords = 2 * (kMaxTiers + 2);
+constexpr int kProfSlots = 256;  // the counters are spread over this many copies (hot-word atomics serialise)
 constexpr int kProfPhases = 8;  // decode, count, fill, end lists, pre-pass, gather, recurrence, emit
 enum DevError { kErrTokCap = 1, kErrScratch = 2, kErrTooLong = 4 };
 
