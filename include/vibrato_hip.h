@@ -188,8 +188,9 @@ VBT_API int vbt_workspace_count_connids(vbt_workspace* ws, int enabled);
 VBT_API int vbt_workspace_connid_counts(vbt_workspace* ws, uint64_t* lid, uint64_t* rid, int reset);
 /* Developer aid: per-phase shader-clock cycles summed over all sentences since the last reset
  * (enabled by VBT_PROFILE=1 in the environment when the workspace is created). out[0..7] =
- * decode, count, fill, end lists, pre-pass, gather, recurrence, emit; out[8] = sentences. */
-VBT_API int vbt_workspace_profile(vbt_workspace* ws, uint64_t out[9], int reset);
+ * decode, count, fill, end lists, pre-pass, pass records, recurrence, emit; out[8] = sentences,
+ * out[9] = lattice steps, out[10] = lattice passes, out[11] = lattice candidates. */
+VBT_API int vbt_workspace_profile(vbt_workspace* ws, uint64_t out[12], int reset);
 VBT_API int vbt_workspace_stats(vbt_workspace* ws, vbt_call_stats* out);
 
 #ifdef __cplusplus

@@ -118,6 +118,18 @@ def test_all_tiers_agree(tiers, fused, monkeypatch):
     _assert_batch_equal(to, tv, text, offs)
 
 
+@pytest.mark.parametrize("env", [{"VBT_LONG_BYTES": "200"}, {"VBT_GEN_LDS": "2048"}, {"VBT_GEN_LDS": "3072", "VBT_LONG_BYTES": "300"}])
+def test_generator_scheduling_variants_agree(env, monkeypatch):
+    """The optional long-first side stream and a tiny bulk-generator LDS (most sentences become stragglers of the
+    large-LDS generator, which then appends to the work lists directly) must not change a single token."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    sd = synth.SynthDict("small")
+    to, tv = _oracle_and_product(sd, ignore_space=True)
+    text, offs = sd.sentences(4000, "mixed", space_p=0.05)
+    _assert_batch_equal(to, tv, text, offs)
+
+
 @pytest.mark.parametrize("shape", ["ipadic", "unidic"])
 def test_full_size_batch_bit_exact(shape):
     """BASELINE configs 2 and 3 at full size: 100k sentences over the ipadic- / unidic-shaped

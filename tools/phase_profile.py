@@ -47,6 +47,8 @@ def main():
     st = ws.stats()
     pr = ws.profile()
     ns = pr.pop("sentences")
+    counts = pr.pop("counts", {})
+    print("per sentence:", {k: round(v / max(ns, 1), 1) for k, v in counts.items()})
     tot = sum(pr.values())
     print(f"tiers={os.environ.get('VBT_TIERS', 'default')} stats={st}")
     print(f"sentences profiled: {ns}; mean cycles/sentence {tot / max(ns, 1):.0f} (~{tot / max(ns, 1) / 2.4e3:.1f} us @2.4GHz)")

@@ -368,10 +368,11 @@ class Workspace:
 
     def profile(self, reset=True):
         """Per-phase cycle totals (needs VBT_PROFILE=1 at workspace creation)."""
-        out = (C.c_uint64 * 9)()
+        out = (C.c_uint64 * 12)()
         N.check(N.lib().vbt_workspace_profile(self._h, out, int(reset)))
         d = dict(zip(self.PHASES, [int(x) for x in out[:8]]))
         d["sentences"] = int(out[8])
+        d["counts"] = {"steps": int(out[9]), "passes": int(out[10]), "candidates": int(out[11])}
         return d
 
     def stats(self):

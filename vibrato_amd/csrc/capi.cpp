@@ -422,7 +422,7 @@ int vbt_workspace_connid_counts(vbt_workspace* ws, uint64_t* lid, uint64_t* rid,
     return guarded([&] { ws->w->read_connid_counts(lid, rid, reset != 0); });
 }
 
-int vbt_workspace_profile(vbt_workspace* ws, uint64_t out[9], int reset) {
+int vbt_workspace_profile(vbt_workspace* ws, uint64_t out[12], int reset) {
     return guarded([&] { ws->w->read_profile(out, reset != 0); });
 }
 

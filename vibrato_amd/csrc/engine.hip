@@ -97,6 +97,13 @@ __device__ __forceinline__ uint64_t group_min_u64(uint64_t key, uint32_t lg) {  
     return key;
 }
 
+// lattice_lds keeps the back pointer in the key as well: low word = (0xFFFE - sequence) << 16 | sequence of the best
+// predecessor.  Sequences are unique, so the back pointer never decides a comparison; candidates number < 65532.
+__device__ __forceinline__ uint64_t node_key(uint32_t best_hi, uint32_t best_lo, uint32_t wcost, uint32_t seq) {
+    return ((uint64_t)(best_hi + wcost) << 32) | ((0xFFFEu - seq) << 16) | (0xFFFEu - (best_lo >> 16));  // lattice.rs:125
+}
+__device__ __forceinline__ uint32_t key_back(uint64_t k) { return (uint32_t)k & 0xFFFFu; }
+
 // The same reduction on split keys: minimum of the high words first, then the minimum low word among
 // the lanes that hold it (u64 order is lexicographic in (hi, lo)).  Each level is one v_min_u32 with a
 // DPP source operand; the 32- and 64-lane levels use the gfx950 row / half-wave swaps
@@ -106,19 +113,32 @@ __device__ __forceinline__ uint32_t dpp_min_u32(uint32_t x) {
     const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, kCtrl, 0xF, 0xF, true);
     return o < x ? o : x;
 }
-__device__ __forceinline__ uint32_t group_min_u32(uint32_t x, uint32_t lg) {  // lg is wave-uniform
-    if (lg >= 1) x = dpp_min_u32<0xB1>(x);
-    if (lg >= 2) x = dpp_min_u32<0x4E>(x);
-    if (lg >= 3) x = dpp_min_u32<0x141>(x);
-    if (lg >= 4) x = dpp_min_u32<0x140>(x);
-    if (lg >= 5) { const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false); x = r[0] < r[1] ? r[0] : r[1]; }
-    if (lg >= 6) { const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false); x = r[0] < r[1] ? r[0] : r[1]; }
+template <int kLevels>
+__device__ __forceinline__ uint32_t group_min_u32(uint32_t x) {
+    if constexpr (kLevels >= 1) x = dpp_min_u32<0xB1>(x);
+    if constexpr (kLevels >= 2) x = dpp_min_u32<0x4E>(x);
+    if constexpr (kLevels >= 3) x = dpp_min_u32<0x141>(x);
+    if constexpr (kLevels >= 4) x = dpp_min_u32<0x140>(x);
+    if constexpr (kLevels >= 5) { const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false); x = r[0] < r[1] ? r[0] : r[1]; }
+    if constexpr (kLevels >= 6) { const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false); x = r[0] < r[1] ? r[0] : r[1]; }
     return x;
 }
-__device__ __forceinline__ void group_min_split(uint32_t& hi, uint32_t& lo, uint32_t lg) {
-    const uint32_t m = group_min_u32(hi, lg);
-    lo = group_min_u32(hi == m ? lo : 0xFFFFFFFFu, lg);
+template <int kLevels>
+__device__ __forceinline__ void group_min_split_n(uint32_t& hi, uint32_t& lo) {
+    const uint32_t m = group_min_u32<kLevels>(hi);
+    lo = group_min_u32<kLevels>(hi == m ? lo : 0xFFFFFFFFu);
     hi = m;
+}
+__device__ __forceinline__ void group_min_split(uint32_t& hi, uint32_t& lo, uint32_t lg) {  // lg is wave-uniform
+    switch (lg) {  // one branch per pass instead of one per level
+        case 0: break;
+        case 1: group_min_split_n<1>(hi, lo); break;
+        case 2: group_min_split_n<2>(hi, lo); break;
+        case 3: group_min_split_n<3>(hi, lo); break;
+        case 4: group_min_split_n<4>(hi, lo); break;
+        case 5: group_min_split_n<5>(hi, lo); break;
+        default: group_min_split_n<6>(hi, lo); break;
+    }
 }
 
 // 128-bit window helpers (shift distances 0..64), by value so everything stays in registers
@@ -680,7 +700,7 @@ __device__ __forceinline__ uint64_t process_sentence(const DevDict& D, const Bat
     }
     PROF_MARK(7);
     if (A.prof && ln == 0) {
-        unsigned long long* pr_ = A.prof + (size_t)(sid & (kProfSlots - 1)) * (kProfPhases + 1);
+        unsigned long long* pr_ = A.prof + (size_t)(sid & (kProfSlots - 1)) * kProfWords;
 #pragma unroll
         for (int i = 0; i < kProfPhases; ++i) atomicAdd(&pr_[i], (unsigned long long)prof_acc[i]);
         atomicAdd(&pr_[kProfPhases], 1ull);
@@ -699,9 +719,11 @@ struct alignas(16) LSlot { uint16_t cbeg, nc, pbeg, np, gabs, ngs, grel, last; }
 
 // LDS bytes of the lattice arrays of lattice_lds (must over-estimate the Arena carve there).
 __host__ __device__ __forceinline__ uint64_t lattice_fixed_bytes(uint32_t n, uint32_t C, uint32_t G, uint32_t ngmax, bool space_mode, uint32_t passes) {
-    return 8ull * (C + 2) + 8ull * (n + 1) + 8ull * (ngmax + 1) + 4ull * (n + 2) + (space_mode ? 4ull * n : 0) +
-           4ull * (n + 1) + sizeof(LSlot) * (passes + 18ull) + 2ull * (n + 1) * 2 + 2ull * (C + 1) * 2 + 2ull * C + 2ull * (C + 2) * 3 +
-           2ull * (G + 1) + (n + 1ull) + (C + 1ull) + 96;
+    const uint64_t persistent = 2ull * (C + 1) + 2ull * (G + 1) + 8ull * (C + 2) + 8ull * (n + 1) + 8ull * (ngmax + 1) + 4ull * (n + 2) +
+                                (space_mode ? 4ull * n : 0) + 4ull * (n + 1) + 4ull * (C + 2) + 2ull * (n + 1) * 2 + 2ull * (C + 2) +
+                                (n + 1ull) + (C + 1ull) + 64;  // + alignment slack
+    const uint64_t setup = 4ull * C, records = sizeof(LSlot) * (passes + 20ull);  // share the same bytes
+    return persistent + (setup > records ? setup : records);
 }
 
 // =====================================================================================
@@ -732,8 +754,11 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
     const uint32_t fallback = A.n_tiers, large_list = A.n_tiers + 1;
     // gen routes a sentence by writing its list index; build_lists turns that into work lists with
     // wave-aggregated atomics (a per-sentence atomic on a hot word caps the kernel at ~88 M/s)
-    auto route = [&](uint32_t t) { if (ln == 0) A.s_tier[sid] = (uint8_t)t; };
-    if (!large && A.s_tier[sid] == kRouteDone) return;  // a long sentence: generated and filed by the early pass
+    auto route = [&](uint32_t t) {
+        if (A.direct_push) list_push(A, t, sid);  // the few stragglers behind build_lists
+        else if (ln == 0) A.s_tier[sid] = (uint8_t)t;
+    };
+    if (!large && A.s_skip && A.s_skip[sid] != 0xFF) return;  // a long sentence: the early pipeline owns it
     if (ln == 0 && !large) { A.s_n[sid] = 0; A.s_C[sid] = 0; A.s_tier[sid] = 0xFF; }
     if (nb64 == 0) {
         if (ln == 0) { A.tok_off[sid] = 0; A.tok_cnt[sid] = 0; }
@@ -764,6 +789,7 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
     uint16_t* goff = ar.take<uint16_t>(n + 1);
     uint32_t* endc = ar.take<uint32_t>(n + 1);  // candidates ending at each position (bounds the pass count)
     uint8_t* ngp = ar.take<uint8_t>(n);
+    uint32_t* hcount = ar.take<uint32_t>(1);  // hits staged so far
     if (!ar.ok) { route(large ? fallback : large_list); return; }
     for (uint32_t i = ln; i < n + 1; i += 64) endc[i] = i == 0 ? 1u : 0u;  // BOS ends at 0
 
@@ -821,7 +847,16 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
     __syncthreads();
     PROF_MARK(0);
 
-    // count candidates per start position (tokenizer.rs:155-198, unknown.rs:69-116)
+    // One trie walk per start position (tokenizer.rs:155-198, unknown.rs:69-116).  The walk is a chain of
+    // dependent loads, so nothing else hangs on it: every hit -- a run of `c` dictionary entries ending at
+    // `end` -- is appended to a staging list in global memory as {first entry, c | lexicon << 16,
+    // end | start << 16, candidates of this start position before the hit} and expanded afterwards by
+    // independent lanes.
+    const uint64_t base = (uint64_t)A.node_factor * slot0;  // this sentence's node region (no allocation atomic)
+    const uint64_t region = (uint64_t)A.node_factor * (nb + 1);
+    uint4* __restrict__ hits = A.g_hits + base;
+    if (ln == 0) *hcount = 0;
+    __syncthreads();
     uint32_t C = 0;
     bool any_long = false;
     for (uint32_t c0 = 0; c0 < n; c0 += 64) {
@@ -830,18 +865,21 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
         uint64_t lmask = 0;
         bool is_long = false;
         if (i < n) {
-            auto seen = [&](uint32_t c, uint32_t end) {
+            auto seen = [&](uint32_t v, uint32_t c, uint32_t end, uint32_t lex) {
+                if (c == 0) return;  // a category without unknown-word entries contributes nothing (unknown.rs:118-130)
+                const uint32_t h = atomicAdd(hcount, 1u);
+                if (h < region) hits[h] = make_uint4(v, c | (lex << 16), end | (i << 16), cnt);
                 cnt += c;
                 const uint32_t len = end - i;
                 if (len <= 64) lmask |= 1ull << (len - 1); else is_long = true;
                 atomicAdd(&endc[end], c);
             };
             bool matched = false;
-            if (D.has_user) matched |= walk_trie(D.user, ucode, i, n, [&](uint32_t, uint32_t c, uint32_t e) { seen(c, e); });
-            matched |= walk_trie(D.sys, code, i, n, [&](uint32_t, uint32_t c, uint32_t e) { seen(c, e); });
+            if (D.has_user) matched |= walk_trie(D.user, ucode, i, n, [&](uint32_t v, uint32_t c, uint32_t e) { seen(v, c, e, 1u); });
+            matched |= walk_trie(D.sys, code, i, n, [&](uint32_t v, uint32_t c, uint32_t e) { seen(v, c, e, 0u); });
             const uint32_t cinfo = ci[i], cate = (cinfo >> 18) & 0xFFu;
-            const uint32_t nunk = D.unk_off[cate + 1] - D.unk_off[cate];
-            unk_spans(cinfo, grp[i], i, matched, D.max_grouping_len, [&](uint32_t e) { seen(nunk, e); });
+            const uint32_t u0 = D.unk_off[cate], nunk = D.unk_off[cate + 1] - u0;
+            unk_spans(cinfo, grp[i], i, matched, D.max_grouping_len, [&](uint32_t e) { seen(u0, nunk, e, 2u); });
             lens[i] = lmask;
         }
         uint32_t tot;
@@ -853,47 +891,82 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
     // words > 64 chars need the generic pre-pass, > 65531 nodes need u32 indices: fused kernel
     if (C >= 65532 || any_long) { route(fallback); return; }
     if (ln == 0) cand_off[n] = C;
-    const uint64_t base = (uint64_t)A.node_factor * slot0;  // this sentence's node region (no allocation atomic)
-    if (C > (uint64_t)A.node_factor * (nb + 1)) { route(fallback); return; }  // denser than the region: fused path
+    if (C > region) { route(fallback); return; }  // denser than the region: fused path
+    uint16_t* cleft = ar.take<uint16_t>(C);  // left id per candidate, for the grouping below
+    uint8_t* cgid = ar.take<uint8_t>(C);
+    if (!ar.ok) { route(large ? fallback : large_list); return; }
+    // The staged hits are read back by this wave only: its stores have to be complete (workgroup scope:
+    // s_waitcnt vmcnt(0); the vector L1 is write-through and never held these lines).  An agent-scope
+    // release would write the whole L2 back (buffer_wbl2) once per sentence.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     PROF_MARK(1);
 
-    // fill candidates in reference insertion order; group them by left_id within a start position
+#if VBT_EXP == 9
+    uint64_t xq[4] = {(uint64_t)clock64(), 0, 0, 0};
+#endif
+    // expand the hits: lanes = hits, every entry load independent of every other
+    {
+        const uint32_t H = *hcount;  // <= C <= region
+        for (uint32_t h0 = 0; h0 < H; h0 += 64) {
+            const uint32_t h = h0 + ln;
+            if (h < H) {
+                const uint4 hr = hits[h];
+                const uint32_t c = hr.y & 0xFFFFu, lex = hr.y >> 16, end = hr.z & 0xFFFFu, pos = hr.z >> 16;
+                const Entry* __restrict__ ent = lex == 0 ? D.sys.entries : lex == 1 ? D.user.entries : D.unk_entries;
+                const uint32_t dest = cand_off[pos] + hr.w;
+                for (uint32_t t0 = 0; t0 < c; t0 += 4) {
+                    Entry e[4];
+#pragma unroll
+                    for (uint32_t q = 0; q < 4; ++q) e[q] = ent[hr.x + (t0 + q < c ? t0 + q : t0)];
+#pragma unroll
+                    for (uint32_t q = 0; q < 4; ++q) {
+                        if (t0 + q < c) {
+                            const uint32_t k = dest + t0 + q;
+                            uint32_t* rec = reinterpret_cast<uint32_t*>(&A.g_nd[base + k]);
+                            rec[0] = e[q].left_right;
+                            rec[1] = (e[q].cost & 0xFFFFu) | (end << 16);
+                            rec[2] = (lex << 30) | e[q].word_id;
+                            cleft[k] = (uint16_t)(e[q].left_right & 0xFFFFu);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+#if VBT_EXP == 9
+    xq[1] = clock64();
+#endif
+    // group the candidates of a start position by left id, in reference insertion order
     uint32_t G = 0, ngmax = 0;
     bool too_many_groups = false;
     for (uint32_t c0 = 0; c0 < n; c0 += 64) {
         const uint32_t i = c0 + ln;
         uint32_t ng = 0;
         if (i < n) {
-            uint64_t k = base + cand_off[i];
             uint32_t gl[8];  // the first 8 distinct left ids of this position (register cache)
 #pragma unroll
             for (int q = 0; q < 8; ++q) gl[q] = 0xFFFFFFFFu;
-            bool matched = false;
-            auto put = [&](const Entry* ent, uint32_t v, uint32_t c, uint32_t end, uint32_t lex) {
-                for (uint32_t t = 0; t < c; ++t, ++k) {
-                    const Entry e = ent[v + t];
-                    const uint32_t left = e.left_right & 0xFFFFu;
-                    uint32_t g = 0xFFFFFFFFu;
+            const uint32_t kb = cand_off[i], ke = i + 1 < n ? cand_off[i + 1] : C;
+            for (uint32_t k = kb; k < ke; ++k) {
+                const uint32_t left = cleft[k];
+                uint32_t g = 0xFFFFFFFFu;
 #pragma unroll
-                    for (int q = 7; q >= 0; --q) g = gl[q] == left ? (uint32_t)q : g;
-                    const bool first = g == 0xFFFFFFFFu;
-                    if (first) {
-                        g = ng;
+                for (int q = 7; q >= 0; --q) g = gl[q] == left ? (uint32_t)q : g;
+                // a left id beyond the 8 cached ones starts a group of its own every time (same gid => same left id is
+                // all the lattice kernel relies on)
+                const bool first = g == 0xFFFFFFFFu;
+                if (first) {
+                    g = ng;
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) gl[q] = (uint32_t)q == ng ? left : gl[q];
-                        ++ng;
-                    }
-                    A.g_nd[k] = make_uint4(e.left_right, (e.cost & 0xFFFFu) | (end << 16), (lex << 30) | e.word_id,
-                                           (g & 0x7Fu) | (first ? 0x80u : 0u));
+                    for (int q = 0; q < 8; ++q) gl[q] = (uint32_t)q == ng ? left : gl[q];
+                    ++ng;
                 }
-            };
-            if (D.has_user)
-                matched |= walk_trie(D.user, ucode, i, n, [&](uint32_t v, uint32_t c, uint32_t e) { put(D.user.entries, v, c, e, 1u); });
-            matched |= walk_trie(D.sys, code, i, n, [&](uint32_t v, uint32_t c, uint32_t e) { put(D.sys.entries, v, c, e, 0u); });
-            const uint32_t cinfo = ci[i], cate = (cinfo >> 18) & 0xFFu;
-            const uint32_t u0 = D.unk_off[cate], nunk = D.unk_off[cate + 1] - u0;
-            unk_spans(cinfo, grp[i], i, matched, D.max_grouping_len, [&](uint32_t e) { put(D.unk_entries, u0, nunk, e, 2u); });
+                cgid[k] = (uint8_t)((g & 0x7Fu) | (first ? 0x80u : 0u));
+            }
             ngp[i] = (uint8_t)ng;
         }
         too_many_groups |= __ballot(ng > 127u) != 0;
@@ -908,6 +981,19 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
     }
     if (too_many_groups) { route(fallback); return; }
     __syncthreads();
+#if VBT_EXP == 9
+    xq[2] = clock64();
+#endif
+    for (uint32_t k = ln; k < C; k += 64) reinterpret_cast<uint32_t*>(&A.g_nd[base + k])[3] = cgid[k];
+#if VBT_EXP == 9
+    xq[3] = clock64();
+    if (A.prof && ln == 0) {
+        unsigned long long* pq_ = A.prof + (size_t)(sid & (kProfSlots - 1)) * kProfWords;
+        atomicAdd(&pq_[9], (unsigned long long)(xq[1] - xq[0]));
+        atomicAdd(&pq_[10], (unsigned long long)(xq[2] - xq[1]));
+        atomicAdd(&pq_[11], (unsigned long long)(xq[3] - xq[2]));
+    }
+#endif
     // upper bound of the number of (step, <= 64 pair lanes) passes of the lattice kernel
     uint32_t passes = 1;  // EOS
     for (uint32_t c0 = 0; c0 < n; c0 += 64) {
@@ -945,42 +1031,59 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
     route(tier);
     PROF_MARK(2);
     if (A.prof && ln == 0) {
-        unsigned long long* pr_ = A.prof + (size_t)(sid & (kProfSlots - 1)) * (kProfPhases + 1);
+        unsigned long long* pr_ = A.prof + (size_t)(sid & (kProfSlots - 1)) * kProfWords;
         for (int i = 0; i < 3; ++i) atomicAdd(&pr_[i], (unsigned long long)prof_acc[i]);
         atomicAdd(&pr_[kProfPhases], 1ull);
     }
 #undef PROF_MARK
 }
 
-// Long-first scheduling: sentences of >= long_bytes bytes are generated and swept before the bulk so
-// that the few slow ones overlap it instead of forming a tail.  Marks them for the large generator.
+// Long sentences are the critical path of the generator (one wavefront each): those of >= long_bytes bytes
+// -- which cannot fit the LDS of the bulk generator anyway -- are listed up front, so that the large-LDS
+// generator works on them on a side stream while the bulk runs.  Few qualify: one atomic each is fine.
 __global__ void __launch_bounds__(256) classify_long(BatchArgs A, uint32_t long_bytes) {
     const uint32_t rel = blockIdx.x * 256 + threadIdx.x;
     if (rel >= A.n) return;
     const uint32_t sid = A.sid0 + rel;
     const uint64_t nb = A.offsets[sid + 1] - A.offsets[sid];
-    A.s_tier[sid] = nb >= long_bytes ? (uint8_t)(A.n_tiers + 1) : (uint8_t)0xFF;
-    if (nb >= long_bytes) { A.s_n[sid] = 0; A.s_C[sid] = 0; }
+    const bool is_long = nb >= long_bytes;
+    A.s_early[sid] = is_long ? (uint8_t)1 : (uint8_t)0xFF;
+    if (is_long) {
+        A.s_n[sid] = 0; A.s_C[sid] = 0;
+        const uint32_t t = A.n_tiers + 1;
+        A.lists[(size_t)t * A.list_stride + A.list_off + atomicAdd(&A.cctrl[2 * t], 1u)] = sid;
+    }
 }
 
 // Turns the per-sentence routing decisions into work lists: one atomic per (wave, list) instead of
 // one per sentence.  only_list >= 0 restricts the pass to that list (the gen_candidates_large input).
-__global__ void __launch_bounds__(256) build_lists(BatchArgs A, int only_list) {
-    const uint32_t rel = blockIdx.x * 256 + threadIdx.x, sid = A.sid0 + rel;
+__global__ void __launch_bounds__(1024) build_lists(BatchArgs A, int only_list) {
+    // One global atomic per (workgroup, list): a returning atomic on a hot word costs ~11 ns, so the
+    // 16 waves of a workgroup first agree on their shares through LDS.
+    __shared__ uint32_t w_cnt[16][kMaxTiers + 2];
+    __shared__ uint32_t l_base[kMaxTiers + 2];
+    const uint32_t rel = blockIdx.x * 1024 + threadIdx.x, sid = A.sid0 + rel;
     const uint32_t t = rel < A.n ? A.s_tier[sid] : 0xFFu;
-    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t n_lists = A.n_tiers + 2;
+    uint32_t my_rank = 0;
     for (uint32_t l = 0; l < n_lists; ++l) {
-        if (only_list >= 0 ? (int)l != only_list : l == A.n_tiers + 1) continue;
-        const uint64_t m = __ballot(t == l);
-        if (m == 0) continue;
-        uint32_t basei = 0;
-        if (lane == (uint32_t)__builtin_ctzll(m)) basei = atomicAdd(&A.cctrl[2 * l], (uint32_t)__popcll(m));
-        basei = __shfl(basei, (int)__builtin_ctzll(m));
-        if (t == l) {
-            A.lists[(size_t)l * A.list_stride + A.list_off + basei + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = sid;
-            if (only_list < 0) A.s_tier[sid] = kRouteDone;  // filed: a later pass must not file it again
-        }
+        const bool mine = t == l && (only_list < 0 || (int)l == only_list);
+        const uint64_t m = __ballot(mine);
+        if (lane == 0) w_cnt[wave][l] = (uint32_t)__popcll(m);
+        if (mine) my_rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    }
+    __syncthreads();
+    if (threadIdx.x < n_lists) {
+        uint32_t tot = 0;
+        for (uint32_t w = 0; w < 16; ++w) { const uint32_t c = w_cnt[w][threadIdx.x]; w_cnt[w][threadIdx.x] = tot; tot += c; }
+        l_base[threadIdx.x] = tot ? atomicAdd(&A.cctrl[2 * threadIdx.x], tot) : 0u;
+    }
+    __syncthreads();
+    const bool filed = t < n_lists && (only_list < 0 || (int)t == only_list);
+    if (filed) {
+        A.lists[(size_t)t * A.list_stride + A.list_off + l_base[t] + w_cnt[wave][t] + my_rank] = sid;
+        if (only_list < 0) A.s_tier[sid] = kRouteDone;  // filed: a later pass must not file it again
     }
 }
 
@@ -1005,20 +1108,33 @@ __global__ void __launch_bounds__(64) gen_candidates_large(DevDict D, BatchArgs 
 // Kernel 2: the lattice sweep of one sentence per wavefront, entirely in LDS.  Persistent waves
 // drain the work list of their tier.  Sentences whose lattice does not fit after all go to the
 // fallback list (fused kernel with global scratch).
+#ifndef VBT_EXP
+#define VBT_EXP 0
+#endif
+#ifndef VBT_STEAL_LOOP
+#define VBT_STEAL_LOOP 0
+#endif
 #ifndef VBT_LAT_WAVES
 #define VBT_LAT_WAVES 4
 #endif
 __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, BatchArgs A, uint32_t tier) {
     const uint32_t ln = threadIdx.x;
     const uint32_t lds_bytes = A.tier_bytes[tier];
-    const uint32_t* list = A.lists + (size_t)tier * A.list_stride + A.list_off;
-    const uint32_t count = A.cctrl[2 * tier];
-    uint32_t* cursor = &A.cctrl[2 * tier + 1];
     const int16_t* __restrict__ matrix = D.matrix;
     const uint32_t NR = D.num_right;
     const bool space_mode = D.space_cateset != 0;
     // long sentences are the critical path of a batch: let their waves win issue arbitration
     if (A.tier_prio && tier + A.tier_prio >= A.n_tiers) __builtin_amdgcn_s_setprio(2);
+    // own work list first; a wave that runs dry helps the smaller tiers (their sentences fit its LDS)
+#if VBT_STEAL_LOOP
+    for (int src = (int)tier; src >= 0 && src + (int)A.steal_depth >= (int)tier; --src) {
+#else
+    {
+    const int src = (int)tier;
+#endif
+    const uint32_t* list = A.lists + (size_t)src * A.list_stride + A.list_off;
+    const uint32_t count = A.cctrl[2 * src];
+    uint32_t* cursor = &A.cctrl[2 * src + 1];
     for (;;) {
         uint32_t item = 0;
         if (ln == 0) item = atomicAdd(cursor, 1u);
@@ -1035,23 +1151,27 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
         const uint4* __restrict__ pc = A.g_pc + slot0;
 
         Arena ar{g_smem, lds_bytes, 0, true};
-        uint64_t* e_key = ar.take<uint64_t>(C + 2);    // end-major packed (cost, sequence) keys
+        // the two left-id arrays come first: pass records address them as u16 element indices from the arena base
+        uint16_t* nd_left = ar.take<uint16_t>(C + 1);
+        uint16_t* g_left = ar.take<uint16_t>(G + 1);
+        uint64_t* e_key = ar.take<uint64_t>(C + 2);    // end-major packed (cost, sequence, back pointer) keys
         uint64_t* lens = ar.take<uint64_t>(n + 1);     // length bitmask per start position (pre-pass), then the token path
         uint64_t* g_best = ar.take<uint64_t>(ngmax + 1);  // per step: best key of each left-id group
         uint32_t* end_off = ar.take<uint32_t>(n + 2);
         uint32_t* grpf = space_mode ? ar.take<uint32_t>(n) : end_off;  // groupable | is_space << 31
         uint32_t* sp = ar.take<uint32_t>(n + 1);  // (start_node | start_word << 16) per sweep step
+        uint32_t* nd_ew = ar.take<uint32_t>(C + 2);  // per candidate: end-list slot | (u16) word_cost << 16
         uint16_t* cand_off = ar.take<uint16_t>(n + 1);
         uint16_t* goff = ar.take<uint16_t>(n + 1);
-        uint16_t* nd_left = ar.take<uint16_t>(C + 1);
-        uint16_t* nd_end = ar.take<uint16_t>(C);
-        uint32_t* nd_ew = ar.take<uint32_t>(C + 2);  // per candidate: end-list slot | (u16) word_cost << 16
         uint16_t* e_right = ar.take<uint16_t>(C + 2);
-        uint16_t* e_back = ar.take<uint16_t>(C + 2);
-        uint16_t* g_left = ar.take<uint16_t>(G + 1);
         uint8_t* ngp = ar.take<uint8_t>(n + 1);
         uint8_t* nd_gid = ar.take<uint8_t>(C + 1);
-        uint16_t* tmp_right = e_back;
+        // set-up scratch (end position and right id per candidate): dead once the end lists exist, so the
+        // pass records, which are built afterwards, take the same bytes
+        const uint64_t union_base = (ar.used + 15) & ~15ull;
+        ar.used = union_base;
+        uint16_t* nd_end = ar.take<uint16_t>(C);
+        uint16_t* tmp_right = ar.take<uint16_t>(C);
         if (!ar.ok) { if (ln == 0) atomicAdd(&A.ctrl[26], 1u); list_push(A, A.n_tiers, sid); __syncthreads(); continue; }
 
         // ---- load: per-char records and candidates from global; count end-list sizes ----
@@ -1122,9 +1242,8 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
         const uint32_t kBosSeq = C + 1;
         if (ln == 0) {
             e_right[0] = 0;
-            e_key[0] = make_key(0u, kBosSeq);
+            e_key[0] = node_key(0x80000000u, 0u, 0u, kBosSeq);  // cost 0, no predecessor
             nd_ew[kBosSeq] = 0;
-            e_back[0] = (uint16_t)kBosSeq;
             nd_left[C] = 0;  // EOS pseudo candidate: left_id 0, its own group G
             nd_ew[C] = C + 1;  // word cost 0
             nd_gid[C] = 0x80u;
@@ -1212,11 +1331,14 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
         // (b) lanes = steps: split every step into passes of <= 64 (group, predecessor) lanes and lay
         //     the pass records out contiguously (exclusive scan of the pass counts).
         uint32_t SL = 0;
-        LSlot* sl = reinterpret_cast<LSlot*>(g_smem + ((ar.used + 15) & ~15ull));
-        const uint32_t sl_cap = lds_bytes > ((ar.used + 15) & ~15ull) ? (uint32_t)((lds_bytes - ((ar.used + 15) & ~15ull)) / sizeof(LSlot)) : 0u;
+        LSlot* sl = reinterpret_cast<LSlot*>(g_smem + union_base);  // over the dead set-up scratch
+        const uint32_t sl_cap = lds_bytes > union_base ? (uint32_t)((lds_bytes - union_base) / sizeof(LSlot)) : 0u;
+        const uint32_t ix_nd_left = (uint32_t)(reinterpret_cast<char*>(nd_left) - g_smem) / 2u;  // u16 element indices
+        const uint32_t ix_g_left = (uint32_t)(reinterpret_cast<char*>(g_left) - g_smem) / 2u;
         for (uint32_t k0 = 0; k0 < S; k0 += 64) {
             const uint32_t k = k0 + ln;
             uint32_t c_beg = 0, nc = 0, p_beg = 0, np = 1, g_beg = 0, ng = 0, nsl = 0, gpp = 64, lgp = 0;
+            bool direct = false;
             if (k < S) {
                 const uint32_t v = sp[k], p = v & 0xFFFFu, sw = v >> 16;
                 p_beg = end_off[p];
@@ -1226,16 +1348,20 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
                 const uint32_t lg = np <= 1 ? 0u : 32u - (uint32_t)__builtin_clz(np - 1);
                 lgp = lg > 6 ? 6 : lg;
                 gpp = 64u >> lgp;
-                nsl = np <= 64 ? (ng + gpp - 1) / gpp : ng * ((np + 63) / 64);
+                direct = np <= 64 && (nc << lgp) <= 64;  // a lane group per candidate fits one pass: no broadcast step
+                nsl = direct ? 1u : np <= 64 ? (ng + gpp - 1) / gpp : ng * ((np + 63) / 64);
             }
             uint32_t tot;
             const uint32_t ex = wave_exscan(nsl, tot);
             if (SL + tot <= sl_cap) {
-                if (np <= 64) {
+                if (direct) {
+                    sl[SL + ex] = LSlot{(uint16_t)c_beg, (uint16_t)nc, (uint16_t)p_beg, (uint16_t)np, (uint16_t)(ix_nd_left + c_beg),
+                                        (uint16_t)nc, (uint16_t)0, (uint16_t)(1u | 4u | 8u | (lgp << 4))};
+                } else if (np <= 64) {
                     for (uint32_t q = 0; q < nsl; ++q) {
                         const uint32_t rem = ng - q * gpp;
                         const uint32_t fl = (q + 1 == nsl ? 1u : 0u) | ((nsl == 1 && nc <= 64) ? 8u : 0u) | (lgp << 4);
-                        sl[SL + ex + q] = LSlot{(uint16_t)c_beg, (uint16_t)nc, (uint16_t)p_beg, (uint16_t)np, (uint16_t)(g_beg + q * gpp),
+                        sl[SL + ex + q] = LSlot{(uint16_t)c_beg, (uint16_t)nc, (uint16_t)p_beg, (uint16_t)np, (uint16_t)(ix_g_left + g_beg + q * gpp),
                                                 (uint16_t)(rem < gpp ? rem : gpp), (uint16_t)(q * gpp), (uint16_t)fl};
                     }
                 } else {  // > 64 predecessors: one group per pass, 64 predecessors at a time, partial minima accumulate
@@ -1246,7 +1372,7 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
                         const uint32_t npc = rem < 64 ? rem : 64;
                         const uint32_t lgc = npc <= 1 ? 0u : 32u - (uint32_t)__builtin_clz(npc - 1);
                         sl[SL + ex + q] = LSlot{(uint16_t)c_beg, (uint16_t)nc, (uint16_t)(p_beg + jc * 64), (uint16_t)npc,
-                                                (uint16_t)(g_beg + g), (uint16_t)1, (uint16_t)g,
+                                                (uint16_t)(ix_g_left + g_beg + g), (uint16_t)1, (uint16_t)g,
                                                 (uint16_t)((q + 1 == nsl ? 1u : 0u) | (jc ? 2u : 0u) | (lgc << 4))};
                     }
                 }
@@ -1254,10 +1380,11 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
             SL += tot;
         }
         // no LDS left for the pass records: fused kernel
+        const uint32_t prof_SL = SL;
         constexpr uint32_t kDepth = 8;  // prefetch distance of the fused loop, in passes
-        if (SL + 2 * kDepth + 1 > sl_cap) { if (ln == 0) atomicAdd(&A.ctrl[29], 1u); list_push(A, A.n_tiers, sid); __syncthreads(); continue; }
+        if (SL + 2 * kDepth + 2 > sl_cap) { if (ln == 0) atomicAdd(&A.ctrl[29], 1u); list_push(A, A.n_tiers, sid); __syncthreads(); continue; }
         // pad with empty passes so the pipelined loop needs no bounds branches
-        if (ln < 2 * kDepth + 1) sl[SL + ln] = LSlot{0, 0, 0, 1, 0, 0, 0, 0};  // np = 1, ngs = 0, lg = 0: nothing to do
+        if (ln < 2 * kDepth + 2) sl[SL + ln] = LSlot{0, 0, 0, 1, 0, 0, 0, 0};  // np = 1, ngs = 0, lg = 0: nothing to do
         __syncthreads();
         PROF_MARK(5);
 
@@ -1276,24 +1403,26 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
             uint32_t ring[kDepth], par[kDepth];  // par[u]: which half of ring[u] is this lane's cell (0 / 16)
             uint4 rw[kDepth];                     // the (wave-uniform) pass record of ring slot u, unpacked once
             const uint32_t* __restrict__ matrix32 = reinterpret_cast<const uint32_t*>(matrix);
+            const uint16_t* __restrict__ ids16 = reinterpret_cast<const uint16_t*>(g_smem);
             auto uniform4 = [](uint4 q) {
                 return make_uint4(__builtin_amdgcn_readfirstlane(q.x), __builtin_amdgcn_readfirstlane(q.y),
                                   __builtin_amdgcn_readfirstlane(q.z), __builtin_amdgcn_readfirstlane(q.w));
             };
-            // the LDS address pair (left id of the lane's group, right id of its predecessor) of a pass
+            // the LDS slots of the id pair (left id of the lane's group, right id of its predecessor) of a pass
             auto id_slots = [&](const uint4& r, uint32_t& li, uint32_t& ri) {
-                const uint32_t p_beg = r.y & 0xFFFFu, np = r.y >> 16, gabs = r.z & 0xFFFFu, ngs = r.z >> 16, lg = (r.w >> 20) & 7u;
+                const uint32_t p_beg = r.y & 0xFFFFu, np = r.y >> 16, lbase = r.z & 0xFFFFu, ngs = r.z >> 16, lg = (r.w >> 20) & 7u;
                 const uint32_t g = ln >> lg, j = ln & ((1u << lg) - 1u);
                 const bool valid = g < ngs && j < np;
-                li = gabs + (valid ? g : 0u);
+                li = lbase + (valid ? g : 0u);
                 ri = p_beg + (valid ? j : 0u);
             };
             auto gather = [&](uint32_t left, uint32_t right, uint32_t u) {
-                uint32_t cell = left * NR + right;  // < 2^32: num_left, num_right <= 65535
-#ifdef VBT_EXP_SMALL_GATHER  // timing experiment only (wrong results): all gathers hit one 16 KiB region
-                cell &= 0x1FFFu;
-#endif
+                const uint32_t cell = left * NR + right;  // < 2^32: num_left, num_right <= 65535
+#if VBT_EXP == 2  // timing experiments only (wrong results)
+                ring[u] = cell;
+#else
                 ring[u] = load_policy<VBT_NT_MATRIX != 0>(&matrix32[cell >> 1]);
+#endif
                 par[u] = (cell & 1u) * 16u;
             };
 #pragma unroll
@@ -1301,46 +1430,82 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
                 rw[u] = uniform4(*reinterpret_cast<const uint4*>(&sl[u]));
                 uint32_t li, ri;
                 id_slots(rw[u], li, ri);
-                gather(g_left[li], e_right[ri], u);
+                gather(ids16[li], e_right[ri], u);
             }
-            uint4 qn = *reinterpret_cast<const uint4*>(&sl[kDepth]);  // record of the next pass to prefetch
+            // two-stage prefetch: the ids of pass si + kDepth + 1 are read from LDS while pass si runs, the gather of
+            // pass si + kDepth is issued from the ids read one pass earlier: no LDS wait in front of the global load
+            uint4 fq = uniform4(*reinterpret_cast<const uint4*>(&sl[kDepth]));
+            uint32_t p_left, p_right;
+            {
+                uint32_t li, ri;
+                id_slots(fq, li, ri);
+                p_left = ids16[li];
+                p_right = e_right[ri];
+            }
+            uint4 qn = *reinterpret_cast<const uint4*>(&sl[kDepth + 1]);
+#if VBT_EXP == 8
+            uint64_t xacc[4] = {0, 0, 0, 0}, tq3;
+            asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tq3) :: "memory");
+#endif
             for (uint32_t s0 = 0; s0 < SL; s0 += kDepth) {
 #pragma unroll
                 for (uint32_t u = 0; u < kDepth; ++u) {
                     const uint32_t si = s0 + u;
+#if VBT_EXP == 8
+                    uint64_t tq0; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tq0) :: "memory");
+                    xacc[3] += tq0 - tq3;
+#endif
                     const uint32_t cword = ring[u], cpar = par[u];
                     const uint4 r = rw[u];
+                    rw[u] = fq;
+                    gather(p_left, p_right, u);  // pass si + kDepth, into the ring slot just consumed
                     const uint32_t c_beg = r.x & 0xFFFFu, nc = r.x >> 16, p_beg = r.y & 0xFFFFu, np = r.y >> 16;
                     const uint32_t ngs = r.z >> 16, grel = r.w & 0xFFFFu, fl = r.w >> 16;
-                    const uint32_t last = fl & 1u, acc = fl & 2u, single = fl & 8u, lg = (fl >> 4) & 7u;
+                    const uint32_t last = fl & 1u, acc = fl & 2u, direct = fl & 4u, single = fl & 8u, lg = (fl >> 4) & 7u;
                     const uint32_t g = ln >> lg, j = ln & ((1u << lg) - 1u);
                     const bool valid = g < ngs && j < np;
-                    // Every LDS read of the pass is issued here, branch-free, so one wait covers them all:
-                    // the record after next, the id pair of the pass to prefetch, and this pass's operands.
-                    const uint4 f = uniform4(qn);
-                    qn = *reinterpret_cast<const uint4*>(&sl[si + kDepth + 1]);
-                    uint32_t li, ri;
-                    id_slots(f, li, ri);
-                    const uint32_t f_left = g_left[li], f_right = e_right[ri];
+                    // every LDS read of the pass is issued here, branch-free, so one wait covers them all
+                    fq = uniform4(qn);
+                    qn = *reinterpret_cast<const uint4*>(&sl[si + kDepth + 2]);
+                    {
+                        uint32_t li, ri;
+                        id_slots(fq, li, ri);
+                        p_left = ids16[li];
+                        p_right = e_right[ri];
+                    }
                     const uint64_t kb = e_key[p_beg + (valid ? j : 0u)];
-                    const uint32_t c = c_beg + (ln < nc ? ln : 0u);
+                    const uint32_t cl = direct ? g : ln;           // the candidate this lane finalises
+                    const uint32_t c = c_beg + (cl < nc ? cl : 0u);
                     const uint32_t ew = nd_ew[c], gid = nd_gid[c];
-                    rw[u] = f;
-                    gather(f_left, f_right, u);  // prefetch into the ring slot just consumed
                     const uint32_t cv = (uint32_t)(int32_t)(int16_t)(cword >> cpar);
                     const bool live = valid && (uint32_t)kb != 0xFFFFFFFFu;
                     uint32_t khi = live ? (uint32_t)(kb >> 32) + cv : 0xFFFFFFFFu;  // wrapping i32 add
                     uint32_t klo = live ? (uint32_t)kb : 0xFFFFFFFFu;
+#if VBT_EXP == 8
+                    uint64_t tq1; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tq1) : "v"(khi), "v"(klo) : "memory");
+                    xacc[0] += tq1 - tq0;
+#endif
+#if VBT_EXP == 5 || VBT_EXP == 7
+                    group_min_split_n<3>(khi, klo);
+#elif VBT_EXP != 1
                     group_min_split(khi, klo, lg);
-                    if (single) {
-                        // the whole step is this pass: group minima go straight to the candidate lanes
+#endif
+#if VBT_EXP == 8
+                    uint64_t tq2; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tq2) : "v"(khi), "v"(klo) : "memory");
+                    xacc[1] += tq2 - tq1;
+#endif
+#if VBT_EXP == 6 || VBT_EXP == 7
+                    if (true) {
+#else
+                    if (direct) {
+#endif
+                        // one lane group per candidate: the group minimum is the candidate's best predecessor
+                        if (valid && j == 0) e_key[ew & 0xFFFFu] = node_key(khi, klo, (uint32_t)(int32_t)(int16_t)(ew >> 16), c);
+                    } else if (single) {
+                        // the whole step is this pass: group minima are broadcast to the candidate lanes
                         const int src = (int)((gid & 0x7Fu) << lg);
                         const uint32_t bhi = __shfl(khi, src), blo = __shfl(klo, src);
-                        if (ln < nc) {
-                            // lattice.rs:125; the biased cost takes the (sign-extended) word cost by wrapping add
-                            e_key[ew & 0xFFFFu] = ((uint64_t)(bhi + (uint32_t)(int32_t)(int16_t)(ew >> 16)) << 32) | (0xFFFFFFFEu - c);
-                            e_back[ew & 0xFFFFu] = (uint16_t)(0xFFFFFFFEu - blo);
-                        }
+                        if (ln < nc) e_key[ew & 0xFFFFu] = node_key(bhi, blo, (uint32_t)(int32_t)(int16_t)(ew >> 16), c);
                     } else {
                         uint64_t key = ((uint64_t)khi << 32) | klo;
                         if (g < ngs && j == 0) {
@@ -1355,8 +1520,7 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
                                     const uint32_t c2 = c_beg + ci_;
                                     const uint64_t best = g_best[nd_gid[c2] & 0x7Fu];
                                     const uint32_t ew2 = nd_ew[c2];
-                                    e_key[ew2 & 0xFFFFu] = make_key(key_cost(best) + (uint32_t)(int32_t)(int16_t)(ew2 >> 16), c2);
-                                    e_back[ew2 & 0xFFFFu] = (uint16_t)key_seq(best);
+                                    e_key[ew2 & 0xFFFFu] = node_key((uint32_t)(best >> 32), (uint32_t)best, (uint32_t)(int32_t)(int16_t)(ew2 >> 16), c2);
                                 }
                             }
                         }
@@ -1364,8 +1528,15 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
                     // LDS operations of one wave execute in order: a compiler-level fence is all the next pass needs
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
+#if VBT_EXP == 8
+                    asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tq3) :: "memory");
+                    xacc[2] += tq3 - tq2;
+#endif
                 }
             }
+#if VBT_EXP == 8
+            prof_acc[3] = xacc[0]; prof_acc[4] = xacc[1]; prof_acc[5] = xacc[2]; prof_acc[7] = xacc[3];
+#endif
             __syncthreads();
         }
         PROF_MARK(6);
@@ -1395,10 +1566,10 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
         uint16_t* path = reinterpret_cast<uint16_t*>(lens);  // the length masks are dead now; tokens <= chars
         uint32_t T = 0;
         if (ln == 0) {
-            uint32_t seq = e_back[C + 1];
+            uint32_t seq = key_back(e_key[C + 1]);
             while (seq != kBosSeq && T < n) {
                 path[T++] = (uint16_t)seq;
-                seq = e_back[nd_ew[seq] & 0xFFFFu];
+                seq = key_back(e_key[nd_ew[seq] & 0xFFFFu]);
             }
         }
         T = __shfl(T, 0);
@@ -1418,22 +1589,29 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
                     const uint32_t mid = (lo + hi) >> 1;
                     if ((uint32_t)cand_off[mid + 1] <= c) lo = mid + 1; else hi = mid;
                 }
-                const uint32_t stp = lo, en = nd_end[c];
+                const uint4 rec = nd[c];
+                const uint32_t stp = lo, en = rec.y >> 16;
                 vbt_token_rec r;
                 r.start_char = stp; r.end_char = en;
                 r.start_byte = c2b[stp]; r.end_byte = c2b[en];
-                r.word_idx = nd[c].z;
+                r.word_idx = rec.z;
                 r.total_cost = (int32_t)key_cost(e_key[nd_ew[c] & 0xFFFFu]);
                 A.tokens[out_base + t] = r;
             }
         }
         PROF_MARK(7);
         if (A.prof && ln == 0) {
-            unsigned long long* pr_ = A.prof + (size_t)(sid & (kProfSlots - 1)) * (kProfPhases + 1);
+            unsigned long long* pr_ = A.prof + (size_t)(sid & (kProfSlots - 1)) * kProfWords;
             for (int i = 3; i < kProfPhases; ++i) atomicAdd(&pr_[i], (unsigned long long)prof_acc[i]);
+#if VBT_EXP != 9
+            atomicAdd(&pr_[kProfPhases + 1], (unsigned long long)S);
+            atomicAdd(&pr_[kProfPhases + 2], (unsigned long long)prof_SL);
+            atomicAdd(&pr_[kProfPhases + 3], (unsigned long long)C);
+#endif
         }
 #undef PROF_MARK
         __syncthreads();
+    }
     }
 }
 
@@ -1612,9 +1790,19 @@ Workspace::Workspace(const Tokenizer& t, uint64_t max_s, uint64_t max_b) : tok(t
     d_over = static_cast<uint32_t*>(alloc(2 * ns * 4 * (tiers.size() + 2)));  // two regions per list: long-first pass + bulk
     d_ctrl = static_cast<uint32_t*>(alloc(kCtrlWords * 4));
     d_cctrl = static_cast<uint32_t*>(alloc((size_t)kMaxChunks * kChunkCtrlWords * 4));
-    n_chunks = std::min<uint32_t>(kMaxChunks / 2, std::max<uint32_t>(1, env_u32("VBT_CHUNKS", 1)));  // > 1 measured slower (launch overhead)
-    d_prof = static_cast<unsigned long long*>(alloc(kProfSlots * (kProfPhases + 1) * 8));
-    HIP_CHECK(hipMemset(d_prof, 0, kProfSlots * (kProfPhases + 1) * 8));
+    n_chunks = 1;
+    if (const char* e = std::getenv("VBT_TIER_WAVES")) {  // experiment: fixed lattice grid per tier
+        std::string spec = e;
+        size_t pos = 0;
+        while (pos < spec.size()) {
+            size_t c = spec.find(',', pos);
+            if (c == std::string::npos) c = spec.size();
+            tier_waves.push_back((uint32_t)std::strtoul(spec.substr(pos, c - pos).c_str(), nullptr, 10));
+            pos = c + 1;
+        }
+    }
+    d_prof = static_cast<unsigned long long*>(alloc(kProfSlots * kProfWords * 8));
+    HIP_CHECK(hipMemset(d_prof, 0, kProfSlots * kProfWords * 8));
     const uint64_t mb = env_u32("VBT_SCRATCH_MB", 0);
     scratch_bytes = mb ? mb << 20 : std::max<uint64_t>(256ull << 20, 256 * nbts);
     d_scratch = static_cast<char*>(alloc(scratch_bytes));
@@ -1635,7 +1823,9 @@ Workspace::Workspace(const Tokenizer& t, uint64_t max_s, uint64_t max_b) : tok(t
         pipe.g_pc = static_cast<uint4*>(alloc(slots * 16));
         pipe.node_factor = std::max<uint32_t>(1, env_u32("VBT_NODE_FACTOR", 8));  // candidate slots per input byte
         pipe.g_nd = static_cast<uint4*>(alloc((size_t)pipe.node_factor * slots * 16));
+        pipe.g_hits = static_cast<uint4*>(alloc((size_t)pipe.node_factor * slots * 16));
         pipe.s_tier = static_cast<uint8_t*>(alloc(ns));
+        pipe.s_early = static_cast<uint8_t*>(alloc(ns));
         for (size_t t = 0; t < tiers.size(); ++t) {
             hipStream_t st;
             HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
@@ -1645,6 +1835,9 @@ Workspace::Workspace(const Tokenizer& t, uint64_t max_s, uint64_t max_b) : tok(t
             tier_events.push_back(e);
         }
         HIP_CHECK(hipEventCreateWithFlags(reinterpret_cast<hipEvent_t*>(&ev_fork), hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(reinterpret_cast<hipEvent_t*>(&ev_fork2), hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(reinterpret_cast<hipEvent_t*>(&ev_early), hipEventDisableTiming));
+        HIP_CHECK(hipStreamCreateWithFlags(reinterpret_cast<hipStream_t*>(&early_stream), hipStreamNonBlocking));
         if (tiers.back() > 65536)  // a single workgroup may use the CU's whole 160 KiB
             HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lattice_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tiers.back()));
     }
@@ -1655,6 +1848,9 @@ Workspace::~Workspace() {
     for (auto& e : ev) if (e) (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(e));
     for (void* e : tier_events) (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(e));
     if (ev_fork) (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(ev_fork));
+    if (ev_fork2) (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(ev_fork2));
+    if (ev_early) (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(ev_early));
+    if (early_stream) (void)hipStreamDestroy(reinterpret_cast<hipStream_t>(early_stream));
     for (void* st : streams) (void)hipStreamDestroy(reinterpret_cast<hipStream_t>(st));
 }
 
@@ -1677,6 +1873,7 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
     a.prof = profile ? d_prof : nullptr;
     a.lists = d_over; a.list_stride = (uint32_t)stride; a.n_tiers = (uint32_t)T;
     a.tier_prio = env_u32("VBT_TIER_PRIO", 3);
+    a.steal_depth = env_u32("VBT_STEAL", 0);
     a.sid0 = 0; a.cctrl = d_cctrl; a.list_off = 0;
     a.lid_count = count_connids ? d_connid : nullptr;
     a.rid_count = count_connids ? d_connid + tok.dict().num_left : nullptr;
@@ -1702,66 +1899,50 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
         hipLaunchKernelGGL(tokenize_global, dim3((uint32_t)std::min<uint64_t>(n, 1024)), dim3(64), 0, stream, D, a,
                            (const uint32_t*)over(T - 1), (const uint32_t*)count(T - 1), cursor(T));
     } else {
-        // The batch is cut into chunks of sentences so that candidate generation of chunk c + 1
-        // (memory-latency bound, no LDS) overlaps the lattice sweep of chunk c (LDS / issue bound).
-        // Every LDS tier has its own stream (largest = slowest sentences first); the launch stream
-        // only forks and joins.
-        const uint32_t gen_lds = env_u32("VBT_GEN_LDS", 6144), gen_lds_large = 65536;
-        uint32_t K = n_chunks;
-        if (K > kMaxChunks / 2) K = kMaxChunks / 2;
-        while (K > 1 && n / K < 8192) --K;
-        last_chunks = K;
+        // Stream plan.  The launch stream runs gen_candidates -> build_lists -> gen_candidates_large (stragglers
+        // that outgrew the bulk generator's LDS) and then forks one lattice_lds launch per LDS tier onto the
+        // tier streams and joins them.  Optional (VBT_LONG_BYTES > 0, off by default): sentences of at least that
+        // many bytes are listed first and generated by the large-LDS generator on a side stream while the bulk
+        // runs.  Measured on MI355X it does not pay: the side stream's few wavefronts are slowed by the bulk
+        // as much as they save (4.40 vs 4.27 ms per 100k sentences).
+        const uint32_t gen_lds = env_u32("VBT_GEN_LDS", 8192), gen_lds_large = 65536;
         const uint32_t long_bytes = env_u32("VBT_LONG_BYTES", 0);
-        auto fork_tiers = [&](uint32_t cn) {
+        last_chunks = 1;
+        const uint32_t cn = (uint32_t)n, lb = (cn + 1023) / 1024;
+        a.sid0 = 0; a.n = cn; a.cctrl = d_cctrl; a.list_off = 0; a.direct_push = 0;
+        a.s_skip = nullptr;
+        HIP_CHECK(hipMemsetAsync(pipe.s_tier, 0xFF, cn, stream));  // nothing routed yet
+        if (long_bytes) {
+            BatchArgs e = a;  // same routing array, own input list (second counter block / list region)
+            e.cctrl = d_cctrl + (size_t)kChunkCtrlWords; e.list_off = (uint32_t)half;
+            hipLaunchKernelGGL(classify_long, dim3((cn + 255) / 256), dim3(256), 0, stream, e, long_bytes);
             HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_fork), stream));
-            for (size_t i = 0; i < T; ++i) {
-                const size_t t = T - 1 - i;
-                hipStream_t side = reinterpret_cast<hipStream_t>(streams[t]);
-                HIP_CHECK(hipStreamWaitEvent(side, reinterpret_cast<hipEvent_t>(ev_fork), 0));
-                hipLaunchKernelGGL(lattice_lds, dim3(waves_for(tiers[t], cn)), dim3(64), tiers[t], side, D, a, (uint32_t)t);
-            }
-        };
-        for (uint32_t c = 0; c < K; ++c) {
-            const uint32_t lo = (uint32_t)(n * c / K), hi = (uint32_t)(n * (c + 1) / K), cn = hi - lo;
-            a.sid0 = lo; a.n = cn;
-            const uint32_t lb = (cn + 255) / 256;
-            a.cctrl = d_cctrl + (size_t)c * kChunkCtrlWords; a.list_off = lo;
-            if (long_bytes) {
-                // optional long-first pass (VBT_LONG_BYTES > 0): sentences of >= long_bytes bytes are generated,
-                // filed and swept before the bulk.  Off by default: on MI355X the 12 extra launches cost more
-                // than the tail they remove (measured 5.67 ms vs 5.22 ms per 100k sentences).
-                a.cctrl = d_cctrl + (size_t)(K + c) * kChunkCtrlWords; a.list_off = (uint32_t)half + lo;
-                hipLaunchKernelGGL(classify_long, dim3(lb), dim3(256), 0, stream, a, long_bytes);
-                hipLaunchKernelGGL(build_lists, dim3(lb), dim3(256), 0, stream, a, (int)(T + 1));
-                hipLaunchKernelGGL(gen_candidates_large, dim3(waves_for(gen_lds_large, cn)), dim3(64), gen_lds_large, stream, D, a, gen_lds_large);
-                hipLaunchKernelGGL(build_lists, dim3(lb), dim3(256), 0, stream, a, -1);
-                fork_tiers(std::min<uint32_t>(cn, 4096));
-                a.cctrl = d_cctrl + (size_t)c * kChunkCtrlWords; a.list_off = lo;
-            } else {
-                HIP_CHECK(hipMemsetAsync(pipe.s_tier + lo, 0xFF, cn, stream));  // nothing filed yet
-            }
-            // 2. the bulk (the small generator skips what step 1 filed); stragglers that outgrow its LDS
-            //    go through the large generator again
-            hipLaunchKernelGGL(gen_candidates, dim3(cn), dim3(64), gen_lds, stream, D, a, gen_lds);
-            hipLaunchKernelGGL(build_lists, dim3(lb), dim3(256), 0, stream, a, (int)(T + 1));
-            hipLaunchKernelGGL(gen_candidates_large, dim3(waves_for(gen_lds_large, cn)), dim3(64), gen_lds_large, stream, D, a, gen_lds_large);
-            hipLaunchKernelGGL(build_lists, dim3(lb), dim3(256), 0, stream, a, -1);
-            if (c == 0) rec(1);
-            fork_tiers(cn);
+            hipStream_t es = reinterpret_cast<hipStream_t>(early_stream);
+            HIP_CHECK(hipStreamWaitEvent(es, reinterpret_cast<hipEvent_t>(ev_fork), 0));
+            hipLaunchKernelGGL(gen_candidates_large, dim3(waves_for(gen_lds_large, cn)), dim3(64), gen_lds_large, es, D, e, gen_lds_large);
+            HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_early), es));
+            a.s_skip = pipe.s_early;  // the bulk generator leaves these alone
         }
-        for (size_t t = 0; t < T; ++t) {
+        hipLaunchKernelGGL(gen_candidates, dim3(cn), dim3(64), gen_lds, stream, D, a, gen_lds);
+        if (long_bytes) HIP_CHECK(hipStreamWaitEvent(stream, reinterpret_cast<hipEvent_t>(ev_early), 0));
+        hipLaunchKernelGGL(build_lists, dim3(lb), dim3(1024), 0, stream, a, -1);
+        a.direct_push = 1;
+        hipLaunchKernelGGL(gen_candidates_large, dim3(waves_for(gen_lds_large, cn)), dim3(64), gen_lds_large, stream, D, a, gen_lds_large);
+        a.direct_push = 0;
+        rec(1);
+        HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_fork2), stream));
+        for (size_t i = 0; i < T; ++i) {
+            const size_t t = T - 1 - i;
             hipStream_t side = reinterpret_cast<hipStream_t>(streams[t]);
+            HIP_CHECK(hipStreamWaitEvent(side, reinterpret_cast<hipEvent_t>(ev_fork2), 0));
+            const uint32_t grid = (t < tier_waves.size() && tier_waves[t]) ? std::min<uint32_t>(tier_waves[t], waves_for(tiers[t], cn)) : waves_for(tiers[t], cn);
+            hipLaunchKernelGGL(lattice_lds, dim3(grid), dim3(64), tiers[t], side, D, a, (uint32_t)t);
             HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(tier_events[t]), side));
-            HIP_CHECK(hipStreamWaitEvent(stream, reinterpret_cast<hipEvent_t>(tier_events[t]), 0));
         }
-        for (uint32_t c = 0; c < (long_bytes ? 2 * K : K); ++c) {  // whatever the pipeline could not take: fused kernel, global-memory lattice
-            const uint32_t cc_i = c % K, phase1 = c / K;
-            const uint32_t lo = (uint32_t)(n * cc_i / K), hi = (uint32_t)(n * (cc_i + 1) / K);
-            uint32_t* cc = d_cctrl + (size_t)(phase1 ? K + cc_i : cc_i) * kChunkCtrlWords;
-            a.sid0 = lo; a.n = hi - lo; a.cctrl = cc; a.list_off = (phase1 ? (uint32_t)half : 0u) + lo;
-            hipLaunchKernelGGL(tokenize_global, dim3((uint32_t)std::min<uint64_t>(hi - lo, phase1 ? 256 : 1024)), dim3(64), 0, stream, D, a,
-                               (const uint32_t*)(over(T) + a.list_off), (const uint32_t*)(cc + 2 * T), cc + 2 * T + 1);
-        }
+        for (size_t t = 0; t < T; ++t) HIP_CHECK(hipStreamWaitEvent(stream, reinterpret_cast<hipEvent_t>(tier_events[t]), 0));
+        // whatever the pipeline could not take: fused kernel, global-memory lattice
+        hipLaunchKernelGGL(tokenize_global, dim3((uint32_t)std::min<uint64_t>(cn, 1024)), dim3(64), 0, stream, D, a,
+                           (const uint32_t*)over(T), (const uint32_t*)(d_cctrl + 2 * T), d_cctrl + 2 * T + 1);
     }
     rec(2);
     HIP_CHECK(hipGetLastError());
@@ -1829,11 +2010,11 @@ void Workspace::read_connid_counts(uint64_t* lid, uint64_t* rid, bool reset) {
 void Workspace::read_profile(uint64_t* out, bool reset) {
     HIP_CHECK(hipSetDevice(tok.device()));
     HIP_CHECK(hipStreamSynchronize(reinterpret_cast<hipStream_t>(last_stream)));
-    std::vector<uint64_t> h((size_t)kProfSlots * (kProfPhases + 1));
+    std::vector<uint64_t> h((size_t)kProfSlots * kProfWords);
     HIP_CHECK(hipMemcpy(h.data(), d_prof, h.size() * 8, hipMemcpyDeviceToHost));
-    for (int i = 0; i <= kProfPhases; ++i) out[i] = 0;
+    for (int i = 0; i < kProfWords; ++i) out[i] = 0;
     for (int k = 0; k < kProfSlots; ++k)
-        for (int i = 0; i <= kProfPhases; ++i) out[i] += h[(size_t)k * (kProfPhases + 1) + i];
+        for (int i = 0; i < kProfWords; ++i) out[i] += h[(size_t)k * kProfWords + i];
     if (reset) HIP_CHECK(hipMemset(d_prof, 0, h.size() * 8));
 }
 

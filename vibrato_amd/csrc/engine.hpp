@@ -46,7 +46,7 @@ struct BatchArgs {
     // global scratch arena for the last tier
     char* scratch;
     uint64_t scratch_bytes;
-    // optional per-phase cycle counters (kProfPhases + 1 u64), nullptr = off
+    // optional per-phase cycle counters (kProfSlots x kProfWords u64), nullptr = off
     unsigned long long* prof;
     // ---- two-kernel pipeline: gen_candidates -> lattice_lds (per LDS tier) ----
     // per sentence
@@ -66,13 +66,18 @@ struct BatchArgs {
     // One 16-byte record: {left_id | right_id << 16, (u16) word_cost | end_char << 16, word_idx,
     //                      left-id group within the start position | 0x80 on the group's first candidate}
     uint4* g_nd;
+    uint4* g_hits;      // staging of the trie hits of gen_candidates, same per-sentence regions as g_nd
     uint32_t node_factor;
     uint8_t* s_tier;    // LDS tier chosen by gen_candidates (0xFF = none / empty sentence)
+    uint8_t* s_early;   // the same for the early (long-sentence) pipeline
+    const uint8_t* s_skip;  // bulk generator: sentences with s_skip[sid] != 0xFF belong to the early pipeline (nullptr = none)
     // work lists: list t (t < n_tiers) feeds LDS tier t, list n_tiers the global-memory fallback (fused kernel),
     // list n_tiers + 1 the large-LDS instance of gen_candidates
     uint32_t* lists;
     uint32_t list_stride;
     uint32_t n_tiers;
+    uint32_t direct_push;  // gen_candidates_large: append to the tier lists directly instead of routing through s_tier
+    uint32_t steal_depth;  // a lattice wave whose list ran dry helps up to this many smaller tiers
     uint32_t tier_prio;  // the top `tier_prio` LDS tiers run at raised wave priority (0 = off)
     // chunked pipeline: a launch covers sentences [sid0, sid0 + n); cctrl = this chunk's list counters
     // (cctrl[2t] = entries of list t, cctrl[2t+1] = its work cursor); list t of the chunk starts at
@@ -94,6 +99,7 @@ constexpr int kMaxTiers = 8;
 constexpr int kMaxChunks = 16;
 constexpr int kChunkCtrlWords = 2 * (kMaxTiers + 2);
 constexpr int kProfSlots = 256;  // the counters are spread over this many copies (hot-word atomics serialise)
+constexpr int kProfWords = 12;   // kProfPhases cycle totals, sentences, lattice steps, lattice passes, candidates
 constexpr int kProfPhases = 8;  // decode, count, fill, end lists, pre-pass, gather, recurrence, emit
 enum DevError { kErrTokCap = 1, kErrScratch = 2, kErrTooLong = 4 };
 
@@ -133,6 +139,9 @@ class Workspace {
     std::vector<void*> streams;      // one side stream per LDS tier
     std::vector<void*> tier_events;
     void* ev_fork = nullptr;
+    void* ev_fork2 = nullptr;
+    void* ev_early = nullptr;
+    void* early_stream = nullptr;  // generator + list building of the long sentences
     bool fused = false;              // VBT_FUSED=1: the single fused kernel per sentence (A/B reference)
     unsigned long long* d_connid = nullptr;  // [num_left + num_right] usage counters, allocated on first use
     bool count_connids = false;
@@ -142,8 +151,9 @@ class Workspace {
     char* d_scratch = nullptr;
     uint64_t scratch_bytes = 0;
     std::vector<uint32_t> tiers;  // LDS bytes per wave of each LDS tier
+    std::vector<uint32_t> tier_waves;  // lattice grid per tier (empty = fill the machine per tier)
     bool timing = false, profile = false;
-    void read_profile(uint64_t* out, bool reset);  // kProfPhases + 1 values (last = sentences counted)
+    void read_profile(uint64_t* out, bool reset);  // kProfWords values
     uint64_t last_n = 0;
     void* last_stream = nullptr;
     void* ev[4] = {nullptr, nullptr, nullptr, nullptr};
