@@ -145,9 +145,12 @@ class Dictionary:
         return self
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().ora_dict_free(self._h)
-            self._h = None
+        try:
+            if getattr(self, "_h", None):
+                lib().ora_dict_free(self._h)
+                self._h = None
+        except Exception:  # interpreter teardown
+            pass
 
     def num_words(self, lex_type=0):
         return lib().ora_dict_num_words(self._h, lex_type)
@@ -199,9 +202,12 @@ class Tokenizer:
             raise OracleError(err.value.decode("utf-8", "replace"))
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().ora_tokenizer_free(self._h)
-            self._h = None
+        try:
+            if getattr(self, "_h", None):
+                lib().ora_tokenizer_free(self._h)
+                self._h = None
+        except Exception:  # interpreter teardown
+            pass
 
     def new_worker(self):
         return Worker(self)
@@ -216,9 +222,12 @@ class Worker:
         self._text = b""
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().ora_worker_free(self._h)
-            self._h = None
+        try:
+            if getattr(self, "_h", None):
+                lib().ora_worker_free(self._h)
+                self._h = None
+        except Exception:  # interpreter teardown
+            pass
 
     def reset_sentence(self, text):
         self._text = _b(text)

@@ -103,11 +103,13 @@ def test_compute_probs_golden():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seg_bytes", ["32768", "16384"])
 @pytest.mark.parametrize("ignore_space", [False, True])
-def test_connid_counts_match_oracle(ignore_space):
+def test_connid_counts_match_oracle(ignore_space, seg_bytes, monkeypatch):
     """The `reorder` statistics (map/src/reorder.rs:34-43) computed on the GPU == the oracle's
     Lattice::add_connid_counts over the same sentences, including trailing-space EOS handling."""
     import torch
+    monkeypatch.setenv("VBT_SEG_BYTES", seg_bytes)  # 16384: the longer third of the sentences is swept in segments
     sd = synth.SynthDict("small")
     text, offs = sd.sentences(3000, "lognormal_40", space_p=0.15 if ignore_space else 0.0)
     do = ora.Dictionary.from_sources_binmatrix(sd.lex, sd.matrix, sd.num_right, sd.num_left, sd.char_def, sd.unk)

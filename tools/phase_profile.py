@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--min-chars", type=int, default=0, help="keep only sentences with at least this many bytes/3")
     ap.add_argument("--max-chars", type=int, default=0)
+    ap.add_argument("--law", default="lognormal_40")
     args = ap.parse_args()
     import torch
     import vibrato_amd as V
@@ -25,7 +26,7 @@ def main():
     sd = synth.SynthDict(args.dict)
     dv = V.SystemDictionaryBuilder.from_readers_binmatrix(sd.lex, sd.matrix, sd.num_right, sd.num_left, sd.char_def, sd.unk)
     tok = V.Tokenizer(dv, device=0)
-    text, offs = sd.sentences(args.sentences, "lognormal_40")
+    text, offs = sd.sentences(args.sentences, args.law)
     if args.min_chars or args.max_chars:
         lens = np.diff(offs).astype(np.int64)
         keep = np.nonzero((lens >= 2.85 * args.min_chars) & ((lens <= 2.85 * args.max_chars) if args.max_chars else True))[0]

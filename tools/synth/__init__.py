@@ -80,9 +80,12 @@ class SynthDict:
         self._matrix = None
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().syn_dict_free(self._h)
-            self._h = None
+        try:
+            if getattr(self, "_h", None):
+                lib().syn_dict_free(self._h)
+                self._h = None
+        except Exception:  # interpreter teardown
+            pass
 
     @property
     def matrix(self):

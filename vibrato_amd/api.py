@@ -26,9 +26,12 @@ class Dictionary:
         self._owned = owned
 
     def __del__(self):
-        if getattr(self, "_h", None) and self._owned:
-            N.lib().vbt_dict_free(self._h)
-        self._h = None
+        try:
+            if getattr(self, "_h", None) and self._owned:
+                N.lib().vbt_dict_free(self._h)
+            self._h = None
+        except Exception:  # interpreter teardown: module globals may be gone
+            pass
 
     def _handle(self):
         if not self._h:
@@ -186,9 +189,12 @@ class Tokenizer:
         return self._h
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            N.lib().vbt_tokenizer_free(self._h)
-            self._h = None
+        try:
+            if getattr(self, "_h", None):
+                N.lib().vbt_tokenizer_free(self._h)
+                self._h = None
+        except Exception:  # interpreter teardown: module globals may be gone
+            pass
 
     def dictionary(self):
         """Tokenizer::dictionary (tokenizer.rs:77-79)."""
@@ -228,9 +234,12 @@ class Worker:
         self._h = h
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            N.lib().vbt_worker_free(self._h)
-            self._h = None
+        try:
+            if getattr(self, "_h", None):
+                N.lib().vbt_worker_free(self._h)
+                self._h = None
+        except Exception:  # interpreter teardown: module globals may be gone
+            pass
 
     def reset_sentence(self, text):
         text = _b(text)
@@ -259,9 +268,12 @@ class Batch:
         self._h = handle
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            N.lib().vbt_batch_free(self._h)
-            self._h = None
+        try:
+            if getattr(self, "_h", None):
+                N.lib().vbt_batch_free(self._h)
+                self._h = None
+        except Exception:  # interpreter teardown: module globals may be gone
+            pass
 
     def __len__(self):
         return N.lib().vbt_batch_num_sentences(self._h)
@@ -336,9 +348,12 @@ class Workspace:
         self._h = h
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            N.lib().vbt_workspace_free(self._h)
-            self._h = None
+        try:
+            if getattr(self, "_h", None):
+                N.lib().vbt_workspace_free(self._h)
+                self._h = None
+        except Exception:  # interpreter teardown: module globals may be gone
+            pass
 
     def set_timing(self, on=True):
         N.check(N.lib().vbt_workspace_set_timing(self._h, int(on)))

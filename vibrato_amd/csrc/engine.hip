@@ -745,13 +745,14 @@ __device__ __forceinline__ void list_push(const BatchArgs& A, uint32_t t, uint32
 // candidates in reference insertion order, each tagged with its (start position, left_id) group:
 // search_min_node's result depends only on that pair (lattice.rs:129-151), so the lattice kernel
 // evaluates one row per group instead of one per candidate.
-__device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, uint32_t sid, uint32_t lds_bytes, bool large) {
+__device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, uint32_t sid, uint32_t lds_bytes, uint32_t level) {
+    const bool large = level != 0;  // level 0: bulk generator; 1, 2: the large- / whole-CU-LDS instances behind it
     const uint32_t ln = threadIdx.x;
     const uint64_t lt_mask = (1ull << ln) - 1ull;
     uint64_t prof_t = A.prof ? clock64() : 0, prof_acc[3] = {};
 #define PROF_MARK(i) do { if (A.prof) { const uint64_t t_ = clock64(); prof_acc[i] += t_ - prof_t; prof_t = t_; } } while (0)
     const uint64_t b0 = A.offsets[sid], nb64 = A.offsets[sid + 1] - b0;
-    const uint32_t fallback = A.n_tiers, large_list = A.n_tiers + 1;
+    const uint32_t fallback = A.n_tiers, large_list = level >= 2 ? A.n_tiers : A.n_tiers + 1 + level;  // where a sentence goes that outgrows this instance
     // gen routes a sentence by writing its list index; build_lists turns that into work lists with
     // wave-aggregated atomics (a per-sentence atomic on a hot word caps the kernel at ~88 M/s)
     auto route = [&](uint32_t t) {
@@ -790,7 +791,7 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
     uint32_t* endc = ar.take<uint32_t>(n + 1);  // candidates ending at each position (bounds the pass count)
     uint8_t* ngp = ar.take<uint8_t>(n);
     uint32_t* hcount = ar.take<uint32_t>(1);  // hits staged so far
-    if (!ar.ok) { route(large ? fallback : large_list); return; }
+    if (!ar.ok) { route(large_list); return; }
     for (uint32_t i = ln; i < n + 1; i += 64) endc[i] = i == 0 ? 1u : 0u;  // BOS ends at 0
 
     // decode (Sentence::compute_basic / compute_categories, sentence.rs:40-55); the 3 bytes after a
@@ -894,7 +895,7 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
     if (C > region) { route(fallback); return; }  // denser than the region: fused path
     uint16_t* cleft = ar.take<uint16_t>(C);  // left id per candidate, for the grouping below
     uint8_t* cgid = ar.take<uint8_t>(C);
-    if (!ar.ok) { route(large ? fallback : large_list); return; }
+    if (!ar.ok) { route(large_list); return; }
     // The staged hits are read back by this wave only: its stores have to be complete (workgroup scope:
     // s_waitcnt vmcnt(0); the vector L1 is write-through and never held these lines).  An agent-scope
     // release would write the whole L2 back (buffer_wbl2) once per sentence.
@@ -994,6 +995,21 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
         atomicAdd(&pq_[11], (unsigned long long)(xq[3] - xq[2]));
     }
 #endif
+#if VBT_EXP == 10  // experiment: how often does no candidate span a position ("clean cut")?
+    if (ln == 0 && A.prof) {
+        uint32_t far = 0, cuts = 0, last = 0, maxgap = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            if (i > 0 && far <= i) { ++cuts; maxgap = i - last > maxgap ? i - last : maxgap; last = i; }
+            const uint64_t lm = lens[i];
+            if (lm) { const uint32_t e = i + 64u - (uint32_t)__builtin_clzll(lm); far = e > far ? e : far; }
+        }
+        maxgap = n - last > maxgap ? n - last : maxgap;
+        unsigned long long* pq_ = A.prof + (size_t)(sid & (kProfSlots - 1)) * kProfWords;
+        atomicAdd(&pq_[9], (unsigned long long)cuts);
+        atomicAdd(&pq_[10], (unsigned long long)maxgap);
+        atomicAdd(&pq_[11], (unsigned long long)n);
+    }
+#endif
     // upper bound of the number of (step, <= 64 pair lanes) passes of the lattice kernel
     uint32_t passes = 1;  // EOS
     for (uint32_t c0 = 0; c0 < n; c0 += 64) {
@@ -1004,30 +1020,63 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
             const uint32_t lg = np <= 1 ? 0u : 32u - (uint32_t)__builtin_clz(np - 1);
             const uint32_t gpp = 64u >> (lg > 6 ? 6 : lg);
             nsl = np <= 64 ? (ng + gpp - 1) / gpp : ng * ((np + 63) / 64);
+            endc[i] = nsl;  // the end counts are dead: keep the per-position pass bound for the records below
         }
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) nsl += __shfl_xor(nsl, d);
         passes += nsl;
     }
-    {   // per-character records for the lattice kernel: {cand_off | goff << 16, grp | ng << 16 | space << 31, lens}
+    __syncthreads();
+    {   // per-character records for the lattice kernel:
+        // {cand_off | goff << 16, grp | ng << 16 | min(passes, 63) << 24 | clean cut << 30 | space << 31, lens}
+        // Clean cut before position i: no candidate of an earlier position ends beyond i (with ignore_space, a
+        // visited space run hands its visit to the position behind the run, tokenizer.rs:113-125, so such a run
+        // counts as spanning up to the furthest end of that position's candidates).  lattice_lds may split
+        // the sweep of a long sentence there.
         uint4* pc = A.g_pc + slot0;
-        for (uint32_t i = ln; i < n; i += 64) {
-            const uint32_t cinfo = ci[i];
-            const uint32_t space = (D.space_cateset && (cinfo & D.space_cateset)) ? 0x80000000u : 0u;
-            const uint64_t lm = lens[i];
-            pc[i] = make_uint4(cand_off[i] | ((uint32_t)goff[i] << 16), (uint32_t)grp[i] | ((uint32_t)ngp[i] << 16) | space,
-                               (uint32_t)lm, (uint32_t)(lm >> 32));
+        uint32_t far = 0;  // furthest end of any candidate of the positions before this chunk
+        for (uint32_t c0 = 0; c0 < n; c0 += 64) {
+            const uint32_t i = c0 + ln;
+            uint32_t e = 0, space = 0;
+            uint64_t lm = 0;
+            if (i < n) {
+                const uint32_t cinfo = ci[i];
+                space = (D.space_cateset && (cinfo & D.space_cateset)) ? 0x80000000u : 0u;
+                lm = lens[i];
+                e = lm ? i + 64u - (uint32_t)__builtin_clzll(lm) : i + 1;
+                if (space) {
+                    const uint32_t sw = i + grp[i];
+                    const uint64_t lw = sw < n ? lens[sw] : 0ull;
+                    const uint32_t e2 = sw < n ? (lw ? sw + 64u - (uint32_t)__builtin_clzll(lw) : sw + 1) : n;
+                    e = e2 > e ? e2 : e;
+                }
+            }
+            uint32_t m = e;  // inclusive prefix maximum over the lanes
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(m, d); if ((int)ln >= d) m = o > m ? o : m; }
+            uint32_t before = __shfl_up(m, 1);
+            before = ln == 0 ? far : (before > far ? before : far);
+            if (i < n) {
+                const uint32_t cut = (i == 0 || before <= i) ? 0x40000000u : 0u;
+                const uint32_t nsl = endc[i] < 63u ? endc[i] : 63u;
+                pc[i] = make_uint4(cand_off[i] | ((uint32_t)goff[i] << 16), (uint32_t)grp[i] | ((uint32_t)ngp[i] << 16) | (nsl << 24) | cut | space,
+                                   (uint32_t)lm, (uint32_t)(lm >> 32));
+            }
+            const uint32_t top = __shfl(m, 63);
+            far = top > far ? top : far;
         }
         if (ln == 0) pc[n] = make_uint4(C | (G << 16), 0, 0, 0);
     }
     if (ln == 0) {
-        A.s_n[sid] = n; A.s_C[sid] = C; A.s_flags[sid] = G | (ngmax << 16);
+        A.s_n[sid] = n; A.s_C[sid] = C; A.s_flags[sid] = G | (ngmax << 16); A.s_passes[sid] = passes;
     }
     // smallest tier whose LDS holds the lattice arrays (connection costs are never staged)
     const uint64_t fixed = lattice_fixed_bytes(n, C, G, ngmax, D.space_cateset != 0, passes);
     uint32_t tier = fallback;
     for (uint32_t t = 0; t < A.n_tiers; ++t)
         if (fixed <= A.tier_bytes[t]) { tier = t; break; }
+    // longer sentences are swept in segments inside the segment tier instead of one huge LDS block
+    if (A.seg_tier < A.n_tiers && tier > A.seg_tier) tier = A.seg_tier;
     route(tier);
     PROF_MARK(2);
     if (A.prof && ln == 0) {
@@ -1060,12 +1109,12 @@ __global__ void __launch_bounds__(256) classify_long(BatchArgs A, uint32_t long_
 __global__ void __launch_bounds__(1024) build_lists(BatchArgs A, int only_list) {
     // One global atomic per (workgroup, list): a returning atomic on a hot word costs ~11 ns, so the
     // 16 waves of a workgroup first agree on their shares through LDS.
-    __shared__ uint32_t w_cnt[16][kMaxTiers + 2];
-    __shared__ uint32_t l_base[kMaxTiers + 2];
+    __shared__ uint32_t w_cnt[16][kMaxTiers + 3];
+    __shared__ uint32_t l_base[kMaxTiers + 3];
     const uint32_t rel = blockIdx.x * 1024 + threadIdx.x, sid = A.sid0 + rel;
     const uint32_t t = rel < A.n ? A.s_tier[sid] : 0xFFu;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t n_lists = A.n_tiers + 2;
+    const uint32_t n_lists = A.n_tiers + 3;
     uint32_t my_rank = 0;
     for (uint32_t l = 0; l < n_lists; ++l) {
         const bool mine = t == l && (only_list < 0 || (int)l == only_list);
@@ -1089,18 +1138,18 @@ __global__ void __launch_bounds__(1024) build_lists(BatchArgs A, int only_list) 
 
 // Kernel 1: one single-wave workgroup per sentence (small LDS, high occupancy) ...
 __global__ void __launch_bounds__(64) gen_candidates(DevDict D, BatchArgs A, uint32_t lds_bytes) {
-    gen_one(D, A, A.sid0 + blockIdx.x, lds_bytes, false);
+    gen_one(D, A, A.sid0 + blockIdx.x, lds_bytes, 0);
 }
 // ... and persistent waves with a large LDS budget for the sentences that did not fit.
-__global__ void __launch_bounds__(64) gen_candidates_large(DevDict D, BatchArgs A, uint32_t lds_bytes) {
-    const uint32_t t = A.n_tiers + 1;
+__global__ void __launch_bounds__(64) gen_candidates_large(DevDict D, BatchArgs A, uint32_t lds_bytes, uint32_t level) {
+    const uint32_t t = A.n_tiers + level;
     const uint32_t count = A.cctrl[2 * t];
     for (;;) {
         uint32_t k = 0;
         if (threadIdx.x == 0) k = atomicAdd(&A.cctrl[2 * t + 1], 1u);
         k = __shfl(k, 0);
         if (k >= count) break;
-        gen_one(D, A, A.lists[(size_t)t * A.list_stride + A.list_off + k], lds_bytes, true);
+        gen_one(D, A, A.lists[(size_t)t * A.list_stride + A.list_off + k], lds_bytes, level);
         __syncthreads();
     }
 }
@@ -1143,18 +1192,73 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
         const uint32_t sid = __builtin_amdgcn_readfirstlane(list[item]);
         uint64_t prof_t = A.prof ? clock64() : 0, prof_acc[kProfPhases] = {};
 #define PROF_MARK(i) do { if (A.prof) { const uint64_t t_ = clock64(); prof_acc[i] += t_ - prof_t; prof_t = t_; } } while (0)
-        const uint32_t n = __builtin_amdgcn_readfirstlane(A.s_n[sid]), C = __builtin_amdgcn_readfirstlane(A.s_C[sid]);
+        const uint32_t nT = __builtin_amdgcn_readfirstlane(A.s_n[sid]), CT = __builtin_amdgcn_readfirstlane(A.s_C[sid]);
         const uint32_t sflags = __builtin_amdgcn_readfirstlane(A.s_flags[sid]);
-        const uint32_t G = sflags & 0xFFFFu, ngmax = sflags >> 16;
+        const uint32_t GT = sflags & 0xFFFFu, ngmax = sflags >> 16;
+        const uint32_t passesT = __builtin_amdgcn_readfirstlane(A.s_passes[sid]);
         const size_t slot0 = (size_t)uniform64(A.offsets[sid]) + sid;
-        const uint4* __restrict__ nd = A.g_nd + (size_t)A.node_factor * slot0;
-        const uint4* __restrict__ pc = A.g_pc + slot0;
+        const size_t node0 = (size_t)A.node_factor * slot0;
+        const uint32_t kBosSeq = CT + 1;
+        // A sentence whose lattice does not fit this tier's LDS is swept in segments that end at clean cuts
+        // (positions no candidate spans, flagged by gen_candidates): only the nodes ending exactly at the cut
+        // -- the interface, carried in registers -- connect a segment to the next.  Sequence numbers and back
+        // pointers stay sentence-global; each segment leaves (cost, back pointer) per node in global memory.
+        uint32_t seg_a = 0, seg_c = 0, seg_g = 0, seg_p = 0, fail = 0;
+        constexpr uint32_t kCarry = 2;  // interface nodes per lane: up to 128 nodes may end at a cut
+        uint64_t carry_key[kCarry];
+        uint32_t carry_right[kCarry], m_in = 1;
+#pragma unroll
+        for (uint32_t q = 0; q < kCarry; ++q) { carry_key[q] = kDeadKey; carry_right[q] = 0; }
+        if (ln == 0) carry_key[0] = node_key(0x80000000u, 0u, 0u, kBosSeq);  // BOS: cost 0, no predecessor
+        bool multi = false, done = false;
+        uint32_t prof_S = 0, prof_SL = 0;
+        uint32_t budget = lds_bytes;  // what a segment may be estimated at; shrinks when an estimate turns out too low
+        while (!done) {
+        uint32_t seg_b = nT, seg_pass = passesT - seg_p;
+        if (lattice_fixed_bytes(nT - seg_a, CT - seg_c, GT - seg_g, ngmax, space_mode, passesT - seg_p) + 10ull * m_in > budget) {
+            // furthest clean cut within 256 positions whose segment fits
+            const uint4* __restrict__ pcg = A.g_pc + slot0;
+            uint32_t best = 0, best_pass = 0, run = 0;
+            for (uint32_t w0 = 0; w0 < 256 && seg_a + w0 < nT; w0 += 64) {
+                const uint32_t b = seg_a + w0 + ln + 1;  // candidate segment end
+                uint32_t nsl = 0, cx = 0, cut = 0;
+                if (b <= nT) {
+                    const uint4 rp = pcg[b - 1], rb = pcg[b];
+                    nsl = (rp.y >> 24) & 63u;
+                    if (nsl == 63u) nsl = 1u << 20;  // saturated: unknown, treat as too many
+                    cx = rb.x;
+                    cut = b == nT ? 1u : (rb.y >> 30) & 1u;
+                }
+                uint32_t tot;
+                const uint32_t incl = wave_exscan(nsl, tot) + nsl + run;
+                const uint64_t bytes = lattice_fixed_bytes(b - seg_a, ((cx & 0xFFFFu) - seg_c) & 0xFFFFu, ((cx >> 16) - seg_g) & 0xFFFFu, ngmax, space_mode, incl + 1);
+                const bool fits = b <= nT && bytes + 10ull * m_in <= budget;
+                const uint64_t m = __ballot(fits && cut);
+                if (m) {
+                    const uint32_t top = 63u - (uint32_t)__builtin_clzll(m);
+                    best = seg_a + w0 + top + 1;
+                    best_pass = __shfl(incl, (int)top) - 0u;
+                }
+                run += tot;
+                if (__ballot(fits) == 0) break;
+            }
+            if (!best) { fail = 30; break; }
+            seg_b = best; seg_pass = best_pass;  // passes of [seg_a, seg_b)
+            multi = true;
+        }
+        const bool last_seg = seg_b == nT;
+        const uint32_t n = seg_b - seg_a;
+        const uint4* __restrict__ pc = A.g_pc + slot0 + seg_a;
+        const uint32_t C = __builtin_amdgcn_readfirstlane((last_seg ? CT : (pc[n].x & 0xFFFFu)) - seg_c) & 0xFFFFu;
+        const uint32_t G = __builtin_amdgcn_readfirstlane((last_seg ? GT : (pc[n].x >> 16)) - seg_g) & 0xFFFFu;
+        const uint4* __restrict__ nd = A.g_nd + node0 + seg_c;
 
         Arena ar{g_smem, lds_bytes, 0, true};
         // the two left-id arrays come first: pass records address them as u16 element indices from the arena base
         uint16_t* nd_left = ar.take<uint16_t>(C + 1);
         uint16_t* g_left = ar.take<uint16_t>(G + 1);
-        uint64_t* e_key = ar.take<uint64_t>(C + 2);    // end-major packed (cost, sequence, back pointer) keys
+        const uint32_t E = C + m_in;                   // end-list slots: interface (BOS) + candidates; slot E is the EOS node's
+        uint64_t* e_key = ar.take<uint64_t>(E + 1);    // end-major packed (cost, sequence, back pointer) keys
         uint64_t* lens = ar.take<uint64_t>(n + 1);     // length bitmask per start position (pre-pass), then the token path
         uint64_t* g_best = ar.take<uint64_t>(ngmax + 1);  // per step: best key of each left-id group
         uint32_t* end_off = ar.take<uint32_t>(n + 2);
@@ -1163,7 +1267,7 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
         uint32_t* nd_ew = ar.take<uint32_t>(C + 2);  // per candidate: end-list slot | (u16) word_cost << 16
         uint16_t* cand_off = ar.take<uint16_t>(n + 1);
         uint16_t* goff = ar.take<uint16_t>(n + 1);
-        uint16_t* e_right = ar.take<uint16_t>(C + 2);
+        uint16_t* e_right = ar.take<uint16_t>(E + 1);
         uint8_t* ngp = ar.take<uint8_t>(n + 1);
         uint8_t* nd_gid = ar.take<uint8_t>(C + 1);
         // set-up scratch (end position and right id per candidate): dead once the end lists exist, so the
@@ -1172,15 +1276,18 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
         ar.used = union_base;
         uint16_t* nd_end = ar.take<uint16_t>(C);
         uint16_t* tmp_right = ar.take<uint16_t>(C);
-        if (!ar.ok) { if (ln == 0) atomicAdd(&A.ctrl[26], 1u); list_push(A, A.n_tiers, sid); __syncthreads(); continue; }
+        if (!ar.ok) {  // the estimate was too low: try a shorter segment before giving up
+            if (budget > lds_bytes / 3) { budget -= lds_bytes / 4; __syncthreads(); continue; }
+            fail = 26; break;
+        }
 
         // ---- load: per-char records and candidates from global; count end-list sizes ----
         for (uint32_t p = ln; p < n + 2; p += 64) end_off[p] = 0;
         __syncthreads();
         for (uint32_t i = ln; i < n + 1; i += 64) {
             const uint4 r = pc[i];
-            cand_off[i] = (uint16_t)(r.x & 0xFFFFu);
-            goff[i] = (uint16_t)(r.x >> 16);
+            cand_off[i] = (uint16_t)((r.x & 0xFFFFu) - seg_c);
+            goff[i] = (uint16_t)((r.x >> 16) - seg_g);
             if (i < n) {
                 lens[i] = ((uint64_t)r.w << 32) | r.z;
                 ngp[i] = (uint8_t)((r.y >> 16) & 0xFFu);
@@ -1198,7 +1305,7 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
             for (int u = 0; u < 8; ++u) {
                 const uint32_t c = c0 + u * 64 + ln;
                 if (c < C) {
-                    const uint32_t end = r[u].y >> 16;
+                    const uint32_t end = (r[u].y >> 16) - seg_a;  // <= n: no candidate spans a clean cut
                     nd_left[c] = (uint16_t)(r[u].x & 0xFFFFu);
                     tmp_right[c] = (uint16_t)(r[u].x >> 16);
                     nd_end[c] = (uint16_t)end;
@@ -1221,7 +1328,7 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
             for (uint32_t c0 = 0; c0 < n + 1; c0 += 64) {
                 const uint32_t p = c0 + ln;
                 uint32_t cnt = 0;
-                if (p < n + 1) cnt = end_off[p] + (p == 0 ? 1u : 0u);
+                if (p < n + 1) cnt = end_off[p] + (p == 0 ? m_in : 0u);  // position 0: BOS / the interface of the previous segment
                 uint32_t tot;
                 const uint32_t ex = wave_exscan(cnt, tot);
                 if (p < n + 1) end_off[p] = running + ex;
@@ -1239,16 +1346,15 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
             e_key[es] = kDeadKey;
         }
         __syncthreads();
-        const uint32_t kBosSeq = C + 1;
+#pragma unroll
+        for (uint32_t q = 0; q < kCarry; ++q)
+            if (q * 64 + ln < m_in) { e_right[q * 64 + ln] = (uint16_t)carry_right[q]; e_key[q * 64 + ln] = carry_key[q]; }
         if (ln == 0) {
-            e_right[0] = 0;
-            e_key[0] = node_key(0x80000000u, 0u, 0u, kBosSeq);  // cost 0, no predecessor
-            nd_ew[kBosSeq] = 0;
             nd_left[C] = 0;  // EOS pseudo candidate: left_id 0, its own group G
-            nd_ew[C] = C + 1;  // word cost 0
+            nd_ew[C] = E;  // word cost 0
             nd_gid[C] = 0x80u;
             g_left[G] = 0;
-            e_key[C + 1] = kDeadKey;
+            e_key[E] = kDeadKey;
         }
         __syncthreads();
         PROF_MARK(3);
@@ -1260,6 +1366,9 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
         // (b) lanes then build the step records in parallel.
         uint32_t S = 0, sn_eos = n;
         bool windowed = true;
+        uint32_t cur0 = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < kCarry; ++q) cur0 |= __ballot(q * 64 + ln < m_in && (uint32_t)carry_key[q] != 0xFFFFFFFFu) != 0 ? 1u : 0u;
         {
             // Bit-serial sweep, all state in SGPRs.  w bit i <=> position p + 1 + i is the end of an inserted
             // node; cur <=> position p is (has_previous_node, tokenizer.rs:108).  A visited position ORs its
@@ -1270,7 +1379,7 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
             auto sweep = [&](auto space_tag) {
                 constexpr bool kSpace = decltype(space_tag)::value;
                 uint64_t w = 0;
-                uint32_t cur = 1, pend = 0, stop = 0;
+                uint32_t cur = cur0, pend = 0, stop = 0;
                 for (uint32_t chunk = 0; chunk < n && !stop; chunk += 64) {
                     const uint32_t i = chunk + ln;
                     const uint64_t lm = i < n ? lens[i] : 0ull;
@@ -1318,14 +1427,11 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
             };
             if (space_mode) sweep(std::true_type{}); else sweep(std::false_type{});
         }
-        if (!windowed) {  // > 63 skipped spaces in a row: generic pre-pass of the fused kernel
-            if (ln == 0) atomicAdd(&A.ctrl[27], 1u);
-            list_push(A, A.n_tiers, sid);
-            __syncthreads();
-            continue;
-        }
-        ++S;  // + the EOS step (insert_eos(start_node), tokenizer.rs:138)
-        if (ln == 0) sp[S - 1] = sn_eos | (0xFFFFu << 16);
+        if (!windowed) { fail = 27; break; }  // > 63 skipped spaces in a row: generic pre-pass of the fused kernel
+        if (last_seg) {
+            ++S;  // + the EOS step (insert_eos(start_node), tokenizer.rs:138)
+            if (ln == 0) sp[S - 1] = sn_eos | (0xFFFFu << 16);
+        } else if (sn_eos != n) { fail = 31; break; }  // cannot happen: a trailing space run spans every later cut
         __syncthreads();
         PROF_MARK(4);
         // (b) lanes = steps: split every step into passes of <= 64 (group, predecessor) lanes and lay
@@ -1380,9 +1486,12 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
             SL += tot;
         }
         // no LDS left for the pass records: fused kernel
-        const uint32_t prof_SL = SL;
+        prof_SL += SL; prof_S += S;
         constexpr uint32_t kDepth = 8;  // prefetch distance of the fused loop, in passes
-        if (SL + 2 * kDepth + 2 > sl_cap) { if (ln == 0) atomicAdd(&A.ctrl[29], 1u); list_push(A, A.n_tiers, sid); __syncthreads(); continue; }
+        if (SL + 2 * kDepth + 2 > sl_cap) {  // more passes than estimated (gen_candidates bounds them per position)
+            if (budget > lds_bytes / 3) { budget -= lds_bytes / 4; __syncthreads(); continue; }
+            fail = 29; break;
+        }
         // pad with empty passes so the pipelined loop needs no bounds branches
         if (ln < 2 * kDepth + 2) sl[SL + ln] = LSlot{0, 0, 0, 1, 0, 0, 0, 0};  // np = 1, ngs = 0, lg = 0: nothing to do
         __syncthreads();
@@ -1500,12 +1609,12 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
                     if (direct) {
 #endif
                         // one lane group per candidate: the group minimum is the candidate's best predecessor
-                        if (valid && j == 0) e_key[ew & 0xFFFFu] = node_key(khi, klo, (uint32_t)(int32_t)(int16_t)(ew >> 16), c);
+                        if (valid && j == 0) e_key[ew & 0xFFFFu] = node_key(khi, klo, (uint32_t)(int32_t)(int16_t)(ew >> 16), seg_c + c);
                     } else if (single) {
                         // the whole step is this pass: group minima are broadcast to the candidate lanes
                         const int src = (int)((gid & 0x7Fu) << lg);
                         const uint32_t bhi = __shfl(khi, src), blo = __shfl(klo, src);
-                        if (ln < nc) e_key[ew & 0xFFFFu] = node_key(bhi, blo, (uint32_t)(int32_t)(int16_t)(ew >> 16), c);
+                        if (ln < nc) e_key[ew & 0xFFFFu] = node_key(bhi, blo, (uint32_t)(int32_t)(int16_t)(ew >> 16), seg_c + c);
                     } else {
                         uint64_t key = ((uint64_t)khi << 32) | klo;
                         if (g < ngs && j == 0) {
@@ -1520,7 +1629,7 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
                                     const uint32_t c2 = c_beg + ci_;
                                     const uint64_t best = g_best[nd_gid[c2] & 0x7Fu];
                                     const uint32_t ew2 = nd_ew[c2];
-                                    e_key[ew2 & 0xFFFFu] = node_key((uint32_t)(best >> 32), (uint32_t)best, (uint32_t)(int32_t)(int16_t)(ew2 >> 16), c2);
+                                    e_key[ew2 & 0xFFFFu] = node_key((uint32_t)(best >> 32), (uint32_t)best, (uint32_t)(int32_t)(int16_t)(ew2 >> 16), seg_c + c2);
                                 }
                             }
                         }
@@ -1547,10 +1656,11 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
             // (left_id 0) against ends[len_char].  Only inserted ("live") nodes exist in the reference's lists.
             for (uint32_t k = 0; k < S; ++k) {
                 const uint32_t v = __builtin_amdgcn_readfirstlane(sp[k]);
-                const uint32_t p = (k + 1 == S) ? n : (v & 0xFFFFu), sw = v >> 16;  // EOS pairs with ends[len_char]
+                const bool eos_step = last_seg && k + 1 == S;
+                const uint32_t p = eos_step ? n : (v & 0xFFFFu), sw = v >> 16;  // EOS pairs with ends[len_char]
                 const uint32_t p_beg = __builtin_amdgcn_readfirstlane(end_off[p]), p_end = __builtin_amdgcn_readfirstlane(end_off[p + 1]);
                 uint32_t c_beg = C, nc = 1;
-                if (k + 1 < S) { c_beg = __builtin_amdgcn_readfirstlane((uint32_t)cand_off[sw]); nc = __builtin_amdgcn_readfirstlane((uint32_t)cand_off[sw + 1]) - c_beg; }
+                if (!eos_step) { c_beg = __builtin_amdgcn_readfirstlane((uint32_t)cand_off[sw]); nc = __builtin_amdgcn_readfirstlane((uint32_t)cand_off[sw + 1]) - c_beg; }
                 uint32_t live = 0;
                 for (uint32_t j0 = p_beg; j0 < p_end; j0 += 64) {
                     const uint32_t j = j0 + ln;
@@ -1562,51 +1672,149 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
             }
         }
 
-        // ---- back-trace + token records ----
-        uint16_t* path = reinterpret_cast<uint16_t*>(lens);  // the length masks are dead now; tokens <= chars
-        uint32_t T = 0;
-        if (ln == 0) {
-            uint32_t seq = key_back(e_key[C + 1]);
-            while (seq != kBosSeq && T < n) {
-                path[T++] = (uint16_t)seq;
-                seq = key_back(e_key[nd_ew[seq] & 0xFFFFu]);
+        if (multi) {
+            // leave (total cost, back pointer) of every node of the segment in the sentence's (dead) hit-staging region
+            uint2* __restrict__ nb = reinterpret_cast<uint2*>(A.g_hits + node0 + seg_c);
+            for (uint32_t c = ln; c < C; c += 64) {
+                const uint64_t k = e_key[nd_ew[c] & 0xFFFFu];
+                nb[2 * c] = make_uint2(key_cost(k), key_back(k));
             }
         }
-        T = __shfl(T, 0);
-        uint32_t out_base = 0;
-        if (ln == 0) out_base = atomicAdd(&A.ctrl[kTotal], T);
-        out_base = __shfl(out_base, 0);
-        __syncthreads();
-        if ((uint64_t)out_base + T > A.tok_cap) {
-            if (ln == 0) { atomicOr(&A.ctrl[kError], (uint32_t)kErrTokCap); A.tok_off[sid] = 0; A.tok_cnt[sid] = 0; }
-        } else {
-            if (ln == 0) { A.tok_off[sid] = out_base; A.tok_cnt[sid] = T; }
-            const uint16_t* __restrict__ c2b = A.g_c2b + slot0;
-            for (uint32_t t = ln; t < T; t += 64) {
-                const uint32_t c = path[T - 1 - t];
-                uint32_t lo = 0, hi = n;
-                while (lo < hi) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if ((uint32_t)cand_off[mid + 1] <= c) lo = mid + 1; else hi = mid;
-                }
-                const uint4 rec = nd[c];
-                const uint32_t stp = lo, en = rec.y >> 16;
-                vbt_token_rec r;
-                r.start_char = stp; r.end_char = en;
-                r.start_byte = c2b[stp]; r.end_byte = c2b[en];
-                r.word_idx = rec.z;
-                r.total_cost = (int32_t)key_cost(e_key[nd_ew[c] & 0xFFFFu]);
-                A.tokens[out_base + t] = r;
+        if (!last_seg) {
+            // the interface: nodes ending exactly at the cut
+            const uint32_t i0 = end_off[n], m_out = end_off[n + 1] - i0;
+            if (m_out > 64 * kCarry || m_out == 0) { fail = 32; break; }
+#pragma unroll
+            for (uint32_t q = 0; q < kCarry; ++q) {
+                carry_key[q] = q * 64 + ln < m_out ? e_key[i0 + q * 64 + ln] : kDeadKey;
+                carry_right[q] = q * 64 + ln < m_out ? (uint32_t)e_right[i0 + q * 64 + ln] : 0u;
             }
+            m_in = m_out;
+            seg_a = seg_b; seg_c += C; seg_g += G; seg_p += seg_pass;
+            __syncthreads();
+            continue;
+        }
+        done = true;
+
+        // ---- back-trace + token records ----
+        uint32_t T = 0, out_base = 0;
+        if (!multi) {
+            uint16_t* path = reinterpret_cast<uint16_t*>(lens);  // the length masks are dead now; tokens <= chars
+            if (ln == 0) {
+                uint32_t seq = key_back(e_key[E]);
+                while (seq != kBosSeq && T < n) {
+                    path[T++] = (uint16_t)seq;
+                    seq = key_back(e_key[nd_ew[seq] & 0xFFFFu]);
+                }
+            }
+            T = __shfl(T, 0);
+            if (ln == 0) out_base = atomicAdd(&A.ctrl[kTotal], T);
+            out_base = __shfl(out_base, 0);
+            __syncthreads();
+            if ((uint64_t)out_base + T > A.tok_cap) {
+                if (ln == 0) { atomicOr(&A.ctrl[kError], (uint32_t)kErrTokCap); A.tok_off[sid] = 0; A.tok_cnt[sid] = 0; }
+            } else {
+                if (ln == 0) { A.tok_off[sid] = out_base; A.tok_cnt[sid] = T; }
+                const uint16_t* __restrict__ c2b = A.g_c2b + slot0;
+                for (uint32_t t = ln; t < T; t += 64) {
+                    const uint32_t c = path[T - 1 - t];
+                    uint32_t lo = 0, hi = n;
+                    while (lo < hi) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if ((uint32_t)cand_off[mid + 1] <= c) lo = mid + 1; else hi = mid;
+                    }
+                    const uint4 rec = nd[c];
+                    const uint32_t stp = lo, en = rec.y >> 16;
+                    vbt_token_rec r;
+                    r.start_char = stp; r.end_char = en;
+                    r.start_byte = c2b[stp]; r.end_byte = c2b[en];
+                    r.word_idx = rec.z;
+                    r.total_cost = (int32_t)key_cost(e_key[nd_ew[c] & 0xFFFFu]);
+                    A.tokens[out_base + t] = r;
+                }
+            }
+        } else {
+            // segmented sentence: pull all back pointers into LDS (the arena is free now), walk, emit from global
+            const uint32_t back_eos = key_back(e_key[E]);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's own dumps: stores complete
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            Arena a2{g_smem, lds_bytes, 0, true};
+            uint16_t* path = a2.take<uint16_t>(nT + 1);
+            uint16_t* back = a2.take<uint16_t>(0);
+            const uint32_t W = a2.ok && lds_bytes > a2.used + 64 ? (uint32_t)((lds_bytes - a2.used - 64) / 2) : 0u;  // window of back pointers
+            if (W < 1024) { fail = 33; break; }
+            const uint2* __restrict__ nbg = reinterpret_cast<const uint2*>(A.g_hits + node0);
+            // Back pointers only point backwards: walk from EOS, pulling windows of them [win_lo, win_hi) into LDS on demand.
+            uint32_t seq = back_eos, win_lo = CT + 2;
+            while (seq != kBosSeq && T < nT) {
+                if (seq < win_lo) {
+                    const uint32_t hi = seq + 1, lo = hi > W ? hi - W : 0u;
+                    __syncthreads();
+                    for (uint32_t c0 = lo; c0 < hi; c0 += 64 * 8) {
+                        uint32_t v[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) { const uint32_t c = c0 + u * 64 + ln; v[u] = c < hi ? nbg[2 * c].y : 0u; }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) { const uint32_t c = c0 + u * 64 + ln; if (c < hi) back[c - lo] = (uint16_t)v[u]; }
+                    }
+                    __syncthreads();
+                    win_lo = lo;
+                }
+                if (ln == 0) {
+                    while (seq != kBosSeq && seq >= win_lo && T < nT) {
+                        path[T++] = (uint16_t)seq;
+                        seq = back[seq - win_lo];
+                    }
+                }
+                seq = __builtin_amdgcn_readfirstlane(seq);
+                T = __builtin_amdgcn_readfirstlane(T);
+            }
+            __syncthreads();
+            T = __shfl(T, 0);
+            if (ln == 0) out_base = atomicAdd(&A.ctrl[kTotal], T);
+            out_base = __shfl(out_base, 0);
+            __syncthreads();
+            if ((uint64_t)out_base + T > A.tok_cap) {
+                if (ln == 0) { atomicOr(&A.ctrl[kError], (uint32_t)kErrTokCap); A.tok_off[sid] = 0; A.tok_cnt[sid] = 0; }
+            } else {
+                if (ln == 0) { A.tok_off[sid] = out_base; A.tok_cnt[sid] = T; }
+                const uint16_t* __restrict__ c2b = A.g_c2b + slot0;
+                const uint4* __restrict__ pcg = A.g_pc + slot0;
+                const uint4* __restrict__ ndg = A.g_nd + node0;
+                for (uint32_t t = ln; t < T; t += 64) {
+                    const uint32_t c = path[T - 1 - t];
+                    uint32_t lo = 0, hi = nT;
+                    while (lo < hi) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if ((pcg[mid + 1].x & 0xFFFFu) <= c) lo = mid + 1; else hi = mid;
+                    }
+                    const uint4 rec = ndg[c];
+                    const uint32_t stp = lo, en = rec.y >> 16;
+                    vbt_token_rec r;
+                    r.start_char = stp; r.end_char = en;
+                    r.start_byte = c2b[stp]; r.end_byte = c2b[en];
+                    r.word_idx = rec.z;
+                    r.total_cost = (int32_t)nbg[2 * c].x;
+                    A.tokens[out_base + t] = r;
+                }
+            }
+        }
+        }  // segments
+        if (fail) {  // whatever went wrong: the fused kernel with the global-memory lattice redoes the sentence
+            if (ln == 0) atomicAdd(&A.ctrl[fail < 32 ? fail : 28], 1u);
+            list_push(A, A.n_tiers, sid);
+            __syncthreads();
+            continue;
         }
         PROF_MARK(7);
         if (A.prof && ln == 0) {
             unsigned long long* pr_ = A.prof + (size_t)(sid & (kProfSlots - 1)) * kProfWords;
             for (int i = 3; i < kProfPhases; ++i) atomicAdd(&pr_[i], (unsigned long long)prof_acc[i]);
-#if VBT_EXP != 9
-            atomicAdd(&pr_[kProfPhases + 1], (unsigned long long)S);
+#if VBT_EXP != 9 && VBT_EXP != 10
+            atomicAdd(&pr_[kProfPhases + 1], (unsigned long long)prof_S);
             atomicAdd(&pr_[kProfPhases + 2], (unsigned long long)prof_SL);
-            atomicAdd(&pr_[kProfPhases + 3], (unsigned long long)C);
+            atomicAdd(&pr_[kProfPhases + 3], (unsigned long long)CT);
 #endif
         }
 #undef PROF_MARK
@@ -1787,7 +1995,7 @@ Workspace::Workspace(const Tokenizer& t, uint64_t max_s, uint64_t max_b) : tok(t
     d_tokens = static_cast<vbt_token_rec*>(alloc(nbts * sizeof(vbt_token_rec)));  // tokens <= chars <= bytes
     d_tok_off = static_cast<uint32_t*>(alloc(ns * 4));
     d_tok_cnt = static_cast<uint32_t*>(alloc(ns * 4));
-    d_over = static_cast<uint32_t*>(alloc(2 * ns * 4 * (tiers.size() + 2)));  // two regions per list: long-first pass + bulk
+    d_over = static_cast<uint32_t*>(alloc(2 * ns * 4 * (tiers.size() + 3)));  // two regions per list: long-first pass + bulk
     d_ctrl = static_cast<uint32_t*>(alloc(kCtrlWords * 4));
     d_cctrl = static_cast<uint32_t*>(alloc((size_t)kMaxChunks * kChunkCtrlWords * 4));
     n_chunks = 1;
@@ -1824,6 +2032,7 @@ Workspace::Workspace(const Tokenizer& t, uint64_t max_s, uint64_t max_b) : tok(t
         pipe.node_factor = std::max<uint32_t>(1, env_u32("VBT_NODE_FACTOR", 8));  // candidate slots per input byte
         pipe.g_nd = static_cast<uint4*>(alloc((size_t)pipe.node_factor * slots * 16));
         pipe.g_hits = static_cast<uint4*>(alloc((size_t)pipe.node_factor * slots * 16));
+        pipe.s_passes = static_cast<uint32_t*>(alloc(ns * 4));
         pipe.s_tier = static_cast<uint8_t*>(alloc(ns));
         pipe.s_early = static_cast<uint8_t*>(alloc(ns));
         for (size_t t = 0; t < tiers.size(); ++t) {
@@ -1838,6 +2047,7 @@ Workspace::Workspace(const Tokenizer& t, uint64_t max_s, uint64_t max_b) : tok(t
         HIP_CHECK(hipEventCreateWithFlags(reinterpret_cast<hipEvent_t*>(&ev_fork2), hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(reinterpret_cast<hipEvent_t*>(&ev_early), hipEventDisableTiming));
         HIP_CHECK(hipStreamCreateWithFlags(reinterpret_cast<hipStream_t*>(&early_stream), hipStreamNonBlocking));
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gen_candidates_large), hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
         if (tiers.back() > 65536)  // a single workgroup may use the CU's whole 160 KiB
             HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lattice_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tiers.back()));
     }
@@ -1874,6 +2084,13 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
     a.lists = d_over; a.list_stride = (uint32_t)stride; a.n_tiers = (uint32_t)T;
     a.tier_prio = env_u32("VBT_TIER_PRIO", 3);
     a.steal_depth = env_u32("VBT_STEAL", 0);
+    {   // tier whose waves sweep longer sentences segment by segment (VBT_SEG_BYTES=0: off, sentences use the big tiers)
+        const uint32_t seg_bytes = env_u32("VBT_SEG_BYTES", 32768);
+        a.seg_tier = 0xFFFFFFFFu;
+        if (seg_bytes)
+            for (size_t t = 0; t < T; ++t)
+                if (tiers[t] >= seg_bytes) { a.seg_tier = (uint32_t)t; break; }
+    }
     a.sid0 = 0; a.cctrl = d_cctrl; a.list_off = 0;
     a.lid_count = count_connids ? d_connid : nullptr;
     a.rid_count = count_connids ? d_connid + tok.dict().num_left : nullptr;
@@ -1905,7 +2122,7 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
         // many bytes are listed first and generated by the large-LDS generator on a side stream while the bulk
         // runs.  Measured on MI355X it does not pay: the side stream's few wavefronts are slowed by the bulk
         // as much as they save (4.40 vs 4.27 ms per 100k sentences).
-        const uint32_t gen_lds = env_u32("VBT_GEN_LDS", 8192), gen_lds_large = 65536;
+        const uint32_t gen_lds = env_u32("VBT_GEN_LDS", 8192), gen_lds_large = 65536, gen_lds_huge = 163840;
         const uint32_t long_bytes = env_u32("VBT_LONG_BYTES", 0);
         last_chunks = 1;
         const uint32_t cn = (uint32_t)n, lb = (cn + 1023) / 1024;
@@ -1919,7 +2136,7 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
             HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_fork), stream));
             hipStream_t es = reinterpret_cast<hipStream_t>(early_stream);
             HIP_CHECK(hipStreamWaitEvent(es, reinterpret_cast<hipEvent_t>(ev_fork), 0));
-            hipLaunchKernelGGL(gen_candidates_large, dim3(waves_for(gen_lds_large, cn)), dim3(64), gen_lds_large, es, D, e, gen_lds_large);
+            hipLaunchKernelGGL(gen_candidates_large, dim3(waves_for(gen_lds_large, cn)), dim3(64), gen_lds_large, es, D, e, gen_lds_large, 1u);
             HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_early), es));
             a.s_skip = pipe.s_early;  // the bulk generator leaves these alone
         }
@@ -1927,7 +2144,9 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
         if (long_bytes) HIP_CHECK(hipStreamWaitEvent(stream, reinterpret_cast<hipEvent_t>(ev_early), 0));
         hipLaunchKernelGGL(build_lists, dim3(lb), dim3(1024), 0, stream, a, -1);
         a.direct_push = 1;
-        hipLaunchKernelGGL(gen_candidates_large, dim3(waves_for(gen_lds_large, cn)), dim3(64), gen_lds_large, stream, D, a, gen_lds_large);
+        hipLaunchKernelGGL(gen_candidates_large, dim3(waves_for(gen_lds_large, cn)), dim3(64), gen_lds_large, stream, D, a, gen_lds_large, 1u);
+        // ... and whatever outgrew 64 KiB (> ~1400 characters) gets a whole CU's LDS
+        hipLaunchKernelGGL(gen_candidates_large, dim3(waves_for(gen_lds_huge, cn)), dim3(64), gen_lds_huge, stream, D, a, gen_lds_huge, 2u);
         a.direct_push = 0;
         rec(1);
         HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_fork2), stream));
@@ -1973,8 +2192,8 @@ void Workspace::stats(vbt_call_stats* out) {
     out->n_tokens = ctrl[kTotal];
     out->error_flags = ctrl[kError];
     if (std::getenv("VBT_DEBUG")) {
-        std::fprintf(stderr, "[vbt] chunks=%u lattice fallbacks: arena=%u window=%u passes=%u; chunk-0 lists:", last_chunks, ctrl[26], ctrl[27], ctrl[29]);
-        for (size_t t = 0; t < T + 2; ++t) std::fprintf(stderr, " %u", cc[2 * t]);
+        std::fprintf(stderr, "[vbt] lattice fallbacks: arena=%u window=%u passes=%u no-cut=%u space-tail=%u interface/backtrace=%u; lists:", ctrl[26], ctrl[27], ctrl[29], ctrl[30], ctrl[31], ctrl[28]);
+        for (size_t t = 0; t < T + 3; ++t) std::fprintf(stderr, " %u", cc[2 * t]);
         std::fprintf(stderr, "\n");
     }
     if (timing && last_n) {
