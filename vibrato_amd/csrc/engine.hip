@@ -752,7 +752,7 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
     uint64_t prof_t = A.prof ? clock64() : 0, prof_acc[3] = {};
 #define PROF_MARK(i) do { if (A.prof) { const uint64_t t_ = clock64(); prof_acc[i] += t_ - prof_t; prof_t = t_; } } while (0)
     const uint64_t b0 = A.offsets[sid], nb64 = A.offsets[sid + 1] - b0;
-    const uint32_t fallback = A.n_tiers, large_list = level >= 2 ? A.n_tiers : A.n_tiers + 1 + level;  // where a sentence goes that outgrows this instance
+    const uint32_t fallback = A.n_tiers, large_list = level >= kGenLevels ? A.n_tiers : A.n_tiers + 1 + level;  // where a sentence goes that outgrows this instance
     // gen routes a sentence by writing its list index; build_lists turns that into work lists with
     // wave-aggregated atomics (a per-sentence atomic on a hot word caps the kernel at ~88 M/s)
     auto route = [&](uint32_t t) {
@@ -1109,12 +1109,12 @@ __global__ void __launch_bounds__(256) classify_long(BatchArgs A, uint32_t long_
 __global__ void __launch_bounds__(1024) build_lists(BatchArgs A, int only_list) {
     // One global atomic per (workgroup, list): a returning atomic on a hot word costs ~11 ns, so the
     // 16 waves of a workgroup first agree on their shares through LDS.
-    __shared__ uint32_t w_cnt[16][kMaxTiers + 3];
-    __shared__ uint32_t l_base[kMaxTiers + 3];
+    __shared__ uint32_t w_cnt[16][kMaxTiers + 1 + kGenLevels];
+    __shared__ uint32_t l_base[kMaxTiers + 1 + kGenLevels];
     const uint32_t rel = blockIdx.x * 1024 + threadIdx.x, sid = A.sid0 + rel;
     const uint32_t t = rel < A.n ? A.s_tier[sid] : 0xFFu;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t n_lists = A.n_tiers + 3;
+    const uint32_t n_lists = A.n_tiers + 1 + kGenLevels;
     uint32_t my_rank = 0;
     for (uint32_t l = 0; l < n_lists; ++l) {
         const bool mine = t == l && (only_list < 0 || (int)l == only_list);
@@ -1160,27 +1160,19 @@ __global__ void __launch_bounds__(64) gen_candidates_large(DevDict D, BatchArgs 
 #ifndef VBT_EXP
 #define VBT_EXP 0
 #endif
-#ifndef VBT_STEAL_LOOP
-#define VBT_STEAL_LOOP 0
-#endif
 #ifndef VBT_LAT_WAVES
 #define VBT_LAT_WAVES 4
 #endif
-__global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, BatchArgs A, uint32_t tier) {
+__global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, BatchArgs A, uint32_t tier, uint32_t list_id) {
     const uint32_t ln = threadIdx.x;
     const uint32_t lds_bytes = A.tier_bytes[tier];
     const int16_t* __restrict__ matrix = D.matrix;
     const uint32_t NR = D.num_right;
     const bool space_mode = D.space_cateset != 0;
     // long sentences are the critical path of a batch: let their waves win issue arbitration
-    if (A.tier_prio && tier + A.tier_prio >= A.n_tiers) __builtin_amdgcn_s_setprio(2);
-    // own work list first; a wave that runs dry helps the smaller tiers (their sentences fit its LDS)
-#if VBT_STEAL_LOOP
-    for (int src = (int)tier; src >= 0 && src + (int)A.steal_depth >= (int)tier; --src) {
-#else
+    if (A.tier_prio && (A.seg_tier < A.n_tiers ? tier >= A.seg_tier : tier + A.tier_prio >= A.n_tiers)) __builtin_amdgcn_s_setprio(2);
     {
-    const int src = (int)tier;
-#endif
+    const int src = (int)list_id;  // normally the tier's own list; helper launches sweep the segment tier's list with less LDS
     const uint32_t* list = A.lists + (size_t)src * A.list_stride + A.list_off;
     const uint32_t count = A.cctrl[2 * src];
     uint32_t* cursor = &A.cctrl[2 * src + 1];
@@ -1213,9 +1205,10 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
         bool multi = false, done = false;
         uint32_t prof_S = 0, prof_SL = 0;
         uint32_t budget = lds_bytes;  // what a segment may be estimated at; shrinks when an estimate turns out too low
+        uint32_t cap_b = nT;          // latest admissible segment end (pulled in when too many nodes end at a cut)
         while (!done) {
         uint32_t seg_b = nT, seg_pass = passesT - seg_p;
-        if (lattice_fixed_bytes(nT - seg_a, CT - seg_c, GT - seg_g, ngmax, space_mode, passesT - seg_p) + 10ull * m_in > budget) {
+        if (lattice_fixed_bytes(nT - seg_a, CT - seg_c, GT - seg_g, ngmax, space_mode, passesT - seg_p) + 10ull * m_in > budget || cap_b < nT) {
             // furthest clean cut within 256 positions whose segment fits
             const uint4* __restrict__ pcg = A.g_pc + slot0;
             uint32_t best = 0, best_pass = 0, run = 0;
@@ -1232,7 +1225,7 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
                 uint32_t tot;
                 const uint32_t incl = wave_exscan(nsl, tot) + nsl + run;
                 const uint64_t bytes = lattice_fixed_bytes(b - seg_a, ((cx & 0xFFFFu) - seg_c) & 0xFFFFu, ((cx >> 16) - seg_g) & 0xFFFFu, ngmax, space_mode, incl + 1);
-                const bool fits = b <= nT && bytes + 10ull * m_in <= budget;
+                const bool fits = b <= cap_b && bytes + 10ull * m_in <= budget;
                 const uint64_t m = __ballot(fits && cut);
                 if (m) {
                     const uint32_t top = 63u - (uint32_t)__builtin_clzll(m);
@@ -1683,14 +1676,17 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
         if (!last_seg) {
             // the interface: nodes ending exactly at the cut
             const uint32_t i0 = end_off[n], m_out = end_off[n + 1] - i0;
-            if (m_out > 64 * kCarry || m_out == 0) { fail = 32; break; }
+            if (m_out > 64 * kCarry || m_out == 0) {  // more nodes end here than the carry holds: cut earlier
+                if (seg_b > seg_a + 1 && m_out) { cap_b = seg_b - 1; __syncthreads(); continue; }
+                fail = 32; break;
+            }
 #pragma unroll
             for (uint32_t q = 0; q < kCarry; ++q) {
                 carry_key[q] = q * 64 + ln < m_out ? e_key[i0 + q * 64 + ln] : kDeadKey;
                 carry_right[q] = q * 64 + ln < m_out ? (uint32_t)e_right[i0 + q * 64 + ln] : 0u;
             }
             m_in = m_out;
-            seg_a = seg_b; seg_c += C; seg_g += G; seg_p += seg_pass;
+            seg_a = seg_b; seg_c += C; seg_g += G; seg_p += seg_pass; cap_b = nT;
             __syncthreads();
             continue;
         }
@@ -1801,9 +1797,13 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
             }
         }
         }  // segments
-        if (fail) {  // whatever went wrong: the fused kernel with the global-memory lattice redoes the sentence
-            if (ln == 0) atomicAdd(&A.ctrl[fail < 32 ? fail : 28], 1u);
-            list_push(A, A.n_tiers, sid);
+        if (fail) {
+            // Could not be swept here (no admissible cut, estimates too low, ...): the next escape tier -- more LDS,
+            // launched behind this one -- retries; after the last one the fused kernel with the global-memory
+            // lattice redoes the sentence.
+            const bool escape = list_id == tier && tier >= A.seg_tier && tier + 1 < A.n_tiers && fail != 27;
+            if (ln == 0 && !escape) atomicAdd(&A.ctrl[fail < 32 ? fail : 28], 1u);
+            list_push(A, escape ? tier + 1 : A.n_tiers, sid);
             __syncthreads();
             continue;
         }
@@ -1973,7 +1973,7 @@ Workspace::Workspace(const Tokenizer& t, uint64_t max_s, uint64_t max_b) : tok(t
     // LDS tiers (bytes per wave), ascending; the global-memory tier always follows
     {
         const char* e = std::getenv("VBT_TIERS");
-        std::string spec = e && *e ? e : (fused ? "16384,32768,65536" : "8192,12288,16384,24576,32768,49152,65536,163840");
+        std::string spec = e && *e ? e : (fused ? "16384,32768,65536" : env_u32("VBT_SEG_BYTES", 16384) ? "8192,12288,16384,163840" : "8192,12288,16384,24576,32768,49152,65536,163840");
         size_t pos = 0;
         while (pos < spec.size()) {
             size_t c = spec.find(',', pos);
@@ -1995,7 +1995,7 @@ Workspace::Workspace(const Tokenizer& t, uint64_t max_s, uint64_t max_b) : tok(t
     d_tokens = static_cast<vbt_token_rec*>(alloc(nbts * sizeof(vbt_token_rec)));  // tokens <= chars <= bytes
     d_tok_off = static_cast<uint32_t*>(alloc(ns * 4));
     d_tok_cnt = static_cast<uint32_t*>(alloc(ns * 4));
-    d_over = static_cast<uint32_t*>(alloc(2 * ns * 4 * (tiers.size() + 3)));  // two regions per list: long-first pass + bulk
+    d_over = static_cast<uint32_t*>(alloc(2 * ns * 4 * (tiers.size() + 1 + kGenLevels)));  // two regions per list: long-first pass + bulk
     d_ctrl = static_cast<uint32_t*>(alloc(kCtrlWords * 4));
     d_cctrl = static_cast<uint32_t*>(alloc((size_t)kMaxChunks * kChunkCtrlWords * 4));
     n_chunks = 1;
@@ -2083,9 +2083,8 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
     a.prof = profile ? d_prof : nullptr;
     a.lists = d_over; a.list_stride = (uint32_t)stride; a.n_tiers = (uint32_t)T;
     a.tier_prio = env_u32("VBT_TIER_PRIO", 3);
-    a.steal_depth = env_u32("VBT_STEAL", 0);
     {   // tier whose waves sweep longer sentences segment by segment (VBT_SEG_BYTES=0: off, sentences use the big tiers)
-        const uint32_t seg_bytes = env_u32("VBT_SEG_BYTES", 32768);
+        const uint32_t seg_bytes = env_u32("VBT_SEG_BYTES", 16384);
         a.seg_tier = 0xFFFFFFFFu;
         if (seg_bytes)
             for (size_t t = 0; t < T; ++t)
@@ -2122,7 +2121,8 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
         // many bytes are listed first and generated by the large-LDS generator on a side stream while the bulk
         // runs.  Measured on MI355X it does not pay: the side stream's few wavefronts are slowed by the bulk
         // as much as they save (4.40 vs 4.27 ms per 100k sentences).
-        const uint32_t gen_lds = env_u32("VBT_GEN_LDS", 8192), gen_lds_large = 65536, gen_lds_huge = 163840;
+        const uint32_t gen_lds = env_u32("VBT_GEN_LDS", 8192), gen_lds_large = 32768;
+        static const uint32_t gen_level_lds[kGenLevels] = {32768, 65536, 163840};  // the instances behind the bulk generator
         const uint32_t long_bytes = env_u32("VBT_LONG_BYTES", 0);
         last_chunks = 1;
         const uint32_t cn = (uint32_t)n, lb = (cn + 1023) / 1024;
@@ -2144,21 +2144,31 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
         if (long_bytes) HIP_CHECK(hipStreamWaitEvent(stream, reinterpret_cast<hipEvent_t>(ev_early), 0));
         hipLaunchKernelGGL(build_lists, dim3(lb), dim3(1024), 0, stream, a, -1);
         a.direct_push = 1;
-        hipLaunchKernelGGL(gen_candidates_large, dim3(waves_for(gen_lds_large, cn)), dim3(64), gen_lds_large, stream, D, a, gen_lds_large, 1u);
-        // ... and whatever outgrew 64 KiB (> ~1400 characters) gets a whole CU's LDS
-        hipLaunchKernelGGL(gen_candidates_large, dim3(waves_for(gen_lds_huge, cn)), dim3(64), gen_lds_huge, stream, D, a, gen_lds_huge, 2u);
+        for (uint32_t lv = 1; lv <= kGenLevels; ++lv)  // each level takes what outgrew the one before (the last: a whole CU's LDS, ~3500 characters)
+            hipLaunchKernelGGL(gen_candidates_large, dim3(waves_for(gen_level_lds[lv - 1], cn)), dim3(64), gen_level_lds[lv - 1], stream, D, a, gen_level_lds[lv - 1], lv);
         a.direct_push = 0;
         rec(1);
         HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_fork2), stream));
-        for (size_t i = 0; i < T; ++i) {
-            const size_t t = T - 1 - i;
+        // One lattice_lds launch per LDS tier, each on its own stream.  The tiers above the segment tier are escape
+        // tiers: nothing is routed to them up front, they take what the tier before them could not sweep, so they are
+        // launched on the segment tier's stream, behind it.
+        const size_t n_conc = a.seg_tier < T ? a.seg_tier + 1 : T;
+        for (size_t i = 0; i < n_conc; ++i) {
+            const size_t t = n_conc - 1 - i;
             hipStream_t side = reinterpret_cast<hipStream_t>(streams[t]);
             HIP_CHECK(hipStreamWaitEvent(side, reinterpret_cast<hipEvent_t>(ev_fork2), 0));
             const uint32_t grid = (t < tier_waves.size() && tier_waves[t]) ? std::min<uint32_t>(tier_waves[t], waves_for(tiers[t], cn)) : waves_for(tiers[t], cn);
-            hipLaunchKernelGGL(lattice_lds, dim3(grid), dim3(64), tiers[t], side, D, a, (uint32_t)t);
+            hipLaunchKernelGGL(lattice_lds, dim3(grid), dim3(64), tiers[t], side, D, a, (uint32_t)t, (uint32_t)t);
+            // optional (VBT_HELP_BYTES): a smaller tier that has drained its own list sweeps the segment tier's list
+            // too, in shorter segments.  Off by default: measured slower on the headline batch.
+            if (a.seg_tier < T && t < a.seg_tier && tiers[t] >= env_u32("VBT_HELP_BYTES", 0xFFFFFFFFu))
+                hipLaunchKernelGGL(lattice_lds, dim3(grid), dim3(64), tiers[t], side, D, a, (uint32_t)t, a.seg_tier);
+            if (t == a.seg_tier)
+                for (size_t x = t + 1; x < T; ++x)
+                    hipLaunchKernelGGL(lattice_lds, dim3(waves_for(tiers[x], std::min<uint32_t>(cn, 4096))), dim3(64), tiers[x], side, D, a, (uint32_t)x, (uint32_t)x);
             HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(tier_events[t]), side));
         }
-        for (size_t t = 0; t < T; ++t) HIP_CHECK(hipStreamWaitEvent(stream, reinterpret_cast<hipEvent_t>(tier_events[t]), 0));
+        for (size_t t = 0; t < n_conc; ++t) HIP_CHECK(hipStreamWaitEvent(stream, reinterpret_cast<hipEvent_t>(tier_events[t]), 0));
         // whatever the pipeline could not take: fused kernel, global-memory lattice
         hipLaunchKernelGGL(tokenize_global, dim3((uint32_t)std::min<uint64_t>(cn, 1024)), dim3(64), 0, stream, D, a,
                            (const uint32_t*)over(T), (const uint32_t*)(d_cctrl + 2 * T), d_cctrl + 2 * T + 1);
@@ -2193,7 +2203,7 @@ void Workspace::stats(vbt_call_stats* out) {
     out->error_flags = ctrl[kError];
     if (std::getenv("VBT_DEBUG")) {
         std::fprintf(stderr, "[vbt] lattice fallbacks: arena=%u window=%u passes=%u no-cut=%u space-tail=%u interface/backtrace=%u; lists:", ctrl[26], ctrl[27], ctrl[29], ctrl[30], ctrl[31], ctrl[28]);
-        for (size_t t = 0; t < T + 3; ++t) std::fprintf(stderr, " %u", cc[2 * t]);
+        for (size_t t = 0; t < T + 1 + kGenLevels; ++t) std::fprintf(stderr, " %u", cc[2 * t]);
         std::fprintf(stderr, "\n");
     }
     if (timing && last_n) {

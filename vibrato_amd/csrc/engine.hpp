@@ -73,13 +73,12 @@ struct BatchArgs {
     uint8_t* s_early;   // the same for the early (long-sentence) pipeline
     const uint8_t* s_skip;  // bulk generator: sentences with s_skip[sid] != 0xFF belong to the early pipeline (nullptr = none)
     // work lists: list t (t < n_tiers) feeds LDS tier t, list n_tiers the global-memory fallback (fused kernel),
-    // lists n_tiers + 1 / + 2 the large- (64 KiB) / whole-CU-LDS (160 KiB) instances of gen_candidates
+    // lists n_tiers + 1 .. n_tiers + kGenLevels the large-LDS instances of gen_candidates
     uint32_t* lists;
     uint32_t list_stride;
     uint32_t n_tiers;
     uint32_t seg_tier;     // LDS tier that sweeps longer sentences in segments (>= n_tiers: none)
     uint32_t direct_push;  // gen_candidates_large: append to the tier lists directly instead of routing through s_tier
-    uint32_t steal_depth;  // a lattice wave whose list ran dry helps up to this many smaller tiers
     uint32_t tier_prio;  // the top `tier_prio` LDS tiers run at raised wave priority (0 = off)
     // chunked pipeline: a launch covers sentences [sid0, sid0 + n); cctrl = this chunk's list counters
     // (cctrl[2t] = entries of list t, cctrl[2t+1] = its work cursor); list t of the chunk starts at
@@ -99,7 +98,8 @@ struct BatchArgs {
 enum CtrlSlot { kTotal = 0, kError = 1, kBump = 2, kNodeCursor = 4, kTierCtrl = 6, kCtrlWords = 32 };
 constexpr int kMaxTiers = 8;
 constexpr int kMaxChunks = 16;
-constexpr int kChunkCtrlWords = 2 * (kMaxTiers + 3);
+constexpr int kGenLevels = 3;  // large-LDS instances of the generator behind the bulk one (32 KiB, 64 KiB, whole CU)
+constexpr int kChunkCtrlWords = 2 * (kMaxTiers + 1 + kGenLevels);
 constexpr int kProfSlots = 256;  // the counters are spread over this many copies (hot-word atomics serialise)
 constexpr int kProfWords = 12;   // kProfPhases cycle totals, sentences, lattice steps, lattice passes, candidates
 constexpr int kProfPhases = 8;  // decode, count, fill, end lists, pre-pass, gather, recurrence, emit
