@@ -6,7 +6,7 @@ pm = collections.OrderedDict()
 for f in sorted(glob.glob(f"gpurun_out/pmc_{tag}/p*/*counter_collection.csv")):
     rows = collections.OrderedDict()
     for r in csv.DictReader(open(f)):
-        m = re.findall(r"(\w+)\(vbt::", r["Kernel_Name"])
+        m = re.findall(r"(\w+)(?:<[^>]*>)?\(vbt::", r["Kernel_Name"])
         if not m:
             continue
         d = rows.setdefault(int(r["Dispatch_Id"]), {"kernel": m[0], "grid": int(r["Grid_Size"])})

@@ -29,7 +29,7 @@ trace = glob.glob(f"{src}/stats/**/*kernel_trace.csv", recursive=True)
 if trace:
     rows = [r for r in csv.DictReader(open(trace[0])) if "vbt::" in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    name = lambda r: (re.findall(r"(\w+)\(vbt::", r["Kernel_Name"]) or ["?"])[0]
+    name = lambda r: (re.findall(r"(\w+)(?:<[^>]*>)?\(vbt::", r["Kernel_Name"]) or ["?"])[0]
     big = max(int(r["Grid_Size_X"]) for r in rows)
     first = name(next(r for r in rows if int(r["Grid_Size_X"]) == big))
     starts = [i for i, r in enumerate(rows) if int(r["Grid_Size_X"]) == big and name(r) == first]
@@ -58,7 +58,7 @@ for f in sorted(glob.glob(f"{src}/pmc*/**/*counter_collection.csv", recursive=Tr
     for r in csv.DictReader(open(f)):
         if "tokenize" not in r["Kernel_Name"] and "lattice" not in r["Kernel_Name"] and "candidates" not in r["Kernel_Name"]:
             continue
-        d = rows.setdefault(int(r["Dispatch_Id"]), {"kernel": (re.findall(r"(\w+)\(vbt::", r["Kernel_Name"]) or [r["Kernel_Name"][:40]])[0], "grid": int(r["Grid_Size"]),
+        d = rows.setdefault(int(r["Dispatch_Id"]), {"kernel": (re.findall(r"(\w+)(?:<[^>]*>)?\(vbt::", r["Kernel_Name"]) or [r["Kernel_Name"][:40]])[0], "grid": int(r["Grid_Size"]),
                                                       "vgpr": r["VGPR_Count"], "agpr": r["Accum_VGPR_Count"], "sgpr": r["SGPR_Count"]})
         d[r["Counter_Name"]] = float(r["Counter_Value"])
         d["dur_us"] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3

@@ -12,6 +12,6 @@ starts=[i for i,r in enumerate(rows) if int(r['Grid_Size_X'])==big]
 i0=starts[-1]; per=starts[-1]-starts[-2]
 t0=int(rows[i0]['Start_Timestamp'])
 for r in rows[i0:i0+per]:
-    name=re.findall(r'(\w+)\(vbt::',r['Kernel_Name'])[0]
+    name=re.findall(r'(\w+)(?:<[^>]*>)?\(vbt::',r['Kernel_Name'])[0]
     print(f"{name:16s} waves={int(r['Grid_Size_X'])//64:6d} lds={r['LDS_Block_Size']:>6s} start={(int(r['Start_Timestamp'])-t0)/1e3:8.1f}us end={(int(r['End_Timestamp'])-t0)/1e3:8.1f}us dur={(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3:8.1f}us")
 PY

@@ -77,26 +77,6 @@ __device__ __forceinline__ uint64_t make_key(uint32_t cost, uint32_t seq) {
 __device__ __forceinline__ uint32_t key_cost(uint64_t k) { return (uint32_t)(k >> 32) ^ 0x80000000u; }
 __device__ __forceinline__ uint32_t key_seq(uint64_t k) { return 0xFFFFFFFEu - (uint32_t)k; }
 
-// Segmented butterfly minimum of 64-bit keys over aligned groups of 2^lg lanes.  Levels inside a
-// 16-lane row are DPP moves (quad_perm / row_half_mirror / row_mirror: a few cycles each); only the
-// 32- and 64-lane levels go through the LDS crossbar.  Every lane of a group ends with the group min.
-template <int kCtrl>
-__device__ __forceinline__ uint64_t dpp_min_u64(uint64_t k) {
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)k, kCtrl, 0xF, 0xF, false);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(k >> 32), kCtrl, 0xF, 0xF, false);
-    const uint64_t o = ((uint64_t)hi << 32) | lo;
-    return o < k ? o : k;
-}
-__device__ __forceinline__ uint64_t group_min_u64(uint64_t key, uint32_t lg) {  // lg is wave-uniform
-    if (lg >= 1) key = dpp_min_u64<0xB1>(key);   // quad_perm [1,0,3,2]
-    if (lg >= 2) key = dpp_min_u64<0x4E>(key);   // quad_perm [2,3,0,1]
-    if (lg >= 3) key = dpp_min_u64<0x141>(key);  // row_half_mirror
-    if (lg >= 4) key = dpp_min_u64<0x140>(key);  // row_mirror
-    if (lg >= 5) { const uint64_t o = __shfl_xor((unsigned long long)key, 16); key = o < key ? o : key; }
-    if (lg >= 6) { const uint64_t o = __shfl_xor((unsigned long long)key, 32); key = o < key ? o : key; }
-    return key;
-}
-
 // lattice_lds keeps the back pointer in the key as well: low word = (0xFFFE - sequence) << 16 | sequence of the best
 // predecessor.  Sequences are unique, so the back pointer never decides a comparison; candidates number < 65532.
 __device__ __forceinline__ uint64_t node_key(uint32_t best_hi, uint32_t best_lo, uint32_t wcost, uint32_t seq) {
@@ -104,8 +84,8 @@ __device__ __forceinline__ uint64_t node_key(uint32_t best_hi, uint32_t best_lo,
 }
 __device__ __forceinline__ uint32_t key_back(uint64_t k) { return (uint32_t)k & 0xFFFFu; }
 
-// The same reduction on split keys: minimum of the high words first, then the minimum low word among
-// the lanes that hold it (u64 order is lexicographic in (hi, lo)).  Each level is one v_min_u32 with a
+// Segmented butterfly minimum of 64-bit keys over aligned groups of 2^lg lanes, on split keys: minimum of the
+// high words first, then the minimum low word among the lanes that hold it (u64 order is lexicographic in (hi, lo)).  Each level is one v_min_u32 with a
 // DPP source operand; the 32- and 64-lane levels use the gfx950 row / half-wave swaps
 // (v_permlane16_swap / v_permlane32_swap) instead of the LDS crossbar.
 template <int kCtrl>
@@ -904,9 +884,6 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     PROF_MARK(1);
 
-#if VBT_EXP == 9
-    uint64_t xq[4] = {(uint64_t)clock64(), 0, 0, 0};
-#endif
     // expand the hits: lanes = hits, every entry load independent of every other
     {
         const uint32_t H = *hcount;  // <= C <= region
@@ -938,9 +915,6 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
     }
     __syncthreads();
 
-#if VBT_EXP == 9
-    xq[1] = clock64();
-#endif
     // group the candidates of a start position by left id, in reference insertion order
     uint32_t G = 0, ngmax = 0;
     bool too_many_groups = false;
@@ -982,34 +956,7 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
     }
     if (too_many_groups) { route(fallback); return; }
     __syncthreads();
-#if VBT_EXP == 9
-    xq[2] = clock64();
-#endif
     for (uint32_t k = ln; k < C; k += 64) reinterpret_cast<uint32_t*>(&A.g_nd[base + k])[3] = cgid[k];
-#if VBT_EXP == 9
-    xq[3] = clock64();
-    if (A.prof && ln == 0) {
-        unsigned long long* pq_ = A.prof + (size_t)(sid & (kProfSlots - 1)) * kProfWords;
-        atomicAdd(&pq_[9], (unsigned long long)(xq[1] - xq[0]));
-        atomicAdd(&pq_[10], (unsigned long long)(xq[2] - xq[1]));
-        atomicAdd(&pq_[11], (unsigned long long)(xq[3] - xq[2]));
-    }
-#endif
-#if VBT_EXP == 10  // experiment: how often does no candidate span a position ("clean cut")?
-    if (ln == 0 && A.prof) {
-        uint32_t far = 0, cuts = 0, last = 0, maxgap = 0;
-        for (uint32_t i = 0; i < n; ++i) {
-            if (i > 0 && far <= i) { ++cuts; maxgap = i - last > maxgap ? i - last : maxgap; last = i; }
-            const uint64_t lm = lens[i];
-            if (lm) { const uint32_t e = i + 64u - (uint32_t)__builtin_clzll(lm); far = e > far ? e : far; }
-        }
-        maxgap = n - last > maxgap ? n - last : maxgap;
-        unsigned long long* pq_ = A.prof + (size_t)(sid & (kProfSlots - 1)) * kProfWords;
-        atomicAdd(&pq_[9], (unsigned long long)cuts);
-        atomicAdd(&pq_[10], (unsigned long long)maxgap);
-        atomicAdd(&pq_[11], (unsigned long long)n);
-    }
-#endif
     // upper bound of the number of (step, <= 64 pair lanes) passes of the lattice kernel
     uint32_t passes = 1;  // EOS
     for (uint32_t c0 = 0; c0 < n; c0 += 64) {
@@ -1157,18 +1104,18 @@ __global__ void __launch_bounds__(64) gen_candidates_large(DevDict D, BatchArgs 
 // Kernel 2: the lattice sweep of one sentence per wavefront, entirely in LDS.  Persistent waves
 // drain the work list of their tier.  Sentences whose lattice does not fit after all go to the
 // fallback list (fused kernel with global scratch).
-#ifndef VBT_EXP
-#define VBT_EXP 0
-#endif
 #ifndef VBT_LAT_WAVES
 #define VBT_LAT_WAVES 4
 #endif
+// (two instances: the ignore_space variant of the reachability sweep is several times the code and register
+// pressure of the plain one)
+template <bool kSpaceMode>
 __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, BatchArgs A, uint32_t tier, uint32_t list_id) {
     const uint32_t ln = threadIdx.x;
     const uint32_t lds_bytes = A.tier_bytes[tier];
     const int16_t* __restrict__ matrix = D.matrix;
     const uint32_t NR = D.num_right;
-    const bool space_mode = D.space_cateset != 0;
+    constexpr bool space_mode = kSpaceMode;
     // long sentences are the critical path of a batch: let their waves win issue arbitration
     if (A.tier_prio && (A.seg_tier < A.n_tiers ? tier >= A.seg_tier : tier + A.tier_prio >= A.n_tiers)) __builtin_amdgcn_s_setprio(2);
     {
@@ -1182,8 +1129,10 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
         item = __builtin_amdgcn_readfirstlane(item);  // lane 0 is always active here; keeps everything below scalar
         if (item >= count) break;
         const uint32_t sid = __builtin_amdgcn_readfirstlane(list[item]);
-        uint64_t prof_t = A.prof ? clock64() : 0, prof_acc[kProfPhases] = {};
-#define PROF_MARK(i) do { if (A.prof) { const uint64_t t_ = clock64(); prof_acc[i] += t_ - prof_t; prof_t = t_; } } while (0)
+        // profiling adds straight into the spread counters: nothing but the last time stamp lives between marks
+        uint64_t prof_t = A.prof ? clock64() : 0;
+        unsigned long long* const pr_ = A.prof ? A.prof + (size_t)(sid & (kProfSlots - 1)) * kProfWords : nullptr;
+#define PROF_MARK(i) do { if (A.prof) { const uint64_t t_ = clock64(); if (ln == 0) atomicAdd(&pr_[i], (unsigned long long)(t_ - prof_t)); prof_t = t_; } } while (0)
         const uint32_t nT = __builtin_amdgcn_readfirstlane(A.s_n[sid]), CT = __builtin_amdgcn_readfirstlane(A.s_C[sid]);
         const uint32_t sflags = __builtin_amdgcn_readfirstlane(A.s_flags[sid]);
         const uint32_t GT = sflags & 0xFFFFu, ngmax = sflags >> 16;
@@ -1418,7 +1367,7 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
                     S += (uint32_t)__popcll(any);
                 }
             };
-            if (space_mode) sweep(std::true_type{}); else sweep(std::false_type{});
+            sweep(std::integral_constant<bool, kSpaceMode>{});
         }
         if (!windowed) { fail = 27; break; }  // > 63 skipped spaces in a row: generic pre-pass of the fused kernel
         if (last_seg) {
@@ -1520,11 +1469,7 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
             };
             auto gather = [&](uint32_t left, uint32_t right, uint32_t u) {
                 const uint32_t cell = left * NR + right;  // < 2^32: num_left, num_right <= 65535
-#if VBT_EXP == 2  // timing experiments only (wrong results)
-                ring[u] = cell;
-#else
                 ring[u] = load_policy<VBT_NT_MATRIX != 0>(&matrix32[cell >> 1]);
-#endif
                 par[u] = (cell & 1u) * 16u;
             };
 #pragma unroll
@@ -1545,18 +1490,10 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
                 p_right = e_right[ri];
             }
             uint4 qn = *reinterpret_cast<const uint4*>(&sl[kDepth + 1]);
-#if VBT_EXP == 8
-            uint64_t xacc[4] = {0, 0, 0, 0}, tq3;
-            asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tq3) :: "memory");
-#endif
             for (uint32_t s0 = 0; s0 < SL; s0 += kDepth) {
 #pragma unroll
                 for (uint32_t u = 0; u < kDepth; ++u) {
                     const uint32_t si = s0 + u;
-#if VBT_EXP == 8
-                    uint64_t tq0; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tq0) :: "memory");
-                    xacc[3] += tq0 - tq3;
-#endif
                     const uint32_t cword = ring[u], cpar = par[u];
                     const uint4 r = rw[u];
                     rw[u] = fq;
@@ -1583,24 +1520,8 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
                     const bool live = valid && (uint32_t)kb != 0xFFFFFFFFu;
                     uint32_t khi = live ? (uint32_t)(kb >> 32) + cv : 0xFFFFFFFFu;  // wrapping i32 add
                     uint32_t klo = live ? (uint32_t)kb : 0xFFFFFFFFu;
-#if VBT_EXP == 8
-                    uint64_t tq1; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tq1) : "v"(khi), "v"(klo) : "memory");
-                    xacc[0] += tq1 - tq0;
-#endif
-#if VBT_EXP == 5 || VBT_EXP == 7
-                    group_min_split_n<3>(khi, klo);
-#elif VBT_EXP != 1
                     group_min_split(khi, klo, lg);
-#endif
-#if VBT_EXP == 8
-                    uint64_t tq2; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tq2) : "v"(khi), "v"(klo) : "memory");
-                    xacc[1] += tq2 - tq1;
-#endif
-#if VBT_EXP == 6 || VBT_EXP == 7
-                    if (true) {
-#else
                     if (direct) {
-#endif
                         // one lane group per candidate: the group minimum is the candidate's best predecessor
                         if (valid && j == 0) e_key[ew & 0xFFFFu] = node_key(khi, klo, (uint32_t)(int32_t)(int16_t)(ew >> 16), seg_c + c);
                     } else if (single) {
@@ -1630,15 +1551,8 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
                     // LDS operations of one wave execute in order: a compiler-level fence is all the next pass needs
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
-#if VBT_EXP == 8
-                    asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tq3) :: "memory");
-                    xacc[2] += tq3 - tq2;
-#endif
                 }
             }
-#if VBT_EXP == 8
-            prof_acc[3] = xacc[0]; prof_acc[4] = xacc[1]; prof_acc[5] = xacc[2]; prof_acc[7] = xacc[3];
-#endif
             __syncthreads();
         }
         PROF_MARK(6);
@@ -1809,13 +1723,9 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
         }
         PROF_MARK(7);
         if (A.prof && ln == 0) {
-            unsigned long long* pr_ = A.prof + (size_t)(sid & (kProfSlots - 1)) * kProfWords;
-            for (int i = 3; i < kProfPhases; ++i) atomicAdd(&pr_[i], (unsigned long long)prof_acc[i]);
-#if VBT_EXP != 9 && VBT_EXP != 10
             atomicAdd(&pr_[kProfPhases + 1], (unsigned long long)prof_S);
             atomicAdd(&pr_[kProfPhases + 2], (unsigned long long)prof_SL);
             atomicAdd(&pr_[kProfPhases + 3], (unsigned long long)CT);
-#endif
         }
 #undef PROF_MARK
         __syncthreads();
@@ -1973,7 +1883,7 @@ Workspace::Workspace(const Tokenizer& t, uint64_t max_s, uint64_t max_b) : tok(t
     // LDS tiers (bytes per wave), ascending; the global-memory tier always follows
     {
         const char* e = std::getenv("VBT_TIERS");
-        std::string spec = e && *e ? e : (fused ? "16384,32768,65536" : env_u32("VBT_SEG_BYTES", 16384) ? "8192,12288,16384,163840" : "8192,12288,16384,24576,32768,49152,65536,163840");
+        std::string spec = e && *e ? e : (fused ? "16384,32768,65536" : env_u32("VBT_SEG_BYTES", 16384) ? "10240,16384,163840" : "8192,12288,16384,24576,32768,49152,65536,163840");
         size_t pos = 0;
         while (pos < spec.size()) {
             size_t c = spec.find(',', pos);
@@ -2049,7 +1959,10 @@ Workspace::Workspace(const Tokenizer& t, uint64_t max_s, uint64_t max_b) : tok(t
         HIP_CHECK(hipStreamCreateWithFlags(reinterpret_cast<hipStream_t*>(&early_stream), hipStreamNonBlocking));
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gen_candidates_large), hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
         if (tiers.back() > 65536)  // a single workgroup may use the CU's whole 160 KiB
-            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lattice_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tiers.back()));
+        {
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lattice_lds<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tiers.back()));
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lattice_lds<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tiers.back()));
+        }
     }
 }
 
@@ -2148,24 +2061,30 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
             hipLaunchKernelGGL(gen_candidates_large, dim3(waves_for(gen_level_lds[lv - 1], cn)), dim3(64), gen_level_lds[lv - 1], stream, D, a, gen_level_lds[lv - 1], lv);
         a.direct_push = 0;
         rec(1);
+        // (forking the small tiers before the straggler generators was measured: 3.33 vs 3.2 ms, the stragglers then
+        // compete with the sweep and the segment tier starts later)
         HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_fork2), stream));
         // One lattice_lds launch per LDS tier, each on its own stream.  The tiers above the segment tier are escape
         // tiers: nothing is routed to them up front, they take what the tier before them could not sweep, so they are
         // launched on the segment tier's stream, behind it.
+        auto launch_lattice = [&](dim3 grid_, uint32_t lds_, hipStream_t st_, uint32_t tier_, uint32_t list_) {
+            if (D.space_cateset) hipLaunchKernelGGL(lattice_lds<true>, grid_, dim3(64), lds_, st_, D, a, tier_, list_);
+            else hipLaunchKernelGGL(lattice_lds<false>, grid_, dim3(64), lds_, st_, D, a, tier_, list_);
+        };
         const size_t n_conc = a.seg_tier < T ? a.seg_tier + 1 : T;
         for (size_t i = 0; i < n_conc; ++i) {
             const size_t t = n_conc - 1 - i;
             hipStream_t side = reinterpret_cast<hipStream_t>(streams[t]);
             HIP_CHECK(hipStreamWaitEvent(side, reinterpret_cast<hipEvent_t>(ev_fork2), 0));
             const uint32_t grid = (t < tier_waves.size() && tier_waves[t]) ? std::min<uint32_t>(tier_waves[t], waves_for(tiers[t], cn)) : waves_for(tiers[t], cn);
-            hipLaunchKernelGGL(lattice_lds, dim3(grid), dim3(64), tiers[t], side, D, a, (uint32_t)t, (uint32_t)t);
+            launch_lattice(dim3(grid), tiers[t], side, (uint32_t)t, (uint32_t)t);
             // optional (VBT_HELP_BYTES): a smaller tier that has drained its own list sweeps the segment tier's list
             // too, in shorter segments.  Off by default: measured slower on the headline batch.
             if (a.seg_tier < T && t < a.seg_tier && tiers[t] >= env_u32("VBT_HELP_BYTES", 0xFFFFFFFFu))
-                hipLaunchKernelGGL(lattice_lds, dim3(grid), dim3(64), tiers[t], side, D, a, (uint32_t)t, a.seg_tier);
+                launch_lattice(dim3(grid), tiers[t], side, (uint32_t)t, a.seg_tier);
             if (t == a.seg_tier)
                 for (size_t x = t + 1; x < T; ++x)
-                    hipLaunchKernelGGL(lattice_lds, dim3(waves_for(tiers[x], std::min<uint32_t>(cn, 4096))), dim3(64), tiers[x], side, D, a, (uint32_t)x, (uint32_t)x);
+                    launch_lattice(dim3(waves_for(tiers[x], std::min<uint32_t>(cn, 4096))), tiers[x], side, (uint32_t)x, (uint32_t)x);
             HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(tier_events[t]), side));
         }
         for (size_t t = 0; t < n_conc; ++t) HIP_CHECK(hipStreamWaitEvent(stream, reinterpret_cast<hipEvent_t>(tier_events[t]), 0));
