@@ -1104,6 +1104,11 @@ __global__ void __launch_bounds__(64) gen_candidates_large(DevDict D, BatchArgs 
 // Kernel 2: the lattice sweep of one sentence per wavefront, entirely in LDS.  Persistent waves
 // drain the work list of their tier.  Sentences whose lattice does not fit after all go to the
 // fallback list (fused kernel with global scratch).
+// prefetch distance of the matrix gathers in passes (= unroll factor of the sweep loop).  2..8 measure the same
+// within 3 % on a full batch (other waves hide the latency); 8 keeps a lone sentence's sweep off the HBM latency.
+#ifndef VBT_DEPTH
+#define VBT_DEPTH 8
+#endif
 #ifndef VBT_LAT_WAVES
 #define VBT_LAT_WAVES 4
 #endif
@@ -1429,7 +1434,7 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
         }
         // no LDS left for the pass records: fused kernel
         prof_SL += SL; prof_S += S;
-        constexpr uint32_t kDepth = 8;  // prefetch distance of the fused loop, in passes
+        constexpr uint32_t kDepth = VBT_DEPTH;  // prefetch distance of the fused loop, in passes
         if (SL + 2 * kDepth + 2 > sl_cap) {  // more passes than estimated (gen_candidates bounds them per position)
             if (budget > lds_bytes / 3) { budget -= lds_bytes / 4; __syncthreads(); continue; }
             fail = 29; break;
