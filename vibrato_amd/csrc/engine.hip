@@ -1912,8 +1912,7 @@ Workspace::Workspace(const Tokenizer& t, uint64_t max_s, uint64_t max_b) : tok(t
     d_tok_cnt = static_cast<uint32_t*>(alloc(ns * 4));
     d_over = static_cast<uint32_t*>(alloc(2 * ns * 4 * (tiers.size() + 1 + kGenLevels)));  // two regions per list: long-first pass + bulk
     d_ctrl = static_cast<uint32_t*>(alloc(kCtrlWords * 4));
-    d_cctrl = static_cast<uint32_t*>(alloc((size_t)kMaxChunks * kChunkCtrlWords * 4));
-    n_chunks = 1;
+    d_cctrl = static_cast<uint32_t*>(alloc((size_t)kCtrlBlocks * kBlockCtrlWords * 4));
     if (const char* e = std::getenv("VBT_TIER_WAVES")) {  // experiment: fixed lattice grid per tier
         std::string spec = e;
         size_t pos = 0;
@@ -1989,7 +1988,7 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
     last_n = n;
     last_stream = stream_;
     HIP_CHECK(hipMemsetAsync(d_ctrl, 0, kCtrlWords * 4, stream));
-    HIP_CHECK(hipMemsetAsync(d_cctrl, 0, kMaxChunks * kChunkCtrlWords * 4, stream));
+    HIP_CHECK(hipMemsetAsync(d_cctrl, 0, kCtrlBlocks * kBlockCtrlWords * 4, stream));
     if (n == 0) return;
     const size_t T = tiers.size();
     const size_t half = std::max<uint64_t>(max_sentences, 1), stride = 2 * half;
@@ -2021,7 +2020,6 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
     };
     rec(0);
     if (fused) {
-        last_chunks = 1;
         auto count = [&](size_t t) { return d_cctrl + 2 * t; };
         auto cursor = [&](size_t t) { return d_cctrl + 2 * t + 1; };
         hipLaunchKernelGGL(tokenize_lds, dim3((uint32_t)n), dim3(64), tiers[0], stream, D, a, tiers[0], (const uint32_t*)nullptr,
@@ -2042,14 +2040,13 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
         const uint32_t gen_lds = env_u32("VBT_GEN_LDS", 8192), gen_lds_large = 32768;
         static const uint32_t gen_level_lds[kGenLevels] = {32768, 65536, 163840};  // the instances behind the bulk generator
         const uint32_t long_bytes = env_u32("VBT_LONG_BYTES", 0);
-        last_chunks = 1;
         const uint32_t cn = (uint32_t)n, lb = (cn + 1023) / 1024;
         a.sid0 = 0; a.n = cn; a.cctrl = d_cctrl; a.list_off = 0; a.direct_push = 0;
         a.s_skip = nullptr;
         HIP_CHECK(hipMemsetAsync(pipe.s_tier, 0xFF, cn, stream));  // nothing routed yet
         if (long_bytes) {
             BatchArgs e = a;  // same routing array, own input list (second counter block / list region)
-            e.cctrl = d_cctrl + (size_t)kChunkCtrlWords; e.list_off = (uint32_t)half;
+            e.cctrl = d_cctrl + (size_t)kBlockCtrlWords; e.list_off = (uint32_t)half;
             hipLaunchKernelGGL(classify_long, dim3((cn + 255) / 256), dim3(256), 0, stream, e, long_bytes);
             HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_fork), stream));
             hipStream_t es = reinterpret_cast<hipStream_t>(early_stream);
@@ -2105,7 +2102,7 @@ void Workspace::stats(vbt_call_stats* out) {
     HIP_CHECK(hipSetDevice(tok.device()));
     HIP_CHECK(hipStreamSynchronize(reinterpret_cast<hipStream_t>(last_stream)));
     uint32_t ctrl[kCtrlWords];
-    std::vector<uint32_t> cc((size_t)kMaxChunks * kChunkCtrlWords);
+    std::vector<uint32_t> cc((size_t)kCtrlBlocks * kBlockCtrlWords);
     HIP_CHECK(hipMemcpy(ctrl, d_ctrl, sizeof(ctrl), hipMemcpyDeviceToHost));
     HIP_CHECK(hipMemcpy(cc.data(), d_cctrl, cc.size() * 4, hipMemcpyDeviceToHost));
     std::memset(out, 0, sizeof(*out));
@@ -2116,8 +2113,8 @@ void Workspace::stats(vbt_call_stats* out) {
         out->n_tier2 = cc[2 * (T - 1)];
         out->n_tier1 = last_n - out->n_tier0 - out->n_tier2;
     } else {
-        for (uint32_t c = 0; c < 2 * last_chunks; ++c) {  // bulk blocks, then the long-first blocks
-            const uint32_t* k = cc.data() + (size_t)c * kChunkCtrlWords;
+        for (uint32_t c = 0; c < (uint32_t)kCtrlBlocks; ++c) {  // the batch, then the long-first input list (tier counts there are 0)
+            const uint32_t* k = cc.data() + (size_t)c * kBlockCtrlWords;
             out->n_tier0 += k[0];
             out->n_tier2 += k[2 * T];
             for (size_t t = 1; t < T; ++t) out->n_tier1 += k[2 * t];

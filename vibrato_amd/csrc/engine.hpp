@@ -80,9 +80,8 @@ struct BatchArgs {
     uint32_t seg_tier;     // LDS tier that sweeps longer sentences in segments (>= n_tiers: none)
     uint32_t direct_push;  // gen_candidates_large: append to the tier lists directly instead of routing through s_tier
     uint32_t tier_prio;  // the top `tier_prio` LDS tiers run at raised wave priority (0 = off)
-    // chunked pipeline: a launch covers sentences [sid0, sid0 + n); cctrl = this chunk's list counters
-    // (cctrl[2t] = entries of list t, cctrl[2t+1] = its work cursor); list t of the chunk starts at
-    // lists[t * list_stride + sid0]
+    // a launch covers sentences [sid0, sid0 + n); cctrl = the list counters it works with (cctrl[2t] = entries of
+    // list t, cctrl[2t+1] = its work cursor); list t starts at lists[t * list_stride + list_off]
     uint32_t sid0;
     uint32_t* cctrl;
     uint32_t list_off;  // offset of this launch's entries inside every list region
@@ -97,9 +96,9 @@ struct BatchArgs {
 // ctrl[kNodeCursor] bump pointer of the candidate arrays
 enum CtrlSlot { kTotal = 0, kError = 1, kBump = 2, kNodeCursor = 4, kTierCtrl = 6, kCtrlWords = 32 };
 constexpr int kMaxTiers = 8;
-constexpr int kMaxChunks = 16;
+constexpr int kCtrlBlocks = 2;   // list-counter blocks: [0] the batch, [1] the input list of the optional long-first side stream
 constexpr int kGenLevels = 3;  // large-LDS instances of the generator behind the bulk one (32 KiB, 64 KiB, whole CU)
-constexpr int kChunkCtrlWords = 2 * (kMaxTiers + 1 + kGenLevels);
+constexpr int kBlockCtrlWords = 2 * (kMaxTiers + 1 + kGenLevels);
 constexpr int kProfSlots = 256;  // the counters are spread over this many copies (hot-word atomics serialise)
 constexpr int kProfWords = 12;   // kProfPhases cycle totals, sentences, lattice steps, lattice passes, candidates
 constexpr int kProfPhases = 8;  // decode, count, fill, end lists, pre-pass, gather, recurrence, emit
@@ -135,7 +134,6 @@ class Workspace {
     uint64_t max_sentences, max_bytes;
     vbt_token_rec* d_tokens = nullptr;
     uint32_t *d_tok_off = nullptr, *d_tok_cnt = nullptr, *d_ctrl = nullptr, *d_over = nullptr, *d_cctrl = nullptr;
-    uint32_t n_chunks = 1, last_chunks = 1;
     std::vector<void*> pipe_allocs;  // buffers of the two-kernel pipeline
     BatchArgs pipe{};                // device pointers of those buffers
     std::vector<void*> streams;      // one side stream per LDS tier
