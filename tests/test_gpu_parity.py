@@ -188,6 +188,22 @@ def test_group_spans_at_length_mask_boundaries(fixture_sources, ignore_space):
     _assert_batch_equal(to, tok, text, offs)
 
 
+def test_very_long_sentences_take_every_generator_level_and_the_fallback():
+    """~600 / ~2 400 / ~3 300 / ~17 000-character sentences (sentence-aligned prefixes of a mixed batch, spaces kept):
+    the 32 KiB, 64 KiB and whole-CU generator levels, the segmented sweep with a windowed back-trace and -- 17 000
+    characters fit no generator level -- the global-memory kernel."""
+    sd = synth.SynthDict("small")
+    to, tv = _oracle_and_product(sd, ignore_space=True)
+    base, offs0 = sd.sentences(600, "mixed", space_p=0.05)
+    enc = [bytes(base[:int(offs0[k])]) for k in (14, 20, 40, 160)]
+    enc = [enc[0], b"", enc[1], enc[3], "京都".encode() * 3, enc[2]]
+    offs = np.zeros(len(enc) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([len(e) for e in enc])
+    text = np.frombuffer(b"".join(enc), dtype=np.uint8)
+    assert max(len(e) for e in enc) > 50000
+    batch, _ = _assert_batch_equal(to, tv, text, offs)
+
+
 def test_cli_output_formats(fixture_sources):
     """Byte-identical tokenize CLI output (tokenize/src/main.rs:83-127) vs the oracle's formatter."""
     s = fixture_sources
