@@ -1133,7 +1133,9 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
         if (ln == 0) item = atomicAdd(cursor, 1u);
         item = __builtin_amdgcn_readfirstlane(item);  // lane 0 is always active here; keeps everything below scalar
         if (item >= count) break;
-        const uint32_t sid = __builtin_amdgcn_readfirstlane(list[item]);
+        // newest entries first: the large-LDS generator levels append their (long, slow) sentences last, level by level,
+        // so reading the list backwards starts the longest sentences first instead of leaving them as the tail
+        const uint32_t sid = __builtin_amdgcn_readfirstlane(list[count - 1 - item]);
         // profiling adds straight into the spread counters: nothing but the last time stamp lives between marks
         uint64_t prof_t = A.prof ? clock64() : 0;
         unsigned long long* const pr_ = A.prof ? A.prof + (size_t)(sid & (kProfSlots - 1)) * kProfWords : nullptr;
