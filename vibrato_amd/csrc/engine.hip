@@ -873,9 +873,15 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
     if (C >= 65532 || any_long) { route(fallback); return; }
     if (ln == 0) cand_off[n] = C;
     if (C > region) { route(fallback); return; }  // denser than the region: fused path
-    uint16_t* cleft = ar.take<uint16_t>(C);  // left id per candidate, for the grouping below
-    uint8_t* cgid = ar.take<uint8_t>(C);
-    if (!ar.ok) { route(large_list); return; }
+    // Left ids (for the grouping) are kept in LDS for a window of candidates only: sentences whose candidates
+    // outgrow it are expanded and grouped in rounds of whole 64-position chunks, so the LDS need of a long
+    // sentence is its per-character arrays plus a window, not 3 bytes per candidate.
+    const uint32_t cap = ar.ok && lds_bytes > ar.used + 16 ? (uint32_t)((lds_bytes - ar.used - 16) / 3) : 0u;
+    const uint32_t win = C < cap ? C : cap;
+    uint16_t* cleft = ar.take<uint16_t>(win);
+    uint8_t* cgid = ar.take<uint8_t>(win);
+    // (the bulk generator stays single-round: re-scanning the hits is cheaper in the levels behind it, which have the LDS)
+    if (!ar.ok || win == 0 || (level == 0 && C > cap)) { route(large_list); return; }
     // The staged hits are read back by this wave only: its stores have to be complete (workgroup scope:
     // s_waitcnt vmcnt(0); the vector L1 is write-through and never held these lines).  An agent-scope
     // release would write the whole L2 back (buffer_wbl2) once per sentence.
@@ -884,79 +890,94 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     PROF_MARK(1);
 
-    // expand the hits: lanes = hits, every entry load independent of every other
-    {
-        const uint32_t H = *hcount;  // <= C <= region
+    const uint32_t H = *hcount;  // <= C <= region
+    uint32_t G = 0, ngmax = 0;
+    bool too_many_groups = false, window_small = false;
+    for (uint32_t r0 = 0; r0 < n;) {
+        // the round: chunks [r0, r1) while their candidates fit the window
+        const uint32_t cbase = cand_off[r0];
+        uint32_t r1 = r0;
+        while (r1 < n) {
+            const uint32_t nx = r1 + 64 < n ? r1 + 64 : n;
+            if (cand_off[nx] - cbase > win) break;
+            r1 = nx;
+        }
+        if (r1 == r0) { window_small = true; break; }  // one chunk alone outgrows the window: next generator level
+        const uint32_t cend = cand_off[r1];
+        // expand the hits of these positions: lanes = hits, every entry load independent of every other
         for (uint32_t h0 = 0; h0 < H; h0 += 64) {
             const uint32_t h = h0 + ln;
             if (h < H) {
                 const uint4 hr = hits[h];
                 const uint32_t c = hr.y & 0xFFFFu, lex = hr.y >> 16, end = hr.z & 0xFFFFu, pos = hr.z >> 16;
-                const Entry* __restrict__ ent = lex == 0 ? D.sys.entries : lex == 1 ? D.user.entries : D.unk_entries;
-                const uint32_t dest = cand_off[pos] + hr.w;
-                for (uint32_t t0 = 0; t0 < c; t0 += 4) {
-                    Entry e[4];
+                if (pos >= r0 && pos < r1) {
+                    const Entry* __restrict__ ent = lex == 0 ? D.sys.entries : lex == 1 ? D.user.entries : D.unk_entries;
+                    const uint32_t dest = cand_off[pos] + hr.w;
+                    for (uint32_t t0 = 0; t0 < c; t0 += 4) {
+                        Entry e[4];
 #pragma unroll
-                    for (uint32_t q = 0; q < 4; ++q) e[q] = ent[hr.x + (t0 + q < c ? t0 + q : t0)];
+                        for (uint32_t q = 0; q < 4; ++q) e[q] = ent[hr.x + (t0 + q < c ? t0 + q : t0)];
 #pragma unroll
-                    for (uint32_t q = 0; q < 4; ++q) {
-                        if (t0 + q < c) {
-                            const uint32_t k = dest + t0 + q;
-                            uint32_t* rec = reinterpret_cast<uint32_t*>(&A.g_nd[base + k]);
-                            rec[0] = e[q].left_right;
-                            rec[1] = (e[q].cost & 0xFFFFu) | (end << 16);
-                            rec[2] = (lex << 30) | e[q].word_id;
-                            cleft[k] = (uint16_t)(e[q].left_right & 0xFFFFu);
+                        for (uint32_t q = 0; q < 4; ++q) {
+                            if (t0 + q < c) {
+                                const uint32_t k = dest + t0 + q;
+                                uint32_t* rec = reinterpret_cast<uint32_t*>(&A.g_nd[base + k]);
+                                rec[0] = e[q].left_right;
+                                rec[1] = (e[q].cost & 0xFFFFu) | (end << 16);
+                                rec[2] = (lex << 30) | e[q].word_id;
+                                cleft[k - cbase] = (uint16_t)(e[q].left_right & 0xFFFFu);
+                            }
                         }
                     }
                 }
             }
         }
-    }
-    __syncthreads();
-
-    // group the candidates of a start position by left id, in reference insertion order
-    uint32_t G = 0, ngmax = 0;
-    bool too_many_groups = false;
-    for (uint32_t c0 = 0; c0 < n; c0 += 64) {
-        const uint32_t i = c0 + ln;
-        uint32_t ng = 0;
-        if (i < n) {
-            uint32_t gl[8];  // the first 8 distinct left ids of this position (register cache)
+        __syncthreads();
+        // group the candidates of a start position by left id, in reference insertion order
+        for (uint32_t c0 = r0; c0 < r1; c0 += 64) {
+            const uint32_t i = c0 + ln;
+            uint32_t ng = 0;
+            if (i < r1) {
+                uint32_t gl[8];  // the first 8 distinct left ids of this position (register cache)
 #pragma unroll
-            for (int q = 0; q < 8; ++q) gl[q] = 0xFFFFFFFFu;
-            const uint32_t kb = cand_off[i], ke = i + 1 < n ? cand_off[i + 1] : C;
-            for (uint32_t k = kb; k < ke; ++k) {
-                const uint32_t left = cleft[k];
-                uint32_t g = 0xFFFFFFFFu;
+                for (int q = 0; q < 8; ++q) gl[q] = 0xFFFFFFFFu;
+                const uint32_t kb = cand_off[i] - cbase, ke = cand_off[i + 1] - cbase;
+                for (uint32_t k = kb; k < ke; ++k) {
+                    const uint32_t left = cleft[k];
+                    uint32_t g = 0xFFFFFFFFu;
 #pragma unroll
-                for (int q = 7; q >= 0; --q) g = gl[q] == left ? (uint32_t)q : g;
-                // a left id beyond the 8 cached ones starts a group of its own every time (same gid => same left id is
-                // all the lattice kernel relies on)
-                const bool first = g == 0xFFFFFFFFu;
-                if (first) {
-                    g = ng;
+                    for (int q = 7; q >= 0; --q) g = gl[q] == left ? (uint32_t)q : g;
+                    // a left id beyond the 8 cached ones starts a group of its own every time (same gid => same left id is
+                    // all the lattice kernel relies on)
+                    const bool first = g == 0xFFFFFFFFu;
+                    if (first) {
+                        g = ng;
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) gl[q] = (uint32_t)q == ng ? left : gl[q];
-                    ++ng;
+                        for (int q = 0; q < 8; ++q) gl[q] = (uint32_t)q == ng ? left : gl[q];
+                        ++ng;
+                    }
+                    cgid[k] = (uint8_t)((g & 0x7Fu) | (first ? 0x80u : 0u));
                 }
-                cgid[k] = (uint8_t)((g & 0x7Fu) | (first ? 0x80u : 0u));
+                ngp[i] = (uint8_t)ng;
             }
-            ngp[i] = (uint8_t)ng;
-        }
-        too_many_groups |= __ballot(ng > 127u) != 0;
-        uint32_t tot;
-        const uint32_t ex = wave_exscan(ng, tot);
-        if (i < n) goff[i] = (uint16_t)(G + ex);
-        G += tot;
-        uint32_t m = ng;
+            too_many_groups |= __ballot(ng > 127u) != 0;
+            uint32_t tot;
+            const uint32_t ex = wave_exscan(ng, tot);
+            if (i < r1) goff[i] = (uint16_t)(G + ex);
+            G += tot;
+            uint32_t m = ng;
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = __shfl_xor(m, d); m = o > m ? o : m; }
-        ngmax = m > ngmax ? m : ngmax;
+            for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = __shfl_xor(m, d); m = o > m ? o : m; }
+            ngmax = m > ngmax ? m : ngmax;
+        }
+        __syncthreads();
+        for (uint32_t k = cbase + ln; k < cend; k += 64) reinterpret_cast<uint32_t*>(&A.g_nd[base + k])[3] = cgid[k - cbase];
+        __syncthreads();
+        r0 = r1;
     }
+    if (window_small) { route(large_list); return; }
     if (too_many_groups) { route(fallback); return; }
     __syncthreads();
-    for (uint32_t k = ln; k < C; k += 64) reinterpret_cast<uint32_t*>(&A.g_nd[base + k])[3] = cgid[k];
     // upper bound of the number of (step, <= 64 pair lanes) passes of the lattice kernel
     uint32_t passes = 1;  // EOS
     for (uint32_t c0 = 0; c0 < n; c0 += 64) {
@@ -2061,7 +2082,7 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
         if (long_bytes) HIP_CHECK(hipStreamWaitEvent(stream, reinterpret_cast<hipEvent_t>(ev_early), 0));
         hipLaunchKernelGGL(build_lists, dim3(lb), dim3(1024), 0, stream, a, -1);
         a.direct_push = 1;
-        for (uint32_t lv = 1; lv <= kGenLevels; ++lv)  // each level takes what outgrew the one before (the last: a whole CU's LDS, ~3500 characters)
+        for (uint32_t lv = 1; lv <= kGenLevels; ++lv)  // each level takes what outgrew the one before (the last: a whole CU's LDS, ~5000 characters)
             hipLaunchKernelGGL(gen_candidates_large, dim3(waves_for(gen_level_lds[lv - 1], cn)), dim3(64), gen_level_lds[lv - 1], stream, D, a, gen_level_lds[lv - 1], lv);
         a.direct_push = 0;
         rec(1);
