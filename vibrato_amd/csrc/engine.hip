@@ -2060,8 +2060,13 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
         // many bytes are listed first and generated by the large-LDS generator on a side stream while the bulk
         // runs.  Measured on MI355X it does not pay: the side stream's few wavefronts are slowed by the bulk
         // as much as they save (4.40 vs 4.27 ms per 100k sentences).
-        const uint32_t gen_lds = env_u32("VBT_GEN_LDS", 8192), gen_lds_large = 32768;
-        static const uint32_t gen_level_lds[kGenLevels] = {32768, 65536, 163840};  // the instances behind the bulk generator
+        const uint32_t gen_lds = env_u32("VBT_GEN_LDS", 8192);
+        uint32_t gen_level_lds[kGenLevels] = {32768, 81920, 163840};  // the instances behind the bulk generator (VBT_GEN_LEVELS=a,b,c)
+        if (const char* e = std::getenv("VBT_GEN_LEVELS")) {
+            unsigned v[3];
+            if (std::sscanf(e, "%u,%u,%u", &v[0], &v[1], &v[2]) == 3 && v[0] >= 4096 && v[0] < v[1] && v[1] < v[2] && v[2] <= 163840)
+                for (int q = 0; q < 3; ++q) gen_level_lds[q] = v[q];
+        }
         const uint32_t long_bytes = env_u32("VBT_LONG_BYTES", 0);
         const uint32_t cn = (uint32_t)n, lb = (cn + 1023) / 1024;
         a.sid0 = 0; a.n = cn; a.cctrl = d_cctrl; a.list_off = 0; a.direct_push = 0;
@@ -2074,7 +2079,7 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
             HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_fork), stream));
             hipStream_t es = reinterpret_cast<hipStream_t>(early_stream);
             HIP_CHECK(hipStreamWaitEvent(es, reinterpret_cast<hipEvent_t>(ev_fork), 0));
-            hipLaunchKernelGGL(gen_candidates_large, dim3(waves_for(gen_lds_large, cn)), dim3(64), gen_lds_large, es, D, e, gen_lds_large, 1u);
+            hipLaunchKernelGGL(gen_candidates_large, dim3(waves_for(gen_level_lds[0], cn)), dim3(64), gen_level_lds[0], es, D, e, gen_level_lds[0], 1u);
             HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_early), es));
             a.s_skip = pipe.s_early;  // the bulk generator leaves these alone
         }
