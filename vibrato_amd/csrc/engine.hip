@@ -1,20 +1,20 @@
-// HIP kernels + launch sequence of the MI355X tokenizer (gfx950, wave64).
+// HIP kernels + launch sequence of the MI355X tokenizer (gfx950, wave64).  DESIGN.md section 3 is the map.
 //
-// One wavefront tokenizes one sentence end to end (fused): UTF-8 decode, char
-// categories and groupable runs (Sentence::compile, sentence.rs:34-71), candidate
-// generation by double-array common-prefix search + unknown-word rules
-// (Tokenizer::add_lattice_edges tokenizer.rs:141-199, UnkHandler::gen_unk_words
-// unknown.rs:69-137), the position sweep with per-node min-cost search over the
-// connection matrix (build_lattice_inner tokenizer.rs:94-139, Lattice::insert_node /
-// search_min_node lattice.rs:103-151, insert_eos 85-101) and the back-trace
-// (append_top_nodes lattice.rs:159-168).  The whole lattice lives in LDS (tier 0/1)
-// or, for sentences that do not fit, in a global scratch slab (tier 2).
+// Pipeline (default): gen_candidates (one wavefront per sentence: UTF-8 decode, char categories and groupable
+// runs -- Sentence::compile, sentence.rs:34-71 -- and candidate generation by double-array common-prefix search +
+// unknown-word rules -- Tokenizer::add_lattice_edges tokenizer.rs:141-199, UnkHandler::gen_unk_words
+// unknown.rs:69-137) -> build_lists -> gen_candidates_large (sentences that outgrew the bulk generator's LDS) ->
+// lattice_lds, one launch per LDS tier (one wavefront per sentence: the position sweep with per-node min-cost
+// search over the connection matrix -- build_lattice_inner tokenizer.rs:94-139, Lattice::insert_node /
+// search_min_node lattice.rs:103-151, insert_eos 85-101 -- and the back-trace, append_top_nodes
+// lattice.rs:159-168; the lattice lives in LDS, longer sentences are swept in segments between clean cuts) ->
+// tokenize_global for whatever is left.  The fused single-kernel design (process_sentence: tokenize_lds /
+// tokenize_global) is the fallback with a global-memory lattice and, with VBT_FUSED=1, an A/B reference.
 //
-// Bit-exactness notes: end lists are built with LDS atomics, so
-// their order is arbitrary; every node carries its insertion sequence number and ties
-// are broken towards the LARGEST sequence number, which is exactly what `<=` does in
-// search_min_node (lattice.rs:141-146).  Candidates of positions the sweep never visits
-// (unreachable or inside a skipped space run) keep cost = kInvalidCost and are ignored.
+// Bit-exactness notes: end lists are built with LDS atomics, so their order is arbitrary;
+// every node carries its insertion sequence number and ties are broken towards the LARGEST sequence number,
+// which is exactly what `<=` does in search_min_node (lattice.rs:141-146).  Candidates of positions the sweep
+// never visits (unreachable or inside a skipped space run) stay "dead" and are ignored as predecessors.
 #include <hip/hip_runtime.h>
 #include <type_traits>
 
