@@ -72,6 +72,8 @@ typedef struct vbt_token {
 } vbt_token;
 
 VBT_API const char* vbt_last_error(void);
+/* 1 when the bytes are a Rust `str` (strict UTF-8), else 0: what every text-taking entry point requires. */
+VBT_API int vbt_utf8_valid(const char* utf8, size_t len);
 
 /* ---- Dictionary ------------------------------------------------------------ */
 
@@ -127,14 +129,34 @@ VBT_API int vbt_worker_reset_sentence(vbt_worker* w, const char* utf8, size_t le
 VBT_API int vbt_worker_tokenize(vbt_worker* w);                                   /* Worker::tokenize */
 VBT_API uint32_t vbt_worker_num_tokens(const vbt_worker* w);                      /* Worker::num_tokens */
 VBT_API int vbt_worker_token(const vbt_worker* w, uint32_t i, vbt_token* out);    /* Worker::token(i) */
+/* vbt_worker_reset_sentence fails with VBT_ERR_UTF8 when the bytes are not a Rust `str` (the reference takes &str,
+ * worker.rs:34); the worker then holds the empty sentence. */
+/* Worker::init_connid_counter, worker.rs:77-84 (ConnIdCounter::new, mapper.rs:94-99): zeroed counters */
+VBT_API int vbt_worker_init_connid_counter(vbt_worker* w);
+/* Worker::update_connid_counts, worker.rs:86-93: adds Lattice::add_connid_counts (lattice.rs:170-183) of the last
+ * vbt_worker_tokenize call.  VBT_ERR_INVALID_STATE where the reference panics (no init_connid_counter). */
+VBT_API int vbt_worker_update_connid_counts(vbt_worker* w);
+/* The raw counters: lid[num_left], rid[num_right]. */
+VBT_API int vbt_worker_connid_counts(const vbt_worker* w, uint64_t* lid, uint64_t* rid);
+/* Worker::compute_connid_probs, worker.rs:95-103 (ConnIdCounter::compute_probs, mapper.rs:108-146): per side the
+ * (id, count / sum) pairs without id 0, sorted by probability descending, then id ascending -- the content of the
+ * reference's *.lmap / *.rmap files.  lid_* hold num_left - 1 entries, rid_* num_right - 1. */
+VBT_API int vbt_worker_compute_connid_probs(const vbt_worker* w, uint32_t* lid_ids, double* lid_probs, uint32_t* rid_ids,
+                                            double* rid_probs);
+/* The same computation for one side of any counter array (e.g. vbt_workspace_connid_counts): n - 1 entries out. */
+VBT_API int vbt_connid_probs(const uint64_t* counts, size_t n, uint32_t* ids, double* probs);
 
 /* ---- Batched host API (new: many sentences per call) ---------------------------- */
 
 /* The 3-call loop of tokenize/src/main.rs:78-82 over n sentences: sentence s is
  * text[offsets[s] .. offsets[s+1]). Copies text to the device, runs the kernels,
- * copies token records back. The batch keeps its own copy of the text. */
+ * copies token records back. The batch keeps its own copy of the text.
+ * Every sentence must be valid UTF-8 (a Rust `str`): otherwise VBT_ERR_UTF8 and no batch.
+ * Thread-safe per tokenizer: each call takes a workspace (device scratch + staging + stream) from the tokenizer's
+ * pool and returns it, so steady-state calls do no device allocation (vbt_tokenizer_pool_stats). */
 VBT_API int vbt_tokenize_batch(const vbt_tokenizer* tok, const uint8_t* text, const uint64_t* offsets, uint64_t n,
                                vbt_batch** out);
+VBT_API int vbt_tokenizer_pool_stats(const vbt_tokenizer* tok, uint64_t* created, uint64_t* reused, uint64_t* idle);
 VBT_API void vbt_batch_free(vbt_batch* b);
 VBT_API uint64_t vbt_batch_num_sentences(const vbt_batch* b);
 VBT_API uint64_t vbt_batch_total_tokens(const vbt_batch* b);
@@ -157,8 +179,13 @@ VBT_API void vbt_free(void* p);
 VBT_API int vbt_workspace_new(const vbt_tokenizer* tok, uint64_t max_sentences, uint64_t max_bytes, vbt_workspace** out);
 VBT_API void vbt_workspace_free(vbt_workspace* ws);
 /* Enqueue the tokenization of n sentences on `hip_stream` (a hipStream_t, NULL = default
- * stream). d_text / d_offsets are DEVICE pointers (offsets: n+1 x u64, bytes into d_text).
- * Asynchronous; results are valid once the stream has been synchronized. */
+ * stream). d_text / d_offsets are DEVICE pointers (offsets: n+1 x u64, bytes into d_text;
+ * offsets[0] need not be 0: the batch may be a window into a larger text buffer).
+ * Asynchronous; results are valid once the stream has been synchronized.
+ * Input contract, checked on the device by the first kernel of the call: offsets non-decreasing,
+ * offsets[n] - offsets[0] <= total_bytes (<= the workspace's max_bytes, checked on the host), text valid UTF-8
+ * with every sentence starting on a character boundary.  A violation skips the batch and shows up as
+ * error_flags 8 (offsets) / 16 (UTF-8) in vbt_workspace_stats; results of that call are undefined. */
 VBT_API int vbt_tokenize_batch_device(vbt_workspace* ws, const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n,
                                       uint64_t total_bytes, void* hip_stream);
 /* Device pointers to the results of the last call:
@@ -172,7 +199,7 @@ VBT_API int vbt_workspace_results(const vbt_workspace* ws, const vbt_token_rec**
  * to the smallest LDS tier of the lattice kernel (n_tier0), to the larger LDS tiers (n_tier1) and to
  * the global-memory fallback kernel (n_tier2; a re-routed sentence is counted twice), tokens
  * written, device error flags (1 = token buffer full, 2 = scratch exhausted, 4 = sentence too
- * long) and, with timing enabled, the hipEvent-measured duration (ms, on the launch stream) of the
+ * long, 8 = bad offsets, 16 = invalid UTF-8) and, with timing enabled, the hipEvent-measured duration (ms, on the launch stream) of the
  * candidate-generation kernels (ms_tier0) and of everything after them (ms_tier12). */
 typedef struct vbt_call_stats {
     uint64_t n_sentences, n_tier0, n_tier1, n_tier2, n_tokens;
@@ -182,8 +209,8 @@ typedef struct vbt_call_stats {
 VBT_API int vbt_workspace_set_timing(vbt_workspace* ws, int enabled);
 /* Worker::init_connid_counter / update_connid_counts (worker.rs:77-93, Lattice::add_connid_counts lattice.rs:170-183):
  * while enabled, every batch adds, for each adjacent (left node, right node) pair of each lattice, 1 to
- * lid[right_node.left_id] and rid[left_node.right_id] (sentences that take the fused fallback kernel are not counted:
- * check vbt_call_stats.n_tier2).  vbt_workspace_connid_counts copies the totals (num_left / num_right u64). */
+ * lid[right_node.left_id] and rid[left_node.right_id] (every sentence exactly once, whichever kernel ends up sweeping
+ * it).  vbt_workspace_connid_counts copies the totals (num_left / num_right u64). */
 VBT_API int vbt_workspace_count_connids(vbt_workspace* ws, int enabled);
 VBT_API int vbt_workspace_connid_counts(vbt_workspace* ws, uint64_t* lid, uint64_t* rid, int reset);
 /* Developer aid: per-phase shader-clock cycles summed over all sentences since the last reset

@@ -149,3 +149,22 @@ def test_tokenizer_fails_loudly_without_gpu(fixture_sources):
         V.Tokenizer(d).new_worker()
     assert e.value.code == 100  # VBT_ERR_DEVICE: no silent CPU fallback
     assert d.num_words(0) == 46  # the dictionary handle survives a failed Tokenizer::new
+
+
+def test_utf8_validity_matches_python_strict_decoder():
+    """vbt_utf8_valid == Rust `str` validity == Python's strict 'utf-8' codec, on hand-picked and random byte strings."""
+    from vibrato_amd.api import utf8_valid
+    cases = [b"", b"abc", "東京都".encode(), "\U0001F600".encode(), b"\x80", b"\xc0\xaf", b"\xc2", b"\xe3\x81", b"\xed\xa0\x80",
+             b"\xed\x9f\xbf", b"\xee\x80\x80", b"\xf4\x8f\xbf\xbf", b"\xf4\x90\x80\x80", b"\xf0\x8f\xbf\xbf", b"\xf0\x90\x80\x80",
+             b"\xe0\x9f\xbf", b"\xe0\xa0\x80", b"a" * 9 + b"\xff", b"a" * 8 + "あ".encode(), b"\xf8\x88\x80\x80\x80", b"\xc2\x80\x80"]
+    rng = random.Random(5)
+    pool = [b"a", b"\x7f", b"\x80", b"\xbf", b"\xc2", b"\xdf", b"\xe0", b"\xed", b"\xef", b"\xf0", b"\xf4", b"\xf5", b"\xa0", b"\x90", "あ".encode(), "\U0001F600".encode()]
+    for _ in range(3000):
+        cases.append(b"".join(rng.choice(pool) for _ in range(rng.randrange(1, 12))))
+    for c in cases:
+        try:
+            c.decode("utf-8")
+            ok = True
+        except UnicodeDecodeError:
+            ok = False
+        assert utf8_valid(c) == ok, c

@@ -132,3 +132,67 @@ def test_connid_counts_match_oracle(ignore_space, seg_bytes, monkeypatch):
     glid, grid = ws.connid_counts()
     assert np.array_equal(glid, lid) and np.array_equal(grid, rid)
     assert V.compute_connid_probs(glid, grid)[0][0][1] > 0
+
+
+@pytest.mark.gpu
+def test_worker_level_connid_api_matches_the_reference_protocol():
+    """The `reorder` CLI's loop (map/src/reorder.rs:34-43): init_connid_counter, then per sentence reset_sentence /
+    tokenize / update_connid_counts, then compute_connid_probs -- through the C ABI's worker entry points."""
+    sd = synth.SynthDict("tiny")
+    text, offs = sd.sentences(60, "lognormal_40", space_p=0.1)
+    do = ora.Dictionary.from_sources_binmatrix(sd.lex, sd.matrix, sd.num_right, sd.num_left, sd.char_def, sd.unk)
+    w = ora.Tokenizer(do, True, 0).new_worker()
+    lid = np.zeros(sd.num_left, dtype=np.uint64)
+    rid = np.zeros(sd.num_right, dtype=np.uint64)
+    dv = V.SystemDictionaryBuilder.from_readers_binmatrix(sd.lex, sd.matrix, sd.num_right, sd.num_left, sd.char_def, sd.unk)
+    wv = V.Tokenizer(dv).ignore_space(True).new_worker()
+    with pytest.raises(V.VibratoError):
+        wv.update_connid_counts()  # the reference panics without init_connid_counter
+    wv.init_connid_counter()
+    for s in range(60):
+        sent = bytes(text[offs[s]:offs[s + 1]])
+        w.reset_sentence(sent)
+        w.tokenize()
+        wv.reset_sentence(sent)
+        wv.tokenize()
+        if s % 3 != 1:  # sentences that are tokenized but never committed must not leak into the counts
+            w.add_connid_counts(lid, rid)
+            wv.update_connid_counts()
+    glid, grid = wv.connid_counts()
+    assert np.array_equal(glid, lid) and np.array_equal(grid, rid)
+    lp, rp = wv.compute_connid_probs()
+    assert (lp, rp) == V.compute_connid_probs(lid, rid)
+    assert len(lp) == sd.num_left - 1 and all(lp[i][1] >= lp[i + 1][1] for i in range(len(lp) - 1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tiers,seg", [("2048,4096", "2048"), ("3072,163840", "3072"), ("1536", "1536")])
+def test_connid_counts_survive_retries_and_escalation(tiers, seg, monkeypatch):
+    """Tiny segment tiers: segments are retried with earlier cuts (more than 128 nodes end at a cut in the 'x' * 300 /
+    kana runs below), estimates run low, sentences escalate to the escape tier and to the global-memory kernel.
+    Every sentence must still be counted exactly once (counts were added before a segment was final)."""
+    import torch
+    monkeypatch.setenv("VBT_TIERS", tiers)
+    monkeypatch.setenv("VBT_SEG_BYTES", seg)
+    sd = synth.SynthDict("small-dense")
+    text, offs = sd.sentences(1500, "mixed", space_p=0.05)
+    do = ora.Dictionary.from_sources_binmatrix(sd.lex, sd.matrix, sd.num_right, sd.num_left, sd.char_def, sd.unk)
+    w = ora.Tokenizer(do, True, 0).new_worker()
+    lid = np.zeros(sd.num_left, dtype=np.uint64)
+    rid = np.zeros(sd.num_right, dtype=np.uint64)
+    for s in range(1500):
+        w.reset_sentence(bytes(text[offs[s]:offs[s + 1]]))
+        w.tokenize()
+        w.add_connid_counts(lid, rid)
+    dv = V.SystemDictionaryBuilder.from_readers_binmatrix(sd.lex, sd.matrix, sd.num_right, sd.num_left, sd.char_def, sd.unk)
+    tok = V.Tokenizer(dv).ignore_space(True)
+    ws = tok.workspace(1500, len(text))
+    ws.count_connids(True)
+    d_text = torch.from_numpy(text).cuda()
+    d_offs = torch.from_numpy(offs.astype(np.int64)).cuda()
+    for _ in range(2):  # twice, resetting in between: the per-sentence watermark must be cleared per batch
+        ws.run(d_text.data_ptr(), d_offs.data_ptr(), 1500, len(text), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert ws.stats()["error_flags"] == 0
+        glid, grid = ws.connid_counts(reset=True)
+        assert np.array_equal(glid, lid) and np.array_equal(grid, rid)

@@ -1,7 +1,8 @@
-"""N>1 path on CPU: two gloo ranks shard a batch, tokenize their ranges independently and
-gather totals / token records; the union must equal the single-process result.  The compute
-stand-in on CPU is the oracle (the HIP path needs a GPU); the sharding + collective code under
-test is exactly what bench.py / a multi-GPU caller uses."""
+"""N>1 path without a GPU: two gloo ranks shard a batch, tokenize their ranges independently, pack
+their results and exchange them with the one collective the path has (sharding.gather_packed); the
+union must equal the single-process result.  The compute stand-in on CPU is the oracle (the HIP path
+needs a GPU -- tests/test_distributed_gpu.py runs the same exchange over the HIP workspace); the
+sharding, packing and collective code under test is exactly what bench.py --gpus N uses."""
 import os
 import sys
 
@@ -13,6 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
+    import torch
     import torch.distributed as dist
     from oracle import oracle as ora
     from tools import synth
@@ -26,12 +28,24 @@ def _worker(rank, world, port, q):
     text, offs = sd.sentences(600, "lognormal_40")
     ltext, loffs, (lo, hi) = sharding.local_shard(text, offs, rank, world)
     toks, toff = w.tokenize_batch(ltext, loffs)
-    totals = sharding.gather_totals(hi - lo, len(toks))
-    parts = sharding.gather_token_records(toks)
+    n_local = hi - lo
+    max_s = sharding.agree_max(n_local)
+    max_t = sharding.agree_max(len(toks))
+    as_u8 = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).copy())
+    send = torch.zeros(sharding.packed_bytes(max_s, max_t), dtype=torch.uint8)
+    sharding.pack_results(send, n_local, len(toks), as_u8(np.array([len(toks)], dtype=np.uint32)),
+                          as_u8(toff[:-1].astype(np.uint32)), as_u8(np.diff(toff).astype(np.uint32)), as_u8(toks), max_s)
+    out, _ = sharding.gather_packed(send)
     dist.barrier()
     dist.destroy_process_group()
     if rank == 0:
-        q.put((totals.tolist(), [p.tobytes() for p in parts], sharding.shard_bounds(offs, world)))
+        parts, totals = [], []
+        for r in range(world):
+            n_s, n_t, off, cnt, tk = sharding.unpack_results(out[r], max_s)
+            ordered, _ = sharding.tokens_in_sentence_order(off, cnt, tk)
+            parts.append(ordered.tobytes())
+            totals.append((n_s, n_t))
+        q.put((totals, parts, sharding.shard_bounds(offs, world)))
 
 
 def test_two_rank_sharding_and_gather():
@@ -70,3 +84,19 @@ def test_shard_bounds_edge_cases():
     offs = np.array([0, 1000, 1001, 1002, 1003], dtype=np.uint64)  # one huge sentence
     b = sharding.shard_bounds(offs, 2)
     assert b == sorted(b) and b[-1] == 4
+
+
+def test_pack_unpack_round_trip():
+    import torch
+    from vibrato_amd import sharding, TOKEN_DTYPE
+    toks = np.zeros(5, dtype=TOKEN_DTYPE)
+    toks["start_char"] = np.arange(5)
+    off = np.array([3, 0, 3], dtype=np.uint32)   # sentence 0 -> records 3,4; sentence 1 -> records 0..2; sentence 2 empty
+    cnt = np.array([2, 3, 0], dtype=np.uint32)
+    as_u8 = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).copy())
+    buf = torch.zeros(sharding.packed_bytes(7, 9), dtype=torch.uint8)
+    sharding.pack_results(buf, 3, 5, as_u8(np.array([5], dtype=np.uint32)), as_u8(off), as_u8(cnt), as_u8(toks), 7)
+    n_s, n_t, o, c, t = sharding.unpack_results(buf, 7)
+    assert (n_s, n_t) == (3, 5) and o.tolist() == [3, 0, 3] and c.tolist() == [2, 3, 0]
+    ordered, ends = sharding.tokens_in_sentence_order(o, c, t)
+    assert ordered["start_char"].tolist() == [3, 4, 0, 1, 2] and ends.tolist() == [0, 2, 5, 5]

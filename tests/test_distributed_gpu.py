@@ -1,0 +1,91 @@
+"""N>1 path on the HIP kernels (run with -m gpu): two processes under torch.distributed share cuda:0 (the box has
+one GPU; RCCL refuses two ranks on one device, so the process group is gloo -- the collective call is the same
+`all_gather_into_tensor` bench.py issues over RCCL).  Each rank takes its byte-balanced shard, runs the HIP
+workspace on it, packs its results on the device and joins the gather; the union must equal the oracle's
+single-process result, bit for bit."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N_SENT = 6000
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    try:
+        import torch
+        import torch.distributed as dist
+        import vibrato_amd as V
+        from tools import synth
+        from vibrato_amd import sharding
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        sd = synth.SynthDict("small")
+        dv = V.SystemDictionaryBuilder.from_readers_binmatrix(sd.lex, sd.matrix, sd.num_right, sd.num_left, sd.char_def, sd.unk)
+        tok = V.Tokenizer(dv, device=0).ignore_space(True).max_grouping_len(24)
+        text, offs = sd.sentences(N_SENT, "mixed", space_p=0.05)
+        ltext, loffs, (lo, hi) = sharding.local_shard(text, offs, rank, world)
+        n_local, nbytes = hi - lo, len(ltext)
+        d_text = torch.from_numpy(np.ascontiguousarray(ltext)).cuda()
+        d_offs = torch.from_numpy(loffs.astype(np.int64)).cuda()
+        ws = tok.workspace(n_local, nbytes)
+        ws.run(d_text.data_ptr(), d_offs.data_ptr(), n_local, nbytes, torch.cuda.current_stream().cuda_stream)
+        st = ws.stats()
+        assert st["error_flags"] == 0
+        max_s = sharding.agree_max(n_local, device="cuda")
+        max_t = sharding.agree_max(st["n_tokens"], device="cuda")
+        v = sharding.workspace_views(ws, n_local, st["n_tokens"])
+        send = torch.zeros(sharding.packed_bytes(max_s, max_t), dtype=torch.uint8, device="cuda")
+        sharding.pack_results(send, n_local, st["n_tokens"], v["total"], v["tok_off"], v["tok_cnt"], v["tokens"], max_s)
+        out, _ = sharding.gather_packed(send)
+        torch.cuda.synchronize()
+        assert out.is_cuda
+        dist.barrier()
+        res = None
+        if rank == 0:
+            parts, totals = [], []
+            for r in range(world):
+                n_s, n_t, off, cnt, tk = sharding.unpack_results(out[r], max_s)
+                ordered, _ = sharding.tokens_in_sentence_order(off, cnt, tk)
+                parts.append(ordered.tobytes())
+                totals.append((n_s, n_t))
+            res = (totals, parts)
+        dist.destroy_process_group()
+        if rank == 0:
+            q.put(("ok", res))
+    except Exception as e:  # surface the failure in the parent instead of a timeout
+        import traceback
+        q.put(("error", f"rank {rank}: {e}\n{traceback.format_exc()}"))
+        raise
+
+
+def test_two_process_hip_shards_and_device_gather():
+    import torch.multiprocessing as mp
+    from oracle import oracle as ora
+    from tools import synth
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    status, payload = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+    assert status == "ok", payload
+    assert all(p.exitcode == 0 for p in procs)
+    totals, parts = payload
+    sd = synth.SynthDict("small")
+    d = ora.Dictionary.from_sources_binmatrix(sd.lex, sd.matrix, sd.num_right, sd.num_left, sd.char_def, sd.unk)
+    text, offs = sd.sentences(N_SENT, "mixed", space_p=0.05)
+    toks, _ = ora.Tokenizer(d, True, 24).new_worker().tokenize_batch(text, offs)
+    assert sum(t[0] for t in totals) == N_SENT
+    assert sum(t[1] for t in totals) == len(toks)
+    assert b"".join(parts) == toks.tobytes()

@@ -53,6 +53,9 @@ def test_golden_vectors_batch_api(tokenize_golden, fixture_sources):
                 for k in ["surface", "feature", "total_cost"]:
                     if k in exp:
                         assert getattr(got, k) == exp[k]
+                for k in ["range_char", "range_byte"]:
+                    if k in exp:
+                        assert list(getattr(got, k)) == exp[k], (case["name"], sent["text"], exp["index"], k)
 
 
 def _oracle_and_product(sd, user_csv=None, ignore_space=False, max_grouping_len=0):
@@ -287,3 +290,144 @@ def test_workspace_device_api_and_roundtrip():
         t = host[off[s]:off[s] + cnt[s]]
         assert t["start_byte"][0] == 0 and t["end_byte"][-1] == offs[s + 1] - offs[s]
         assert np.array_equal(t["start_byte"][1:], t["end_byte"][:-1])
+
+
+def test_config5_full_size_bit_exact():
+    """BASELINE config 5 at full size: unidic-shaped dictionary (458.6 MiB matrix) + user.csv of 1000 compounds, -S -M 24,
+    100k mixed-length sentences (5 % of 500-2000 characters) with injected spaces; every token record vs the oracle."""
+    sd = synth.SynthDict("unidic")
+    to, tv = _oracle_and_product(sd, user_csv=sd.user_csv(1000), ignore_space=True, max_grouping_len=24)
+    text, offs = sd.sentences(100000, "mixed", space_p=0.10)
+    batch, ntok = _assert_batch_equal(to, tv, text, offs)
+    toks, off, cnt = batch.arrays()
+    assert ntok > 4_000_000
+    assert (toks["word_idx"] >> 30 == 1).sum() > 0 and (toks["word_idx"] >> 30 == 2).sum() > 0
+    # size-independent property: inside a sentence, tokens never overlap and the gaps between them are spaces only
+    sample = np.nonzero(cnt > 1)[0][:3000]
+    for s in sample:
+        t = toks[off[s]:off[s] + cnt[s]]
+        assert np.all(t["start_byte"][1:] >= t["end_byte"][:-1])
+        base = int(offs[s])
+        for a, b in zip(t["end_byte"][:-1], t["start_byte"][1:]):
+            assert bytes(text[base + a:base + b]).strip(b" ") == b""
+
+
+@pytest.mark.parametrize("shape,n", [("small-dense", 8000), ("unidic-dense", 30000)])
+def test_dense_lattice_law_bit_exact(shape, n):
+    """The denser synthetic law (>= 12 lattice nodes and >= 80 deduplicated connection pairs per character, what
+    SURVEY.md 8(a) estimates for the real unidic; the default law has 5.7 / 29): more groups per position, more
+    multi-pass steps, more sentences in the segment tier."""
+    sd = synth.SynthDict(shape)
+    to, tv = _oracle_and_product(sd)
+    text, offs = sd.sentences(n, "lognormal_40")
+    w = to.new_worker()
+    w.reset_counters()
+    w.tokenize_batch(text[:int(offs[500])], offs[:501], counted=True, want_tokens=False)
+    c = w.counters()
+    assert c["n_nodes"] / c["n_chars"] >= 12 and c["n_pairs_dedup"] / c["n_chars"] >= 80
+    _assert_batch_equal(to, tv, text, offs)
+
+
+BAD_UTF8 = [b"\x80abc", b"abc\xe3\x81", b"\xc0\xaf", b"\xed\xa0\x80", b"\xf4\x90\x80\x80", b"\xe0\x80\xaf", b"a\xffb",
+            b"\xe3\x81\x82\x81", b"\xf0\x82\x82\xac", b"\xf8\x88\x80\x80\x80"]
+
+
+def test_invalid_utf8_is_rejected_like_the_reference(fixture_sources):
+    """The reference takes &str and its CLI fails on an invalid line; the product must not decode garbage silently:
+    host entry points return VBT_ERR_UTF8 for exactly the inputs the oracle rejects, the device entry point flags them."""
+    import torch
+    s = fixture_sources
+    tok = V.Tokenizer(V.SystemDictionaryBuilder.from_readers(s["lex.csv"], s["matrix.def"], s["char.def"], s["unk.def"]))
+    do = ora.Dictionary.from_sources(s["lex.csv"], s["matrix.def"], s["char.def"], s["unk.def"])
+    wo = ora.Tokenizer(do).new_worker()
+    wv = tok.new_worker()
+    good = ["東京都".encode(), b"", b"abc", "\U0001F600".encode(), "京都 ".encode()]
+    for sent in BAD_UTF8 + good:
+        try:
+            wo.reset_sentence(sent)
+            oracle_ok = True
+        except ora.OracleError:
+            oracle_ok = False
+        assert oracle_ok == (sent in good)
+        assert V.api.utf8_valid(sent) == oracle_ok
+        if oracle_ok:
+            wv.reset_sentence(sent)
+            wv.tokenize()
+        else:
+            with pytest.raises(V.VibratoError) as e:
+                wv.reset_sentence(sent)
+            assert e.value.code == 5
+    for bad in BAD_UTF8:
+        enc = [good[0], bad, good[2]]
+        offs = np.zeros(4, dtype=np.uint64)
+        offs[1:] = np.cumsum([len(x) for x in enc])
+        text = np.frombuffer(b"".join(enc), dtype=np.uint8)
+        with pytest.raises(V.VibratoError) as e:
+            tok.tokenize_batch(text=text, offsets=offs)
+        assert e.value.code == 5
+        # device API: flagged (16), batch skipped
+        ws = tok.workspace(3, len(text))
+        d_text = torch.from_numpy(text.copy()).cuda()
+        d_offs = torch.from_numpy(offs.astype(np.int64)).cuda()
+        ws.run(d_text.data_ptr(), d_offs.data_ptr(), 3, len(text), torch.cuda.current_stream().cuda_stream)
+        assert ws.stats()["error_flags"] & 16
+    # a sentence boundary inside a character is invalid even though the stream as a whole is valid
+    text = np.frombuffer("東京".encode(), dtype=np.uint8)
+    offs = np.array([0, 2, 6], dtype=np.uint64)
+    with pytest.raises(V.VibratoError):
+        tok.tokenize_batch(text=text, offsets=offs)
+    ws = tok.workspace(2, 6)
+    d_text = torch.from_numpy(text.copy()).cuda()
+    d_offs = torch.from_numpy(offs.astype(np.int64)).cuda()
+    ws.run(d_text.data_ptr(), d_offs.data_ptr(), 2, 6, torch.cuda.current_stream().cuda_stream)
+    assert ws.stats()["error_flags"] & 16
+
+
+def test_device_api_accepts_a_window_and_rejects_bad_offsets():
+    """offsets[0] != 0 (a window into a larger device text buffer) gives the same records as the rebased batch;
+    decreasing offsets or a span beyond total_bytes are flagged (8) and the batch is skipped."""
+    import torch
+    sd = synth.SynthDict("small")
+    to, tv = _oracle_and_product(sd)
+    text, offs = sd.sentences(3000, "lognormal_40")
+    lo, hi = 700, 2900
+    nloc, nbytes = hi - lo, int(offs[hi] - offs[lo])
+    d_text = torch.from_numpy(text).cuda()
+    d_offs = torch.from_numpy(offs.astype(np.int64)).cuda()
+    ws = tv.workspace(nloc, nbytes)
+    stream = torch.cuda.current_stream().cuda_stream
+    ws.run(d_text.data_ptr(), d_offs.data_ptr() + 8 * lo, nloc, nbytes, stream)  # window: offsets[lo..hi] of the big buffer
+    st = ws.stats()
+    assert st["error_flags"] == 0
+    from vibrato_amd import sharding
+    v = sharding.workspace_views(ws, nloc, st["n_tokens"])
+    got, _ = sharding.tokens_in_sentence_order(v["tok_off"].cpu().numpy().view(np.uint32), v["tok_cnt"].cpu().numpy().view(np.uint32),
+                                               v["tokens"].cpu().numpy().view(V.TOKEN_DTYPE))
+    exp, _ = to.new_worker().tokenize_batch(text[int(offs[lo]):int(offs[hi])], offs[lo:hi + 1] - offs[lo])
+    assert got.tobytes() == exp.tobytes()
+    bad = offs.astype(np.int64).copy()
+    bad[10], bad[11] = bad[11], bad[10] + 1
+    d_bad = torch.from_numpy(bad).cuda()
+    ws2 = tv.workspace(3000, len(text))
+    ws2.run(d_text.data_ptr(), d_bad.data_ptr(), 3000, len(text), stream)
+    assert ws2.stats()["error_flags"] & 8
+    ws2.run(d_text.data_ptr(), d_offs.data_ptr(), 3000, len(text) - 1, stream)  # declared span too small
+    assert ws2.stats()["error_flags"] & 8
+    ws2.run(d_text.data_ptr(), d_offs.data_ptr(), 3000, len(text), stream)  # and the workspace still works afterwards
+    st = ws2.stats()
+    assert st["error_flags"] == 0 and st["n_tokens"] == len(to.new_worker().tokenize_batch(text, offs)[0])
+
+
+def test_host_batches_reuse_pooled_workspaces():
+    sd = synth.SynthDict("tiny")
+    to, tv = _oracle_and_product(sd)
+    text, offs = sd.sentences(500, "lognormal_40")
+    for _ in range(4):
+        _assert_batch_equal(to, tv, text, offs)
+    created, reused, idle = tv.pool_stats()
+    assert (created, reused, idle) == (1, 3, 1)
+    text2, offs2 = sd.sentences(5000, "lognormal_40")  # larger: a second size class
+    _assert_batch_equal(to, tv, text2, offs2)
+    _assert_batch_equal(to, tv, text, offs)
+    created, reused, idle = tv.pool_stats()
+    assert created == 2 and reused == 4 and idle == 2

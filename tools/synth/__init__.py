@@ -21,6 +21,11 @@ SHAPES = {
     "ipadic": (392126, 1316, 1316),       # ipadic-mecab-2.7.0 shape
     "unidic": (876803, 15626, 15388),     # unidic-cwj-3.1.1 shape (458.6 MiB matrix)
 }
+# lexicon laws (dup_p, len_lambda, kanji_zipf, n_kanji); None = SURVEY.md 8(d)'s default law
+# measured with the oracle: unidic-dense 13.3 nodes / 147 deduplicated pairs per char, small-dense 13.7 / 127 (default law: 5.6 / 29)
+LAWS = {"unidic-dense": (0.38, 1.75, 0.8, 2500), "small-dense": (0.65, 1.1, 0.9, 300)}
+SHAPES["unidic-dense"] = SHAPES["unidic"]
+SHAPES["small-dense"] = SHAPES["small"]
 LEN_LAWS = {"uniform_5_20": 0, "lognormal_40": 1, "mixed": 2}
 
 
@@ -43,6 +48,8 @@ def lib():
         L = C.CDLL(_SO)
         L.syn_dict_new.restype = C.c_void_p
         L.syn_dict_new.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64]
+        L.syn_dict_new_law.restype = C.c_void_p
+        L.syn_dict_new_law.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_double, C.c_double, C.c_double, C.c_uint32]
         L.syn_dict_free.argtypes = [C.c_void_p]
         for f in ["syn_dict_lex", "syn_dict_unk"]:
             getattr(L, f).restype = C.POINTER(C.c_char)
@@ -63,16 +70,21 @@ def lib():
 class SynthDict:
     """Text sources + binary matrix of one synthetic dictionary."""
 
-    def __init__(self, shape="ipadic", seed=SEED):
+    def __init__(self, shape="ipadic", seed=SEED, law=None):
         if isinstance(shape, str):
             self.name = "syn-" + shape
+            law = law or LAWS.get(shape)
             shape = SHAPES[shape]
         else:
             self.name = "syn-custom"
         self.n_words, self.num_right, self.num_left = shape
         self.seed = seed
         L = lib()
-        self._h = L.syn_dict_new(self.n_words, self.num_right, self.num_left, seed)
+        self.law = law
+        if law is None:
+            self._h = L.syn_dict_new(self.n_words, self.num_right, self.num_left, seed)
+        else:
+            self._h = L.syn_dict_new_law(self.n_words, self.num_right, self.num_left, seed, *law)
         n = C.c_size_t()
         self.lex = C.string_at(L.syn_dict_lex(self._h, C.byref(n)), n.value)
         self.unk = C.string_at(L.syn_dict_unk(self._h, C.byref(n)), n.value)

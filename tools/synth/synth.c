@@ -87,6 +87,12 @@ typedef struct syn_dict {
     uint64_t seed;
 } syn_dict;
 
+/* Knobs of the lexicon law.  The default law is SURVEY.md 8(d)'s; the "dense" law raises the duplicate-surface rate,
+ * shortens the words and shrinks the kanji pool so that the lattices get as dense as SURVEY 8(a) estimates for
+ * the real unidic (>= 12 nodes and >= 80 connection pairs per character). */
+typedef struct { double dup_p, len_lambda, kanji_zipf; uint32_t n_kanji; } syn_law;
+static const syn_law SYN_LAW_DEFAULT = {0.15, 2.2, 0.8, 3000};
+
 #define N_KANJI 3000
 #define HIRA_LO 0x3041
 #define HIRA_N 83 /* U+3041..U+3093 */
@@ -154,14 +160,14 @@ static int sset_insert(sset_t *s, const syn_dict *d, uint32_t w, uint32_t len) {
     }
 }
 
-SYN_API syn_dict *syn_dict_new(uint32_t n_words, uint32_t num_right, uint32_t num_left, uint64_t seed) {
+static syn_dict *syn_dict_build(uint32_t n_words, uint32_t num_right, uint32_t num_left, uint64_t seed, syn_law law) {
     syn_dict *d = (syn_dict *)calloc(1, sizeof(*d));
     d->n_words = n_words; d->num_right = num_right; d->num_left = num_left; d->seed = seed;
     d->surf_off = (uint32_t *)malloc(sizeof(uint32_t) * (n_words + 1));
     d->surf_chars = (uint16_t *)malloc(sizeof(uint16_t) * n_words);
     rng_t r; rng_seed(&r, seed);
     zipf_t zk, zl, zr;
-    zipf_init(&zk, N_KANJI, 0.8);
+    zipf_init(&zk, law.n_kanji, law.kanji_zipf);
     uint32_t nl = num_left > 1 ? num_left - 1 : 1, nr = num_right > 1 ? num_right - 1 : 1;
     zipf_init(&zl, nl, 1.1);
     zipf_init(&zr, nr, 1.1);
@@ -193,16 +199,18 @@ SYN_API syn_dict *syn_dict_new(uint32_t n_words, uint32_t num_right, uint32_t nu
     }
     for (; w < n_words; w++) {
         d->surf_off[w] = (uint32_t)d->surf.len;
-        if (w > 1000 && rng_u01(&r) < 0.15) { /* duplicate surface (multi-POS) */
+        if (w > 1000 && rng_u01(&r) < law.dup_p) { /* duplicate surface (multi-POS) */
             uint32_t src = rng_below(&r, w);
-            buf_put(&d->surf, d->surf.p + d->surf_off[src], d->surf_off[src + 1] - d->surf_off[src]);
+            const uint32_t sl = d->surf_off[src + 1] - d->surf_off[src];
+            buf_reserve(&d->surf, sl);  /* (the source lies in the same buffer: grow first, then take the pointer) */
+            buf_put(&d->surf, d->surf.p + d->surf_off[src], sl);
             d->surf_chars[w] = d->surf_chars[src];
             d->surf_off[w + 1] = (uint32_t)d->surf.len;
             continue;
         }
         for (int attempt = 0;; attempt++) {
             d->surf.len = d->surf_off[w];
-            uint32_t len = 1 + rng_poisson(&r, 2.2) + (uint32_t)(attempt / 4);
+            uint32_t len = 1 + rng_poisson(&r, law.len_lambda) + (uint32_t)(attempt / 4);
             if (len > 12) len = 12;
             double u = rng_u01(&r);
             uint32_t nch = 0;
@@ -256,6 +264,15 @@ SYN_API syn_dict *syn_dict_new(uint32_t n_words, uint32_t num_right, uint32_t nu
     }
     free(zk.cdf); free(zl.cdf); free(zr.cdf); free(tmp.p);
     return d;
+}
+
+SYN_API syn_dict *syn_dict_new(uint32_t n_words, uint32_t num_right, uint32_t num_left, uint64_t seed) {
+    return syn_dict_build(n_words, num_right, num_left, seed, SYN_LAW_DEFAULT);
+}
+SYN_API syn_dict *syn_dict_new_law(uint32_t n_words, uint32_t num_right, uint32_t num_left, uint64_t seed, double dup_p,
+                                   double len_lambda, double kanji_zipf, uint32_t n_kanji) {
+    syn_law law = {dup_p, len_lambda, kanji_zipf, n_kanji < 16 ? 16 : n_kanji > N_KANJI ? N_KANJI : n_kanji};
+    return syn_dict_build(n_words, num_right, num_left, seed, law);
 }
 
 SYN_API const char *syn_dict_lex(const syn_dict *d, size_t *len) { *len = d->lex.len; return d->lex.p; }

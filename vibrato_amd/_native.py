@@ -45,6 +45,7 @@ _vp, _cp, _sz, _u32, _u64, _int = C.c_void_p, C.c_char_p, C.c_size_t, C.c_uint32
 _PP = C.POINTER(C.c_void_p)
 SIGNATURES = {
     "vbt_last_error": (C.c_char_p, []),
+    "vbt_utf8_valid": (_int, [_cp, _sz]),
     "vbt_dict_from_sources": (_int, [_cp, _sz, _cp, _sz, _cp, _sz, _cp, _sz, _PP]),
     "vbt_dict_from_sources_binmatrix": (_int, [_cp, _sz, _vp, _u32, _u32, _cp, _sz, _cp, _sz, _PP]),
     "vbt_dict_set_user_lexicon": (_int, [_vp, _cp, _sz]),
@@ -68,7 +69,13 @@ SIGNATURES = {
     "vbt_worker_tokenize": (_int, [_vp]),
     "vbt_worker_num_tokens": (_u32, [_vp]),
     "vbt_worker_token": (_int, [_vp, _u32, C.POINTER(Token)]),
+    "vbt_worker_init_connid_counter": (_int, [_vp]),
+    "vbt_worker_update_connid_counts": (_int, [_vp]),
+    "vbt_worker_connid_counts": (_int, [_vp, _vp, _vp]),
+    "vbt_worker_compute_connid_probs": (_int, [_vp, _vp, _vp, _vp, _vp]),
+    "vbt_connid_probs": (_int, [_vp, _sz, _vp, _vp]),
     "vbt_tokenize_batch": (_int, [_vp, _vp, _vp, _u64, _PP]),
+    "vbt_tokenizer_pool_stats": (_int, [_vp, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64)]),
     "vbt_batch_free": (None, [_vp]),
     "vbt_batch_num_sentences": (_u64, [_vp]),
     "vbt_batch_total_tokens": (_u64, [_vp]),

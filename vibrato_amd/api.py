@@ -21,9 +21,10 @@ def _b(x):
 class Dictionary:
     """vibrato::Dictionary (dictionary.rs:53-259)."""
 
-    def __init__(self, handle, owned=True):
+    def __init__(self, handle, owned=True, owner=None):
         self._h = handle
         self._owned = owned
+        self._owner = owner  # a borrowed view keeps the Tokenizer that owns the memory alive
 
     def __del__(self):
         try:
@@ -163,9 +164,9 @@ class Tokenizer:
     def ignore_space(self, yes):
         """Tokenizer::ignore_space (tokenizer.rs:42-55)."""
         self._require_unbuilt()
-        self._ignore_space = bool(yes)
-        if yes and self._dict_in.cate_id("SPACE") < 0:
+        if yes and self._dict_in.cate_id("SPACE") < 0:  # checked before anything changes (tokenizer.rs:44-49)
             raise VibratoError(1, "dict: SPACE is not defined in the input dictionary (i.e., char.def).")
+        self._ignore_space = bool(yes)
         return self
 
     def max_grouping_len(self, n):
@@ -185,7 +186,7 @@ class Tokenizer:
                                               self._device, C.byref(h)))
             self._h = h
             self._dict_in._h = None  # moved (Tokenizer::new consumes the dictionary)
-            self._dict = Dictionary(C.c_void_p(N.lib().vbt_tokenizer_dictionary(h)), owned=False)
+            self._dict = C.c_void_p(N.lib().vbt_tokenizer_dictionary(h))
         return self._h
 
     def __del__(self):
@@ -199,7 +200,13 @@ class Tokenizer:
     def dictionary(self):
         """Tokenizer::dictionary (tokenizer.rs:77-79)."""
         self._handle()
-        return self._dict
+        return Dictionary(self._dict, owned=False, owner=self)
+
+    def pool_stats(self):
+        """(created, reused, idle) workspaces of the host-buffer entry point's pool."""
+        c, r, i = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        N.check(N.lib().vbt_tokenizer_pool_stats(self._handle(), C.byref(c), C.byref(r), C.byref(i)))
+        return c.value, r.value, i.value
 
     def new_worker(self):
         """Tokenizer::new_worker (tokenizer.rs:82-84)."""
@@ -257,7 +264,32 @@ class Worker:
         return Token(t)
 
     def token_iter(self):
+        """Worker::token_iter (worker.rs:71-75)."""
         return (self.token(i) for i in range(self.num_tokens()))
+
+    def init_connid_counter(self):
+        """Worker::init_connid_counter (worker.rs:77-84)."""
+        N.check(N.lib().vbt_worker_init_connid_counter(self._h))
+
+    def update_connid_counts(self):
+        """Worker::update_connid_counts (worker.rs:86-93)."""
+        N.check(N.lib().vbt_worker_update_connid_counts(self._h))
+
+    def connid_counts(self):
+        d = self.tokenizer.dictionary()
+        lid = np.zeros(d.num_left, dtype=np.uint64)
+        rid = np.zeros(d.num_right, dtype=np.uint64)
+        N.check(N.lib().vbt_worker_connid_counts(self._h, lid.ctypes.data, rid.ctypes.data))
+        return lid, rid
+
+    def compute_connid_probs(self):
+        """Worker::compute_connid_probs (worker.rs:95-103): ([(left_id, prob)], [(right_id, prob)])."""
+        d = self.tokenizer.dictionary()
+        nl, nr = d.num_left - 1, d.num_right - 1
+        li, lp = np.zeros(nl, dtype=np.uint32), np.zeros(nl, dtype=np.float64)
+        ri, rp = np.zeros(nr, dtype=np.uint32), np.zeros(nr, dtype=np.float64)
+        N.check(N.lib().vbt_worker_compute_connid_probs(self._h, li.ctypes.data, lp.ctypes.data, ri.ctypes.data, rp.ctypes.data))
+        return list(zip(li.tolist(), lp.tolist())), list(zip(ri.tolist(), rp.tolist()))
 
 
 class Batch:
@@ -330,12 +362,17 @@ def compute_connid_probs(lid_count, rid_count):
     """ConnIdCounter::compute_probs (mapper.rs:108-146): per side, (id, count / sum) without id 0, sorted by
     probability descending then id ascending -- the content of the reference's *.lmap / *.rmap files."""
     out = []
-    for cnt in (np.asarray(lid_count, dtype=np.float64), np.asarray(rid_count, dtype=np.float64)):
-        probs = cnt / cnt.sum()
-        items = [(i, float(probs[i])) for i in range(1, len(probs))]
-        items.sort(key=lambda t: (-t[1], t[0]))
-        out.append(items)
+    for cnt in (lid_count, rid_count):
+        cnt = np.ascontiguousarray(cnt, dtype=np.uint64)
+        ids, probs = np.zeros(len(cnt) - 1, dtype=np.uint32), np.zeros(len(cnt) - 1, dtype=np.float64)
+        N.check(N.lib().vbt_connid_probs(cnt.ctypes.data, len(cnt), ids.ctypes.data, probs.ctypes.data))
+        out.append(list(zip(ids.tolist(), probs.tolist())))
     return out[0], out[1]
+
+
+def utf8_valid(data):
+    data = _b(data)
+    return bool(N.lib().vbt_utf8_valid(data, len(data)))
 
 
 class Workspace:

@@ -4,7 +4,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -17,9 +19,30 @@ struct vbt_dict {
     bool owned = true;
     ~vbt_dict() { if (owned) delete d; }
 };
+// One pooled set of device buffers for the host-buffer entry point: a Workspace plus the text / offsets
+// staging it reads, all on a private stream.  vbt_tokenize_batch takes one from its tokenizer's pool and
+// puts it back, so steady-state calls allocate nothing on the device (SURVEY.md 8(b) "threading").
+struct PooledWorkspace {
+    std::unique_ptr<Workspace> ws;
+    void* d_text = nullptr;
+    uint64_t* d_off = nullptr;
+    hipStream_t stream = nullptr;
+    uint64_t cap_sentences = 0, cap_bytes = 0;
+    ~PooledWorkspace() {
+        ws.reset();
+        (void)hipFree(d_text);
+        (void)hipFree(d_off);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
 struct vbt_tokenizer {
     std::unique_ptr<Tokenizer> t;
     vbt_dict dict_view;  // borrowed view handed out by vbt_tokenizer_dictionary
+    std::mutex pool_mu;
+    std::vector<std::unique_ptr<PooledWorkspace>> pool;  // idle workspaces
+    uint64_t pool_created = 0, pool_reused = 0;
+    ~vbt_tokenizer() { pool.clear(); }  // before the Tokenizer (workspaces reference it)
 };
 struct vbt_workspace { std::unique_ptr<Workspace> w; };
 
@@ -39,6 +62,8 @@ struct vbt_worker {
     uint64_t* d_offsets = nullptr;
     size_t d_text_cap = 0;
     std::vector<vbt_token_rec> tokens;
+    // ConnIdCounter of Worker::init_connid_counter (worker.rs:77-84, mapper.rs:87-106); empty = never initialised
+    std::vector<uint64_t> lid_count, rid_count;
     ~vbt_worker() { (void)hipFree(d_text); (void)hipFree(d_offsets); }
 };
 
@@ -76,6 +101,8 @@ const Lexicon& lexicon_of(const Dictionary& d, uint32_t lex_type) {
 }
 
 void check_device_errors(uint32_t flags) {
+    if (flags & kErrOffsets) throw Error(VBT_ERR_INVALID_ARGUMENT, "offsets must be non-decreasing and span at most total_bytes");
+    if (flags & kErrUtf8) throw Error(VBT_ERR_UTF8, "sentence text is not valid UTF-8");
     if (flags & kErrTokCap) throw Error(VBT_ERR_INVALID_STATE, "device token buffer overflow");
     if (flags & kErrScratch) throw Error(VBT_ERR_UNSUPPORTED, "device scratch arena exhausted (raise VBT_SCRATCH_MB)");
     if (flags & kErrTooLong) throw Error(VBT_ERR_UNSUPPORTED, "sentence too long for the device image (>= 4 GiB or >= 2^32 lattice nodes)");
@@ -105,8 +132,9 @@ void fill_token(const Dictionary& d, const uint8_t* sentence, const vbt_token_re
 
 // Runs one batch through a workspace and copies the compact results to the host.
 void run_and_fetch(Workspace& ws, const uint8_t* d_text, const uint64_t* d_off, uint64_t n, uint64_t bytes,
-                   std::vector<uint32_t>& tok_off, std::vector<uint32_t>& tok_cnt, std::vector<vbt_token_rec>& tokens) {
-    ws.run(d_text, d_off, n, bytes, nullptr);
+                   std::vector<uint32_t>& tok_off, std::vector<uint32_t>& tok_cnt, std::vector<vbt_token_rec>& tokens,
+                   hipStream_t stream = nullptr) {
+    ws.run(d_text, d_off, n, bytes, stream);
     vbt_call_stats st;
     ws.stats(&st);
     check_device_errors(st.error_flags);
@@ -118,11 +146,64 @@ void run_and_fetch(Workspace& ws, const uint8_t* d_text, const uint64_t* d_off, 
     if (st.n_tokens) HIPX(hipMemcpy(tokens.data(), ws.d_tokens, st.n_tokens * sizeof(vbt_token_rec), hipMemcpyDeviceToHost));
 }
 
+uint64_t round_up_pow2(uint64_t v, uint64_t lo) {
+    uint64_t r = lo;
+    while (r < v) r <<= 1;
+    return r;
+}
+
+// Smallest idle workspace that holds the request, else a new one (capacities rounded up to powers of two so
+// that batches of similar size share it).  At most kPoolIdle workspaces stay idle; the smallest is dropped first.
+constexpr size_t kPoolIdle = 4;
+std::unique_ptr<PooledWorkspace> pool_take(vbt_tokenizer* tok, uint64_t n, uint64_t bytes) {
+    {
+        std::lock_guard<std::mutex> g(tok->pool_mu);
+        size_t best = tok->pool.size();
+        for (size_t i = 0; i < tok->pool.size(); ++i) {
+            const auto& p = tok->pool[i];
+            if (p->cap_sentences >= n && p->cap_bytes >= bytes && (best == tok->pool.size() || p->cap_bytes < tok->pool[best]->cap_bytes)) best = i;
+        }
+        if (best != tok->pool.size()) {
+            auto p = std::move(tok->pool[best]);
+            tok->pool.erase(tok->pool.begin() + (long)best);
+            ++tok->pool_reused;
+            return p;
+        }
+        ++tok->pool_created;
+    }
+    auto p = std::make_unique<PooledWorkspace>();
+    p->cap_sentences = round_up_pow2(n, 64);
+    p->cap_bytes = round_up_pow2(bytes, 4096);
+    p->ws = std::make_unique<Workspace>(*tok->t, p->cap_sentences, p->cap_bytes);
+    HIPX(hipMalloc(&p->d_text, p->cap_bytes));
+    HIPX(hipMalloc(reinterpret_cast<void**>(&p->d_off), (p->cap_sentences + 1) * 8));
+    HIPX(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+    return p;
+}
+
+void pool_give(vbt_tokenizer* tok, std::unique_ptr<PooledWorkspace> p) {
+    std::lock_guard<std::mutex> g(tok->pool_mu);
+    tok->pool.push_back(std::move(p));
+    if (tok->pool.size() > kPoolIdle) {
+        size_t smallest = 0;
+        for (size_t i = 1; i < tok->pool.size(); ++i)
+            if (tok->pool[i]->cap_bytes < tok->pool[smallest]->cap_bytes) smallest = i;
+        tok->pool.erase(tok->pool.begin() + (long)smallest);
+    }
+}
+
+const Dictionary& dict_of(const vbt_dict* dict) {
+    if (!dict || !dict->d) throw Error(VBT_ERR_INVALID_ARGUMENT, "dict: null or consumed by vbt_tokenizer_new");
+    return *dict->d;
+}
+
 }  // namespace
 
 extern "C" {
 
 const char* vbt_last_error(void) { return g_last_error.c_str(); }
+
+int vbt_utf8_valid(const char* utf8, size_t len) { return (!len || (utf8 && valid_utf8(reinterpret_cast<const uint8_t*>(utf8), len))) ? 1 : 0; }
 
 int vbt_dict_from_sources(const char* lex, size_t lex_len, const char* matrix_def, size_t matrix_len, const char* char_def,
                           size_t char_len, const char* unk_def, size_t unk_len, vbt_dict** out) {
@@ -160,17 +241,18 @@ int vbt_dict_map_connection_ids(vbt_dict* dict, const uint16_t* lmap, size_t n_l
 void vbt_dict_free(vbt_dict* dict) { delete dict; }
 
 uint32_t vbt_dict_num_words(const vbt_dict* dict, uint32_t lex_type) {
+    if (!dict || !dict->d) return 0;
     const Dictionary& d = *dict->d;
     if (lex_type == VBT_LEX_SYSTEM) return (uint32_t)d.system.params.size();
     if (lex_type == VBT_LEX_USER) return d.has_user ? (uint32_t)d.user.params.size() : 0;
     return (uint32_t)d.unk_entries.size();
 }
-uint32_t vbt_dict_num_left(const vbt_dict* dict) { return dict->d->num_left; }
-uint32_t vbt_dict_num_right(const vbt_dict* dict) { return dict->d->num_right; }
+uint32_t vbt_dict_num_left(const vbt_dict* dict) { return dict && dict->d ? dict->d->num_left : 0; }
+uint32_t vbt_dict_num_right(const vbt_dict* dict) { return dict && dict->d ? dict->d->num_right : 0; }
 
 int vbt_dict_word_feature(const vbt_dict* dict, uint32_t lex_type, uint32_t word_id, const char** ptr, size_t* len) {
     return guarded([&] {
-        const Dictionary& d = *dict->d;
+        const Dictionary& d = dict_of(dict);
         const std::string* s;
         if (lex_type == VBT_LEX_UNKNOWN) {
             if (word_id >= d.unk_features.size()) throw Error(VBT_ERR_INVALID_ARGUMENT, "word_id out of range");
@@ -187,7 +269,7 @@ int vbt_dict_word_feature(const vbt_dict* dict, uint32_t lex_type, uint32_t word
 
 int vbt_dict_word_param(const vbt_dict* dict, uint32_t lex_type, uint32_t word_id, int32_t out[3]) {
     return guarded([&] {
-        const Dictionary& d = *dict->d;
+        const Dictionary& d = dict_of(dict);
         if (lex_type == VBT_LEX_UNKNOWN) {
             if (word_id >= d.unk_entries.size()) throw Error(VBT_ERR_INVALID_ARGUMENT, "word_id out of range");
             const Entry& e = d.unk_entries[word_id];
@@ -202,17 +284,18 @@ int vbt_dict_word_param(const vbt_dict* dict, uint32_t lex_type, uint32_t word_i
 
 int vbt_dict_conn_cost(const vbt_dict* dict, uint32_t right_id, uint32_t left_id, int32_t* out) {
     return guarded([&] {
-        const Dictionary& d = *dict->d;
+        const Dictionary& d = dict_of(dict);
         if (right_id >= d.num_right || left_id >= d.num_left) throw Error(VBT_ERR_INVALID_ARGUMENT, "connection id out of range");
         *out = d.matrix[(size_t)left_id * d.num_right + right_id];
     });
 }
 
-uint32_t vbt_dict_char_info(const vbt_dict* dict, uint32_t cp) { return dict->d->chr2inf[cp < 65536 ? cp : 0]; }
+uint32_t vbt_dict_char_info(const vbt_dict* dict, uint32_t cp) { return dict && dict->d ? dict->d->chr2inf[cp < 65536 ? cp : 0] : 0; }
 
-int vbt_dict_cate_id(const vbt_dict* dict, const char* name, size_t len) { return dict->d->cate_id({name, len}); }
+int vbt_dict_cate_id(const vbt_dict* dict, const char* name, size_t len) { return dict && dict->d && name ? dict->d->cate_id({name, len}) : -1; }
 
 uint32_t vbt_dict_common_prefix(const vbt_dict* dict, uint32_t lex_type, const uint32_t* cps, uint32_t n, uint32_t* out, uint32_t cap) {
+    if (!dict || !dict->d) return 0;
     const Dictionary& d = *dict->d;
     if (lex_type == VBT_LEX_USER && !d.has_user) return 0;
     const Lexicon& lx = lex_type == VBT_LEX_USER ? d.user : d.system;
@@ -229,7 +312,8 @@ int vbt_tokenizer_new(vbt_dict* dict, int ignore_space, uint32_t max_grouping_le
         auto t = std::make_unique<Tokenizer>(dict->d, ignore_space != 0, max_grouping_len, device);
         t->adopt(std::unique_ptr<Dictionary>(dict->d));
         dict->d = nullptr;
-        auto* h = new vbt_tokenizer{std::move(t), {}};
+        auto* h = new vbt_tokenizer();
+        h->t = std::move(t);
         h->dict_view.d = const_cast<Dictionary*>(&h->t->dict());
         h->dict_view.owned = false;
         *out = h;
@@ -254,7 +338,13 @@ void vbt_worker_free(vbt_worker* w) { delete w; }
 
 int vbt_worker_reset_sentence(vbt_worker* w, const char* utf8, size_t len) {
     return guarded([&] {
+        if (!w) throw Error(VBT_ERR_INVALID_ARGUMENT, "null argument");
         w->tokens.clear();
+        // the reference takes &str (worker.rs:34): anything else is rejected here instead of being decoded as garbage
+        if (utf8 && len && !valid_utf8(reinterpret_cast<const uint8_t*>(utf8), len)) {
+            w->text.clear();
+            throw Error(VBT_ERR_UTF8, "sentence is not valid UTF-8");
+        }
         w->text.assign(utf8 ? utf8 : "", utf8 ? len : 0);
     });
 }
@@ -268,6 +358,7 @@ int vbt_worker_tokenize(vbt_worker* w) {
         if (!w->ws || w->ws->max_bytes < len) {
             const size_t cap = std::max<size_t>(len * 2, 4096);
             w->ws = std::make_unique<Workspace>(*w->tok->t, 1, cap);
+            if (!w->lid_count.empty()) w->ws->enable_connid_counts(true);
             (void)hipFree(w->d_text); (void)hipFree(w->d_offsets);
             w->d_text = nullptr; w->d_offsets = nullptr;
             HIPX(hipMalloc(&w->d_text, cap));
@@ -277,8 +368,75 @@ int vbt_worker_tokenize(vbt_worker* w) {
         HIPX(hipMemcpy(w->d_text, w->text.data(), len, hipMemcpyHostToDevice));
         HIPX(hipMemcpy(w->d_offsets, offs, 16, hipMemcpyHostToDevice));
         std::vector<uint32_t> off, cnt;
+        if (!w->lid_count.empty()) w->ws->reset_connid_counts();  // the device holds the counts of the last lattice only
         run_and_fetch(*w->ws, static_cast<const uint8_t*>(w->d_text), w->d_offsets, 1, len, off, cnt, w->tokens);
     });
+}
+
+// Worker::init_connid_counter (worker.rs:77-84): fresh zeroed counters of num_left / num_right entries.
+int vbt_worker_init_connid_counter(vbt_worker* w) {
+    return guarded([&] {
+        if (!w) throw Error(VBT_ERR_INVALID_ARGUMENT, "null argument");
+        const Dictionary& d = w->tok->t->dict();
+        w->lid_count.assign(d.num_left, 0);
+        w->rid_count.assign(d.num_right, 0);
+        if (w->ws) {
+            HIPX(hipSetDevice(w->tok->t->device()));
+            w->ws->enable_connid_counts(true);
+            w->ws->reset_connid_counts();
+        }
+    });
+}
+
+// Worker::update_connid_counts (worker.rs:86-93): adds the lattice of the LAST tokenize() call
+// (Lattice::add_connid_counts, lattice.rs:170-183).  The reference panics without init_connid_counter: here
+// VBT_ERR_INVALID_STATE.  Calling it twice for one tokenize() adds the lattice twice, as the reference does.
+int vbt_worker_update_connid_counts(vbt_worker* w) {
+    return guarded([&] {
+        if (!w) throw Error(VBT_ERR_INVALID_ARGUMENT, "null argument");
+        if (w->lid_count.empty()) throw Error(VBT_ERR_INVALID_STATE, "init_connid_counter() has never been called");
+        if (!w->ws || w->text.empty()) return;  // no lattice was built for an empty sentence (worker.rs:50-52)
+        HIPX(hipSetDevice(w->tok->t->device()));
+        std::vector<uint64_t> l(w->lid_count.size()), r(w->rid_count.size());
+        w->ws->read_connid_counts(l.data(), r.data(), false);  // kept on the device: a second update adds it again
+        for (size_t i = 0; i < l.size(); ++i) w->lid_count[i] += l[i];
+        for (size_t i = 0; i < r.size(); ++i) w->rid_count[i] += r[i];
+    });
+}
+
+int vbt_worker_connid_counts(const vbt_worker* w, uint64_t* lid, uint64_t* rid) {
+    return guarded([&] {
+        if (!w || !lid || !rid) throw Error(VBT_ERR_INVALID_ARGUMENT, "null argument");
+        if (w->lid_count.empty()) throw Error(VBT_ERR_INVALID_STATE, "init_connid_counter() has never been called");
+        std::copy(w->lid_count.begin(), w->lid_count.end(), lid);
+        std::copy(w->rid_count.begin(), w->rid_count.end(), rid);
+    });
+}
+
+// ConnIdCounter::compute_probs (mapper.rs:108-146) for one side: drops id 0, sorts by probability descending, then id.
+int vbt_connid_probs(const uint64_t* counts, size_t n, uint32_t* ids, double* probs) {
+    return guarded([&] {
+        if (!counts || !ids || !probs || n == 0) throw Error(VBT_ERR_INVALID_ARGUMENT, "null argument");
+        double sum = 0;
+        for (size_t i = 0; i < n; ++i) sum += (double)counts[i];
+        std::vector<std::pair<uint32_t, double>> v;
+        v.reserve(n - 1);
+        for (size_t i = 1; i < n; ++i) v.emplace_back((uint32_t)i, (double)counts[i] / sum);
+        std::sort(v.begin(), v.end(), [](const auto& a, const auto& b) {
+            // partial_cmp(...).unwrap_or(Equal): NaN (0/0) compares equal to everything, then the id decides
+            if (a.second > b.second) return true;
+            if (a.second < b.second) return false;
+            return a.first < b.first;
+        });
+        for (size_t i = 0; i + 1 < n; ++i) { ids[i] = v[i].first; probs[i] = v[i].second; }
+    });
+}
+
+int vbt_worker_compute_connid_probs(const vbt_worker* w, uint32_t* lid_ids, double* lid_probs, uint32_t* rid_ids, double* rid_probs) {
+    if (!w || w->lid_count.empty()) { g_last_error = "init_connid_counter() has never been called"; return VBT_ERR_INVALID_STATE; }
+    int rc = vbt_connid_probs(w->lid_count.data(), w->lid_count.size(), lid_ids, lid_probs);
+    if (rc != VBT_OK) return rc;
+    return vbt_connid_probs(w->rid_count.data(), w->rid_count.size(), rid_ids, rid_probs);
 }
 
 uint32_t vbt_worker_num_tokens(const vbt_worker* w) { return (uint32_t)w->tokens.size(); }
@@ -290,34 +448,50 @@ int vbt_worker_token(const vbt_worker* w, uint32_t i, vbt_token* out) {
     });
 }
 
-int vbt_tokenize_batch(const vbt_tokenizer* tok, const uint8_t* text, const uint64_t* offsets, uint64_t n, vbt_batch** out) {
+int vbt_tokenize_batch(const vbt_tokenizer* tok_, const uint8_t* text, const uint64_t* offsets, uint64_t n, vbt_batch** out) {
     return guarded([&] {
+        vbt_tokenizer* tok = const_cast<vbt_tokenizer*>(tok_);  // the pool is internally synchronised: the handle stays logically const
         if (!tok || !offsets || !out || (!text && n && offsets[n] != offsets[0])) throw Error(VBT_ERR_INVALID_ARGUMENT, "null argument");
         auto b = std::make_unique<vbt_batch>();
         b->tok = tok;
-        const uint64_t lo = offsets[0], bytes = offsets[n] - lo;
-        b->text.assign(text + lo, text + lo + bytes);
+        const uint64_t lo = offsets[0];
         b->offsets.resize(n + 1);
         for (uint64_t i = 0; i <= n; ++i) {
             if (offsets[i] < lo || (i && offsets[i] < offsets[i - 1])) throw Error(VBT_ERR_INVALID_ARGUMENT, "offsets must be non-decreasing");
             b->offsets[i] = offsets[i] - lo;
         }
+        const uint64_t bytes = offsets[n] - lo;
+        if (bytes >= 0xFFFFFFFFull || n >= 0xFFFFFFFFull) throw Error(VBT_ERR_INVALID_ARGUMENT, "batch too large (split it)");
+        b->text.assign(text + lo, text + lo + bytes);
+        // every sentence must be a Rust `str` (the reference's callers pass &str; its CLI fails on invalid input lines)
+        for (uint64_t i = 0; i < n; ++i)
+            if (!valid_utf8(b->text.data() + b->offsets[i], b->offsets[i + 1] - b->offsets[i]))
+                throw Error(VBT_ERR_UTF8, "sentence " + std::to_string(i) + " is not valid UTF-8");
         HIPX(hipSetDevice(tok->t->device()));
-        Workspace ws(*tok->t, n, bytes);
-        void* d_text = nullptr;
-        uint64_t* d_off = nullptr;
-        HIPX(hipMalloc(&d_text, std::max<uint64_t>(bytes, 16)));
-        if (hipMalloc(reinterpret_cast<void**>(&d_off), (n + 1) * 8) != hipSuccess) { (void)hipFree(d_text); throw Error(VBT_ERR_DEVICE, "hipMalloc failed"); }
+        auto p = pool_take(tok, n, bytes);
         try {
-            if (bytes) HIPX(hipMemcpy(d_text, b->text.data(), bytes, hipMemcpyHostToDevice));
-            HIPX(hipMemcpy(d_off, b->offsets.data(), (n + 1) * 8, hipMemcpyHostToDevice));
-            run_and_fetch(ws, static_cast<const uint8_t*>(d_text), d_off, n, bytes, b->tok_off, b->tok_cnt, b->tokens);
+            if (bytes) HIPX(hipMemcpyAsync(p->d_text, b->text.data(), bytes, hipMemcpyHostToDevice, p->stream));
+            HIPX(hipMemcpyAsync(p->d_off, b->offsets.data(), (n + 1) * 8, hipMemcpyHostToDevice, p->stream));
+            run_and_fetch(*p->ws, static_cast<const uint8_t*>(p->d_text), p->d_off, n, bytes, b->tok_off, b->tok_cnt, b->tokens, p->stream);
         } catch (...) {
-            (void)hipFree(d_text); (void)hipFree(d_off);
+            (void)hipStreamSynchronize(p->stream);
+            pool_give(tok, std::move(p));
             throw;
         }
-        (void)hipFree(d_text); (void)hipFree(d_off);
+        pool_give(tok, std::move(p));
         *out = b.release();
+    });
+}
+
+// Workspaces created / reused by vbt_tokenize_batch so far (steady state: created stops growing).
+int vbt_tokenizer_pool_stats(const vbt_tokenizer* tok_, uint64_t* created, uint64_t* reused, uint64_t* idle) {
+    return guarded([&] {
+        vbt_tokenizer* tok = const_cast<vbt_tokenizer*>(tok_);
+        if (!tok) throw Error(VBT_ERR_INVALID_ARGUMENT, "null argument");
+        std::lock_guard<std::mutex> g(tok->pool_mu);
+        if (created) *created = tok->pool_created;
+        if (reused) *reused = tok->pool_reused;
+        if (idle) *idle = tok->pool.size();
     });
 }
 

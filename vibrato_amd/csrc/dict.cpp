@@ -51,6 +51,27 @@ int decode_utf8(const unsigned char* s, size_t n, uint32_t& cp) {
     return 0;
 }
 
+}  // namespace
+
+// Rust `str` validity of a byte range (what the reference's API takes by type, sentence.rs:28-32).
+bool valid_utf8(const uint8_t* s, size_t n) {
+    size_t i = 0;
+    while (i < n) {
+        if (i + 8 <= n) {  // ASCII fast path
+            uint64_t w;
+            std::memcpy(&w, s + i, 8);
+            if (!(w & 0x8080808080808080ull)) { i += 8; continue; }
+        }
+        uint32_t cp;
+        const int k = decode_utf8(s + i, n - i, cp);
+        if (!k) return false;
+        i += (size_t)k;
+    }
+    return true;
+}
+
+namespace {
+
 std::u32string to_code_points(std::string_view s, const char* what) {
     std::u32string out;
     out.reserve(s.size());

@@ -88,6 +88,9 @@ Dictionary* build_dictionary(std::string_view lex, std::string_view matrix_def, 
 // is the OLD id that becomes new id i (ConnIdMapper::parse, mapper.rs:49-80).
 void map_connection_ids(Dictionary& d, const uint16_t* lmap, size_t n_lmap, const uint16_t* rmap, size_t n_rmap);
 
+// Rust `str` validity (strict UTF-8: no overlongs, surrogates or code points above U+10FFFF).
+bool valid_utf8(const uint8_t* s, size_t n);
+
 // Dictionary::reset_user_lexicon_from_reader (dictionary.rs:209-229).
 void set_user_lexicon(Dictionary& d, const char* csv, size_t len);
 

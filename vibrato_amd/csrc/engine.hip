@@ -642,6 +642,31 @@ __device__ __forceinline__ uint64_t process_sentence(const DevDict& D, const Bat
         k = kend;
     }
 
+    if (A.lid_count) {
+        // Lattice::add_connid_counts (lattice.rs:170-183), see lattice_lds; steps of positions below the sentence's
+        // watermark were counted by the LDS pipeline before it passed the sentence on (candidates are in start order)
+        const uint32_t counted = __builtin_amdgcn_readfirstlane(A.s_counted[sid]);
+        const uint32_t c_skip = counted >= n ? C : (uint32_t)cand_off[counted];
+        for (uint32_t k = 0; k < S && counted <= n; ++k) {
+            const StepRec<IdxT> r = st[k];
+            const bool eos_step = k + 1 == S;
+            uint32_t c_beg = __builtin_amdgcn_readfirstlane((uint32_t)r.cbeg), nc = __builtin_amdgcn_readfirstlane((uint32_t)r.nc);
+            uint32_t p_beg = __builtin_amdgcn_readfirstlane((uint32_t)r.pbeg), p_end = p_beg + __builtin_amdgcn_readfirstlane((uint32_t)r.np);
+            if (!eos_step && c_beg < c_skip) continue;
+            if (eos_step) { p_beg = __builtin_amdgcn_readfirstlane(end_off[n]); p_end = __builtin_amdgcn_readfirstlane(end_off[n + 1]); }  // EOS pairs with ends[len_char]
+            uint32_t live = 0;
+            for (uint32_t j0 = p_beg; j0 < p_end; j0 += 64) {
+                const uint32_t j = j0 + ln;
+                const bool alive = j < p_end && (uint32_t)e_key[j] != 0xFFFFFFFFu;
+                live += (uint32_t)__popcll(__ballot(alive));
+                if (alive) atomicAdd(&A.rid_count[e_right[j]], (unsigned long long)nc);
+            }
+            for (uint32_t c = c_beg + ln; c < c_beg + nc; c += 64) atomicAdd(&A.lid_count[nd_left[c]], (unsigned long long)live);
+        }
+        if (ln == 0) A.s_counted[sid] = n + 1;
+        __syncthreads();
+    }
+
     // ---- P5: back-trace (append_top_nodes lattice.rs:159-168) + token records ------------------
     IdxT* path = grp;  // groupable is dead after the sweep; tokens <= chars
     uint32_t T = 0;
@@ -715,6 +740,63 @@ __host__ __device__ __forceinline__ uint64_t lattice_fixed_bytes(uint32_t n, uin
 
 extern __shared__ __attribute__((aligned(16))) char g_smem[];
 
+// Per-sentence regions of the workspace (per-character records, candidates, staged hits) are addressed by the
+// sentence's byte offset RELATIVE to the batch (offsets[0] may be anything: a window into a larger text buffer)
+// plus its index: sentence s owns the character slots [off(s) + s, off(s + 1) + s + 1).
+__device__ __forceinline__ size_t sentence_slot(const BatchArgs& A, uint64_t b0, uint32_t sid) {
+    return (size_t)(b0 - uniform64(A.offsets[0])) + sid;
+}
+__device__ __forceinline__ bool batch_rejected(const BatchArgs& A) {
+    return (__builtin_amdgcn_readfirstlane(A.ctrl[kError]) & (uint32_t)kErrFatal) != 0;
+}
+
+// First kernel of every batch: the device-side input contract.  Offsets must not decrease and must span at most
+// `total_bytes` (what the caller declared, <= the workspace capacity); the text must be valid UTF-8 (Rust `str`
+// validity: the reference takes `&str`, sentence.rs:28-32) with every sentence starting on a character boundary.
+// A violation sets kErrOffsets / kErrUtf8 and the batch is skipped: no later kernel touches a per-sentence region.
+__global__ void __launch_bounds__(256) validate_batch(BatchArgs A, uint64_t total_bytes) {
+    const uint64_t o0 = A.offsets[0], oN = A.offsets[A.n];
+    const uint64_t tid = (uint64_t)blockIdx.x * 256 + threadIdx.x, nthreads = (uint64_t)gridDim.x * 256;
+    uint32_t bad = 0;
+    if (oN < o0 || oN - o0 > total_bytes) bad |= kErrOffsets;
+    for (uint64_t s = tid; s < A.n; s += nthreads) {
+        const uint64_t a = A.offsets[s], b = A.offsets[s + 1];
+        if (b < a || a < o0 || b > oN) bad |= kErrOffsets;
+        else if (a < oN && (A.text[a] & 0xC0) == 0x80) bad |= kErrUtf8;  // a sentence starts inside a character
+    }
+    if (!(bad & kErrOffsets) && oN - o0 <= total_bytes) {
+        const uint8_t* __restrict__ t = A.text + o0;
+        const uint64_t nb = oN - o0;
+        for (uint64_t i0 = tid * 8; i0 < nb; i0 += nthreads * 8) {
+            uint32_t b[12];  // 8 lead positions + 4 bytes of look-ahead; past the end = 0 (not a continuation byte)
+#pragma unroll
+            for (int k = 0; k < 12; ++k) b[k] = i0 + k < nb ? t[i0 + k] : 0u;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t c = b[k];
+                if (i0 + k >= nb || (c & 0xC0) == 0x80) continue;  // continuation bytes are checked from their lead byte
+                const uint32_t len = c < 0x80 ? 1u : c < 0xE0 ? 2u : c < 0xF0 ? 3u : 4u;
+                bool ok = c < 0x80 || (c >= 0xC2 && c < 0xF5);
+#pragma unroll
+                for (uint32_t q = 1; q <= 4; ++q) {
+                    const bool cont = (b[k + q] & 0xC0) == 0x80;
+                    if (q < len) ok &= cont;
+                    if (q == len) ok &= !cont;  // a stray continuation byte behind a complete character
+                }
+                const uint32_t b1 = b[k + 1];
+                if (c == 0xE0) ok &= b1 >= 0xA0;  // overlong 3-byte form
+                if (c == 0xED) ok &= b1 < 0xA0;   // surrogates
+                if (c == 0xF0) ok &= b1 >= 0x90;  // overlong 4-byte form
+                if (c == 0xF4) ok &= b1 < 0x90;   // above U+10FFFF
+                if (!ok) bad |= kErrUtf8;
+            }
+        }
+    }
+    if (__ballot(bad != 0)) {  // rare: one atomic per offending lane
+        if (bad) atomicOr(&A.ctrl[kError], bad);
+    }
+}
+
 __device__ __forceinline__ void list_push(const BatchArgs& A, uint32_t t, uint32_t sid) {
     if (threadIdx.x == 0) A.lists[(size_t)t * A.list_stride + A.list_off + atomicAdd(&A.cctrl[2 * t], 1u)] = sid;
 }
@@ -748,7 +830,7 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
     if (nb64 >= 65535) { route(fallback); return; }  // positions are u16 in the LDS lattice
     const uint32_t nb = (uint32_t)nb64;
     const uint8_t* __restrict__ txt = A.text + b0;
-    const size_t slot0 = (size_t)b0 + sid;
+    const size_t slot0 = sentence_slot(A, b0, sid);
 
     uint32_t n = 0;
     for (uint32_t c0 = 0; c0 < nb; c0 += 64) {
@@ -1060,7 +1142,7 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
 // generator works on them on a side stream while the bulk runs.  Few qualify: one atomic each is fine.
 __global__ void __launch_bounds__(256) classify_long(BatchArgs A, uint32_t long_bytes) {
     const uint32_t rel = blockIdx.x * 256 + threadIdx.x;
-    if (rel >= A.n) return;
+    if (rel >= A.n || (A.ctrl[kError] & (uint32_t)kErrFatal)) return;
     const uint32_t sid = A.sid0 + rel;
     const uint64_t nb = A.offsets[sid + 1] - A.offsets[sid];
     const bool is_long = nb >= long_bytes;
@@ -1106,6 +1188,7 @@ __global__ void __launch_bounds__(1024) build_lists(BatchArgs A, int only_list) 
 
 // Kernel 1: one single-wave workgroup per sentence (small LDS, high occupancy) ...
 __global__ void __launch_bounds__(64) gen_candidates(DevDict D, BatchArgs A, uint32_t lds_bytes) {
+    if (batch_rejected(A)) return;  // nothing gets routed: every later kernel finds empty work lists
     gen_one(D, A, A.sid0 + blockIdx.x, lds_bytes, 0);
 }
 // ... and persistent waves with a large LDS budget for the sentences that did not fit.
@@ -1165,7 +1248,7 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
         const uint32_t sflags = __builtin_amdgcn_readfirstlane(A.s_flags[sid]);
         const uint32_t GT = sflags & 0xFFFFu, ngmax = sflags >> 16;
         const uint32_t passesT = __builtin_amdgcn_readfirstlane(A.s_passes[sid]);
-        const size_t slot0 = (size_t)uniform64(A.offsets[sid]) + sid;
+        const size_t slot0 = sentence_slot(A, uniform64(A.offsets[sid]), sid);
         const size_t node0 = (size_t)A.node_factor * slot0;
         const uint32_t kBosSeq = CT + 1;
         // A sentence whose lattice does not fit this tier's LDS is swept in segments that end at clean cuts
@@ -1180,6 +1263,7 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
         for (uint32_t q = 0; q < kCarry; ++q) { carry_key[q] = kDeadKey; carry_right[q] = 0; }
         if (ln == 0) carry_key[0] = node_key(0x80000000u, 0u, 0u, kBosSeq);  // BOS: cost 0, no predecessor
         bool multi = false, done = false;
+        uint32_t counted = A.lid_count ? __builtin_amdgcn_readfirstlane(A.s_counted[sid]) : 0u;
         uint32_t prof_S = 0, prof_SL = 0;
         uint32_t budget = lds_bytes;  // what a segment may be estimated at; shrinks when an estimate turns out too low
         uint32_t cap_b = nT;          // latest admissible segment end (pulled in when too many nodes end at a cut)
@@ -1585,14 +1669,34 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
         }
         PROF_MARK(6);
 
+        if (multi) {
+            // leave (total cost, back pointer) of every node of the segment in the sentence's (dead) hit-staging region
+            uint2* __restrict__ nb = reinterpret_cast<uint2*>(A.g_hits + node0 + seg_c);
+            for (uint32_t c = ln; c < C; c += 64) {
+                const uint64_t k = e_key[nd_ew[c] & 0xFFFFu];
+                nb[2 * c] = make_uint2(key_cost(k), key_back(k));
+            }
+        }
+        uint32_t i0 = 0, m_out = 0;
+        if (!last_seg) {
+            // the interface: nodes ending exactly at the cut
+            i0 = end_off[n]; m_out = end_off[n + 1] - i0;
+            if (m_out > 64 * kCarry || m_out == 0) {  // more nodes end here than the carry holds: cut earlier
+                if (seg_b > seg_a + 1 && m_out) { cap_b = seg_b - 1; __syncthreads(); continue; }
+                fail = 32; break;
+            }
+        }
         if (A.lid_count) {
             // Lattice::add_connid_counts (lattice.rs:170-183): for every inserted node r and every node l in
             // ends[r.start_node]: lid_count[r.left_id] += 1, rid_count[l.right_id] += 1; then the same for EOS
             // (left_id 0) against ends[len_char].  Only inserted ("live") nodes exist in the reference's lists.
+            // A segment is counted once it is final (its interface fits the carry); s_counted[sid] remembers how far
+            // the sentence has been counted, so a retry in an escape tier or in the fused kernel never counts a step twice.
             for (uint32_t k = 0; k < S; ++k) {
                 const uint32_t v = __builtin_amdgcn_readfirstlane(sp[k]);
                 const bool eos_step = last_seg && k + 1 == S;
                 const uint32_t p = eos_step ? n : (v & 0xFFFFu), sw = v >> 16;  // EOS pairs with ends[len_char]
+                if ((eos_step ? nT : seg_a + p) < counted) continue;
                 const uint32_t p_beg = __builtin_amdgcn_readfirstlane(end_off[p]), p_end = __builtin_amdgcn_readfirstlane(end_off[p + 1]);
                 uint32_t c_beg = C, nc = 1;
                 if (!eos_step) { c_beg = __builtin_amdgcn_readfirstlane((uint32_t)cand_off[sw]); nc = __builtin_amdgcn_readfirstlane((uint32_t)cand_off[sw + 1]) - c_beg; }
@@ -1605,23 +1709,10 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
                 }
                 for (uint32_t c = c_beg + ln; c < c_beg + nc; c += 64) atomicAdd(&A.lid_count[nd_left[c]], (unsigned long long)live);
             }
-        }
-
-        if (multi) {
-            // leave (total cost, back pointer) of every node of the segment in the sentence's (dead) hit-staging region
-            uint2* __restrict__ nb = reinterpret_cast<uint2*>(A.g_hits + node0 + seg_c);
-            for (uint32_t c = ln; c < C; c += 64) {
-                const uint64_t k = e_key[nd_ew[c] & 0xFFFFu];
-                nb[2 * c] = make_uint2(key_cost(k), key_back(k));
-            }
+            const uint32_t upto = last_seg ? nT + 1 : seg_b;
+            if (upto > counted) { counted = upto; if (ln == 0) A.s_counted[sid] = counted; }
         }
         if (!last_seg) {
-            // the interface: nodes ending exactly at the cut
-            const uint32_t i0 = end_off[n], m_out = end_off[n + 1] - i0;
-            if (m_out > 64 * kCarry || m_out == 0) {  // more nodes end here than the carry holds: cut earlier
-                if (seg_b > seg_a + 1 && m_out) { cap_b = seg_b - 1; __syncthreads(); continue; }
-                fail = 32; break;
-            }
 #pragma unroll
             for (uint32_t q = 0; q < kCarry; ++q) {
                 carry_key[q] = q * 64 + ln < m_out ? e_key[i0 + q * 64 + ln] : kDeadKey;
@@ -1772,6 +1863,7 @@ __global__ void __launch_bounds__(64) tokenize_lds(DevDict D, BatchArgs A, uint3
                                                    const uint32_t* in_count, uint32_t* cursor, uint32_t* out_list,
                                                    uint32_t* out_count) {
     if (in_list == nullptr) {
+        if (batch_rejected(A)) return;
         const uint32_t sid = blockIdx.x;
         if (process_sentence<uint16_t, false>(D, A, sid, g_smem, lds_bytes) != 0) push_overflow(out_list, out_count, sid);
         return;
@@ -1905,6 +1997,7 @@ Tokenizer::~Tokenizer() {
 // ------------------------------------------------------------------ Workspace
 
 Workspace::Workspace(const Tokenizer& t, uint64_t max_s, uint64_t max_b) : tok(t), max_sentences(max_s), max_bytes(max_b) {
+    try {
     HIP_CHECK(hipSetDevice(tok.device()));
     if (max_b >= 0xFFFFFFFFull || max_s >= 0xFFFFFFFFull) throw Error(VBT_ERR_INVALID_ARGUMENT, "workspace: batch too large (split it)");
     fused = env_u32("VBT_FUSED", 0) != 0;
@@ -1949,7 +2042,8 @@ Workspace::Workspace(const Tokenizer& t, uint64_t max_s, uint64_t max_b) : tok(t
     d_prof = static_cast<unsigned long long*>(alloc(kProfSlots * kProfWords * 8));
     HIP_CHECK(hipMemset(d_prof, 0, kProfSlots * kProfWords * 8));
     const uint64_t mb = env_u32("VBT_SCRATCH_MB", 0);
-    scratch_bytes = mb ? mb << 20 : std::max<uint64_t>(256ull << 20, 256 * nbts);
+    // (fused fallback only: rare sentences; a one-sentence Worker must not pin 256 MiB)
+    scratch_bytes = mb ? mb << 20 : std::max<uint64_t>(std::min<uint64_t>(256ull << 20, (16ull << 20) + 512 * nbts), 64 * nbts);
     d_scratch = static_cast<char*>(alloc(scratch_bytes));
     profile = env_u32("VBT_PROFILE", 0) != 0;
     for (auto& e : ev) HIP_CHECK(hipEventCreate(reinterpret_cast<hipEvent_t*>(&e)));
@@ -1957,13 +2051,8 @@ Workspace::Workspace(const Tokenizer& t, uint64_t max_s, uint64_t max_b) : tok(t
     const size_t slots = nbts + ns + 1;
     pipe.s_n = static_cast<uint32_t*>(alloc(ns * 4));
     pipe.s_C = static_cast<uint32_t*>(alloc(ns * 4));
-    pipe.s_base = static_cast<uint32_t*>(alloc(ns * 4));
     pipe.s_flags = static_cast<uint32_t*>(alloc(ns * 4));
     if (!fused) {
-        pipe.g_code = static_cast<uint16_t*>(alloc(slots * 2));
-        pipe.g_ucode = static_cast<uint16_t*>(alloc(slots * 2));
-        pipe.g_ci = static_cast<uint32_t*>(alloc(slots * 4));
-        pipe.g_grp = static_cast<uint16_t*>(alloc(slots * 2));
         pipe.g_c2b = static_cast<uint16_t*>(alloc(slots * 2));
         pipe.g_pc = static_cast<uint4*>(alloc(slots * 16));
         pipe.node_factor = std::max<uint32_t>(1, env_u32("VBT_NODE_FACTOR", 8));  // candidate slots per input byte
@@ -1991,18 +2080,29 @@ Workspace::Workspace(const Tokenizer& t, uint64_t max_s, uint64_t max_b) : tok(t
             HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lattice_lds<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tiers.back()));
         }
     }
+    } catch (...) {  // a failed hipMalloc / stream / event must not leak what was created before it
+        release();
+        throw;
+    }
 }
 
-Workspace::~Workspace() {
+void Workspace::release() {
     for (void* p : pipe_allocs) (void)hipFree(p);
-    for (auto& e : ev) if (e) (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(e));
+    pipe_allocs.clear();
+    for (auto& e : ev) if (e) { (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(e)); e = nullptr; }
     for (void* e : tier_events) (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(e));
+    tier_events.clear();
     if (ev_fork) (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(ev_fork));
     if (ev_fork2) (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(ev_fork2));
     if (ev_early) (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(ev_early));
+    ev_fork = ev_fork2 = ev_early = nullptr;
     if (early_stream) (void)hipStreamDestroy(reinterpret_cast<hipStream_t>(early_stream));
+    early_stream = nullptr;
     for (void* st : streams) (void)hipStreamDestroy(reinterpret_cast<hipStream_t>(st));
+    streams.clear();
 }
+
+Workspace::~Workspace() { release(); }
 
 void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n, uint64_t total_bytes, void* stream_) {
     if (n > max_sentences || total_bytes > max_bytes) throw Error(VBT_ERR_INVALID_ARGUMENT, "batch exceeds the workspace capacity");
@@ -2033,6 +2133,8 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
     a.sid0 = 0; a.cctrl = d_cctrl; a.list_off = 0;
     a.lid_count = count_connids ? d_connid : nullptr;
     a.rid_count = count_connids ? d_connid + tok.dict().num_left : nullptr;
+    a.s_counted = count_connids ? d_counted : nullptr;
+    if (count_connids) HIP_CHECK(hipMemsetAsync(d_counted, 0, n * 4, stream));
     for (size_t t = 0; t < T; ++t) a.tier_bytes[t] = tiers[t];
     const DevDict& D = tok.dev();
     auto rec = [&](int i) { if (timing) HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(ev[i]), stream)); };
@@ -2042,6 +2144,10 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
         return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(items, (uint64_t)per_cu * 256));
     };
     rec(0);
+    {   // device-side input contract (offsets, UTF-8); a rejected batch is skipped by every kernel below
+        const uint64_t work = std::max<uint64_t>(n, total_bytes / 8 + 1);
+        hipLaunchKernelGGL(validate_batch, dim3((uint32_t)std::min<uint64_t>((work + 255) / 256, 1u << 16)), dim3(256), 0, stream, a, total_bytes);
+    }
     if (fused) {
         auto count = [&](size_t t) { return d_cctrl + 2 * t; };
         auto cursor = [&](size_t t) { return d_cctrl + 2 * t + 1; };
@@ -2171,6 +2277,10 @@ void Workspace::enable_connid_counts(bool on) {
         pipe_allocs.push_back(p);
         d_connid = static_cast<unsigned long long*>(p);
         HIP_CHECK(hipMemset(d_connid, 0, words * 8));
+        void* q = nullptr;
+        HIP_CHECK(hipMalloc(&q, std::max<size_t>(max_sentences * 4, 16)));
+        pipe_allocs.push_back(q);
+        d_counted = static_cast<uint32_t*>(q);
     }
     count_connids = on;
 }
@@ -2183,6 +2293,13 @@ void Workspace::read_connid_counts(uint64_t* lid, uint64_t* rid, bool reset) {
     HIP_CHECK(hipMemcpy(lid, d_connid, nl * 8, hipMemcpyDeviceToHost));
     HIP_CHECK(hipMemcpy(rid, d_connid + nl, nr * 8, hipMemcpyDeviceToHost));
     if (reset) HIP_CHECK(hipMemset(d_connid, 0, (nl + nr) * 8));
+}
+
+void Workspace::reset_connid_counts() {
+    HIP_CHECK(hipSetDevice(tok.device()));
+    if (!d_connid) return;
+    HIP_CHECK(hipStreamSynchronize(reinterpret_cast<hipStream_t>(last_stream)));
+    HIP_CHECK(hipMemset(d_connid, 0, ((size_t)tok.dict().num_left + tok.dict().num_right) * 8));
 }
 
 void Workspace::read_profile(uint64_t* out, bool reset) {

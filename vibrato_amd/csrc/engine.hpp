@@ -52,14 +52,9 @@ struct BatchArgs {
     // per sentence
     uint32_t* s_n;      // characters
     uint32_t* s_C;      // lattice candidates
-    uint32_t* s_base;   // first node index in the node arrays
     uint32_t* s_flags;  // left-id groups | max groups of a position << 16
     uint32_t* s_passes; // upper bound of the lattice passes
     // per character slot (sentence s, char i -> slot offsets[s] + s + i; nb + 1 slots per sentence)
-    uint16_t* g_code;
-    uint16_t* g_ucode;
-    uint32_t* g_ci;
-    uint16_t* g_grp;
     uint16_t* g_c2b;
     uint4* g_pc;        // {cand_off, groupable | is_space << 31, lens lo, lens hi}
     // per candidate (insertion order, contiguous per sentence; sentence s owns the node slots
@@ -88,6 +83,7 @@ struct BatchArgs {
     // optional connection-id usage counters (Worker::update_connid_counts, worker.rs:77-93): nullptr = off
     unsigned long long* lid_count;
     unsigned long long* rid_count;
+    uint32_t* s_counted;  // per sentence: the steps of positions below this are already counted (a retry must not count them again)
     uint32_t tier_bytes[8];
 };
 
@@ -102,7 +98,8 @@ constexpr int kBlockCtrlWords = 2 * (kMaxTiers + 1 + kGenLevels);
 constexpr int kProfSlots = 256;  // the counters are spread over this many copies (hot-word atomics serialise)
 constexpr int kProfWords = 12;   // kProfPhases cycle totals, sentences, lattice steps, lattice passes, candidates
 constexpr int kProfPhases = 8;  // decode, count, fill, end lists, pre-pass, gather, recurrence, emit
-enum DevError { kErrTokCap = 1, kErrScratch = 2, kErrTooLong = 4 };
+// kErrOffsets / kErrUtf8 are set by validate_batch; the batch is then skipped (no kernel touches the per-sentence regions)
+enum DevError { kErrTokCap = 1, kErrScratch = 2, kErrTooLong = 4, kErrOffsets = 8, kErrUtf8 = 16, kErrFatal = kErrOffsets | kErrUtf8 };
 
 class Tokenizer {
   public:
@@ -144,9 +141,11 @@ class Workspace {
     void* early_stream = nullptr;  // generator + list building of the long sentences
     bool fused = false;              // VBT_FUSED=1: the single fused kernel per sentence (A/B reference)
     unsigned long long* d_connid = nullptr;  // [num_left + num_right] usage counters, allocated on first use
+    uint32_t* d_counted = nullptr;           // per-sentence watermark of the counted steps
     bool count_connids = false;
     void enable_connid_counts(bool on);
     void read_connid_counts(uint64_t* lid, uint64_t* rid, bool reset);
+    void reset_connid_counts();
     unsigned long long* d_prof = nullptr;
     char* d_scratch = nullptr;
     uint64_t scratch_bytes = 0;
@@ -157,6 +156,9 @@ class Workspace {
     uint64_t last_n = 0;
     void* last_stream = nullptr;
     void* ev[4] = {nullptr, nullptr, nullptr, nullptr};
+
+  private:
+    void release();  // frees every device allocation, stream and event (also on a constructor failure)
 };
 
 }  // namespace vbt

@@ -1,8 +1,13 @@
 """Sentence sharding for multi-GPU runs: one process per GPU, each tokenizes an independent
 contiguous range of sentences (a Worker holds only per-sentence state, worker.rs:13-19, and the
-dictionary is immutable), so there is no data-path collective; only per-rank totals (and, if the
-caller wants them on one rank, token records) are gathered at the end over RCCL/xGMI."""
+dictionary is immutable), so there is no data-path collective.  The only exchange is the final
+gather of the per-rank results, which stays device-resident: one padded `all_gather_into_tensor`
+(RCCL over xGMI when the backend is "nccl"; RCCL has no gatherv) of a buffer that carries the
+rank's totals, per-sentence token ranges and 24-byte token records."""
 import numpy as np
+
+TOKEN_BYTES = 24
+_HEADER = 32  # bytes: n_sentences (u64), n_tokens (u32), padding: keeps the payload 16-byte aligned
 
 
 def shard_bounds(offsets, world_size):
@@ -29,32 +34,96 @@ def local_shard(text, offsets, rank, world_size):
     return np.asarray(text)[int(offs[0]):int(offs[-1])], offs - offs[0], (lo, hi)
 
 
-def gather_totals(local_sentences, local_tokens, device=None):
-    """all_gather of (sentences, tokens) per rank (torch.distributed must be initialised:
-    backend "nccl" = RCCL on ROCm, or "gloo" in CPU tests). Returns an int64 array [world, 2]."""
-    import torch
-    import torch.distributed as dist
-    world = dist.get_world_size()
-    mine = torch.tensor([local_sentences, local_tokens], dtype=torch.int64, device=device)
-    out = torch.zeros(world * 2, dtype=torch.int64, device=device)
-    dist.all_gather_into_tensor(out, mine)
-    return out.view(world, 2).cpu().numpy()
+class _DevicePtr:
+    """Raw device memory as a `__cuda_array_interface__` object (uint8), so torch can alias it
+    without a copy.  `keep` pins whatever owns the memory."""
+
+    def __init__(self, ptr, nbytes, keep=None):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+        self._keep = keep
 
 
-def gather_token_records(tokens_np, device=None):
-    """Variable-length gather of token records to every rank (padded all_gather; RCCL has no
-    gatherv). tokens_np: structured array of 24-byte records. Returns a list of arrays by rank."""
+def device_view(ptr, nbytes, keep=None):
+    """torch.uint8 tensor aliasing `nbytes` of device memory at `ptr` (plumbing: no copy, no compute)."""
+    import torch
+    if nbytes == 0:
+        return torch.empty(0, dtype=torch.uint8, device="cuda")
+    return torch.as_tensor(_DevicePtr(ptr, nbytes, keep), device="cuda")
+
+
+def packed_bytes(max_sentences, max_tokens):
+    """Size of one rank's slot in the gather buffer."""
+    return _HEADER + 8 * int(max_sentences) + TOKEN_BYTES * int(max_tokens)
+
+
+def pack_results(out, n_sentences, n_tokens, total_dev, tok_off, tok_cnt, tokens, max_sentences):
+    """Lays one rank's results out in `out` (uint8 tensor of packed_bytes(...) bytes, 8-byte aligned):
+    header {n_sentences u64, n_tokens u32 (copied from the device counter `total_dev`), 0}, tok_off[u32 x
+    max_sentences], tok_cnt[u32 x max_sentences], then the first `n_tokens` token records.  tok_off / tok_cnt /
+    tokens / total_dev are uint8 views of the workspace's result buffers (device_view); only device-side copies and
+    fills are issued, on the current stream -- nothing passes through host memory."""
+    import torch
+    out[:8].view(torch.int64).fill_(int(n_sentences))
+    out[8:16].zero_()
+    out[8:12].copy_(total_dev[:4], non_blocking=True)
+    base = _HEADER
+    out[base:base + 4 * n_sentences].copy_(tok_off[:4 * n_sentences], non_blocking=True)
+    base += 4 * max_sentences
+    out[base:base + 4 * n_sentences].copy_(tok_cnt[:4 * n_sentences], non_blocking=True)
+    base += 4 * max_sentences
+    out[base:base + TOKEN_BYTES * n_tokens].copy_(tokens[:TOKEN_BYTES * n_tokens], non_blocking=True)
+    return out
+
+
+def gather_packed(send, world_out=None, group=None, async_op=False):
+    """One collective: every rank contributes its packed slot (same size on every rank) and receives all of
+    them, device-resident.  Returns (out tensor [world, slot_bytes], work or None)."""
     import torch
     import torch.distributed as dist
-    world = dist.get_world_size()
-    raw = torch.from_numpy(np.ascontiguousarray(tokens_np).view(np.uint8).copy())
-    n = torch.tensor([raw.numel()], dtype=torch.int64, device=device)
-    sizes = torch.zeros(world, dtype=torch.int64, device=device)
-    dist.all_gather_into_tensor(sizes, n)
-    cap = int(sizes.max().item())
-    buf = torch.zeros(cap, dtype=torch.uint8, device=device)
-    buf[:raw.numel()] = raw.to(buf.device)
-    out = torch.zeros(world * cap, dtype=torch.uint8, device=device)
-    dist.all_gather_into_tensor(out, buf)
-    out = out.cpu().numpy().reshape(world, cap)
-    return [out[r, :int(sizes[r].item())].view(tokens_np.dtype) for r in range(world)]
+    world = dist.get_world_size(group)
+    if world_out is None:
+        world_out = torch.empty(world * send.numel(), dtype=torch.uint8, device=send.device)
+    try:
+        work = dist.all_gather_into_tensor(world_out, send, group=group, async_op=async_op)
+    except (RuntimeError, NotImplementedError):  # a backend without the flat form (old gloo builds)
+        parts = list(world_out.view(world, -1).unbind(0))
+        work = dist.all_gather(parts, send, group=group, async_op=async_op)
+    return world_out.view(world, -1), work
+
+
+def unpack_results(slot, max_sentences):
+    """Host view of one rank's slot: (n_sentences, n_tokens, tok_off, tok_cnt, tokens[structured])."""
+    from .api import TOKEN_DTYPE
+    raw = slot.cpu().numpy()
+    n_s, n_t = int(raw[:8].view(np.int64)[0]), int(raw[8:12].view(np.uint32)[0])
+    base = _HEADER
+    off = raw[base:base + 4 * n_s].view(np.uint32)
+    base += 4 * max_sentences
+    cnt = raw[base:base + 4 * n_s].view(np.uint32)
+    base += 4 * max_sentences
+    toks = raw[base:base + TOKEN_BYTES * n_t].view(TOKEN_DTYPE)
+    return n_s, n_t, off, cnt, toks
+
+
+def tokens_in_sentence_order(off, cnt, toks):
+    """Token records of one rank re-ordered by sentence (the device hands out token ranges in arrival order)."""
+    ends = np.zeros(len(cnt) + 1, dtype=np.int64)
+    ends[1:] = np.cumsum(cnt, dtype=np.int64)
+    idx = np.repeat(off.astype(np.int64) - ends[:-1], cnt) + np.arange(int(ends[-1]), dtype=np.int64)
+    return toks[idx], ends
+
+
+def agree_max(value, device=None, group=None):
+    """all_reduce(MAX) of one integer (slot sizes must be equal on every rank)."""
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([int(value)], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return int(t.item())
+
+
+def workspace_views(ws, n_sentences, max_tokens):
+    """uint8 device views (no copies) of a Workspace's result buffers, ready for pack_results."""
+    p = ws.result_ptrs()
+    return {"tokens": device_view(p["tokens"], TOKEN_BYTES * int(max_tokens), ws), "tok_off": device_view(p["tok_off"], 4 * int(n_sentences), ws),
+            "tok_cnt": device_view(p["tok_cnt"], 4 * int(n_sentences), ws), "total": device_view(p["total"], 4, ws)}
