@@ -89,3 +89,22 @@ def test_two_process_hip_shards_and_device_gather():
     assert sum(t[0] for t in totals) == N_SENT
     assert sum(t[1] for t in totals) == len(toks)
     assert b"".join(parts) == toks.tobytes()
+
+
+def test_bench_py_multi_rank_path_runs_config4_shape():
+    """bench.py --gpus 2 end to end (sharded corpus, HIP per rank, packed device-resident gather on the communication
+    stream, parity of the gathered records) with both ranks on this box's single GPU and gloo instead of RCCL."""
+    import json
+    import subprocess
+    env = dict(os.environ, VBT_BENCH_BACKEND="gloo", VBT_BENCH_SINGLE_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    port = 29600 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--dict", "small", "--sentences", "20000"]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    r = json.loads(line)
+    assert r["n_gpus"] == 2 and r["scaling"] == "strong" and r["parity_vs_oracle_sample"] is True
+    assert r["gather"]["delivered_all_shards"] is True and r["gather"]["device_resident"] is True
+    assert r["value"] > 0 and r["tokens_per_step"] > 20000
