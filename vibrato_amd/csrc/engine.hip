@@ -84,43 +84,6 @@ __device__ __forceinline__ uint64_t node_key(uint32_t best_hi, uint32_t best_lo,
 }
 __device__ __forceinline__ uint32_t key_back(uint64_t k) { return (uint32_t)k & 0xFFFFu; }
 
-// Segmented butterfly minimum of 64-bit keys over aligned groups of 2^lg lanes, on split keys: minimum of the
-// high words first, then the minimum low word among the lanes that hold it (u64 order is lexicographic in (hi, lo)).  Each level is one v_min_u32 with a
-// DPP source operand; the 32- and 64-lane levels use the gfx950 row / half-wave swaps
-// (v_permlane16_swap / v_permlane32_swap) instead of the LDS crossbar.
-template <int kCtrl>
-__device__ __forceinline__ uint32_t dpp_min_u32(uint32_t x) {
-    const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, kCtrl, 0xF, 0xF, true);
-    return o < x ? o : x;
-}
-template <int kLevels>
-__device__ __forceinline__ uint32_t group_min_u32(uint32_t x) {
-    if constexpr (kLevels >= 1) x = dpp_min_u32<0xB1>(x);
-    if constexpr (kLevels >= 2) x = dpp_min_u32<0x4E>(x);
-    if constexpr (kLevels >= 3) x = dpp_min_u32<0x141>(x);
-    if constexpr (kLevels >= 4) x = dpp_min_u32<0x140>(x);
-    if constexpr (kLevels >= 5) { const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false); x = r[0] < r[1] ? r[0] : r[1]; }
-    if constexpr (kLevels >= 6) { const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false); x = r[0] < r[1] ? r[0] : r[1]; }
-    return x;
-}
-template <int kLevels>
-__device__ __forceinline__ void group_min_split_n(uint32_t& hi, uint32_t& lo) {
-    const uint32_t m = group_min_u32<kLevels>(hi);
-    lo = group_min_u32<kLevels>(hi == m ? lo : 0xFFFFFFFFu);
-    hi = m;
-}
-__device__ __forceinline__ void group_min_split(uint32_t& hi, uint32_t& lo, uint32_t lg) {  // lg is wave-uniform
-    switch (lg) {  // one branch per pass instead of one per level
-        case 0: break;
-        case 1: group_min_split_n<1>(hi, lo); break;
-        case 2: group_min_split_n<2>(hi, lo); break;
-        case 3: group_min_split_n<3>(hi, lo); break;
-        case 4: group_min_split_n<4>(hi, lo); break;
-        case 5: group_min_split_n<5>(hi, lo); break;
-        default: group_min_split_n<6>(hi, lo); break;
-    }
-}
-
 // 128-bit window helpers (shift distances 0..64), by value so everything stays in registers
 struct U128 { uint64_t lo, hi; };
 __device__ __forceinline__ U128 shr128(U128 w, uint32_t d) {
@@ -714,21 +677,30 @@ __device__ __forceinline__ uint64_t process_sentence(const DevDict& D, const Bat
     return 0;
 }
 
-// One sweep step of lattice_lds: candidates [cbeg, cbeg+nc) in ng left-id groups [gbeg, gbeg+ng)
-// connect to the end-list slots [pbeg, pbeg+np).
-struct LStep { uint16_t cbeg, nc, pbeg, np, gbeg, ng; };
-// One pass of the fused gather+recurrence loop: up to 64 (group, predecessor) lanes of one step.
-// gabs = first group of the pass (absolute), grel = its index within the step, last = 1 on the
-// step's final pass (the candidates are then finalised).
-struct alignas(16) LSlot { uint16_t cbeg, nc, pbeg, np, gabs, ngs, grel, last; };
+// prefetch distance of the matrix gathers of lattice_lds in passes (= unroll factor of its sweep loop).  2..8 measure the
+// same within 3 % on a full batch (other waves hide the latency); 8 keeps a lone sentence's sweep off the HBM latency.
+#ifndef VBT_DEPTH
+#define VBT_DEPTH 8
+#endif
+#ifndef VBT_LAT_WAVES
+#define VBT_LAT_WAVES 4
+#endif
+// One pass of the fused gather+recurrence loop of lattice_lds: up to 64 (left-id group, predecessor) lanes of one step.
+//   w0 = first end-list slot of the step's predecessors | their number << 16
+//   w1 = first left-id group of the step | number of groups << 16
+//   w2 = first candidate of the step | number of candidates << 16
+//   w3 = pair offset of the pass (lane ln handles padded pair q0 + ln) | lg << 24 | first pass of its step << 30 | last << 31
+// Padded pair q = (group g = q >> lg, predecessor j = q & (2^lg - 1)), 2^lg >= the number of predecessors.
+struct alignas(16) LPass { uint32_t w0, w1, w2, w3; };
+constexpr uint32_t kPassPad = 2 * VBT_DEPTH + 3;  // empty passes behind the last one: the software pipeline reads ahead without bounds checks
 
-// LDS bytes of the lattice arrays of lattice_lds (must over-estimate the Arena carve there).
-__host__ __device__ __forceinline__ uint64_t lattice_fixed_bytes(uint32_t n, uint32_t C, uint32_t G, uint32_t ngmax, bool space_mode, uint32_t passes) {
-    const uint64_t persistent = 2ull * (C + 1) + 2ull * (G + 1) + 8ull * (C + 2) + 8ull * (n + 1) + 8ull * (ngmax + 1) + 4ull * (n + 2) +
-                                (space_mode ? 4ull * n : 0) + 4ull * (n + 1) + 4ull * (C + 2) + 2ull * (n + 1) * 2 + 2ull * (C + 2) +
-                                (n + 1ull) + (C + 1ull) + 64;  // + alignment slack
-    const uint64_t setup = 4ull * C, records = sizeof(LSlot) * (passes + 20ull);  // share the same bytes
-    return persistent + (setup > records ? setup : records);
+// LDS bytes of the lattice arrays of lattice_lds for a (segment of a) sentence with C candidates in G left-id groups
+// (at most ngmax per position), `passes` passes and m_in nodes ending at its first position.  Must over-estimate the
+// Arena carve there; gen_candidates routes sentences to LDS tiers with it.
+__host__ __device__ __forceinline__ uint64_t lattice_fixed_bytes(uint32_t C, uint32_t G, uint32_t ngmax, uint32_t passes, uint32_t m_in) {
+    const uint64_t E = (uint64_t)C + m_in;
+    return 8 * (E + 1) + 8 * (ngmax + 1ull) + 4 * (C + 1ull) + sizeof(LPass) * (passes + (uint64_t)kPassPad) + 2 * (E + 1) + 2 * (C + 1ull) +
+           2 * (G + 1ull) + 64;  // + alignment slack
 }
 
 // =====================================================================================
@@ -954,6 +926,23 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
     // words > 64 chars need the generic pre-pass, > 65531 nodes need u32 indices: fused kernel
     if (C >= 65532 || any_long) { route(fallback); return; }
     if (ln == 0) cand_off[n] = C;
+    // End lists (`ends[e]` of lattice.rs:39-43) are laid out here once and for all: node slots are numbered by end
+    // position (BOS is slot 0, the only node ending at 0), so the lattice kernel reads every candidate with its slot
+    // attached and builds no lists.  endc[] turns from counts into running cursors: exclusive prefix now, after the
+    // expansion below the inclusive one (eo() recovers the exclusive offsets).  Order inside a list is arbitrary.
+    __syncthreads();
+    {
+        uint32_t running = 0;
+        for (uint32_t c0 = 0; c0 < n + 1; c0 += 64) {
+            const uint32_t p = c0 + ln;
+            const uint32_t cnt = p < n + 1 ? endc[p] : 0u;
+            uint32_t tot;
+            const uint32_t ex = wave_exscan(cnt, tot);
+            if (p < n + 1) endc[p] = running + ex;
+            running += tot;
+        }
+    }
+    __syncthreads();
     if (C > region) { route(fallback); return; }  // denser than the region: fused path
     // Left ids (for the grouping) are kept in LDS for a window of candidates only: sentences whose candidates
     // outgrow it are expanded and grouped in rounds of whole 64-position chunks, so the LDS need of a long
@@ -985,7 +974,6 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
             r1 = nx;
         }
         if (r1 == r0) { window_small = true; break; }  // one chunk alone outgrows the window: next generator level
-        const uint32_t cend = cand_off[r1];
         // expand the hits of these positions: lanes = hits, every entry load independent of every other
         for (uint32_t h0 = 0; h0 < H; h0 += 64) {
             const uint32_t h = h0 + ln;
@@ -995,6 +983,7 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
                 if (pos >= r0 && pos < r1) {
                     const Entry* __restrict__ ent = lex == 0 ? D.sys.entries : lex == 1 ? D.user.entries : D.unk_entries;
                     const uint32_t dest = cand_off[pos] + hr.w;
+                    const uint32_t slot0 = atomicAdd(&endc[end], c);  // the hit's run of slots in ends[end]
                     for (uint32_t t0 = 0; t0 < c; t0 += 4) {
                         Entry e[4];
 #pragma unroll
@@ -1005,8 +994,9 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
                                 const uint32_t k = dest + t0 + q;
                                 uint32_t* rec = reinterpret_cast<uint32_t*>(&A.g_nd[base + k]);
                                 rec[0] = e[q].left_right;
-                                rec[1] = (e[q].cost & 0xFFFFu) | (end << 16);
+                                rec[1] = (e[q].cost & 0xFFFFu) | ((slot0 + t0 + q) << 16);
                                 rec[2] = (lex << 30) | e[q].word_id;
+                                reinterpret_cast<uint16_t*>(rec)[7] = (uint16_t)end;  // (the low half of this word is the group, below)
                                 cleft[k - cbase] = (uint16_t)(e[q].left_right & 0xFFFFu);
                             }
                         }
@@ -1045,7 +1035,13 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
             too_many_groups |= __ballot(ng > 127u) != 0;
             uint32_t tot;
             const uint32_t ex = wave_exscan(ng, tot);
-            if (i < r1) goff[i] = (uint16_t)(G + ex);
+            if (i < r1) {
+                goff[i] = (uint16_t)(G + ex);
+                // sentence-wide group number of every candidate (groups are numbered in order of first appearance)
+                const uint32_t kb = cand_off[i], ke = cand_off[i + 1];
+                for (uint32_t k = kb; k < ke; ++k)
+                    reinterpret_cast<uint16_t*>(&A.g_nd[base + k])[6] = (uint16_t)(G + ex + (cgid[k - cbase] & 0x7Fu));
+            }
             G += tot;
             uint32_t m = ng;
 #pragma unroll
@@ -1053,53 +1049,47 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
             ngmax = m > ngmax ? m : ngmax;
         }
         __syncthreads();
-        for (uint32_t k = cbase + ln; k < cend; k += 64) reinterpret_cast<uint32_t*>(&A.g_nd[base + k])[3] = cgid[k - cbase];
-        __syncthreads();
         r0 = r1;
     }
     if (window_small) { route(large_list); return; }
     if (too_many_groups) { route(fallback); return; }
     __syncthreads();
-    // upper bound of the number of (step, <= 64 pair lanes) passes of the lattice kernel
-    uint32_t passes = 1;  // EOS
-    for (uint32_t c0 = 0; c0 < n; c0 += 64) {
-        const uint32_t i = c0 + ln;
-        uint32_t nsl = 0;
-        if (i < n) {
-            const uint32_t np = endc[i], ng = ngp[i];
-            const uint32_t lg = np <= 1 ? 0u : 32u - (uint32_t)__builtin_clz(np - 1);
-            const uint32_t gpp = 64u >> (lg > 6 ? 6 : lg);
-            nsl = np <= 64 ? (ng + gpp - 1) / gpp : ng * ((np + 63) / 64);
-            endc[i] = nsl;  // the end counts are dead: keep the per-position pass bound for the records below
-        }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) nsl += __shfl_xor(nsl, d);
-        passes += nsl;
-    }
-    __syncthreads();
+    // exclusive end-list offset of position p (0 .. n + 1): the cursors now hold the inclusive prefix
+    auto eo = [&](uint32_t p) { return p == 0 ? 0u : p == 1 ? 1u : endc[p - 1]; };
+    // passes of the lattice kernel that the step at one position takes: ceil(groups x 2^lg / 64), 2^lg >= predecessors
+    auto step_passes = [](uint32_t ng, uint32_t np) {
+        const uint32_t lg = np <= 1 ? 0u : 32u - (uint32_t)__builtin_clz(np - 1);
+        return (uint32_t)((((uint64_t)ng << lg) + 63) >> 6);
+    };
+    uint32_t passes = 0, maxcnt = 1;
     {   // per-character records for the lattice kernel:
-        // {cand_off | goff << 16, grp | ng << 16 | min(passes, 63) << 24 | clean cut << 30 | space << 31, lens}
+        // {cand_off | goff << 16, end-list offset | pass bound of the position's step << 16 | clean cut << 30 | space << 31,
+        //  length mask (64 bits; for a space position of ignore_space mode its groupable run instead: the sweep never
+        //  starts a word there, tokenizer.rs:113-125)}
         // Clean cut before position i: no candidate of an earlier position ends beyond i (with ignore_space, a
-        // visited space run hands its visit to the position behind the run, tokenizer.rs:113-125, so such a run
-        // counts as spanning up to the furthest end of that position's candidates).  lattice_lds may split
-        // the sweep of a long sentence there.
+        // visited space run hands its visit to the position behind the run, so such a run counts as spanning up to the
+        // furthest end of that position's candidates).  lattice_lds may split the sweep of a long sentence there.
         uint4* pc = A.g_pc + slot0;
         uint32_t far = 0;  // furthest end of any candidate of the positions before this chunk
         for (uint32_t c0 = 0; c0 < n; c0 += 64) {
             const uint32_t i = c0 + ln;
-            uint32_t e = 0, space = 0;
+            uint32_t e = 0, space = 0, nsl = 0, cnt = 0;
             uint64_t lm = 0;
             if (i < n) {
                 const uint32_t cinfo = ci[i];
                 space = (D.space_cateset && (cinfo & D.space_cateset)) ? 0x80000000u : 0u;
                 lm = lens[i];
                 e = lm ? i + 64u - (uint32_t)__builtin_clzll(lm) : i + 1;
+                uint32_t ng = ngp[i];
                 if (space) {
                     const uint32_t sw = i + grp[i];
                     const uint64_t lw = sw < n ? lens[sw] : 0ull;
                     const uint32_t e2 = sw < n ? (lw ? sw + 64u - (uint32_t)__builtin_clzll(lw) : sw + 1) : n;
                     e = e2 > e ? e2 : e;
+                    ng = sw < n ? ngp[sw] : 0u;  // the step taken from a space position starts its words behind the run
                 }
+                cnt = eo(i + 1) - eo(i);
+                nsl = step_passes(ng, cnt);
             }
             uint32_t m = e;  // inclusive prefix maximum over the lanes
 #pragma unroll
@@ -1108,20 +1098,31 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
             before = ln == 0 ? far : (before > far ? before : far);
             if (i < n) {
                 const uint32_t cut = (i == 0 || before <= i) ? 0x40000000u : 0u;
-                const uint32_t nsl = endc[i] < 63u ? endc[i] : 63u;
-                pc[i] = make_uint4(cand_off[i] | ((uint32_t)goff[i] << 16), (uint32_t)grp[i] | ((uint32_t)ngp[i] << 16) | (nsl << 24) | cut | space,
-                                   (uint32_t)lm, (uint32_t)(lm >> 32));
+                const uint64_t third = space ? (uint64_t)grp[i] : lm;
+                pc[i] = make_uint4(cand_off[i] | ((uint32_t)goff[i] << 16), eo(i) | ((nsl < 0x3FFFu ? nsl : 0x3FFFu) << 16) | cut | space,
+                                   (uint32_t)third, (uint32_t)(third >> 32));
             }
             const uint32_t top = __shfl(m, 63);
             far = top > far ? top : far;
+            uint32_t mc = cnt;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) { nsl += __shfl_xor(nsl, d); const uint32_t o = __shfl_xor(mc, d); mc = o > mc ? o : mc; }
+            passes += nsl;
+            maxcnt = mc > maxcnt ? mc : maxcnt;
         }
-        if (ln == 0) pc[n] = make_uint4(C | (G << 16), 0, 0, 0);
+        {   // EOS connects to the end list of the last visited position: bounded by the longest list
+            const uint32_t last = eo(n + 1) - eo(n);
+            maxcnt = last > maxcnt ? last : maxcnt;
+            passes += step_passes(1u, maxcnt);
+        }
+        // terminator: totals (candidates, groups, end-list slots)
+        if (ln == 0) pc[n] = make_uint4(C | (G << 16), eo(n), eo(n + 1), 0);
     }
     if (ln == 0) {
         A.s_n[sid] = n; A.s_C[sid] = C; A.s_flags[sid] = G | (ngmax << 16); A.s_passes[sid] = passes;
     }
     // smallest tier whose LDS holds the lattice arrays (connection costs are never staged)
-    const uint64_t fixed = lattice_fixed_bytes(n, C, G, ngmax, D.space_cateset != 0, passes);
+    const uint64_t fixed = lattice_fixed_bytes(C, G, ngmax, passes, 1u);
     uint32_t tier = fallback;
     for (uint32_t t = 0; t < A.n_tiers; ++t)
         if (fixed <= A.tier_bytes[t]) { tier = t; break; }
@@ -1208,30 +1209,34 @@ __global__ void __launch_bounds__(64) gen_candidates_large(DevDict D, BatchArgs 
 // Kernel 2: the lattice sweep of one sentence per wavefront, entirely in LDS.  Persistent waves
 // drain the work list of their tier.  Sentences whose lattice does not fit after all go to the
 // fallback list (fused kernel with global scratch).
-// prefetch distance of the matrix gathers in passes (= unroll factor of the sweep loop).  2..8 measure the same
-// within 3 % on a full batch (other waves hide the latency); 8 keeps a lone sentence's sweep off the HBM latency.
-#ifndef VBT_DEPTH
-#define VBT_DEPTH 8
-#endif
-#ifndef VBT_LAT_WAVES
-#define VBT_LAT_WAVES 4
-#endif
-// (two instances: the ignore_space variant of the reachability sweep is several times the code and register
-// pressure of the plain one)
+//
+// What lives in LDS per (segment of a) sentence: per end-list slot the packed key (8 B) and the right id (2 B); per
+// candidate its slot | word cost (4 B) and its left-id group (2 B); per group the left id (2 B); the per-step group
+// minima (8 B x the most groups of a position) and the pass records (16 B each).  Nothing per character: the
+// per-character records of gen_candidates are consumed straight from global memory by the reachability sweep, 64
+// positions at a time, and the end lists were laid out by gen_candidates (every candidate arrives with its slot).
+//
+// The recurrence runs over PASSES: 64 lanes = 64 (group g, predecessor j) pairs of one sweep step.  A lane adds the
+// connection cost of its pair (loaded kDepth passes ahead into a register ring) to the predecessor's key and
+// folds the sum into the group's minimum with ONE LDS atomic (ds_min_u64 on the packed key: minimum cost, ties to the
+// last inserted predecessor = the `<=` of lattice.rs:141-146); the last pass of a step hands the minima to the
+// step's candidates.  LDS operations of one wave execute in order, so no barrier separates these phases.
 template <bool kSpaceMode>
 __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, BatchArgs A, uint32_t tier, uint32_t list_id) {
     const uint32_t ln = threadIdx.x;
     const uint32_t lds_bytes = A.tier_bytes[tier];
-    const int16_t* __restrict__ matrix = D.matrix;
     const uint32_t NR = D.num_right;
-    constexpr bool space_mode = kSpaceMode;
+    constexpr uint32_t kDepth = VBT_DEPTH;  // prefetch distance of the matrix gathers, in passes
     // long sentences are the critical path of a batch: let their waves win issue arbitration
     if (A.tier_prio && (A.seg_tier < A.n_tiers ? tier >= A.seg_tier : tier + A.tier_prio >= A.n_tiers)) __builtin_amdgcn_s_setprio(2);
-    {
     const int src = (int)list_id;  // normally the tier's own list; helper launches sweep the segment tier's list with less LDS
     const uint32_t* list = A.lists + (size_t)src * A.list_stride + A.list_off;
     const uint32_t count = A.cctrl[2 * src];
     uint32_t* cursor = &A.cctrl[2 * src + 1];
+    auto uniform4 = [](uint4 q) {
+        return make_uint4(__builtin_amdgcn_readfirstlane(q.x), __builtin_amdgcn_readfirstlane(q.y),
+                          __builtin_amdgcn_readfirstlane(q.z), __builtin_amdgcn_readfirstlane(q.w));
+    };
     for (;;) {
         uint32_t item = 0;
         if (ln == 0) item = atomicAdd(cursor, 1u);
@@ -1250,18 +1255,21 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
         const uint32_t passesT = __builtin_amdgcn_readfirstlane(A.s_passes[sid]);
         const size_t slot0 = sentence_slot(A, uniform64(A.offsets[sid]), sid);
         const size_t node0 = (size_t)A.node_factor * slot0;
+        const uint4* __restrict__ pcg = A.g_pc + slot0;   // per-character records (+ the terminator at nT)
+        const uint4* __restrict__ ndg = A.g_nd + node0;   // candidate records in insertion order
+        const uint32_t ET = __builtin_amdgcn_readfirstlane(pcg[nT].z);  // end-list slots of the sentence (BOS included)
         const uint32_t kBosSeq = CT + 1;
         // A sentence whose lattice does not fit this tier's LDS is swept in segments that end at clean cuts
         // (positions no candidate spans, flagged by gen_candidates): only the nodes ending exactly at the cut
-        // -- the interface, carried in registers -- connect a segment to the next.  Sequence numbers and back
+        // -- the interface, carried in registers -- connect a segment to the next.  Sequence numbers, slots and back
         // pointers stay sentence-global; each segment leaves (cost, back pointer) per node in global memory.
-        uint32_t seg_a = 0, seg_c = 0, seg_g = 0, seg_p = 0, fail = 0;
+        uint32_t seg_a = 0, seg_c = 0, seg_g = 0, seg_p = 0, seg_s = 0, fail = 0;
         constexpr uint32_t kCarry = 2;  // interface nodes per lane: up to 128 nodes may end at a cut
         uint64_t carry_key[kCarry];
         uint32_t carry_right[kCarry], m_in = 1;
 #pragma unroll
         for (uint32_t q = 0; q < kCarry; ++q) { carry_key[q] = kDeadKey; carry_right[q] = 0; }
-        if (ln == 0) carry_key[0] = node_key(0x80000000u, 0u, 0u, kBosSeq);  // BOS: cost 0, no predecessor
+        if (ln == 0) carry_key[0] = node_key(0x80000000u, 0u, 0u, kBosSeq);  // BOS: cost 0, no predecessor (right id 0)
         bool multi = false, done = false;
         uint32_t counted = A.lid_count ? __builtin_amdgcn_readfirstlane(A.s_counted[sid]) : 0u;
         uint32_t prof_S = 0, prof_SL = 0;
@@ -1269,29 +1277,29 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
         uint32_t cap_b = nT;          // latest admissible segment end (pulled in when too many nodes end at a cut)
         while (!done) {
         uint32_t seg_b = nT, seg_pass = passesT - seg_p;
-        if (lattice_fixed_bytes(nT - seg_a, CT - seg_c, GT - seg_g, ngmax, space_mode, passesT - seg_p) + 10ull * m_in > budget || cap_b < nT) {
+        if (lattice_fixed_bytes(CT - seg_c, GT - seg_g, ngmax, passesT - seg_p, m_in) > budget || cap_b < nT) {
             // furthest clean cut within 256 positions whose segment fits
-            const uint4* __restrict__ pcg = A.g_pc + slot0;
             uint32_t best = 0, best_pass = 0, run = 0;
             for (uint32_t w0 = 0; w0 < 256 && seg_a + w0 < nT; w0 += 64) {
                 const uint32_t b = seg_a + w0 + ln + 1;  // candidate segment end
                 uint32_t nsl = 0, cx = 0, cut = 0;
                 if (b <= nT) {
                     const uint4 rp = pcg[b - 1], rb = pcg[b];
-                    nsl = (rp.y >> 24) & 63u;
-                    if (nsl == 63u) nsl = 1u << 20;  // saturated: unknown, treat as too many
+                    nsl = (rp.y >> 16) & 0x3FFFu;
+                    if (nsl == 0x3FFFu) nsl = 1u << 20;  // saturated: unknown, treat as too many
                     cx = rb.x;
                     cut = b == nT ? 1u : (rb.y >> 30) & 1u;
                 }
                 uint32_t tot;
                 const uint32_t incl = wave_exscan(nsl, tot) + nsl + run;
-                const uint64_t bytes = lattice_fixed_bytes(b - seg_a, ((cx & 0xFFFFu) - seg_c) & 0xFFFFu, ((cx >> 16) - seg_g) & 0xFFFFu, ngmax, space_mode, incl + 1);
-                const bool fits = b <= cap_b && bytes + 10ull * m_in <= budget;
+                const uint32_t est = b == nT ? passesT - seg_p : incl;  // (the sentence's bound includes the EOS step)
+                const uint64_t bytes = lattice_fixed_bytes(((cx & 0xFFFFu) - seg_c) & 0xFFFFu, ((cx >> 16) - seg_g) & 0xFFFFu, ngmax, est, m_in);
+                const bool fits = b <= cap_b && bytes <= budget;
                 const uint64_t m = __ballot(fits && cut);
                 if (m) {
                     const uint32_t top = 63u - (uint32_t)__builtin_clzll(m);
                     best = seg_a + w0 + top + 1;
-                    best_pass = __shfl(incl, (int)top) - 0u;
+                    best_pass = __shfl(est, (int)top);
                 }
                 run += tot;
                 if (__ballot(fits) == 0) break;
@@ -1302,361 +1310,246 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
         }
         const bool last_seg = seg_b == nT;
         const uint32_t n = seg_b - seg_a;
-        const uint4* __restrict__ pc = A.g_pc + slot0 + seg_a;
-        const uint32_t C = __builtin_amdgcn_readfirstlane((last_seg ? CT : (pc[n].x & 0xFFFFu)) - seg_c) & 0xFFFFu;
-        const uint32_t G = __builtin_amdgcn_readfirstlane((last_seg ? GT : (pc[n].x >> 16)) - seg_g) & 0xFFFFu;
-        const uint4* __restrict__ nd = A.g_nd + node0 + seg_c;
+        const uint4* __restrict__ pc = pcg + seg_a;
+        const uint4 rend = uniform4(pcg[seg_b]);  // record of the segment's end position (the terminator for the last segment)
+        const uint32_t C = ((rend.x & 0xFFFFu) - seg_c) & 0xFFFFu, G = ((rend.x >> 16) - seg_g) & 0xFFFFu;
+        const uint32_t E = m_in + C;  // end-list slots: interface (BOS) + the segment's candidates; slot E is the EOS node's
+        const uint32_t sb = seg_s;    // sentence-global slot of local slot 0
+        const uint4* __restrict__ nd = ndg + seg_c;
 
         Arena ar{g_smem, lds_bytes, 0, true};
-        // the two left-id arrays come first: pass records address them as u16 element indices from the arena base
-        uint16_t* nd_left = ar.take<uint16_t>(C + 1);
-        uint16_t* g_left = ar.take<uint16_t>(G + 1);
-        const uint32_t E = C + m_in;                   // end-list slots: interface (BOS) + candidates; slot E is the EOS node's
-        uint64_t* e_key = ar.take<uint64_t>(E + 1);    // end-major packed (cost, sequence, back pointer) keys
-        uint64_t* lens = ar.take<uint64_t>(n + 1);     // length bitmask per start position (pre-pass), then the token path
+        uint64_t* e_key = ar.take<uint64_t>(E + 1);       // end-major packed (cost, sequence, back pointer) keys
         uint64_t* g_best = ar.take<uint64_t>(ngmax + 1);  // per step: best key of each left-id group
-        uint32_t* end_off = ar.take<uint32_t>(n + 2);
-        uint32_t* grpf = space_mode ? ar.take<uint32_t>(n) : end_off;  // groupable | is_space << 31
-        uint32_t* sp = ar.take<uint32_t>(n + 1);  // (start_node | start_word << 16) per sweep step
-        uint32_t* nd_ew = ar.take<uint32_t>(C + 2);  // per candidate: end-list slot | (u16) word_cost << 16
-        uint16_t* cand_off = ar.take<uint16_t>(n + 1);
-        uint16_t* goff = ar.take<uint16_t>(n + 1);
+        uint32_t* nd_ew = ar.take<uint32_t>(C + 1);       // per candidate: end-list slot | (u16) word_cost << 16
         uint16_t* e_right = ar.take<uint16_t>(E + 1);
-        uint8_t* ngp = ar.take<uint8_t>(n + 1);
-        uint8_t* nd_gid = ar.take<uint8_t>(C + 1);
-        // set-up scratch (end position and right id per candidate): dead once the end lists exist, so the
-        // pass records, which are built afterwards, take the same bytes
-        const uint64_t union_base = (ar.used + 15) & ~15ull;
-        ar.used = union_base;
-        uint16_t* nd_end = ar.take<uint16_t>(C);
-        uint16_t* tmp_right = ar.take<uint16_t>(C);
-        if (!ar.ok) {  // the estimate was too low: try a shorter segment before giving up
+        uint16_t* nd_g = ar.take<uint16_t>(C + 1);        // per candidate: its left-id group (segment-relative)
+        uint16_t* g_left = ar.take<uint16_t>(G + 1);
+        ar.used = (ar.used + 15) & ~15ull;
+        LPass* rec = reinterpret_cast<LPass*>(g_smem + ar.used);  // pass records take the rest; afterwards the token path
+        const uint32_t sl_cap = ar.ok && lds_bytes > ar.used ? (uint32_t)((lds_bytes - ar.used) / sizeof(LPass)) : 0u;
+        if (!ar.ok || sl_cap < kPassPad + 2) {  // the estimate was too low: try a shorter segment before giving up
             if (budget > lds_bytes / 3) { budget -= lds_bytes / 4; __syncthreads(); continue; }
             fail = 26; break;
         }
 
-        // ---- load: per-char records and candidates from global; count end-list sizes ----
-        for (uint32_t p = ln; p < n + 2; p += 64) end_off[p] = 0;
-        __syncthreads();
-        for (uint32_t i = ln; i < n + 1; i += 64) {
-            const uint4 r = pc[i];
-            cand_off[i] = (uint16_t)((r.x & 0xFFFFu) - seg_c);
-            goff[i] = (uint16_t)((r.x >> 16) - seg_g);
-            if (i < n) {
-                lens[i] = ((uint64_t)r.w << 32) | r.z;
-                ngp[i] = (uint8_t)((r.y >> 16) & 0xFFu);
-                if (space_mode) grpf[i] = (r.y & 0xFFFFu) | (r.y & 0x80000000u);
-            }
-        }
-        for (uint32_t c0 = 0; c0 < C; c0 += 64 * 8) {  // 8 independent 16-byte loads per lane in flight
-            uint4 r[8];
+        // ---- load: candidates from global (every record carries its slot and group); interface; EOS ----
+        for (uint32_t c0 = 0; c0 < C; c0 += 64 * 4) {  // 4 independent 16-byte loads per lane in flight
+            uint4 r[4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < 4; ++u) {
                 const uint32_t c = c0 + u * 64 + ln;
-                r[u] = c < C ? nd[c] : make_uint4(0, 0, 0, 0);
+                r[u] = nd[c < C ? c : 0u];
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < 4; ++u) {
                 const uint32_t c = c0 + u * 64 + ln;
                 if (c < C) {
-                    const uint32_t end = (r[u].y >> 16) - seg_a;  // <= n: no candidate spans a clean cut
-                    nd_left[c] = (uint16_t)(r[u].x & 0xFFFFu);
-                    tmp_right[c] = (uint16_t)(r[u].x >> 16);
-                    nd_end[c] = (uint16_t)end;
-                    nd_gid[c] = (uint8_t)r[u].w;
-                    nd_ew[c] = atomicAdd(&end_off[end], 1u) | (r[u].y << 16);
+                    const uint32_t es = (r[u].y >> 16) - sb, g = ((r[u].w & 0xFFFFu) - seg_g) & 0xFFFFu;
+                    e_right[es] = (uint16_t)(r[u].x >> 16);
+                    e_key[es] = kDeadKey;  // never inserted until a sweep step reaches its start position
+                    nd_ew[c] = es | (r[u].y << 16);
+                    nd_g[c] = (uint16_t)g;
+                    g_left[g] = (uint16_t)(r[u].x & 0xFFFFu);  // (all candidates of a group write the same id)
                 }
             }
         }
-        __syncthreads();
-        // left id of every group (first candidate of the group carries flag 0x80)
-        for (uint32_t i = ln; i < n; i += 64) {
-            const uint32_t gb = goff[i];
-            for (uint32_t c = cand_off[i], ce = cand_off[i + 1]; c < ce; ++c) {
-                const uint32_t gid = nd_gid[c];
-                if (gid & 0x80u) g_left[gb + (gid & 0x7Fu)] = nd_left[c];
-            }
-        }
-        {   // end lists: exclusive scan of per-end counts; slot 0 is BOS (lattice.rs:72-83)
-            uint32_t running = 0;
-            for (uint32_t c0 = 0; c0 < n + 1; c0 += 64) {
-                const uint32_t p = c0 + ln;
-                uint32_t cnt = 0;
-                if (p < n + 1) cnt = end_off[p] + (p == 0 ? m_in : 0u);  // position 0: BOS / the interface of the previous segment
-                uint32_t tot;
-                const uint32_t ex = wave_exscan(cnt, tot);
-                if (p < n + 1) end_off[p] = running + ex;
-                running += tot;
-            }
-            if (ln == 0) end_off[n + 1] = running;
-        }
-        __syncthreads();
-        for (uint32_t c = ln; c < C; c += 64) {
-            const uint32_t ew = nd_ew[c];
-            const uint32_t es = end_off[nd_end[c]] + (ew & 0xFFFFu);
-            const uint16_t r = tmp_right[c];
-            nd_ew[c] = (ew & 0xFFFF0000u) | es;
-            e_right[es] = r;
-            e_key[es] = kDeadKey;
-        }
-        __syncthreads();
 #pragma unroll
         for (uint32_t q = 0; q < kCarry; ++q)
             if (q * 64 + ln < m_in) { e_right[q * 64 + ln] = (uint16_t)carry_right[q]; e_key[q * 64 + ln] = carry_key[q]; }
         if (ln == 0) {
-            nd_left[C] = 0;  // EOS pseudo candidate: left_id 0, its own group G
-            nd_ew[C] = E;  // word cost 0
-            nd_gid[C] = 0x80u;
+            nd_ew[C] = E;  // EOS pseudo candidate (insert_eos, lattice.rs:85-101): left_id 0, word cost 0, its own group G
+            nd_g[C] = (uint16_t)G;
             g_left[G] = 0;
             e_key[E] = kDeadKey;
         }
-        __syncthreads();
         PROF_MARK(3);
 
-        // ---- structural pre-pass (tokenizer.rs:106-138, control flow only) ----
-        // (a) a scalar state machine walks the positions with a 128-bit reachability window; the
-        //     length masks of 64 consecutive positions sit in one VGPR pair and are read with
-        //     v_readlane, so the loop touches LDS only when it crosses a 64-position boundary;
-        // (b) lanes then build the step records in parallel.
-        uint32_t S = 0, sn_eos = n;
-        bool windowed = true;
-        uint32_t cur0 = 0;
-#pragma unroll
-        for (uint32_t q = 0; q < kCarry; ++q) cur0 |= __ballot(q * 64 + ln < m_in && (uint32_t)carry_key[q] != 0xFFFFFFFFu) != 0 ? 1u : 0u;
+        // ---- structural pre-pass (tokenizer.rs:106-138, control flow only) + pass records ----
+        // Bit-serial sweep, all state in SGPRs.  w bit i <=> position p + 1 + i is the end of an inserted node;
+        // cur <=> position p is reachable (has_previous_node, tokenizer.rs:108).  A visited position ORs its length
+        // mask into w; a visited space run of r characters (ignore_space, tokenizer.rs:113-125) hands its visit over to
+        // position p + r and drops the reachability of everything in between (the reference continues from
+        // start_word + 1).  The length masks of 64 positions come straight from the per-character records in global
+        // memory into one VGPR pair and are read with v_readlane.  The visited positions of a chunk become sweep steps,
+        // every step is cut into passes of 64 padded (group, predecessor) pairs, and the pass records are laid out
+        // contiguously (exclusive scan of the pass counts).
+        uint32_t SL = 0, S = 0, sn_eos = n;
+        bool windowed = true, overflow = false;
         {
-            // Bit-serial sweep, all state in SGPRs.  w bit i <=> position p + 1 + i is the end of an inserted
-            // node; cur <=> position p is (has_previous_node, tokenizer.rs:108).  A visited position ORs its
-            // length mask into w; a visited space run of r characters (ignore_space, tokenizer.rs:113-125)
-            // hands its visit over to position p + r and drops the reachability of everything in between
-            // (the reference continues from start_word + 1).  The visited set of 64 positions is collected
-            // in a mask and turned into step records by the lanes afterwards.
-            auto sweep = [&](auto space_tag) {
-                constexpr bool kSpace = decltype(space_tag)::value;
-                uint64_t w = 0;
-                uint32_t cur = cur0, pend = 0, stop = 0;
-                for (uint32_t chunk = 0; chunk < n && !stop; chunk += 64) {
-                    const uint32_t i = chunk + ln;
-                    const uint64_t lm = i < n ? lens[i] : 0ull;
-                    const uint32_t l_lo = (uint32_t)lm, l_hi = (uint32_t)(lm >> 32);
-                    const uint32_t gf = (kSpace && i < n) ? grpf[i] : 0u;
-                    const uint64_t spm = kSpace ? __ballot((gf >> 31) != 0) : 0ull;
-                    const uint32_t cnt = n - chunk < 64 ? n - chunk : 64;
-                    uint64_t vis = 0, visp = 0;
+            uint32_t cur0 = 0;
 #pragma unroll
-                    for (uint32_t k = 0; k < 64; ++k) {
-                        if ((k & 7u) == 0 && k >= cnt) break;
-                        const uint64_t bit = 1ull << k;
-                        const uint64_t m = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(l_hi, k) << 32) | (uint32_t)__builtin_amdgcn_readlane(l_lo, k);
-                        if constexpr (kSpace) {
-                            if (cur && !pend && (spm & bit)) {  // rare: a reachable space run
-                                const uint32_t r = __builtin_amdgcn_readlane(gf, k) & 0x7FFFFFFFu;
-                                if (chunk + k + r >= n) { sn_eos = chunk + k; stop = 1; w = 0; }  // only spaces left: EOS connects here
-                                else if (r > 63) { windowed = false; stop = 1; w = 0; }
-                                else {
-                                    visp |= bit;
-                                    w = (w & ~((1ull << r) - 1ull)) | (1ull << (r - 1));
-                                    pend = 1;
-                                }
-                            } else {
-                                w |= cur ? m : 0ull;
-                                vis |= (cur && !pend) ? bit : 0ull;
-                                pend = cur ? 0u : pend;
+            for (uint32_t q = 0; q < kCarry; ++q) cur0 |= __ballot(q * 64 + ln < m_in && (uint32_t)carry_key[q] != 0xFFFFFFFFu) != 0 ? 1u : 0u;
+            uint64_t w = 0;
+            uint32_t cur = cur0, pend = 0, stop = 0;
+            for (uint32_t chunk = 0; chunk < n && !stop; chunk += 64) {
+                const uint32_t i = chunk + ln;
+                const bool in = i < n;
+                const uint4 rc = pc[in ? i : n], rn = pc[in ? i + 1 : n];  // this position's record and the next one's (n = the end record)
+                const bool is_space = kSpaceMode && in && (rc.y >> 31) != 0;
+                const uint32_t l_lo = (in && !is_space) ? rc.z : 0u, l_hi = (in && !is_space) ? rc.w : 0u;
+                const uint32_t gf = is_space ? rc.z : 0u;  // groupable run of a space position
+                const uint64_t spm = kSpaceMode ? __ballot(is_space) : 0ull;
+                const uint32_t cnt = n - chunk < 64 ? n - chunk : 64;
+                uint64_t vis = 0, visp = 0;
+#pragma unroll
+                for (uint32_t k = 0; k < 64; ++k) {
+                    if ((k & 7u) == 0 && k >= cnt) break;
+                    const uint64_t bit = 1ull << k;
+                    const uint64_t m = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(l_hi, k) << 32) | (uint32_t)__builtin_amdgcn_readlane(l_lo, k);
+                    if constexpr (kSpaceMode) {
+                        if (cur && !pend && (spm & bit)) {  // rare: a reachable space run
+                            const uint32_t r = __builtin_amdgcn_readlane(gf, k);
+                            if (chunk + k + r >= n) { sn_eos = chunk + k; stop = 1; w = 0; }  // only spaces left: EOS connects here
+                            else if (r > 63) { windowed = false; stop = 1; w = 0; }
+                            else {
+                                visp |= bit;
+                                w = (w & ~((1ull << r) - 1ull)) | (1ull << (r - 1));
+                                pend = 1;
                             }
                         } else {
                             w |= cur ? m : 0ull;
-                            vis |= cur ? bit : 0ull;
+                            vis |= (cur && !pend) ? bit : 0ull;
+                            pend = cur ? 0u : pend;
                         }
-                        cur = (uint32_t)w & 1u;
-                        w >>= 1;
+                    } else {
+                        w |= cur ? m : 0ull;
+                        vis |= cur ? bit : 0ull;
                     }
-                    if (cnt < 64) { vis &= (1ull << cnt) - 1ull; visp &= (1ull << cnt) - 1ull; }
-                    const uint64_t any = vis | visp;
-                    if ((any >> ln) & 1ull) {
-                        const uint32_t idx = S + (uint32_t)__popcll(any & ((1ull << ln) - 1ull));
-                        const uint32_t sw = ((visp >> ln) & 1ull) ? i + (gf & 0x7FFFFFFFu) : i;
-                        sp[idx] = i | (sw << 16);
-                    }
-                    S += (uint32_t)__popcll(any);
+                    cur = (uint32_t)w & 1u;
+                    w >>= 1;
                 }
-            };
-            sweep(std::integral_constant<bool, kSpaceMode>{});
+                if (cnt < 64) { vis &= (1ull << cnt) - 1ull; visp &= (1ull << cnt) - 1ull; }
+                const uint64_t any = vis | visp;
+                // lanes = the visited positions of the chunk: step (start_node i, start_word sw)
+                const bool step = (any >> ln) & 1ull;
+                uint32_t xa = rc.x, xb = rn.x;  // candidate / group ranges of the start word
+                if (kSpaceMode && ((visp >> ln) & 1ull)) {
+                    const uint32_t sw = i + gf;  // < n: a run that reaches the end stops the sweep above
+                    xa = pc[sw].x; xb = pc[sw + 1].x;
+                }
+                const uint32_t p_beg = (rc.y & 0xFFFFu) - sb, np = ((rn.y & 0xFFFFu) - (rc.y & 0xFFFFu)) & 0xFFFFu;
+                const uint32_t c_beg = ((xa & 0xFFFFu) - seg_c) & 0xFFFFu, nc = ((xb & 0xFFFFu) - (xa & 0xFFFFu)) & 0xFFFFu;
+                const uint32_t g_beg = ((xa >> 16) - seg_g) & 0xFFFFu, ng = ((xb >> 16) - (xa >> 16)) & 0xFFFFu;
+                const uint32_t lg = np <= 1 ? 0u : 32u - (uint32_t)__builtin_clz(np - 1);
+                const uint32_t nsl = step ? (uint32_t)((((uint64_t)ng << lg) + 63) >> 6) : 0u;
+                uint32_t tot;
+                const uint32_t ex = wave_exscan(nsl, tot);
+                if (SL + tot + kPassPad > sl_cap) overflow = true;
+                if (!overflow) {
+                    for (uint32_t q = 0; q < nsl; ++q)
+                        rec[SL + ex + q] = LPass{p_beg | (np << 16), g_beg | (ng << 16), c_beg | (nc << 16),
+                                                 (q << 6) | (lg << 24) | (q == 0 ? 1u << 30 : 0u) | (q + 1 == nsl ? 1u << 31 : 0u)};
+                }
+                SL += tot;
+                S += (uint32_t)__popcll(any);
+            }
         }
         if (!windowed) { fail = 27; break; }  // > 63 skipped spaces in a row: generic pre-pass of the fused kernel
         if (last_seg) {
-            ++S;  // + the EOS step (insert_eos(start_node), tokenizer.rs:138)
-            if (ln == 0) sp[S - 1] = sn_eos | (0xFFFFu << 16);
+            // + the EOS step (insert_eos(start_node), tokenizer.rs:138): predecessors = ends[sn_eos]
+            const uint32_t y0 = __builtin_amdgcn_readfirstlane(pc[sn_eos].y) & 0xFFFFu;
+            const uint32_t y1 = sn_eos < n ? __builtin_amdgcn_readfirstlane(pc[sn_eos + 1].y) & 0xFFFFu : ET;
+            const uint32_t p_beg = y0 - sb, np = y1 - y0;
+            const uint32_t lg = np <= 1 ? 0u : 32u - (uint32_t)__builtin_clz(np - 1);
+            const uint32_t nsl = ((1u << lg) + 63) >> 6;
+            if (SL + nsl + kPassPad > sl_cap) overflow = true;
+            if (!overflow)
+                for (uint32_t q = ln; q < nsl; q += 64)
+                    rec[SL + q] = LPass{p_beg | (np << 16), G | (1u << 16), C | (1u << 16), (q << 6) | (lg << 24) | (q == 0 ? 1u << 30 : 0u) | (q + 1 == nsl ? 1u << 31 : 0u)};
+            SL += nsl;
+            ++S;
         } else if (sn_eos != n) { fail = 31; break; }  // cannot happen: a trailing space run spans every later cut
-        __syncthreads();
-        PROF_MARK(4);
-        // (b) lanes = steps: split every step into passes of <= 64 (group, predecessor) lanes and lay
-        //     the pass records out contiguously (exclusive scan of the pass counts).
-        uint32_t SL = 0;
-        LSlot* sl = reinterpret_cast<LSlot*>(g_smem + union_base);  // over the dead set-up scratch
-        const uint32_t sl_cap = lds_bytes > union_base ? (uint32_t)((lds_bytes - union_base) / sizeof(LSlot)) : 0u;
-        const uint32_t ix_nd_left = (uint32_t)(reinterpret_cast<char*>(nd_left) - g_smem) / 2u;  // u16 element indices
-        const uint32_t ix_g_left = (uint32_t)(reinterpret_cast<char*>(g_left) - g_smem) / 2u;
-        for (uint32_t k0 = 0; k0 < S; k0 += 64) {
-            const uint32_t k = k0 + ln;
-            uint32_t c_beg = 0, nc = 0, p_beg = 0, np = 1, g_beg = 0, ng = 0, nsl = 0, gpp = 64, lgp = 0;
-            bool direct = false;
-            if (k < S) {
-                const uint32_t v = sp[k], p = v & 0xFFFFu, sw = v >> 16;
-                p_beg = end_off[p];
-                np = end_off[p + 1] - p_beg;
-                if (sw == 0xFFFFu) { c_beg = C; nc = 1; g_beg = G; ng = 1; }
-                else { c_beg = cand_off[sw]; nc = cand_off[sw + 1] - c_beg; g_beg = goff[sw]; ng = ngp[sw]; }
-                const uint32_t lg = np <= 1 ? 0u : 32u - (uint32_t)__builtin_clz(np - 1);
-                lgp = lg > 6 ? 6 : lg;
-                gpp = 64u >> lgp;
-                direct = np <= 64 && (nc << lgp) <= 64;  // a lane group per candidate fits one pass: no broadcast step
-                nsl = direct ? 1u : np <= 64 ? (ng + gpp - 1) / gpp : ng * ((np + 63) / 64);
-            }
-            uint32_t tot;
-            const uint32_t ex = wave_exscan(nsl, tot);
-            if (SL + tot <= sl_cap) {
-                if (direct) {
-                    sl[SL + ex] = LSlot{(uint16_t)c_beg, (uint16_t)nc, (uint16_t)p_beg, (uint16_t)np, (uint16_t)(ix_nd_left + c_beg),
-                                        (uint16_t)nc, (uint16_t)0, (uint16_t)(1u | 4u | 8u | (lgp << 4))};
-                } else if (np <= 64) {
-                    for (uint32_t q = 0; q < nsl; ++q) {
-                        const uint32_t rem = ng - q * gpp;
-                        const uint32_t fl = (q + 1 == nsl ? 1u : 0u) | ((nsl == 1 && nc <= 64) ? 8u : 0u) | (lgp << 4);
-                        sl[SL + ex + q] = LSlot{(uint16_t)c_beg, (uint16_t)nc, (uint16_t)p_beg, (uint16_t)np, (uint16_t)(ix_g_left + g_beg + q * gpp),
-                                                (uint16_t)(rem < gpp ? rem : gpp), (uint16_t)(q * gpp), (uint16_t)fl};
-                    }
-                } else {  // > 64 predecessors: one group per pass, 64 predecessors at a time, partial minima accumulate
-                    const uint32_t nch = (np + 63) / 64;
-                    for (uint32_t q = 0; q < nsl; ++q) {
-                        const uint32_t g = q / nch, jc = q - g * nch;
-                        const uint32_t rem = np - jc * 64;
-                        const uint32_t npc = rem < 64 ? rem : 64;
-                        const uint32_t lgc = npc <= 1 ? 0u : 32u - (uint32_t)__builtin_clz(npc - 1);
-                        sl[SL + ex + q] = LSlot{(uint16_t)c_beg, (uint16_t)nc, (uint16_t)(p_beg + jc * 64), (uint16_t)npc,
-                                                (uint16_t)(ix_g_left + g_beg + g), (uint16_t)1, (uint16_t)g,
-                                                (uint16_t)((q + 1 == nsl ? 1u : 0u) | (jc ? 2u : 0u) | (lgc << 4))};
-                    }
-                }
-            }
-            SL += tot;
-        }
-        // no LDS left for the pass records: fused kernel
         prof_SL += SL; prof_S += S;
-        constexpr uint32_t kDepth = VBT_DEPTH;  // prefetch distance of the fused loop, in passes
-        if (SL + 2 * kDepth + 2 > sl_cap) {  // more passes than estimated (gen_candidates bounds them per position)
+        if (overflow || SL >= (1u << 18)) {  // more passes than estimated (gen_candidates bounds them per position)
             if (budget > lds_bytes / 3) { budget -= lds_bytes / 4; __syncthreads(); continue; }
             fail = 29; break;
         }
-        // pad with empty passes so the pipelined loop needs no bounds branches
-        if (ln < 2 * kDepth + 2) sl[SL + ln] = LSlot{0, 0, 0, 1, 0, 0, 0, 0};  // np = 1, ngs = 0, lg = 0: nothing to do
-        __syncthreads();
-        PROF_MARK(5);
+        // pad with empty passes (one predecessor, no group: no lane is valid) so the pipelined loop needs no bounds branches
+        if (ln < kPassPad) rec[SL + ln] = LPass{1u << 16, 0u, 0u, 0u};
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        PROF_MARK(4);
 
         // ---- fused gather + cost recurrence (matrix_connector.rs:79-85, lattice.rs:103-151) ----
-        // Per pass the lanes are (left-id group g, predecessor j) pairs: g = lane >> lg, j = lane & (2^lg - 1)
-        // with 2^lg >= np.  The connection cost of a lane's pair depends on ids only, so it is loaded
-        // kDepth passes ahead into a register ring (software pipeline): the recurrence never waits for
-        // HBM, and nothing is staged in LDS.  Per pass: key = e_key[pred] + (conn << 32); segmented
-        // butterfly min over the 2^lg lanes of a group (minimum cost, ties -> last inserted = `<=`).
-        // The loop body contains no branch around a global load, so the compiler keeps counted
-        // s_waitcnt vmcnt(kDepth-1) at the use of a ring slot.
         {
-            // ring[u]: the aligned 32-bit word holding this lane's i16 cell of pass (s0 + u); the half is
-            // picked at use.  (A 16-bit destination would be packed two-per-VGPR by the compiler, which
-            // forces a vmcnt(0) right behind every load and serialises the pipeline.)
-            uint32_t ring[kDepth], par[kDepth];  // par[u]: which half of ring[u] is this lane's cell (0 / 16)
-            uint4 rw[kDepth];                     // the (wave-uniform) pass record of ring slot u, unpacked once
-            const uint32_t* __restrict__ matrix32 = reinterpret_cast<const uint32_t*>(matrix);
-            const uint16_t* __restrict__ ids16 = reinterpret_cast<const uint16_t*>(g_smem);
-            auto uniform4 = [](uint4 q) {
-                return make_uint4(__builtin_amdgcn_readfirstlane(q.x), __builtin_amdgcn_readfirstlane(q.y),
-                                  __builtin_amdgcn_readfirstlane(q.z), __builtin_amdgcn_readfirstlane(q.w));
+            const uint32_t* __restrict__ matrix32 = reinterpret_cast<const uint32_t*>(D.matrix);
+            uint32_t ring[kDepth];  // ring[u]: the aligned 32-bit word holding this lane's i16 cell of pass (s0 + u)
+            uint32_t pk[kDepth];    // this lane's pair of that pass: slot | group within the step << 16 | cell parity * 16 << 24 | valid << 31
+            uint32_t sc[kDepth], sg[kDepth], sf[kDepth];  // (wave-uniform) record words w2, w1, w3 of that pass
+            // the lane's pair of a pass: end-list slot of its predecessor, its group, validity
+            auto decode = [&](const uint4& r, uint32_t& slot, uint32_t& g, bool& valid) {
+                const uint32_t p_beg = r.x & 0xFFFFu, np = r.x >> 16, ng = r.y >> 16, lg = (r.w >> 24) & 31u;
+                const uint32_t q = (r.w & 0xFFFFFFu) + ln;
+                const uint32_t gg = q >> lg, j = q & ((1u << lg) - 1u);
+                valid = gg < ng && j < np;
+                g = valid ? gg : 0u;
+                slot = p_beg + (valid ? j : 0u);
             };
-            // the LDS slots of the id pair (left id of the lane's group, right id of its predecessor) of a pass
-            auto id_slots = [&](const uint4& r, uint32_t& li, uint32_t& ri) {
-                const uint32_t p_beg = r.y & 0xFFFFu, np = r.y >> 16, lbase = r.z & 0xFFFFu, ngs = r.z >> 16, lg = (r.w >> 20) & 7u;
-                const uint32_t g = ln >> lg, j = ln & ((1u << lg) - 1u);
-                const bool valid = g < ngs && j < np;
-                li = lbase + (valid ? g : 0u);
-                ri = p_beg + (valid ? j : 0u);
-            };
-            auto gather = [&](uint32_t left, uint32_t right, uint32_t u) {
-                const uint32_t cell = left * NR + right;  // < 2^32: num_left, num_right <= 65535
-                ring[u] = load_policy<VBT_NT_MATRIX != 0>(&matrix32[cell >> 1]);
-                par[u] = (cell & 1u) * 16u;
+            auto gather = [&](uint32_t left, uint32_t right, uint32_t& word, uint32_t& par) {
+                const uint32_t cell = __umul24(left, NR) + right;  // < 2^32: num_left, num_right <= 65535
+                word = load_policy<VBT_NT_MATRIX != 0>(&matrix32[cell >> 1]);  // (a 16-bit destination would be packed by the compiler and serialise the loads)
+                par = (cell & 1u) << 4;
             };
 #pragma unroll
             for (uint32_t u = 0; u < kDepth; ++u) {  // passes >= SL are empty padding
-                rw[u] = uniform4(*reinterpret_cast<const uint4*>(&sl[u]));
-                uint32_t li, ri;
-                id_slots(rw[u], li, ri);
-                gather(ids16[li], e_right[ri], u);
+                const uint4 r = uniform4(*reinterpret_cast<const uint4*>(&rec[u]));
+                uint32_t slot, g, par; bool valid;
+                decode(r, slot, g, valid);
+                gather(g_left[(r.y & 0xFFFFu) + g], e_right[slot], ring[u], par);
+                pk[u] = slot | (g << 16) | (par << 24) | (valid ? 0x80000000u : 0u);
+                sc[u] = r.z; sg[u] = r.y; sf[u] = r.w;
             }
             // two-stage prefetch: the ids of pass si + kDepth + 1 are read from LDS while pass si runs, the gather of
             // pass si + kDepth is issued from the ids read one pass earlier: no LDS wait in front of the global load
-            uint4 fq = uniform4(*reinterpret_cast<const uint4*>(&sl[kDepth]));
-            uint32_t p_left, p_right;
+            uint4 fq = uniform4(*reinterpret_cast<const uint4*>(&rec[kDepth]));
+            uint32_t p_left, p_right, p_pk;
             {
-                uint32_t li, ri;
-                id_slots(fq, li, ri);
-                p_left = ids16[li];
-                p_right = e_right[ri];
+                uint32_t slot, g; bool valid;
+                decode(fq, slot, g, valid);
+                p_left = g_left[(fq.y & 0xFFFFu) + g];
+                p_right = e_right[slot];
+                p_pk = slot | (g << 16) | (valid ? 0x80000000u : 0u);
             }
-            uint4 qn = *reinterpret_cast<const uint4*>(&sl[kDepth + 1]);
+            uint4 qn = *reinterpret_cast<const uint4*>(&rec[kDepth + 1]);
             for (uint32_t s0 = 0; s0 < SL; s0 += kDepth) {
 #pragma unroll
                 for (uint32_t u = 0; u < kDepth; ++u) {
                     const uint32_t si = s0 + u;
-                    const uint32_t cword = ring[u], cpar = par[u];
-                    const uint4 r = rw[u];
-                    rw[u] = fq;
-                    gather(p_left, p_right, u);  // pass si + kDepth, into the ring slot just consumed
-                    const uint32_t c_beg = r.x & 0xFFFFu, nc = r.x >> 16, p_beg = r.y & 0xFFFFu, np = r.y >> 16;
-                    const uint32_t ngs = r.z >> 16, grel = r.w & 0xFFFFu, fl = r.w >> 16;
-                    const uint32_t last = fl & 1u, acc = fl & 2u, direct = fl & 4u, single = fl & 8u, lg = (fl >> 4) & 7u;
-                    const uint32_t g = ln >> lg, j = ln & ((1u << lg) - 1u);
-                    const bool valid = g < ngs && j < np;
-                    // every LDS read of the pass is issued here, branch-free, so one wait covers them all
-                    fq = uniform4(qn);
-                    qn = *reinterpret_cast<const uint4*>(&sl[si + kDepth + 2]);
-                    {
-                        uint32_t li, ri;
-                        id_slots(fq, li, ri);
-                        p_left = ids16[li];
-                        p_right = e_right[ri];
+                    const uint32_t cword = ring[u], cpk = pk[u], w2 = sc[u], w1 = sg[u], w3 = sf[u];
+                    {   // pass si + kDepth: gather into the ring slot just consumed
+                        uint32_t par;
+                        gather(p_left, p_right, ring[u], par);
+                        pk[u] = p_pk | (par << 24);
+                        sc[u] = fq.z; sg[u] = fq.y; sf[u] = fq.w;
                     }
-                    const uint64_t kb = e_key[p_beg + (valid ? j : 0u)];
-                    const uint32_t cl = direct ? g : ln;           // the candidate this lane finalises
-                    const uint32_t c = c_beg + (cl < nc ? cl : 0u);
-                    const uint32_t ew = nd_ew[c], gid = nd_gid[c];
-                    const uint32_t cv = (uint32_t)(int32_t)(int16_t)(cword >> cpar);
-                    const bool live = valid && (uint32_t)kb != 0xFFFFFFFFu;
-                    uint32_t khi = live ? (uint32_t)(kb >> 32) + cv : 0xFFFFFFFFu;  // wrapping i32 add
-                    uint32_t klo = live ? (uint32_t)kb : 0xFFFFFFFFu;
-                    group_min_split(khi, klo, lg);
-                    if (direct) {
-                        // one lane group per candidate: the group minimum is the candidate's best predecessor
-                        if (valid && j == 0) e_key[ew & 0xFFFFu] = node_key(khi, klo, (uint32_t)(int32_t)(int16_t)(ew >> 16), seg_c + c);
-                    } else if (single) {
-                        // the whole step is this pass: group minima are broadcast to the candidate lanes
-                        const int src = (int)((gid & 0x7Fu) << lg);
-                        const uint32_t bhi = __shfl(khi, src), blo = __shfl(klo, src);
-                        if (ln < nc) e_key[ew & 0xFFFFu] = node_key(bhi, blo, (uint32_t)(int32_t)(int16_t)(ew >> 16), seg_c + c);
-                    } else {
-                        uint64_t key = ((uint64_t)khi << 32) | klo;
-                        if (g < ngs && j == 0) {
-                            if (acc) { const uint64_t prev = g_best[grel + g]; key = prev < key ? prev : key; }
-                            g_best[grel + g] = key;
-                        }
+                    {   // pass si + kDepth + 1: ids
+                        fq = uniform4(qn);
+                        qn = *reinterpret_cast<const uint4*>(&rec[si + kDepth + 2]);
+                        uint32_t slot, g; bool valid;
+                        decode(fq, slot, g, valid);
+                        p_left = g_left[(fq.y & 0xFFFFu) + g];
+                        p_right = e_right[slot];
+                        p_pk = slot | (g << 16) | (valid ? 0x80000000u : 0u);
+                    }
+                    // pass si
+                    const uint32_t ng = w1 >> 16;
+                    if (w3 & (1u << 30))  // first pass of a step: no minimum yet
+                        for (uint32_t t = ln; t < ng; t += 64) g_best[t] = kDeadKey;
+                    const uint64_t kb = e_key[cpk & 0xFFFFu];
+                    const uint32_t cv = (uint32_t)(int32_t)(int16_t)(cword >> ((cpk >> 24) & 31u));
+                    const bool live = (int32_t)cpk < 0 && (uint32_t)kb != 0xFFFFFFFFu;
+                    const uint64_t key = live ? (((uint64_t)((uint32_t)(kb >> 32) + cv) << 32) | (uint32_t)kb) : kDeadKey;  // wrapping i32 add
+                    __hip_atomic_fetch_min(&g_best[(cpk >> 16) & 0xFFu], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (w3 & (1u << 31)) {  // last pass of the step: its candidates take their group's minimum
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                        if (last) {
-                            for (uint32_t cb = 0; cb < nc; cb += 64) {
-                                const uint32_t ci_ = cb + ln;
-                                if (ci_ < nc) {
-                                    const uint32_t c2 = c_beg + ci_;
-                                    const uint64_t best = g_best[nd_gid[c2] & 0x7Fu];
-                                    const uint32_t ew2 = nd_ew[c2];
-                                    e_key[ew2 & 0xFFFFu] = node_key((uint32_t)(best >> 32), (uint32_t)best, (uint32_t)(int32_t)(int16_t)(ew2 >> 16), seg_c + c2);
-                                }
+                        const uint32_t c_beg = w2 & 0xFFFFu, nc = w2 >> 16, g_beg = w1 & 0xFFFFu;
+                        for (uint32_t cb = 0; cb < nc; cb += 64) {
+                            const uint32_t ci_ = cb + ln;
+                            if (ci_ < nc) {
+                                const uint32_t c = c_beg + ci_;
+                                const uint32_t ew = nd_ew[c];
+                                const uint64_t best = g_best[(uint32_t)nd_g[c] - g_beg];
+                                e_key[ew & 0xFFFFu] = node_key((uint32_t)(best >> 32), (uint32_t)best, (uint32_t)(int32_t)(int16_t)(ew >> 16), seg_c + c);
                             }
                         }
                     }
@@ -1665,7 +1558,6 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
                     __builtin_amdgcn_wave_barrier();
                 }
             }
-            __syncthreads();
         }
         PROF_MARK(6);
 
@@ -1680,7 +1572,8 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
         uint32_t i0 = 0, m_out = 0;
         if (!last_seg) {
             // the interface: nodes ending exactly at the cut
-            i0 = end_off[n]; m_out = end_off[n + 1] - i0;
+            i0 = (rend.y & 0xFFFFu) - sb;
+            m_out = E - i0;
             if (m_out > 64 * kCarry || m_out == 0) {  // more nodes end here than the carry holds: cut earlier
                 if (seg_b > seg_a + 1 && m_out) { cap_b = seg_b - 1; __syncthreads(); continue; }
                 fail = 32; break;
@@ -1692,14 +1585,15 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
             // (left_id 0) against ends[len_char].  Only inserted ("live") nodes exist in the reference's lists.
             // A segment is counted once it is final (its interface fits the carry); s_counted[sid] remembers how far
             // the sentence has been counted, so a retry in an escape tier or in the fused kernel never counts a step twice.
-            for (uint32_t k = 0; k < S; ++k) {
-                const uint32_t v = __builtin_amdgcn_readfirstlane(sp[k]);
-                const bool eos_step = last_seg && k + 1 == S;
-                const uint32_t p = eos_step ? n : (v & 0xFFFFu), sw = v >> 16;  // EOS pairs with ends[len_char]
-                if ((eos_step ? nT : seg_a + p) < counted) continue;
-                const uint32_t p_beg = __builtin_amdgcn_readfirstlane(end_off[p]), p_end = __builtin_amdgcn_readfirstlane(end_off[p + 1]);
-                uint32_t c_beg = C, nc = 1;
-                if (!eos_step) { c_beg = __builtin_amdgcn_readfirstlane((uint32_t)cand_off[sw]); nc = __builtin_amdgcn_readfirstlane((uint32_t)cand_off[sw + 1]) - c_beg; }
+            const uint32_t c_skip = counted >= nT ? CT : __builtin_amdgcn_readfirstlane(pcg[counted].x) & 0xFFFFu;  // candidates are in start order
+            for (uint32_t k = 0; k < SL; ++k) {
+                const uint4 r = uniform4(*reinterpret_cast<const uint4*>(&rec[k]));
+                if (!(r.w & (1u << 30))) continue;  // one record per step
+                const uint32_t c_beg = r.z & 0xFFFFu, nc = r.z >> 16;
+                const bool eos_step = last_seg && c_beg == C;
+                if (eos_step ? counted > nT : seg_c + c_beg < c_skip) continue;
+                uint32_t p_beg = r.x & 0xFFFFu, p_end = p_beg + (r.x >> 16);
+                if (eos_step) { p_beg = (rend.y & 0xFFFFu) - sb; p_end = E; }  // EOS pairs with ends[len_char]
                 uint32_t live = 0;
                 for (uint32_t j0 = p_beg; j0 < p_end; j0 += 64) {
                     const uint32_t j = j0 + ln;
@@ -1707,7 +1601,7 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
                     live += (uint32_t)__popcll(__ballot(alive));
                     if (alive) atomicAdd(&A.rid_count[e_right[j]], (unsigned long long)nc);
                 }
-                for (uint32_t c = c_beg + ln; c < c_beg + nc; c += 64) atomicAdd(&A.lid_count[nd_left[c]], (unsigned long long)live);
+                for (uint32_t c = c_beg + ln; c < c_beg + nc; c += 64) atomicAdd(&A.lid_count[g_left[nd_g[c]]], (unsigned long long)live);
             }
             const uint32_t upto = last_seg ? nT + 1 : seg_b;
             if (upto > counted) { counted = upto; if (ln == 0) A.s_counted[sid] = counted; }
@@ -1719,16 +1613,28 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
                 carry_right[q] = q * 64 + ln < m_out ? (uint32_t)e_right[i0 + q * 64 + ln] : 0u;
             }
             m_in = m_out;
-            seg_a = seg_b; seg_c += C; seg_g += G; seg_p += seg_pass; cap_b = nT;
+            seg_a = seg_b; seg_c += C; seg_g += G; seg_p += seg_pass; seg_s = rend.y & 0xFFFFu; cap_b = nT;
             __syncthreads();
             continue;
         }
         done = true;
 
-        // ---- back-trace + token records ----
+        // ---- back-trace + token records (append_top_nodes lattice.rs:159-168, token.rs:21-92) ----
+        // A token starts where its best predecessor ends -- behind the space run there, if that position is a skipped
+        // space (tokenizer.rs:113-125) -- so a lane needs its own candidate record and the previous token's.
         uint32_t T = 0, out_base = 0;
+        const uint16_t* __restrict__ c2b = A.g_c2b + slot0;
+        auto start_of = [&](uint32_t prev_end) {
+            if constexpr (kSpaceMode) {
+                if (prev_end < nT) {
+                    const uint4 rp = pcg[prev_end];
+                    if (rp.y >> 31) return prev_end + rp.z;
+                }
+            }
+            return prev_end;
+        };
         if (!multi) {
-            uint16_t* path = reinterpret_cast<uint16_t*>(lens);  // the length masks are dead now; tokens <= chars
+            uint16_t* path = reinterpret_cast<uint16_t*>(rec);  // the pass records are dead now; tokens <= steps
             if (ln == 0) {
                 uint32_t seq = key_back(e_key[E]);
                 while (seq != kBosSeq && T < n) {
@@ -1744,22 +1650,17 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
                 if (ln == 0) { atomicOr(&A.ctrl[kError], (uint32_t)kErrTokCap); A.tok_off[sid] = 0; A.tok_cnt[sid] = 0; }
             } else {
                 if (ln == 0) { A.tok_off[sid] = out_base; A.tok_cnt[sid] = T; }
-                const uint16_t* __restrict__ c2b = A.g_c2b + slot0;
                 for (uint32_t t = ln; t < T; t += 64) {
                     const uint32_t c = path[T - 1 - t];
-                    uint32_t lo = 0, hi = n;
-                    while (lo < hi) {
-                        const uint32_t mid = (lo + hi) >> 1;
-                        if ((uint32_t)cand_off[mid + 1] <= c) lo = mid + 1; else hi = mid;
-                    }
-                    const uint4 rec = nd[c];
-                    const uint32_t stp = lo, en = rec.y >> 16;
-                    vbt_token_rec r;
-                    r.start_char = stp; r.end_char = en;
-                    r.start_byte = c2b[stp]; r.end_byte = c2b[en];
-                    r.word_idx = rec.z;
-                    r.total_cost = (int32_t)key_cost(e_key[nd_ew[c] & 0xFFFFu]);
-                    A.tokens[out_base + t] = r;
+                    const uint4 r = nd[c];
+                    const uint32_t prev_end = t ? nd[path[T - t]].w >> 16 : 0u;
+                    const uint32_t stp = start_of(prev_end), en = r.w >> 16;
+                    vbt_token_rec o;
+                    o.start_char = stp; o.end_char = en;
+                    o.start_byte = c2b[stp]; o.end_byte = c2b[en];
+                    o.word_idx = r.z;
+                    o.total_cost = (int32_t)key_cost(e_key[nd_ew[c] & 0xFFFFu]);
+                    A.tokens[out_base + t] = o;
                 }
             }
         } else {
@@ -1808,24 +1709,17 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
                 if (ln == 0) { atomicOr(&A.ctrl[kError], (uint32_t)kErrTokCap); A.tok_off[sid] = 0; A.tok_cnt[sid] = 0; }
             } else {
                 if (ln == 0) { A.tok_off[sid] = out_base; A.tok_cnt[sid] = T; }
-                const uint16_t* __restrict__ c2b = A.g_c2b + slot0;
-                const uint4* __restrict__ pcg = A.g_pc + slot0;
-                const uint4* __restrict__ ndg = A.g_nd + node0;
                 for (uint32_t t = ln; t < T; t += 64) {
                     const uint32_t c = path[T - 1 - t];
-                    uint32_t lo = 0, hi = nT;
-                    while (lo < hi) {
-                        const uint32_t mid = (lo + hi) >> 1;
-                        if ((pcg[mid + 1].x & 0xFFFFu) <= c) lo = mid + 1; else hi = mid;
-                    }
-                    const uint4 rec = ndg[c];
-                    const uint32_t stp = lo, en = rec.y >> 16;
-                    vbt_token_rec r;
-                    r.start_char = stp; r.end_char = en;
-                    r.start_byte = c2b[stp]; r.end_byte = c2b[en];
-                    r.word_idx = rec.z;
-                    r.total_cost = (int32_t)nbg[2 * c].x;
-                    A.tokens[out_base + t] = r;
+                    const uint4 r = ndg[c];
+                    const uint32_t prev_end = t ? ndg[path[T - t]].w >> 16 : 0u;
+                    const uint32_t stp = start_of(prev_end), en = r.w >> 16;
+                    vbt_token_rec o;
+                    o.start_char = stp; o.end_char = en;
+                    o.start_byte = c2b[stp]; o.end_byte = c2b[en];
+                    o.word_idx = r.z;
+                    o.total_cost = (int32_t)nbg[2 * c].x;
+                    A.tokens[out_base + t] = o;
                 }
             }
         }
@@ -1848,7 +1742,6 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
         }
 #undef PROF_MARK
         __syncthreads();
-    }
     }
 }
 
