@@ -680,27 +680,26 @@ __device__ __forceinline__ uint64_t process_sentence(const DevDict& D, const Bat
 // prefetch distance of the matrix gathers of lattice_lds in passes (= unroll factor of its sweep loop).  2..8 measure the
 // same within 3 % on a full batch (other waves hide the latency); 8 keeps a lone sentence's sweep off the HBM latency.
 #ifndef VBT_DEPTH
-#define VBT_DEPTH 8
+#define VBT_DEPTH 7
 #endif
 #ifndef VBT_LAT_WAVES
 #define VBT_LAT_WAVES 4
 #endif
-// One pass of the fused gather+recurrence loop of lattice_lds: up to 64 (left-id group, predecessor) lanes of one step.
-//   w0 = first end-list slot of the step's predecessors | their number << 16
-//   w1 = first left-id group of the step | number of groups << 16
-//   w2 = first candidate of the step | number of candidates << 16
-//   w3 = pair offset of the pass (lane ln handles padded pair q0 + ln) | lg << 24 | first pass of its step << 30 | last << 31
-// Padded pair q = (group g = q >> lg, predecessor j = q & (2^lg - 1)), 2^lg >= the number of predecessors.
-struct alignas(16) LPass { uint32_t w0, w1, w2, w3; };
-constexpr uint32_t kPassPad = 2 * VBT_DEPTH + 3;  // empty passes behind the last one: the software pipeline reads ahead without bounds checks
+// One pass of the fused gather+recurrence loop of lattice_lds: 64 lanes = 64 padded (left-id group g, predecessor j)
+// pairs of one sweep step, pair q = q0 + lane, g = q >> lg, j = q & (2^lg - 1), 2^lg >= the number of predecessors.
+// The record is built once per pass by the lane that owns the step, so everything a pass needs is precomputed: LDS
+// byte addresses (of the first predecessor's right id and key, of the first group's left id, of the first candidate),
+// the mask of the lanes that hold a real pair, and the step's shape.
+//   meta = lg | first pass of its step << 5 | last << 6 | simple << 7 | candidates of the step << 8
+//   (simple: the step is this pass alone and has fewer than 64 candidates and at most 64 groups)
+struct alignas(16) LPass { uint32_t baseR, baseK, baseL, q0, mlo, mhi, baseC, meta; };
 
 // LDS bytes of the lattice arrays of lattice_lds for a (segment of a) sentence with C candidates in G left-id groups
 // (at most ngmax per position), `passes` passes and m_in nodes ending at its first position.  Must over-estimate the
 // Arena carve there; gen_candidates routes sentences to LDS tiers with it.
 __host__ __device__ __forceinline__ uint64_t lattice_fixed_bytes(uint32_t C, uint32_t G, uint32_t ngmax, uint32_t passes, uint32_t m_in) {
     const uint64_t E = (uint64_t)C + m_in;
-    return 8 * (E + 1) + 8 * (ngmax + 1ull) + 4 * (C + 1ull) + sizeof(LPass) * (passes + (uint64_t)kPassPad) + 2 * (E + 1) + 2 * (C + 1ull) +
-           2 * (G + 1ull) + 64;  // + alignment slack
+    return 8ull * (ngmax < 64 ? 64 : ngmax + 1) + 8 * (E + 1) + 8 * (C + 1ull) + 2 * (E + 1) + 2 * (G + 1ull) + sizeof(LPass) * (passes + 2ull) + 64;
 }
 
 // =====================================================================================
@@ -992,11 +991,11 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
                         for (uint32_t q = 0; q < 4; ++q) {
                             if (t0 + q < c) {
                                 const uint32_t k = dest + t0 + q;
+                                // (the group half of the second word is written by the grouping pass below: disjoint bytes)
                                 uint32_t* rec = reinterpret_cast<uint32_t*>(&A.g_nd[base + k]);
-                                rec[0] = e[q].left_right;
-                                rec[1] = (e[q].cost & 0xFFFFu) | ((slot0 + t0 + q) << 16);
-                                rec[2] = (lex << 30) | e[q].word_id;
-                                reinterpret_cast<uint16_t*>(rec)[7] = (uint16_t)end;  // (the low half of this word is the group, below)
+                                rec[0] = (e[q].left_right >> 16) | ((slot0 + t0 + q) << 16);
+                                reinterpret_cast<uint16_t*>(rec)[2] = (uint16_t)e[q].cost;
+                                A.g_em[base + k] = make_uint2((lex << 30) | e[q].word_id, end);
                                 cleft[k - cbase] = (uint16_t)(e[q].left_right & 0xFFFFu);
                             }
                         }
@@ -1037,10 +1036,13 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
             const uint32_t ex = wave_exscan(ng, tot);
             if (i < r1) {
                 goff[i] = (uint16_t)(G + ex);
-                // sentence-wide group number of every candidate (groups are numbered in order of first appearance)
+                // every candidate gets its group within the position; the group's left id goes to the sentence-wide group table
                 const uint32_t kb = cand_off[i], ke = cand_off[i + 1];
-                for (uint32_t k = kb; k < ke; ++k)
-                    reinterpret_cast<uint16_t*>(&A.g_nd[base + k])[6] = (uint16_t)(G + ex + (cgid[k - cbase] & 0x7Fu));
+                for (uint32_t k = kb; k < ke; ++k) {
+                    const uint32_t gid = cgid[k - cbase];
+                    reinterpret_cast<uint16_t*>(&A.g_nd[base + k])[3] = (uint16_t)(gid & 0x7Fu);
+                    if (gid & 0x80u) A.g_gl[base + G + ex + (gid & 0x7Fu)] = cleft[k - cbase];
+                }
             }
             G += tot;
             uint32_t m = ng;
@@ -1256,7 +1258,8 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
         const size_t slot0 = sentence_slot(A, uniform64(A.offsets[sid]), sid);
         const size_t node0 = (size_t)A.node_factor * slot0;
         const uint4* __restrict__ pcg = A.g_pc + slot0;   // per-character records (+ the terminator at nT)
-        const uint4* __restrict__ ndg = A.g_nd + node0;   // candidate records in insertion order
+        const uint2* __restrict__ ndg = A.g_nd + node0;   // candidate records in insertion order (sweep part)
+        const uint2* __restrict__ em = A.g_em + node0;    // (token part)
         const uint32_t ET = __builtin_amdgcn_readfirstlane(pcg[nT].z);  // end-list slots of the sentence (BOS included)
         const uint32_t kBosSeq = CT + 1;
         // A sentence whose lattice does not fit this tier's LDS is swept in segments that end at clean cuts
@@ -1315,26 +1318,27 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
         const uint32_t C = ((rend.x & 0xFFFFu) - seg_c) & 0xFFFFu, G = ((rend.x >> 16) - seg_g) & 0xFFFFu;
         const uint32_t E = m_in + C;  // end-list slots: interface (BOS) + the segment's candidates; slot E is the EOS node's
         const uint32_t sb = seg_s;    // sentence-global slot of local slot 0
-        const uint4* __restrict__ nd = ndg + seg_c;
+        const uint2* __restrict__ nd = ndg + seg_c;
 
         Arena ar{g_smem, lds_bytes, 0, true};
+        uint64_t* g_best = ar.take<uint64_t>(ngmax < 64 ? 64 : ngmax + 1);  // per step: best key of each left-id group (offset 0)
         uint64_t* e_key = ar.take<uint64_t>(E + 1);       // end-major packed (cost, sequence, back pointer) keys
-        uint64_t* g_best = ar.take<uint64_t>(ngmax + 1);  // per step: best key of each left-id group
-        uint32_t* nd_ew = ar.take<uint32_t>(C + 1);       // per candidate: end-list slot | (u16) word_cost << 16
+        uint2* cnd = ar.take<uint2>(C + 1);               // per candidate: {end-list slot | (u16) word_cost << 16, group * 8 | (0xFFFE - sequence) << 16}
         uint16_t* e_right = ar.take<uint16_t>(E + 1);
-        uint16_t* nd_g = ar.take<uint16_t>(C + 1);        // per candidate: its left-id group (segment-relative)
         uint16_t* g_left = ar.take<uint16_t>(G + 1);
         ar.used = (ar.used + 15) & ~15ull;
         LPass* rec = reinterpret_cast<LPass*>(g_smem + ar.used);  // pass records take the rest; afterwards the token path
         const uint32_t sl_cap = ar.ok && lds_bytes > ar.used ? (uint32_t)((lds_bytes - ar.used) / sizeof(LPass)) : 0u;
-        if (!ar.ok || sl_cap < kPassPad + 2) {  // the estimate was too low: try a shorter segment before giving up
+        if (!ar.ok || sl_cap < 3) {  // the estimate was too low: try a shorter segment before giving up
             if (budget > lds_bytes / 3) { budget -= lds_bytes / 4; __syncthreads(); continue; }
             fail = 26; break;
         }
+        const uint32_t offK = (uint32_t)(reinterpret_cast<char*>(e_key) - g_smem), offC = (uint32_t)(reinterpret_cast<char*>(cnd) - g_smem);
+        const uint32_t offR = (uint32_t)(reinterpret_cast<char*>(e_right) - g_smem), offL = (uint32_t)(reinterpret_cast<char*>(g_left) - g_smem);
 
-        // ---- load: candidates from global (every record carries its slot and group); interface; EOS ----
-        for (uint32_t c0 = 0; c0 < C; c0 += 64 * 4) {  // 4 independent 16-byte loads per lane in flight
-            uint4 r[4];
+        // ---- load: candidates from global (every record carries its slot and group); group left ids; interface; EOS ----
+        for (uint32_t c0 = 0; c0 < C; c0 += 64 * 4) {  // 4 independent 8-byte loads per lane in flight
+            uint2 r[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const uint32_t c = c0 + u * 64 + ln;
@@ -1344,21 +1348,23 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
             for (int u = 0; u < 4; ++u) {
                 const uint32_t c = c0 + u * 64 + ln;
                 if (c < C) {
-                    const uint32_t es = (r[u].y >> 16) - sb, g = ((r[u].w & 0xFFFFu) - seg_g) & 0xFFFFu;
-                    e_right[es] = (uint16_t)(r[u].x >> 16);
+                    const uint32_t es = (r[u].x >> 16) - sb;
+                    e_right[es] = (uint16_t)r[u].x;
                     e_key[es] = kDeadKey;  // never inserted until a sweep step reaches its start position
-                    nd_ew[c] = es | (r[u].y << 16);
-                    nd_g[c] = (uint16_t)g;
-                    g_left[g] = (uint16_t)(r[u].x & 0xFFFFu);  // (all candidates of a group write the same id)
+                    cnd[c] = make_uint2(es | (r[u].y << 16), ((r[u].y >> 16) << 3) | ((0xFFFEu - (seg_c + c)) << 16));
                 }
             }
+        }
+        {
+            const uint16_t* __restrict__ gl = A.g_gl + node0 + seg_g;
+            for (uint32_t g = ln; g < G; g += 64) g_left[g] = gl[g];
         }
 #pragma unroll
         for (uint32_t q = 0; q < kCarry; ++q)
             if (q * 64 + ln < m_in) { e_right[q * 64 + ln] = (uint16_t)carry_right[q]; e_key[q * 64 + ln] = carry_key[q]; }
         if (ln == 0) {
-            nd_ew[C] = E;  // EOS pseudo candidate (insert_eos, lattice.rs:85-101): left_id 0, word cost 0, its own group G
-            nd_g[C] = (uint16_t)G;
+            // EOS pseudo candidate (insert_eos, lattice.rs:85-101): left_id 0, word cost 0, the only member of group G
+            cnd[C] = make_uint2(E, (0xFFFEu - (seg_c + C)) << 16);
             g_left[G] = 0;
             e_key[E] = kDeadKey;
         }
@@ -1375,6 +1381,25 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
         // contiguously (exclusive scan of the pass counts).
         uint32_t SL = 0, S = 0, sn_eos = n;
         bool windowed = true, overflow = false;
+        // the q-th of the nsl passes of a step (executed by the lane that owns the step)
+        auto make_pass = [&](uint32_t p_beg, uint32_t np, uint32_t g_beg, uint32_t ng, uint32_t c_beg, uint32_t nc, uint32_t lg, uint32_t q, uint32_t nsl) {
+            const uint32_t q0 = q << 6;
+            uint64_t mask;
+            if (lg >= 6) {  // one group per pass, 64 of its predecessors at a time
+                const uint32_t j0 = q0 & ((1u << lg) - 1u);
+                const uint32_t cnt = np > j0 ? (np - j0 < 64 ? np - j0 : 64u) : 0u;
+                mask = cnt >= 64 ? ~0ull : (1ull << cnt) - 1ull;
+            } else {        // 64 >> lg groups per pass, np of every 2^lg lanes hold a pair
+                const uint32_t g0 = q0 >> lg, gs = ng - g0 < (64u >> lg) ? ng - g0 : (64u >> lg);
+                const uint64_t one = lg == 0 ? ~0ull : lg == 1 ? 0x5555555555555555ull : lg == 2 ? 0x1111111111111111ull : lg == 3 ? 0x0101010101010101ull
+                                   : lg == 4 ? 0x0001000100010001ull : 0x0000000100000001ull;
+                const uint32_t span = gs << lg;
+                mask = (one & (span >= 64 ? ~0ull : (1ull << span) - 1ull)) * (uint64_t)((1ull << np) - 1ull);  // no carries: np <= 2^lg
+            }
+            const bool simple = nsl == 1 && nc < 64 && ng <= 64;
+            return LPass{offR + (p_beg << 1), offK + (p_beg << 3), offL + (g_beg << 1), q0, (uint32_t)mask, (uint32_t)(mask >> 32), offC + (c_beg << 3),
+                         lg | (q == 0 ? 32u : 0u) | (q + 1 == nsl ? 64u : 0u) | (simple ? 128u : 0u) | (nc << 8)};
+        };
         {
             uint32_t cur0 = 0;
 #pragma unroll
@@ -1434,12 +1459,9 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
                 const uint32_t nsl = step ? (uint32_t)((((uint64_t)ng << lg) + 63) >> 6) : 0u;
                 uint32_t tot;
                 const uint32_t ex = wave_exscan(nsl, tot);
-                if (SL + tot + kPassPad > sl_cap) overflow = true;
-                if (!overflow) {
-                    for (uint32_t q = 0; q < nsl; ++q)
-                        rec[SL + ex + q] = LPass{p_beg | (np << 16), g_beg | (ng << 16), c_beg | (nc << 16),
-                                                 (q << 6) | (lg << 24) | (q == 0 ? 1u << 30 : 0u) | (q + 1 == nsl ? 1u << 31 : 0u)};
-                }
+                if (SL + tot + 2 > sl_cap) overflow = true;
+                if (!overflow)
+                    for (uint32_t q = 0; q < nsl; ++q) rec[SL + ex + q] = make_pass(p_beg, np, g_beg, ng, c_beg, nc, lg, q, nsl);
                 SL += tot;
                 S += (uint32_t)__popcll(any);
             }
@@ -1452,10 +1474,9 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
             const uint32_t p_beg = y0 - sb, np = y1 - y0;
             const uint32_t lg = np <= 1 ? 0u : 32u - (uint32_t)__builtin_clz(np - 1);
             const uint32_t nsl = ((1u << lg) + 63) >> 6;
-            if (SL + nsl + kPassPad > sl_cap) overflow = true;
+            if (SL + nsl + 2 > sl_cap) overflow = true;
             if (!overflow)
-                for (uint32_t q = ln; q < nsl; q += 64)
-                    rec[SL + q] = LPass{p_beg | (np << 16), G | (1u << 16), C | (1u << 16), (q << 6) | (lg << 24) | (q == 0 ? 1u << 30 : 0u) | (q + 1 == nsl ? 1u << 31 : 0u)};
+                for (uint32_t q = ln; q < nsl; q += 64) rec[SL + q] = make_pass(p_beg, np, G, 1u, C, 1u, lg, q, nsl);
             SL += nsl;
             ++S;
         } else if (sn_eos != n) { fail = 31; break; }  // cannot happen: a trailing space run spans every later cut
@@ -1464,8 +1485,8 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
             if (budget > lds_bytes / 3) { budget -= lds_bytes / 4; __syncthreads(); continue; }
             fail = 29; break;
         }
-        // pad with empty passes (one predecessor, no group: no lane is valid) so the pipelined loop needs no bounds branches
-        if (ln < kPassPad) rec[SL + ln] = LPass{1u << 16, 0u, 0u, 0u};
+        // one empty pass behind the last one (no lane holds a pair): the software pipeline reads ahead up to it
+        if (ln == 0) rec[SL] = LPass{offR, offK, offL, 0u, 0u, 0u, offC, 0u};
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         PROF_MARK(4);
@@ -1473,89 +1494,102 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
         // ---- fused gather + cost recurrence (matrix_connector.rs:79-85, lattice.rs:103-151) ----
         {
             const uint32_t* __restrict__ matrix32 = reinterpret_cast<const uint32_t*>(D.matrix);
-            uint32_t ring[kDepth];  // ring[u]: the aligned 32-bit word holding this lane's i16 cell of pass (s0 + u)
-            uint32_t pk[kDepth];    // this lane's pair of that pass: slot | group within the step << 16 | cell parity * 16 << 24 | valid << 31
-            uint32_t sc[kDepth], sg[kDepth], sf[kDepth];  // (wave-uniform) record words w2, w1, w3 of that pass
-            // the lane's pair of a pass: end-list slot of its predecessor, its group, validity
-            auto decode = [&](const uint4& r, uint32_t& slot, uint32_t& g, bool& valid) {
-                const uint32_t p_beg = r.x & 0xFFFFu, np = r.x >> 16, ng = r.y >> 16, lg = (r.w >> 24) & 31u;
-                const uint32_t q = (r.w & 0xFFFFFFu) + ln;
-                const uint32_t gg = q >> lg, j = q & ((1u << lg) - 1u);
-                valid = gg < ng && j < np;
-                g = valid ? gg : 0u;
-                slot = p_beg + (valid ? j : 0u);
+            // lane-wise select by a wave-uniform 64-bit lane mask held in SGPRs: bit ? b : a
+            auto select_mask = [](uint64_t mask, uint32_t a, uint32_t b) {
+                uint32_t out;
+                asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(out) : "v"(a), "v"(b), "s"(mask));
+                return out;
             };
-            auto gather = [&](uint32_t left, uint32_t right, uint32_t& word, uint32_t& par) {
-                const uint32_t cell = __umul24(left, NR) + right;  // < 2^32: num_left, num_right <= 65535
-                word = load_policy<VBT_NT_MATRIX != 0>(&matrix32[cell >> 1]);  // (a 16-bit destination would be packed by the compiler and serialise the loads)
-                par = (cell & 1u) << 4;
+            // Software pipeline over a ring of kRing = kDepth + 1 slots, pass p lives in slot p % kRing from its stage A
+            // (record -> this lane's pair -> addresses, ids read from LDS; at iteration p - kRing) over its stage B (gather
+            // of the pair's connection cost; at iteration p - kDepth) to its execution.  The loop is unrolled kRing
+            // times, so every slot index is static and nothing is copied from slot to slot.
+            constexpr uint32_t kRing = kDepth + 1;
+            uint32_t word[kRing], csh[kRing], keyaddr[kRing], gaddr[kRing];  // VGPRs: cost word in flight, shift that brings the cell down, LDS addresses
+            uint32_t smlo[kRing], smhi[kRing], sbc[kRing], smeta[kRing];      // SGPRs (wave-uniform): lane mask, first candidate, shape
+            uint32_t a_left = 0, a_right = 0;                                // ids of the pass whose stage B is next
+            auto stage_a = [&](uint32_t idx, uint32_t u) {
+                const uint4 r0 = *reinterpret_cast<const uint4*>(&rec[idx]);  // (every lane reads the same record: broadcast)
+                const uint4 r1 = *(reinterpret_cast<const uint4*>(&rec[idx]) + 1);
+                const uint32_t lg = r1.w & 31u;
+                const uint32_t q = ln + r0.w, gg = q >> lg, j = q & ((1u << lg) - 1u);
+                a_left = *reinterpret_cast<const uint16_t*>(g_smem + r0.z + (gg << 1));
+                a_right = *reinterpret_cast<const uint16_t*>(g_smem + r0.x + (j << 1));
+                keyaddr[u] = r0.y + (j << 3);
+                gaddr[u] = gg << 3;
+                smlo[u] = __builtin_amdgcn_readfirstlane(r1.x); smhi[u] = __builtin_amdgcn_readfirstlane(r1.y);
+                sbc[u] = __builtin_amdgcn_readfirstlane(r1.z); smeta[u] = __builtin_amdgcn_readfirstlane(r1.w);
+            };
+            // stage B: the gather (lanes without a pair load cell 0)
+            auto stage_b = [&](uint32_t u) {
+                const uint64_t mask = ((uint64_t)smhi[u] << 32) | smlo[u];
+                const uint32_t cell = select_mask(mask, 0u, __umul24(a_left, NR) + a_right);  // < 2^32: num_left, num_right <= 65535
+                word[u] = load_policy<VBT_NT_MATRIX != 0>(&matrix32[cell >> 1]);  // (a 16-bit destination would be packed by the compiler and serialise the loads)
+                csh[u] = cell << 4;  // shift count = its low 5 bits: 16 for an odd cell
             };
 #pragma unroll
-            for (uint32_t u = 0; u < kDepth; ++u) {  // passes >= SL are empty padding
-                const uint4 r = uniform4(*reinterpret_cast<const uint4*>(&rec[u]));
-                uint32_t slot, g, par; bool valid;
-                decode(r, slot, g, valid);
-                gather(g_left[(r.y & 0xFFFFu) + g], e_right[slot], ring[u], par);
-                pk[u] = slot | (g << 16) | (par << 24) | (valid ? 0x80000000u : 0u);
-                sc[u] = r.z; sg[u] = r.y; sf[u] = r.w;
+            for (uint32_t u = 0; u < kRing; ++u) {  // passes > SL do not exist: they re-read the empty one
+                stage_a(u < SL ? u : SL, u);
+                if (u + 1 < kRing) stage_b(u);
             }
-            // two-stage prefetch: the ids of pass si + kDepth + 1 are read from LDS while pass si runs, the gather of
-            // pass si + kDepth is issued from the ids read one pass earlier: no LDS wait in front of the global load
-            uint4 fq = uniform4(*reinterpret_cast<const uint4*>(&rec[kDepth]));
-            uint32_t p_left, p_right, p_pk;
-            {
-                uint32_t slot, g; bool valid;
-                decode(fq, slot, g, valid);
-                p_left = g_left[(fq.y & 0xFFFFu) + g];
-                p_right = e_right[slot];
-                p_pk = slot | (g << 16) | (valid ? 0x80000000u : 0u);
-            }
-            uint4 qn = *reinterpret_cast<const uint4*>(&rec[kDepth + 1]);
-            for (uint32_t s0 = 0; s0 < SL; s0 += kDepth) {
+            for (uint32_t s0 = 0; s0 < SL; s0 += kRing) {
 #pragma unroll
-                for (uint32_t u = 0; u < kDepth; ++u) {
+                for (uint32_t u = 0; u < kRing; ++u) {
                     const uint32_t si = s0 + u;
-                    const uint32_t cword = ring[u], cpk = pk[u], w2 = sc[u], w1 = sg[u], w3 = sf[u];
-                    {   // pass si + kDepth: gather into the ring slot just consumed
-                        uint32_t par;
-                        gather(p_left, p_right, ring[u], par);
-                        pk[u] = p_pk | (par << 24);
-                        sc[u] = fq.z; sg[u] = fq.y; sf[u] = fq.w;
-                    }
-                    {   // pass si + kDepth + 1: ids
-                        fq = uniform4(qn);
-                        qn = *reinterpret_cast<const uint4*>(&rec[si + kDepth + 2]);
-                        uint32_t slot, g; bool valid;
-                        decode(fq, slot, g, valid);
-                        p_left = g_left[(fq.y & 0xFFFFu) + g];
-                        p_right = e_right[slot];
-                        p_pk = slot | (g << 16) | (valid ? 0x80000000u : 0u);
-                    }
-                    // pass si
-                    const uint32_t ng = w1 >> 16;
-                    if (w3 & (1u << 30))  // first pass of a step: no minimum yet
-                        for (uint32_t t = ln; t < ng; t += 64) g_best[t] = kDeadKey;
-                    const uint64_t kb = e_key[cpk & 0xFFFFu];
-                    const uint32_t cv = (uint32_t)(int32_t)(int16_t)(cword >> ((cpk >> 24) & 31u));
-                    const bool live = (int32_t)cpk < 0 && (uint32_t)kb != 0xFFFFFFFFu;
-                    const uint64_t key = live ? (((uint64_t)((uint32_t)(kb >> 32) + cv) << 32) | (uint32_t)kb) : kDeadKey;  // wrapping i32 add
-                    __hip_atomic_fetch_min(&g_best[(cpk >> 16) & 0xFFu], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (w3 & (1u << 31)) {  // last pass of the step: its candidates take their group's minimum
+                    stage_b((u + kDepth) % kRing);  // gather of pass si + kDepth
+                    const uint32_t cword = word[u], csh_ = csh[u], ka = keyaddr[u], ga = gaddr[u];
+                    const uint64_t mask = ((uint64_t)smhi[u] << 32) | smlo[u];
+                    const uint32_t bc = sbc[u], meta = smeta[u];
+                    // ---- pass si ----
+                    const uint32_t nc = meta >> 8;
+                    if (meta & 128u) {
+                        // the whole step in one pass (the common case): clear the minima, fold the pairs, hand out the results
+                        g_best[ln] = kDeadKey;
+                        const uint64_t kb = *reinterpret_cast<const uint64_t*>(g_smem + ka);
+                        const uint32_t khi = (uint32_t)(kb >> 32) + (uint32_t)(int32_t)(int16_t)(cword >> (csh_ & 31u));  // wrapping i32 add
+                        const uint64_t live = __ballot((uint32_t)kb != 0xFFFFFFFFu) & mask;
+                        const uint64_t key = ((uint64_t)select_mask(live, 0xFFFFFFFFu, khi) << 32) | select_mask(live, 0xFFFFFFFFu, (uint32_t)kb);
+                        __hip_atomic_fetch_min(static_cast<uint64_t*>(__builtin_assume_aligned(g_smem + ga, 8)), key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                        const uint32_t c_beg = w2 & 0xFFFFu, nc = w2 >> 16, g_beg = w1 & 0xFFFFu;
-                        for (uint32_t cb = 0; cb < nc; cb += 64) {
-                            const uint32_t ci_ = cb + ln;
-                            if (ci_ < nc) {
-                                const uint32_t c = c_beg + ci_;
-                                const uint32_t ew = nd_ew[c];
-                                const uint64_t best = g_best[(uint32_t)nd_g[c] - g_beg];
-                                e_key[ew & 0xFFFFu] = node_key((uint32_t)(best >> 32), (uint32_t)best, (uint32_t)(int32_t)(int16_t)(ew >> 16), seg_c + c);
+                        if (ln < nc) {
+                            const uint2 cd = *reinterpret_cast<const uint2*>(g_smem + bc + (ln << 3));
+                            const uint64_t best = *reinterpret_cast<const uint64_t*>(g_smem + (cd.y & 0xFFFFu));
+                            const uint32_t hi = (uint32_t)(best >> 32) + (uint32_t)(int32_t)(int16_t)(cd.x >> 16);  // lattice.rs:125
+                            const uint32_t lo = (cd.y & 0xFFFF0000u) | (0xFFFEu - ((uint32_t)best >> 16));
+                            *reinterpret_cast<uint64_t*>(g_smem + offK + ((cd.x & 0xFFFFu) << 3)) = ((uint64_t)hi << 32) | lo;
+                        }
+                    } else {
+                        // a step of several passes, or with many candidates / groups
+                        if (meta & 32u) {  // first pass: no minimum yet
+                            const uint32_t ng_hi = ngmax + 1;
+                            for (uint32_t t = ln; t < ng_hi; t += 64) g_best[t] = kDeadKey;
+                        }
+                        const uint64_t kb = *reinterpret_cast<const uint64_t*>(g_smem + ka);
+                        const uint32_t khi = (uint32_t)(kb >> 32) + (uint32_t)(int32_t)(int16_t)(cword >> (csh_ & 31u));
+                        const uint64_t live = __ballot((uint32_t)kb != 0xFFFFFFFFu) & mask;
+                        const uint64_t key = ((uint64_t)select_mask(live, 0xFFFFFFFFu, khi) << 32) | select_mask(live, 0xFFFFFFFFu, (uint32_t)kb);
+                        __hip_atomic_fetch_min(static_cast<uint64_t*>(__builtin_assume_aligned(g_smem + ga, 8)), key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        if (meta & 64u) {  // last pass of the step: its candidates take their group's minimum
+                            for (uint32_t cb = 0; cb < nc; cb += 64) {
+                                const uint32_t ci_ = cb + ln;
+                                if (ci_ < nc) {
+                                    const uint2 cd = *reinterpret_cast<const uint2*>(g_smem + bc + (ci_ << 3));
+                                    const uint64_t best = *reinterpret_cast<const uint64_t*>(g_smem + (cd.y & 0xFFFFu));
+                                    const uint32_t hi = (uint32_t)(best >> 32) + (uint32_t)(int32_t)(int16_t)(cd.x >> 16);
+                                    const uint32_t lo = (cd.y & 0xFFFF0000u) | (0xFFFEu - ((uint32_t)best >> 16));
+                                    *reinterpret_cast<uint64_t*>(g_smem + offK + ((cd.x & 0xFFFFu) << 3)) = ((uint64_t)hi << 32) | lo;
+                                }
                             }
                         }
                     }
                     // LDS operations of one wave execute in order: a compiler-level fence is all the next pass needs
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
+                    {   // stage A of pass si + kRing, into the slot just freed
+                        const uint32_t nx = si + kRing;
+                        stage_a(nx < SL ? nx : SL, u);
+                    }
                 }
             }
         }
@@ -1565,7 +1599,7 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
             // leave (total cost, back pointer) of every node of the segment in the sentence's (dead) hit-staging region
             uint2* __restrict__ nb = reinterpret_cast<uint2*>(A.g_hits + node0 + seg_c);
             for (uint32_t c = ln; c < C; c += 64) {
-                const uint64_t k = e_key[nd_ew[c] & 0xFFFFu];
+                const uint64_t k = e_key[cnd[c].x & 0xFFFFu];
                 nb[2 * c] = make_uint2(key_cost(k), key_back(k));
             }
         }
@@ -1587,12 +1621,19 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
             // the sentence has been counted, so a retry in an escape tier or in the fused kernel never counts a step twice.
             const uint32_t c_skip = counted >= nT ? CT : __builtin_amdgcn_readfirstlane(pcg[counted].x) & 0xFFFFu;  // candidates are in start order
             for (uint32_t k = 0; k < SL; ++k) {
-                const uint4 r = uniform4(*reinterpret_cast<const uint4*>(&rec[k]));
-                if (!(r.w & (1u << 30))) continue;  // one record per step
-                const uint32_t c_beg = r.z & 0xFFFFu, nc = r.z >> 16;
+                const uint4 r0 = uniform4(*reinterpret_cast<const uint4*>(&rec[k])), r1 = uniform4(*(reinterpret_cast<const uint4*>(&rec[k]) + 1));
+                if (!(r1.w & 32u)) continue;  // one record per step: its first pass
+                const uint32_t c_beg = (r1.z - offC) >> 3, nc = r1.w >> 8, g_beg = (r0.z - offL) >> 1, lg = r1.w & 31u;
                 const bool eos_step = last_seg && c_beg == C;
                 if (eos_step ? counted > nT : seg_c + c_beg < c_skip) continue;
-                uint32_t p_beg = r.x & 0xFFFFu, p_end = p_beg + (r.x >> 16);
+                // predecessors of the step: the lanes of its first group (spread over 2^(lg-6) passes when there are more than 64)
+                uint32_t np = 0;
+                if (lg < 6) np = (uint32_t)__popcll((((uint64_t)r1.y << 32) | r1.x) & ((1ull << (1u << lg)) - 1ull));
+                else for (uint32_t t = 0; t < (1u << (lg - 6)); ++t) {
+                    const uint4 m = uniform4(*(reinterpret_cast<const uint4*>(&rec[k + t]) + 1));
+                    np += (uint32_t)__popcll(((uint64_t)m.y << 32) | m.x);
+                }
+                uint32_t p_beg = (r0.y - offK) >> 3, p_end = p_beg + np;
                 if (eos_step) { p_beg = (rend.y & 0xFFFFu) - sb; p_end = E; }  // EOS pairs with ends[len_char]
                 uint32_t live = 0;
                 for (uint32_t j0 = p_beg; j0 < p_end; j0 += 64) {
@@ -1601,7 +1642,8 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
                     live += (uint32_t)__popcll(__ballot(alive));
                     if (alive) atomicAdd(&A.rid_count[e_right[j]], (unsigned long long)nc);
                 }
-                for (uint32_t c = c_beg + ln; c < c_beg + nc; c += 64) atomicAdd(&A.lid_count[g_left[nd_g[c]]], (unsigned long long)live);
+                for (uint32_t c = c_beg + ln; c < c_beg + nc; c += 64)
+                    atomicAdd(&A.lid_count[g_left[g_beg + ((cnd[c].y & 0xFFFFu) >> 3)]], (unsigned long long)live);
             }
             const uint32_t upto = last_seg ? nT + 1 : seg_b;
             if (upto > counted) { counted = upto; if (ln == 0) A.s_counted[sid] = counted; }
@@ -1639,7 +1681,7 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
                 uint32_t seq = key_back(e_key[E]);
                 while (seq != kBosSeq && T < n) {
                     path[T++] = (uint16_t)seq;
-                    seq = key_back(e_key[nd_ew[seq] & 0xFFFFu]);
+                    seq = key_back(e_key[cnd[seq].x & 0xFFFFu]);
                 }
             }
             T = __shfl(T, 0);
@@ -1652,14 +1694,14 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
                 if (ln == 0) { A.tok_off[sid] = out_base; A.tok_cnt[sid] = T; }
                 for (uint32_t t = ln; t < T; t += 64) {
                     const uint32_t c = path[T - 1 - t];
-                    const uint4 r = nd[c];
-                    const uint32_t prev_end = t ? nd[path[T - t]].w >> 16 : 0u;
-                    const uint32_t stp = start_of(prev_end), en = r.w >> 16;
+                    const uint2 r = em[c];
+                    const uint32_t prev_end = t ? em[path[T - t]].y : 0u;
+                    const uint32_t stp = start_of(prev_end), en = r.y;
                     vbt_token_rec o;
                     o.start_char = stp; o.end_char = en;
                     o.start_byte = c2b[stp]; o.end_byte = c2b[en];
-                    o.word_idx = r.z;
-                    o.total_cost = (int32_t)key_cost(e_key[nd_ew[c] & 0xFFFFu]);
+                    o.word_idx = r.x;
+                    o.total_cost = (int32_t)key_cost(e_key[cnd[c].x & 0xFFFFu]);
                     A.tokens[out_base + t] = o;
                 }
             }
@@ -1711,13 +1753,13 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
                 if (ln == 0) { A.tok_off[sid] = out_base; A.tok_cnt[sid] = T; }
                 for (uint32_t t = ln; t < T; t += 64) {
                     const uint32_t c = path[T - 1 - t];
-                    const uint4 r = ndg[c];
-                    const uint32_t prev_end = t ? ndg[path[T - t]].w >> 16 : 0u;
-                    const uint32_t stp = start_of(prev_end), en = r.w >> 16;
+                    const uint2 r = em[c];
+                    const uint32_t prev_end = t ? em[path[T - t]].y : 0u;
+                    const uint32_t stp = start_of(prev_end), en = r.y;
                     vbt_token_rec o;
                     o.start_char = stp; o.end_char = en;
                     o.start_byte = c2b[stp]; o.end_byte = c2b[en];
-                    o.word_idx = r.z;
+                    o.word_idx = r.x;
                     o.total_cost = (int32_t)nbg[2 * c].x;
                     A.tokens[out_base + t] = o;
                 }
@@ -1949,7 +1991,9 @@ Workspace::Workspace(const Tokenizer& t, uint64_t max_s, uint64_t max_b) : tok(t
         pipe.g_c2b = static_cast<uint16_t*>(alloc(slots * 2));
         pipe.g_pc = static_cast<uint4*>(alloc(slots * 16));
         pipe.node_factor = std::max<uint32_t>(1, env_u32("VBT_NODE_FACTOR", 8));  // candidate slots per input byte
-        pipe.g_nd = static_cast<uint4*>(alloc((size_t)pipe.node_factor * slots * 16));
+        pipe.g_nd = static_cast<uint2*>(alloc((size_t)pipe.node_factor * slots * 8));
+        pipe.g_em = static_cast<uint2*>(alloc((size_t)pipe.node_factor * slots * 8));
+        pipe.g_gl = static_cast<uint16_t*>(alloc((size_t)pipe.node_factor * slots * 2));
         pipe.g_hits = static_cast<uint4*>(alloc((size_t)pipe.node_factor * slots * 16));
         pipe.s_passes = static_cast<uint32_t*>(alloc(ns * 4));
         pipe.s_tier = static_cast<uint8_t*>(alloc(ns));

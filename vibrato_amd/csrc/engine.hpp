@@ -59,9 +59,13 @@ struct BatchArgs {
     uint4* g_pc;        // {cand_off, groupable | is_space << 31, lens lo, lens hi}
     // per candidate (insertion order, contiguous per sentence; sentence s owns the node slots
     // [node_factor * (offsets[s] + s), node_factor * (offsets[s+1] + s + 1)): no allocation atomics).
-    // One 16-byte record: {left_id | right_id << 16, (u16) word_cost | end_char << 16, word_idx,
-    //                      left-id group within the start position | 0x80 on the group's first candidate}
-    uint4* g_nd;
+    //   g_nd: what the sweep needs, 8 bytes: {right_id | end-list slot << 16, (u16) word_cost | left-id group within the
+    //         start position << 16}
+    //   g_em: what only the tokens of the best path need, 8 bytes: {word_idx, end_char}
+    //   g_gl: left id of every left-id group (sentence-wide group numbering, same region as the candidates)
+    uint2* g_nd;
+    uint2* g_em;
+    uint16_t* g_gl;
     uint4* g_hits;      // staging of the trie hits of gen_candidates, same per-sentence regions as g_nd
     uint32_t node_factor;
     uint8_t* s_tier;    // LDS tier chosen by gen_candidates (0xFF = none / empty sentence)
