@@ -84,6 +84,46 @@ __device__ __forceinline__ uint64_t node_key(uint32_t best_hi, uint32_t best_lo,
 }
 __device__ __forceinline__ uint32_t key_back(uint64_t k) { return (uint32_t)k & 0xFFFFu; }
 
+// Minimum of a 32-bit value over aligned groups of 2^kLevels lanes, left in every lane of the group.  Each level is one
+// v_min_u32 with a DPP source operand (quad_perm / row_half_mirror / row_mirror: the mirrors are fine because the
+// sub-blocks are already uniform); the 32- and 64-lane levels use the gfx950 row / half-wave swaps
+// (v_permlane16_swap / v_permlane32_swap) instead of the LDS crossbar.
+template <int kCtrl>
+__device__ __forceinline__ uint32_t dpp_min_u32(uint32_t x) {
+    const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, kCtrl, 0xF, 0xF, true);
+    return o < x ? o : x;
+}
+template <int kLevels>
+__device__ __forceinline__ uint32_t group_min_u32(uint32_t x) {
+    if constexpr (kLevels >= 1) x = dpp_min_u32<0xB1>(x);
+    if constexpr (kLevels >= 2) x = dpp_min_u32<0x4E>(x);
+    if constexpr (kLevels >= 3) x = dpp_min_u32<0x141>(x);
+    if constexpr (kLevels >= 4) x = dpp_min_u32<0x140>(x);
+    if constexpr (kLevels >= 5) { const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false); x = r[0] < r[1] ? r[0] : r[1]; }
+    if constexpr (kLevels >= 6) { const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false); x = r[0] < r[1] ? r[0] : r[1]; }
+    return x;
+}
+__device__ __forceinline__ uint32_t group_min_u32(uint32_t x, uint32_t lg) {  // lg is wave-uniform, <= 6
+    // nested, ascending: one scalar compare + branch per level actually taken (a switch becomes a compare tree with flow blocks)
+    if (lg >= 1) {
+        x = dpp_min_u32<0xB1>(x);
+        if (lg >= 2) {
+            x = dpp_min_u32<0x4E>(x);
+            if (lg >= 3) {
+                x = dpp_min_u32<0x141>(x);
+                if (lg >= 4) {
+                    x = dpp_min_u32<0x140>(x);
+                    if (lg >= 5) {
+                        { const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false); x = r[0] < r[1] ? r[0] : r[1]; }
+                        if (lg >= 6) { const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false); x = r[0] < r[1] ? r[0] : r[1]; }
+                    }
+                }
+            }
+        }
+    }
+    return x;
+}
+
 // 128-bit window helpers (shift distances 0..64), by value so everything stays in registers
 struct U128 { uint64_t lo, hi; };
 __device__ __forceinline__ U128 shr128(U128 w, uint32_t d) {
@@ -680,7 +720,7 @@ __device__ __forceinline__ uint64_t process_sentence(const DevDict& D, const Bat
 // prefetch distance of the matrix gathers of lattice_lds in passes (= unroll factor of its sweep loop).  2..8 measure the
 // same within 3 % on a full batch (other waves hide the latency); 8 keeps a lone sentence's sweep off the HBM latency.
 #ifndef VBT_DEPTH
-#define VBT_DEPTH 7
+#define VBT_DEPTH 6
 #endif
 #ifndef VBT_LAT_WAVES
 #define VBT_LAT_WAVES 4
@@ -1500,96 +1540,106 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
                 asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(out) : "v"(a), "v"(b), "s"(mask));
                 return out;
             };
-            // Software pipeline over a ring of kRing = kDepth + 1 slots, pass p lives in slot p % kRing from its stage A
-            // (record -> this lane's pair -> addresses, ids read from LDS; at iteration p - kRing) over its stage B (gather
-            // of the pair's connection cost; at iteration p - kDepth) to its execution.  The loop is unrolled kRing
-            // times, so every slot index is static and nothing is copied from slot to slot.
-            constexpr uint32_t kRing = kDepth + 1;
+            // Software pipeline, three stages ahead of a pass's execution at iteration p:
+            //   A1 (iteration p - kDepth - 2): read its record from LDS (broadcast);
+            //   A2 (iteration p - kDepth - 1): record -> this lane's pair -> LDS addresses; read the pair's two ids;
+            //   B  (iteration p - kDepth)    : gather the pair's connection cost from the matrix (lanes without a pair load cell 0).
+            // Every stage consumes what the previous iteration requested, so an iteration issues all its independent LDS
+            // reads up front (next record, next ids, this pass's predecessor keys and candidates) and waits for them once; the
+            // second and last round trip is the read of the group minima behind the atomics.  Pass p lives in ring slot
+            // p % kRing from A2 on; the loop is unrolled kRing times, so slot indices are static and nothing is copied around.
+            constexpr uint32_t kRing = kDepth + 2;
             uint32_t word[kRing], csh[kRing], keyaddr[kRing], gaddr[kRing];  // VGPRs: cost word in flight, shift that brings the cell down, LDS addresses
             uint32_t smlo[kRing], smhi[kRing], sbc[kRing], smeta[kRing];      // SGPRs (wave-uniform): lane mask, first candidate, shape
-            uint32_t a_left = 0, a_right = 0;                                // ids of the pass whose stage B is next
-            auto stage_a = [&](uint32_t idx, uint32_t u) {
-                const uint4 r0 = *reinterpret_cast<const uint4*>(&rec[idx]);  // (every lane reads the same record: broadcast)
-                const uint4 r1 = *(reinterpret_cast<const uint4*>(&rec[idx]) + 1);
+            auto stage_a1 = [&](uint32_t p, uint4& r0, uint4& r1) {
+                const uint4* r = reinterpret_cast<const uint4*>(&rec[p < SL ? p : SL]);  // passes > SL do not exist: they re-read the empty one
+                r0 = r[0]; r1 = r[1];
+            };
+            auto stage_a2 = [&](const uint4& r0, const uint4& r1, uint32_t u, uint32_t& left, uint32_t& right) {
                 const uint32_t lg = r1.w & 31u;
                 const uint32_t q = ln + r0.w, gg = q >> lg, j = q & ((1u << lg) - 1u);
-                a_left = *reinterpret_cast<const uint16_t*>(g_smem + r0.z + (gg << 1));
-                a_right = *reinterpret_cast<const uint16_t*>(g_smem + r0.x + (j << 1));
+                left = *reinterpret_cast<const uint16_t*>(g_smem + r0.z + (gg << 1));
+                right = *reinterpret_cast<const uint16_t*>(g_smem + r0.x + (j << 1));
                 keyaddr[u] = r0.y + (j << 3);
                 gaddr[u] = gg << 3;
                 smlo[u] = __builtin_amdgcn_readfirstlane(r1.x); smhi[u] = __builtin_amdgcn_readfirstlane(r1.y);
                 sbc[u] = __builtin_amdgcn_readfirstlane(r1.z); smeta[u] = __builtin_amdgcn_readfirstlane(r1.w);
             };
-            // stage B: the gather (lanes without a pair load cell 0)
-            auto stage_b = [&](uint32_t u) {
+            auto stage_b = [&](uint32_t u, uint32_t left, uint32_t right) {
                 const uint64_t mask = ((uint64_t)smhi[u] << 32) | smlo[u];
-                const uint32_t cell = select_mask(mask, 0u, __umul24(a_left, NR) + a_right);  // < 2^32: num_left, num_right <= 65535
+                const uint32_t cell = select_mask(mask, 0u, __umul24(left, NR) + right);  // < 2^32: num_left, num_right <= 65535
                 word[u] = load_policy<VBT_NT_MATRIX != 0>(&matrix32[cell >> 1]);  // (a 16-bit destination would be packed by the compiler and serialise the loads)
                 csh[u] = cell << 4;  // shift count = its low 5 bits: 16 for an odd cell
             };
+            uint4 pr0, pr1;             // record of the pass whose A2 is next
+            uint32_t p_left, p_right;   // ids of the pass whose B is next
+            stage_a1(0, pr0, pr1);
 #pragma unroll
-            for (uint32_t u = 0; u < kRing; ++u) {  // passes > SL do not exist: they re-read the empty one
-                stage_a(u < SL ? u : SL, u);
-                if (u + 1 < kRing) stage_b(u);
+            for (uint32_t p = 0; p <= kDepth; ++p) {
+                uint4 n0, n1;
+                uint32_t nl, nr;
+                stage_a1(p + 1, n0, n1);
+                stage_a2(pr0, pr1, p, nl, nr);
+                if (p > 0) stage_b(p - 1, p_left, p_right);
+                pr0 = n0; pr1 = n1; p_left = nl; p_right = nr;
             }
             for (uint32_t s0 = 0; s0 < SL; s0 += kRing) {
 #pragma unroll
                 for (uint32_t u = 0; u < kRing; ++u) {
                     const uint32_t si = s0 + u;
-                    stage_b((u + kDepth) % kRing);  // gather of pass si + kDepth
-                    const uint32_t cword = word[u], csh_ = csh[u], ka = keyaddr[u], ga = gaddr[u];
+                    const uint32_t bc = sbc[u], meta = smeta[u], nc = meta >> 8;
                     const uint64_t mask = ((uint64_t)smhi[u] << 32) | smlo[u];
-                    const uint32_t bc = sbc[u], meta = smeta[u];
+                    // ---- all independent LDS reads of the iteration ----
+                    uint4 n0, n1;
+                    uint32_t nl, nr;
+                    stage_a1(si + kDepth + 2, n0, n1);
+                    stage_a2(pr0, pr1, (u + kRing - 1) % kRing, nl, nr);                       // pass si + kDepth + 1
+                    const uint64_t kb = *reinterpret_cast<const uint64_t*>(g_smem + keyaddr[u]);  // key of this lane's predecessor
+                    const uint2 cd = *reinterpret_cast<const uint2*>(g_smem + bc + (ln << 3));    // candidate this lane may finalise
+                    __builtin_amdgcn_sched_barrier(0);  // (keep these reads together, ahead of their first consumer: one wait for all)
+                    stage_b((u + kDepth) % kRing, p_left, p_right);                           // pass si + kDepth
+                    pr0 = n0; pr1 = n1; p_left = nl; p_right = nr;
                     // ---- pass si ----
-                    const uint32_t nc = meta >> 8;
+                    const uint32_t ga = gaddr[u];
+                    const uint32_t khi = (uint32_t)(kb >> 32) + (uint32_t)(int32_t)(int16_t)(word[u] >> (csh[u] & 31u));  // wrapping i32 add
+                    const uint64_t live = __ballot((uint32_t)kb != 0xFFFFFFFFu) & mask;
+                    // (a lane without a live pair carries the dead key, a no-op for the minimum should it tie with m)
+                    const uint32_t hi = select_mask(live, 0xFFFFFFFFu, khi), lo = select_mask(live, 0xFFFFFFFFu, (uint32_t)kb);
+                    const uint32_t lg = meta & 31u;
+                    // minimum cost of every group in registers; only the lanes that hold it go to LDS, where the atomic on the
+                    // whole key settles ties (rare) towards the last inserted predecessor: no same-address pile-up
+                    const uint32_t m = group_min_u32(hi, lg < 6 ? lg : 6u);  // (more than 64 predecessors: one group per pass)
+                    auto finalise = [&](const uint2& c) {  // the candidate takes its group's minimum (lattice.rs:125)
+                        const uint64_t best = *reinterpret_cast<const uint64_t*>(g_smem + (c.y & 0xFFFFu));
+                        const uint32_t fhi = (uint32_t)(best >> 32) + (uint32_t)(int32_t)(int16_t)(c.x >> 16);
+                        const uint32_t flo = (c.y & 0xFFFF0000u) | (0xFFFEu - ((uint32_t)best >> 16));
+                        *reinterpret_cast<uint64_t*>(g_smem + offK + ((c.x & 0xFFFFu) << 3)) = ((uint64_t)fhi << 32) | flo;
+                    };
                     if (meta & 128u) {
                         // the whole step in one pass (the common case): clear the minima, fold the pairs, hand out the results
                         g_best[ln] = kDeadKey;
-                        const uint64_t kb = *reinterpret_cast<const uint64_t*>(g_smem + ka);
-                        const uint32_t khi = (uint32_t)(kb >> 32) + (uint32_t)(int32_t)(int16_t)(cword >> (csh_ & 31u));  // wrapping i32 add
-                        const uint64_t live = __ballot((uint32_t)kb != 0xFFFFFFFFu) & mask;
-                        const uint64_t key = ((uint64_t)select_mask(live, 0xFFFFFFFFu, khi) << 32) | select_mask(live, 0xFFFFFFFFu, (uint32_t)kb);
-                        __hip_atomic_fetch_min(static_cast<uint64_t*>(__builtin_assume_aligned(g_smem + ga, 8)), key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (hi == m)
+                            __hip_atomic_fetch_min(static_cast<uint64_t*>(__builtin_assume_aligned(g_smem + ga, 8)), ((uint64_t)hi << 32) | lo,
+                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                        if (ln < nc) {
-                            const uint2 cd = *reinterpret_cast<const uint2*>(g_smem + bc + (ln << 3));
-                            const uint64_t best = *reinterpret_cast<const uint64_t*>(g_smem + (cd.y & 0xFFFFu));
-                            const uint32_t hi = (uint32_t)(best >> 32) + (uint32_t)(int32_t)(int16_t)(cd.x >> 16);  // lattice.rs:125
-                            const uint32_t lo = (cd.y & 0xFFFF0000u) | (0xFFFEu - ((uint32_t)best >> 16));
-                            *reinterpret_cast<uint64_t*>(g_smem + offK + ((cd.x & 0xFFFFu) << 3)) = ((uint64_t)hi << 32) | lo;
-                        }
+                        if (ln < nc) finalise(cd);
                     } else {
                         // a step of several passes, or with many candidates / groups
                         if (meta & 32u) {  // first pass: no minimum yet
                             const uint32_t ng_hi = ngmax + 1;
                             for (uint32_t t = ln; t < ng_hi; t += 64) g_best[t] = kDeadKey;
                         }
-                        const uint64_t kb = *reinterpret_cast<const uint64_t*>(g_smem + ka);
-                        const uint32_t khi = (uint32_t)(kb >> 32) + (uint32_t)(int32_t)(int16_t)(cword >> (csh_ & 31u));
-                        const uint64_t live = __ballot((uint32_t)kb != 0xFFFFFFFFu) & mask;
-                        const uint64_t key = ((uint64_t)select_mask(live, 0xFFFFFFFFu, khi) << 32) | select_mask(live, 0xFFFFFFFFu, (uint32_t)kb);
-                        __hip_atomic_fetch_min(static_cast<uint64_t*>(__builtin_assume_aligned(g_smem + ga, 8)), key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (hi == m)
+                            __hip_atomic_fetch_min(static_cast<uint64_t*>(__builtin_assume_aligned(g_smem + ga, 8)), ((uint64_t)hi << 32) | lo,
+                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                        if (meta & 64u) {  // last pass of the step: its candidates take their group's minimum
-                            for (uint32_t cb = 0; cb < nc; cb += 64) {
-                                const uint32_t ci_ = cb + ln;
-                                if (ci_ < nc) {
-                                    const uint2 cd = *reinterpret_cast<const uint2*>(g_smem + bc + (ci_ << 3));
-                                    const uint64_t best = *reinterpret_cast<const uint64_t*>(g_smem + (cd.y & 0xFFFFu));
-                                    const uint32_t hi = (uint32_t)(best >> 32) + (uint32_t)(int32_t)(int16_t)(cd.x >> 16);
-                                    const uint32_t lo = (cd.y & 0xFFFF0000u) | (0xFFFEu - ((uint32_t)best >> 16));
-                                    *reinterpret_cast<uint64_t*>(g_smem + offK + ((cd.x & 0xFFFFu) << 3)) = ((uint64_t)hi << 32) | lo;
-                                }
-                            }
-                        }
+                        if (meta & 64u)  // last pass of the step
+                            for (uint32_t cb = 0; cb < nc; cb += 64)
+                                if (cb + ln < nc) finalise(*reinterpret_cast<const uint2*>(g_smem + bc + ((cb + ln) << 3)));
                     }
                     // LDS operations of one wave execute in order: a compiler-level fence is all the next pass needs
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
-                    {   // stage A of pass si + kRing, into the slot just freed
-                        const uint32_t nx = si + kRing;
-                        stage_a(nx < SL ? nx : SL, u);
-                    }
                 }
             }
         }
