@@ -66,6 +66,18 @@ __device__ __forceinline__ uint32_t wave_exscan(uint32_t v, uint32_t& total) {
     return x - v;
 }
 
+__device__ __forceinline__ uint32_t wave_exscan_any(uint32_t v, uint32_t& total) {  // (workgroups of several waves)
+    uint32_t x = v;
+    const int lane = (int)(threadIdx.x & 63u);
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t y = __shfl_up(x, d);
+        if (lane >= d) x += y;
+    }
+    total = __shfl(x, 63);
+    return x - v;
+}
+
 // Packed lattice key: high word = min_cost biased to unsigned order (cost ^ 0x80000000), low word =
 // 0xFFFFFFFE - insertion sequence number.  Unsigned-minimum over keys = minimum cost with ties broken
 // towards the LAST inserted node, the `<=` rule of search_min_node (lattice.rs:141-146).  Adding a
@@ -139,6 +151,16 @@ __device__ __forceinline__ U128 or_shl128(U128 w, uint64_t m, uint32_t d) {
 __device__ __forceinline__ uint64_t uniform64(uint64_t v) {
     // (the builtin returns int: without the casts the low half would sign-extend into the high half)
     return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v);
+}
+
+// Per-sentence regions of the workspace (per-character records, candidates, staged hits) are addressed by the
+// sentence's byte offset RELATIVE to the batch (offsets[0] may be anything: a window into a larger text buffer)
+// plus its index: sentence s owns the character slots [off(s) + s, off(s + 1) + s + 1).
+__device__ __forceinline__ size_t sentence_slot(const BatchArgs& A, uint64_t b0, uint32_t sid) {
+    return (size_t)(b0 - uniform64(A.offsets[0])) + sid;
+}
+__device__ __forceinline__ bool batch_rejected(const BatchArgs& A) {
+    return (__builtin_amdgcn_readfirstlane(A.ctrl[kError]) & (uint32_t)kErrFatal) != 0;
 }
 
 // One step of the position sweep: candidates [cbeg, cbeg+nc) connect to end-list slots [pbeg, pbeg+np).
@@ -232,7 +254,7 @@ __device__ __forceinline__ uint64_t process_sentence(const DevDict& D, const Bat
     constexpr uint64_t kIdxMax = (uint64_t)(IdxT) ~(IdxT)0;
     const uint64_t b0 = A.offsets[sid], nb64 = A.offsets[sid + 1] - b0;
     if (nb64 == 0) {
-        if (ln == 0) { A.tok_off[sid] = 0; A.tok_cnt[sid] = 0; }
+        if (ln == 0) A.tok_cnt[sid] = 0;
         return 0;
     }
     if (nb64 >= kIdxMax) return kNoFit;
@@ -247,7 +269,7 @@ __device__ __forceinline__ uint64_t process_sentence(const DevDict& D, const Bat
         n += (uint32_t)__popcll(__ballot(lead));
     }
     if (n == 0) {
-        if (ln == 0) { A.tok_off[sid] = 0; A.tok_cnt[sid] = 0; }
+        if (ln == 0) A.tok_cnt[sid] = 0;
         return 0;
     }
 
@@ -681,15 +703,11 @@ __device__ __forceinline__ uint64_t process_sentence(const DevDict& D, const Bat
         }
     }
     T = __shfl(T, 0);
-    uint32_t out_base = 0;
-    if (ln == 0) out_base = atomicAdd(&A.ctrl[kTotal], T);
-    out_base = __shfl(out_base, 0);
+    // tokens go to the sentence's own region of the staging buffer (tokens <= characters <= bytes: it cannot overflow);
+    // compact_tokens packs them in sentence order afterwards -- no allocation atomic on a hot counter
+    const size_t out_base = sentence_slot(A, b0, sid);
     __syncthreads();
-    if ((uint64_t)out_base + T > A.tok_cap) {
-        if (ln == 0) { atomicOr(&A.ctrl[kError], (uint32_t)kErrTokCap); A.tok_off[sid] = 0; A.tok_cnt[sid] = 0; }
-        return 0;
-    }
-    if (ln == 0) { A.tok_off[sid] = out_base; A.tok_cnt[sid] = T; }
+    if (ln == 0) A.tok_cnt[sid] = T;
     for (uint32_t t = ln; t < T; t += 64) {
         const uint32_t c = path[T - 1 - t];  // Worker::token: index = n-1-i (worker.rs:65-68)
         // start_word = the position whose candidate range contains c: upper_bound(cand_off, c) - 1
@@ -704,7 +722,7 @@ __device__ __forceinline__ uint64_t process_sentence(const DevDict& D, const Bat
         r.start_byte = c2b[stp]; r.end_byte = c2b[en];
         r.word_idx = nd_word[c];
         r.total_cost = (int32_t)key_cost(e_key[nd_eslot[c]]);
-        A.tokens[out_base + t] = r;
+        A.tok_stage[out_base + t] = r;
     }
     PROF_MARK(7);
     if (A.prof && ln == 0) {
@@ -750,16 +768,6 @@ __host__ __device__ __forceinline__ uint64_t lattice_fixed_bytes(uint32_t C, uin
 // =====================================================================================
 
 extern __shared__ __attribute__((aligned(16))) char g_smem[];
-
-// Per-sentence regions of the workspace (per-character records, candidates, staged hits) are addressed by the
-// sentence's byte offset RELATIVE to the batch (offsets[0] may be anything: a window into a larger text buffer)
-// plus its index: sentence s owns the character slots [off(s) + s, off(s + 1) + s + 1).
-__device__ __forceinline__ size_t sentence_slot(const BatchArgs& A, uint64_t b0, uint32_t sid) {
-    return (size_t)(b0 - uniform64(A.offsets[0])) + sid;
-}
-__device__ __forceinline__ bool batch_rejected(const BatchArgs& A) {
-    return (__builtin_amdgcn_readfirstlane(A.ctrl[kError]) & (uint32_t)kErrFatal) != 0;
-}
 
 // First kernel of every batch: the device-side input contract.  Offsets must not decrease and must span at most
 // `total_bytes` (what the caller declared, <= the workspace capacity); the text must be valid UTF-8 (Rust `str`
@@ -835,7 +843,7 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
     if (!large && A.s_skip && A.s_skip[sid] != 0xFF) return;  // a long sentence: the early pipeline owns it
     if (ln == 0 && !large) { A.s_n[sid] = 0; A.s_C[sid] = 0; A.s_tier[sid] = 0xFF; }
     if (nb64 == 0) {
-        if (ln == 0) { A.tok_off[sid] = 0; A.tok_cnt[sid] = 0; }
+        if (ln == 0) A.tok_cnt[sid] = 0;
         return;
     }
     if (nb64 >= 65535) { route(fallback); return; }  // positions are u16 in the LDS lattice
@@ -850,7 +858,7 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
         n += (uint32_t)__popcll(__ballot(lead));
     }
     if (n == 0) {
-        if (ln == 0) { A.tok_off[sid] = 0; A.tok_cnt[sid] = 0; }
+        if (ln == 0) A.tok_cnt[sid] = 0;
         return;
     }
     Arena ar{g_smem, lds_bytes, 0, true};
@@ -1264,7 +1272,7 @@ __global__ void __launch_bounds__(64) gen_candidates_large(DevDict D, BatchArgs 
 // last inserted predecessor = the `<=` of lattice.rs:141-146); the last pass of a step hands the minima to the
 // step's candidates.  LDS operations of one wave execute in order, so no barrier separates these phases.
 template <bool kSpaceMode>
-__global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, BatchArgs A, uint32_t tier, uint32_t list_id) {
+__global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, BatchArgs A, uint32_t tier, uint32_t list_id, uint32_t persistent) {
     const uint32_t ln = threadIdx.x;
     const uint32_t lds_bytes = A.tier_bytes[tier];
     const uint32_t NR = D.num_right;
@@ -1279,10 +1287,17 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
         return make_uint4(__builtin_amdgcn_readfirstlane(q.x), __builtin_amdgcn_readfirstlane(q.y),
                           __builtin_amdgcn_readfirstlane(q.z), __builtin_amdgcn_readfirstlane(q.w));
     };
+    // Work distribution: one list entry per workgroup (the grid covers the batch; a returning atomic on a hot word costs
+    // ~11 ns of a serial resource, which bounds a kernel at ~88 M entries/s however fast the waves are), or -- escape tiers,
+    // whose lists are short -- persistent waves that draw entries from a cursor.
+    bool first_item = true;
     for (;;) {
-        uint32_t item = 0;
-        if (ln == 0) item = atomicAdd(cursor, 1u);
-        item = __builtin_amdgcn_readfirstlane(item);  // lane 0 is always active here; keeps everything below scalar
+        uint32_t item = blockIdx.x;
+        if (persistent) {
+            if (ln == 0) item = atomicAdd(cursor, 1u);
+            item = __builtin_amdgcn_readfirstlane(item);  // lane 0 is always active here; keeps everything below scalar
+        } else if (!first_item) break;
+        first_item = false;
         if (item >= count) break;
         // newest entries first: the large-LDS generator levels append their (long, slow) sentences last, level by level,
         // so reading the list backwards starts the longest sentences first instead of leaving them as the tail
@@ -1714,7 +1729,7 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
         // ---- back-trace + token records (append_top_nodes lattice.rs:159-168, token.rs:21-92) ----
         // A token starts where its best predecessor ends -- behind the space run there, if that position is a skipped
         // space (tokenizer.rs:113-125) -- so a lane needs its own candidate record and the previous token's.
-        uint32_t T = 0, out_base = 0;
+        uint32_t T = 0;
         const uint16_t* __restrict__ c2b = A.g_c2b + slot0;
         auto start_of = [&](uint32_t prev_end) {
             if constexpr (kSpaceMode) {
@@ -1735,25 +1750,19 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
                 }
             }
             T = __shfl(T, 0);
-            if (ln == 0) out_base = atomicAdd(&A.ctrl[kTotal], T);
-            out_base = __shfl(out_base, 0);
             __syncthreads();
-            if ((uint64_t)out_base + T > A.tok_cap) {
-                if (ln == 0) { atomicOr(&A.ctrl[kError], (uint32_t)kErrTokCap); A.tok_off[sid] = 0; A.tok_cnt[sid] = 0; }
-            } else {
-                if (ln == 0) { A.tok_off[sid] = out_base; A.tok_cnt[sid] = T; }
-                for (uint32_t t = ln; t < T; t += 64) {
-                    const uint32_t c = path[T - 1 - t];
-                    const uint2 r = em[c];
-                    const uint32_t prev_end = t ? em[path[T - t]].y : 0u;
-                    const uint32_t stp = start_of(prev_end), en = r.y;
-                    vbt_token_rec o;
-                    o.start_char = stp; o.end_char = en;
-                    o.start_byte = c2b[stp]; o.end_byte = c2b[en];
-                    o.word_idx = r.x;
-                    o.total_cost = (int32_t)key_cost(e_key[cnd[c].x & 0xFFFFu]);
-                    A.tokens[out_base + t] = o;
-                }
+            if (ln == 0) A.tok_cnt[sid] = T;
+            for (uint32_t t = ln; t < T; t += 64) {
+                const uint32_t c = path[T - 1 - t];
+                const uint2 r = em[c];
+                const uint32_t prev_end = t ? em[path[T - t]].y : 0u;
+                const uint32_t stp = start_of(prev_end), en = r.y;
+                vbt_token_rec o;
+                o.start_char = stp; o.end_char = en;
+                o.start_byte = c2b[stp]; o.end_byte = c2b[en];
+                o.word_idx = r.x;
+                o.total_cost = (int32_t)key_cost(e_key[cnd[c].x & 0xFFFFu]);
+                A.tok_stage[slot0 + t] = o;  // the sentence's own staging region: no allocation atomic (compact_tokens packs them)
             }
         } else {
             // segmented sentence: pull all back pointers into LDS (the arena is free now), walk, emit from global
@@ -1794,25 +1803,19 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
             }
             __syncthreads();
             T = __shfl(T, 0);
-            if (ln == 0) out_base = atomicAdd(&A.ctrl[kTotal], T);
-            out_base = __shfl(out_base, 0);
             __syncthreads();
-            if ((uint64_t)out_base + T > A.tok_cap) {
-                if (ln == 0) { atomicOr(&A.ctrl[kError], (uint32_t)kErrTokCap); A.tok_off[sid] = 0; A.tok_cnt[sid] = 0; }
-            } else {
-                if (ln == 0) { A.tok_off[sid] = out_base; A.tok_cnt[sid] = T; }
-                for (uint32_t t = ln; t < T; t += 64) {
-                    const uint32_t c = path[T - 1 - t];
-                    const uint2 r = em[c];
-                    const uint32_t prev_end = t ? em[path[T - t]].y : 0u;
-                    const uint32_t stp = start_of(prev_end), en = r.y;
-                    vbt_token_rec o;
-                    o.start_char = stp; o.end_char = en;
-                    o.start_byte = c2b[stp]; o.end_byte = c2b[en];
-                    o.word_idx = r.x;
-                    o.total_cost = (int32_t)nbg[2 * c].x;
-                    A.tokens[out_base + t] = o;
-                }
+            if (ln == 0) A.tok_cnt[sid] = T;
+            for (uint32_t t = ln; t < T; t += 64) {
+                const uint32_t c = path[T - 1 - t];
+                const uint2 r = em[c];
+                const uint32_t prev_end = t ? em[path[T - t]].y : 0u;
+                const uint32_t stp = start_of(prev_end), en = r.y;
+                vbt_token_rec o;
+                o.start_char = stp; o.end_char = en;
+                o.start_byte = c2b[stp]; o.end_byte = c2b[en];
+                o.word_idx = r.x;
+                o.total_cost = (int32_t)nbg[2 * c].x;
+                A.tok_stage[slot0 + t] = o;
             }
         }
         }  // segments
@@ -1894,7 +1897,6 @@ __global__ void __launch_bounds__(64) tokenize_global(DevDict D, BatchArgs A, co
             if (failed) {
                 if (threadIdx.x == 0) {
                     atomicOr(&A.ctrl[kError], need == kNoFit ? (uint32_t)kErrTooLong : (uint32_t)kErrScratch);
-                    A.tok_off[sid] = 0;
                     A.tok_cnt[sid] = 0;
                 }
                 break;
@@ -1902,6 +1904,76 @@ __global__ void __launch_bounds__(64) tokenize_global(DevDict D, BatchArgs A, co
             __syncthreads();
         }
         __syncthreads();
+    }
+}
+
+// Token compaction.  The sweep kernels leave the tokens of sentence s in its own region of the staging buffer and its
+// count in tok_cnt[s]; these three small kernels turn that into the compact result: tok_off = exclusive prefix of the
+// counts (so token ranges are in sentence order), the records packed back to back, the total in ctrl[kTotal].
+constexpr uint32_t kScanBlock = 256, kScanItems = 1, kScanTile = kScanBlock * kScanItems;  // sentences per workgroup (small tiles: the copy needs the parallelism)
+__device__ __forceinline__ uint32_t block_exscan(uint32_t v, uint32_t* warp_sums, uint32_t& block_total) {
+    uint32_t wtot;
+    const uint32_t ex = wave_exscan_any(v, wtot);
+    const uint32_t w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if ((threadIdx.x & 63u) == 0) warp_sums[w] = wtot;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+    for (uint32_t i = 0; i < nw; ++i) { const uint32_t t = warp_sums[i]; if (i < w) base += t; tot += t; }
+    __syncthreads();
+    block_total = tot;
+    return base + ex;
+}
+__global__ void __launch_bounds__(kScanBlock) tok_tile_sums(BatchArgs A, uint32_t* tile_sums) {
+    __shared__ uint32_t ws[kScanBlock / 64];
+    if (A.ctrl[kError] & (uint32_t)kErrFatal) { if (threadIdx.x == 0) tile_sums[blockIdx.x] = 0; return; }
+    const uint32_t s0 = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+    uint32_t v = 0;
+    for (uint32_t i = 0; i < kScanItems; ++i) v += s0 + i < A.n ? A.tok_cnt[s0 + i] : 0u;
+    uint32_t tot;
+    block_exscan(v, ws, tot);
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = tot;
+}
+__global__ void __launch_bounds__(1024) tok_tile_scan(BatchArgs A, uint32_t* tile_sums, uint32_t n_tiles) {
+    __shared__ uint32_t ws[16];
+    uint32_t running = 0;
+    for (uint32_t t0 = 0; t0 < n_tiles; t0 += 1024) {
+        const uint32_t t = t0 + threadIdx.x;
+        const uint32_t v = t < n_tiles ? tile_sums[t] : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_exscan(v, ws, tot);
+        if (t < n_tiles) tile_sums[t] = running + ex;
+        running += tot;
+    }
+    if (threadIdx.x == 0) A.ctrl[kTotal] = running;
+}
+__global__ void __launch_bounds__(kScanBlock) compact_tokens(BatchArgs A, const uint32_t* tile_sums) {
+    __shared__ uint32_t ws[kScanBlock / 64];
+    __shared__ uint32_t offs[kScanTile + 1];  // exclusive token offsets of the tile's sentences, relative to the tile
+    if (A.ctrl[kError] & (uint32_t)kErrFatal) return;
+    const uint32_t tile0 = blockIdx.x * kScanTile, s0 = tile0 + threadIdx.x * kScanItems;
+    uint32_t c[kScanItems], v = 0;
+    for (uint32_t i = 0; i < kScanItems; ++i) { c[i] = s0 + i < A.n ? A.tok_cnt[s0 + i] : 0u; v += c[i]; }
+    uint32_t tot;
+    uint32_t ex = block_exscan(v, ws, tot);
+    const uint32_t base = tile_sums[blockIdx.x];
+    for (uint32_t i = 0; i < kScanItems; ++i) {
+        offs[threadIdx.x * kScanItems + i] = ex;
+        if (s0 + i < A.n) A.tok_off[s0 + i] = base + ex;
+        ex += c[i];
+    }
+    if (threadIdx.x == 0) offs[kScanTile] = tot;
+    __syncthreads();
+    const uint64_t o0 = A.offsets[0];
+    const uint64_t* __restrict__ src = reinterpret_cast<const uint64_t*>(A.tok_stage);
+    uint64_t* __restrict__ dst = reinterpret_cast<uint64_t*>(A.tokens);
+    for (uint32_t k = threadIdx.x; k < tot; k += kScanBlock) {
+        uint32_t lo = 0, hi = kScanTile;  // last sentence of the tile whose offset is <= k (empty sentences share offsets: take the last)
+        while (lo + 1 < hi) { const uint32_t mid = (lo + hi) >> 1; if (offs[mid] <= k) lo = mid; else hi = mid; }
+        const uint32_t s = tile0 + lo;
+        const size_t from = (size_t)(A.offsets[s] - o0) + s + (k - offs[lo]);
+        const size_t to = (size_t)base + k;
+#pragma unroll
+        for (int w = 0; w < 3; ++w) dst[3 * to + w] = src[3 * from + w];
     }
 }
 
@@ -2009,6 +2081,8 @@ Workspace::Workspace(const Tokenizer& t, uint64_t max_s, uint64_t max_b) : tok(t
         return p;
     };
     d_tokens = static_cast<vbt_token_rec*>(alloc(nbts * sizeof(vbt_token_rec)));  // tokens <= chars <= bytes
+    d_tok_stage = static_cast<vbt_token_rec*>(alloc((nbts + ns + 1) * sizeof(vbt_token_rec)));  // per-sentence regions
+    d_tile_sums = static_cast<uint32_t*>(alloc(((ns + kScanTile - 1) / kScanTile + 1) * 4));
     d_tok_off = static_cast<uint32_t*>(alloc(ns * 4));
     d_tok_cnt = static_cast<uint32_t*>(alloc(ns * 4));
     d_over = static_cast<uint32_t*>(alloc(2 * ns * 4 * (tiers.size() + 1 + kGenLevels)));  // two regions per list: long-first pass + bulk
@@ -2104,7 +2178,7 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
     const size_t half = std::max<uint64_t>(max_sentences, 1), stride = 2 * half;
     BatchArgs a = pipe;
     a.text = d_text; a.offsets = d_offsets; a.n = (uint32_t)n;
-    a.tokens = d_tokens; a.tok_cap = (uint32_t)std::max<uint64_t>(max_bytes, 1);
+    a.tokens = d_tokens; a.tok_stage = d_tok_stage; a.tok_cap = (uint32_t)std::max<uint64_t>(max_bytes, 1);
     a.tok_off = d_tok_off; a.tok_cnt = d_tok_cnt; a.ctrl = d_ctrl;
     a.scratch = d_scratch; a.scratch_bytes = scratch_bytes;
     a.prof = profile ? d_prof : nullptr;
@@ -2190,30 +2264,39 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
         // One lattice_lds launch per LDS tier, each on its own stream.  The tiers above the segment tier are escape
         // tiers: nothing is routed to them up front, they take what the tier before them could not sweep, so they are
         // launched on the segment tier's stream, behind it.
-        auto launch_lattice = [&](dim3 grid_, uint32_t lds_, hipStream_t st_, uint32_t tier_, uint32_t list_) {
-            if (D.space_cateset) hipLaunchKernelGGL(lattice_lds<true>, grid_, dim3(64), lds_, st_, D, a, tier_, list_);
-            else hipLaunchKernelGGL(lattice_lds<false>, grid_, dim3(64), lds_, st_, D, a, tier_, list_);
+        const uint32_t persist = env_u32("VBT_LAT_PERSIST", 0);
+        auto launch_lattice = [&](dim3 grid_, uint32_t lds_, hipStream_t st_, uint32_t tier_, uint32_t list_, uint32_t persistent_) {
+            if (D.space_cateset) hipLaunchKernelGGL(lattice_lds<true>, grid_, dim3(64), lds_, st_, D, a, tier_, list_, persistent_);
+            else hipLaunchKernelGGL(lattice_lds<false>, grid_, dim3(64), lds_, st_, D, a, tier_, list_, persistent_);
         };
         const size_t n_conc = a.seg_tier < T ? a.seg_tier + 1 : T;
         for (size_t i = 0; i < n_conc; ++i) {
             const size_t t = n_conc - 1 - i;
             hipStream_t side = reinterpret_cast<hipStream_t>(streams[t]);
             HIP_CHECK(hipStreamWaitEvent(side, reinterpret_cast<hipEvent_t>(ev_fork2), 0));
-            const uint32_t grid = (t < tier_waves.size() && tier_waves[t]) ? std::min<uint32_t>(tier_waves[t], waves_for(tiers[t], cn)) : waves_for(tiers[t], cn);
-            launch_lattice(dim3(grid), tiers[t], side, (uint32_t)t, (uint32_t)t);
+            // one workgroup per list entry: the lists are built on the device, so the grid covers the whole batch and the
+            // workgroups beyond a list's length exit at once (VBT_LAT_PERSIST=1: persistent waves with a work cursor)
+            const uint32_t grid = !persist ? cn : (t < tier_waves.size() && tier_waves[t]) ? std::min<uint32_t>(tier_waves[t], waves_for(tiers[t], cn)) : waves_for(tiers[t], cn);
+            launch_lattice(dim3(grid), tiers[t], side, (uint32_t)t, (uint32_t)t, persist);
             // optional (VBT_HELP_BYTES): a smaller tier that has drained its own list sweeps the segment tier's list
             // too, in shorter segments.  Off by default: measured slower on the headline batch.
             if (a.seg_tier < T && t < a.seg_tier && tiers[t] >= env_u32("VBT_HELP_BYTES", 0xFFFFFFFFu))
-                launch_lattice(dim3(grid), tiers[t], side, (uint32_t)t, a.seg_tier);
+                launch_lattice(dim3(waves_for(tiers[t], cn)), tiers[t], side, (uint32_t)t, a.seg_tier, 1u);
             if (t == a.seg_tier)
                 for (size_t x = t + 1; x < T; ++x)
-                    launch_lattice(dim3(waves_for(tiers[x], std::min<uint32_t>(cn, 4096))), tiers[x], side, (uint32_t)x, (uint32_t)x);
+                    launch_lattice(dim3(waves_for(tiers[x], std::min<uint32_t>(cn, 4096))), tiers[x], side, (uint32_t)x, (uint32_t)x, 1u);
             HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(tier_events[t]), side));
         }
         for (size_t t = 0; t < n_conc; ++t) HIP_CHECK(hipStreamWaitEvent(stream, reinterpret_cast<hipEvent_t>(tier_events[t]), 0));
         // whatever the pipeline could not take: fused kernel, global-memory lattice
         hipLaunchKernelGGL(tokenize_global, dim3((uint32_t)std::min<uint64_t>(cn, 1024)), dim3(64), 0, stream, D, a,
                            (const uint32_t*)over(T), (const uint32_t*)(d_cctrl + 2 * T), d_cctrl + 2 * T + 1);
+    }
+    {   // pack the tokens in sentence order (tok_off, total)
+        const uint32_t n_tiles = (uint32_t)((n + kScanTile - 1) / kScanTile);
+        hipLaunchKernelGGL(tok_tile_sums, dim3(n_tiles), dim3(kScanBlock), 0, stream, a, d_tile_sums);
+        hipLaunchKernelGGL(tok_tile_scan, dim3(1), dim3(1024), 0, stream, a, d_tile_sums, n_tiles);
+        hipLaunchKernelGGL(compact_tokens, dim3(n_tiles), dim3(kScanBlock), 0, stream, a, (const uint32_t*)d_tile_sums);
     }
     rec(2);
     HIP_CHECK(hipGetLastError());

@@ -37,7 +37,8 @@ struct BatchArgs {
     const uint64_t* offsets;
     uint32_t n;
     // outputs
-    vbt_token_rec* tokens;
+    vbt_token_rec* tokens;     // compact result (sentence order)
+    vbt_token_rec* tok_stage;  // staging: sentence s writes its tokens at its own slot (offsets[s] - offsets[0] + s)
     uint32_t tok_cap;
     uint32_t* tok_off;
     uint32_t* tok_cnt;
@@ -134,6 +135,8 @@ class Workspace {
     const Tokenizer& tok;
     uint64_t max_sentences, max_bytes;
     vbt_token_rec* d_tokens = nullptr;
+    vbt_token_rec* d_tok_stage = nullptr;
+    uint32_t* d_tile_sums = nullptr;
     uint32_t *d_tok_off = nullptr, *d_tok_cnt = nullptr, *d_ctrl = nullptr, *d_over = nullptr, *d_cctrl = nullptr;
     std::vector<void*> pipe_allocs;  // buffers of the two-kernel pipeline
     BatchArgs pipe{};                // device pointers of those buffers
