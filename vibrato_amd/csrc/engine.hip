@@ -89,13 +89,6 @@ __device__ __forceinline__ uint64_t make_key(uint32_t cost, uint32_t seq) {
 __device__ __forceinline__ uint32_t key_cost(uint64_t k) { return (uint32_t)(k >> 32) ^ 0x80000000u; }
 __device__ __forceinline__ uint32_t key_seq(uint64_t k) { return 0xFFFFFFFEu - (uint32_t)k; }
 
-// lattice_lds keeps the back pointer in the key as well: low word = (0xFFFE - sequence) << 16 | sequence of the best
-// predecessor.  Sequences are unique, so the back pointer never decides a comparison; candidates number < 65532.
-__device__ __forceinline__ uint64_t node_key(uint32_t best_hi, uint32_t best_lo, uint32_t wcost, uint32_t seq) {
-    return ((uint64_t)(best_hi + wcost) << 32) | ((0xFFFEu - seq) << 16) | (0xFFFEu - (best_lo >> 16));  // lattice.rs:125
-}
-__device__ __forceinline__ uint32_t key_back(uint64_t k) { return (uint32_t)k & 0xFFFFu; }
-
 // Minimum of a 32-bit value over aligned groups of 2^kLevels lanes, left in every lane of the group.  Each level is one
 // v_min_u32 with a DPP source operand (quad_perm / row_half_mirror / row_mirror: the mirrors are fine because the
 // sub-blocks are already uniform); the 32- and 64-lane levels use the gfx950 row / half-wave swaps
@@ -743,21 +736,19 @@ __device__ __forceinline__ uint64_t process_sentence(const DevDict& D, const Bat
 #ifndef VBT_LAT_WAVES
 #define VBT_LAT_WAVES 4
 #endif
-// One pass of the fused gather+recurrence loop of lattice_lds: 64 lanes = 64 padded (left-id group g, predecessor j)
-// pairs of one sweep step, pair q = q0 + lane, g = q >> lg, j = q & (2^lg - 1), 2^lg >= the number of predecessors.
-// The record is built once per pass by the lane that owns the step, so everything a pass needs is precomputed: LDS
-// byte addresses (of the first predecessor's right id and key, of the first group's left id, of the first candidate),
-// the mask of the lanes that hold a real pair, and the step's shape.
-//   meta = lg | first pass of its step << 5 | last << 6 | simple << 7 | candidates of the step << 8
-//   (simple: the step is this pass alone and has fewer than 64 candidates and at most 64 groups)
-struct alignas(16) LPass { uint32_t baseR, baseK, baseL, q0, mlo, mhi, baseC, meta; };
+// One pass of the fused gather+recurrence loop of lattice_lds: 64 lanes = 64 padded (candidate c, predecessor j) pairs
+// of one sweep step, pair q = q0 + lane, c = q >> lg, j = q & (2^lg - 1), 2^lg >= the number of predecessors.  The
+// record is built once per pass by the lane that owns the step, so everything a pass needs is precomputed: absolute LDS
+// byte addresses (of the first predecessor's right id and key, of the first candidate) and the mask of the lanes that
+// hold a real pair.
+struct alignas(16) LPass { uint32_t baseR, baseK, baseC, q0, mlo, mhi, lg, pad; };
 
-// LDS bytes of the lattice arrays of lattice_lds for a (segment of a) sentence with C candidates in G left-id groups
-// (at most ngmax per position), `passes` passes and m_in nodes ending at its first position.  Must over-estimate the
-// Arena carve there; gen_candidates routes sentences to LDS tiers with it.
-__host__ __device__ __forceinline__ uint64_t lattice_fixed_bytes(uint32_t C, uint32_t G, uint32_t ngmax, uint32_t passes, uint32_t m_in) {
+// LDS bytes of the lattice arrays of lattice_lds for a (segment of a) sentence with C candidates, `passes` passes and
+// m_in nodes ending at its first position.  Must over-estimate the Arena carve there; gen_candidates routes sentences
+// to LDS tiers with it.
+__host__ __device__ __forceinline__ uint64_t lattice_fixed_bytes(uint32_t C, uint32_t passes, uint32_t m_in) {
     const uint64_t E = (uint64_t)C + m_in;
-    return 8ull * (ngmax < 64 ? 64 : ngmax + 1) + 8 * (E + 1) + 8 * (C + 1ull) + 2 * (E + 1) + 2 * (G + 1ull) + sizeof(LPass) * (passes + 2ull) + 64;
+    return 8 * (E + 1) + 8 * (C + 1ull) + 2 * (E + 1) + sizeof(LPass) * (passes + 2ull) + 48;
 }
 
 // =====================================================================================
@@ -868,9 +859,7 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
     uint16_t* code = ar.take<uint16_t>(n);
     uint16_t* ucode = D.has_user ? ar.take<uint16_t>(n) : code;
     uint16_t* grp = ar.take<uint16_t>(n);
-    uint16_t* goff = ar.take<uint16_t>(n + 1);
     uint32_t* endc = ar.take<uint32_t>(n + 1);  // candidates ending at each position (bounds the pass count)
-    uint8_t* ngp = ar.take<uint8_t>(n);
     uint32_t* hcount = ar.take<uint32_t>(1);  // hits staged so far
     if (!ar.ok) { route(large_list); return; }
     for (uint32_t i = ln; i < n + 1; i += 64) endc[i] = i == 0 ? 1u : 0u;  // BOS ends at 0
@@ -991,15 +980,6 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
     }
     __syncthreads();
     if (C > region) { route(fallback); return; }  // denser than the region: fused path
-    // Left ids (for the grouping) are kept in LDS for a window of candidates only: sentences whose candidates
-    // outgrow it are expanded and grouped in rounds of whole 64-position chunks, so the LDS need of a long
-    // sentence is its per-character arrays plus a window, not 3 bytes per candidate.
-    const uint32_t cap = ar.ok && lds_bytes > ar.used + 16 ? (uint32_t)((lds_bytes - ar.used - 16) / 3) : 0u;
-    const uint32_t win = C < cap ? C : cap;
-    uint16_t* cleft = ar.take<uint16_t>(win);
-    uint8_t* cgid = ar.take<uint8_t>(win);
-    // (the bulk generator stays single-round: re-scanning the hits is cheaper in the levels behind it, which have the LDS)
-    if (!ar.ok || win == 0 || (level == 0 && C > cap)) { route(large_list); return; }
     // The staged hits are read back by this wave only: its stores have to be complete (workgroup scope:
     // s_waitcnt vmcnt(0); the vector L1 is write-through and never held these lines).  An agent-scope
     // release would write the whole L2 back (buffer_wbl2) once per sentence.
@@ -1008,112 +988,44 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     PROF_MARK(1);
 
+    // expand the hits: lanes = hits, every entry load independent of every other; a candidate becomes an 8-byte sweep record
+    // {right_id | end-list slot << 16, (u16) word_cost | left_id << 16} and an 8-byte token record {word_idx, end_char},
+    // at its place in the reference's insertion order (cand_off[start] + candidates of that start before the hit)
     const uint32_t H = *hcount;  // <= C <= region
-    uint32_t G = 0, ngmax = 0;
-    bool too_many_groups = false, window_small = false;
-    for (uint32_t r0 = 0; r0 < n;) {
-        // the round: chunks [r0, r1) while their candidates fit the window
-        const uint32_t cbase = cand_off[r0];
-        uint32_t r1 = r0;
-        while (r1 < n) {
-            const uint32_t nx = r1 + 64 < n ? r1 + 64 : n;
-            if (cand_off[nx] - cbase > win) break;
-            r1 = nx;
-        }
-        if (r1 == r0) { window_small = true; break; }  // one chunk alone outgrows the window: next generator level
-        // expand the hits of these positions: lanes = hits, every entry load independent of every other
-        for (uint32_t h0 = 0; h0 < H; h0 += 64) {
-            const uint32_t h = h0 + ln;
-            if (h < H) {
-                const uint4 hr = hits[h];
-                const uint32_t c = hr.y & 0xFFFFu, lex = hr.y >> 16, end = hr.z & 0xFFFFu, pos = hr.z >> 16;
-                if (pos >= r0 && pos < r1) {
-                    const Entry* __restrict__ ent = lex == 0 ? D.sys.entries : lex == 1 ? D.user.entries : D.unk_entries;
-                    const uint32_t dest = cand_off[pos] + hr.w;
-                    const uint32_t slot0 = atomicAdd(&endc[end], c);  // the hit's run of slots in ends[end]
-                    for (uint32_t t0 = 0; t0 < c; t0 += 4) {
-                        Entry e[4];
+    for (uint32_t h0 = 0; h0 < H; h0 += 64) {
+        const uint32_t h = h0 + ln;
+        if (h < H) {
+            const uint4 hr = hits[h];
+            const uint32_t c = hr.y & 0xFFFFu, lex = hr.y >> 16, end = hr.z & 0xFFFFu, pos = hr.z >> 16;
+            const Entry* __restrict__ ent = lex == 0 ? D.sys.entries : lex == 1 ? D.user.entries : D.unk_entries;
+            const uint32_t dest = cand_off[pos] + hr.w;
+            const uint32_t slot0 = atomicAdd(&endc[end], c);  // the hit's run of slots in ends[end]
+            for (uint32_t t0 = 0; t0 < c; t0 += 4) {
+                Entry e[4];
 #pragma unroll
-                        for (uint32_t q = 0; q < 4; ++q) e[q] = ent[hr.x + (t0 + q < c ? t0 + q : t0)];
+                for (uint32_t q = 0; q < 4; ++q) e[q] = ent[hr.x + (t0 + q < c ? t0 + q : t0)];
 #pragma unroll
-                        for (uint32_t q = 0; q < 4; ++q) {
-                            if (t0 + q < c) {
-                                const uint32_t k = dest + t0 + q;
-                                // (the group half of the second word is written by the grouping pass below: disjoint bytes)
-                                uint32_t* rec = reinterpret_cast<uint32_t*>(&A.g_nd[base + k]);
-                                rec[0] = (e[q].left_right >> 16) | ((slot0 + t0 + q) << 16);
-                                reinterpret_cast<uint16_t*>(rec)[2] = (uint16_t)e[q].cost;
-                                A.g_em[base + k] = make_uint2((lex << 30) | e[q].word_id, end);
-                                cleft[k - cbase] = (uint16_t)(e[q].left_right & 0xFFFFu);
-                            }
-                        }
+                for (uint32_t q = 0; q < 4; ++q) {
+                    if (t0 + q < c) {
+                        const uint32_t k = dest + t0 + q;
+                        A.g_nd[base + k] = make_uint2((e[q].left_right >> 16) | ((slot0 + t0 + q) << 16), (e[q].cost & 0xFFFFu) | (e[q].left_right << 16));
+                        A.g_em[base + k] = make_uint2((lex << 30) | e[q].word_id, end);
                     }
                 }
             }
         }
-        __syncthreads();
-        // group the candidates of a start position by left id, in reference insertion order
-        for (uint32_t c0 = r0; c0 < r1; c0 += 64) {
-            const uint32_t i = c0 + ln;
-            uint32_t ng = 0;
-            if (i < r1) {
-                uint32_t gl[8];  // the first 8 distinct left ids of this position (register cache)
-#pragma unroll
-                for (int q = 0; q < 8; ++q) gl[q] = 0xFFFFFFFFu;
-                const uint32_t kb = cand_off[i] - cbase, ke = cand_off[i + 1] - cbase;
-                for (uint32_t k = kb; k < ke; ++k) {
-                    const uint32_t left = cleft[k];
-                    uint32_t g = 0xFFFFFFFFu;
-#pragma unroll
-                    for (int q = 7; q >= 0; --q) g = gl[q] == left ? (uint32_t)q : g;
-                    // a left id beyond the 8 cached ones starts a group of its own every time (same gid => same left id is
-                    // all the lattice kernel relies on)
-                    const bool first = g == 0xFFFFFFFFu;
-                    if (first) {
-                        g = ng;
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) gl[q] = (uint32_t)q == ng ? left : gl[q];
-                        ++ng;
-                    }
-                    cgid[k] = (uint8_t)((g & 0x7Fu) | (first ? 0x80u : 0u));
-                }
-                ngp[i] = (uint8_t)ng;
-            }
-            too_many_groups |= __ballot(ng > 127u) != 0;
-            uint32_t tot;
-            const uint32_t ex = wave_exscan(ng, tot);
-            if (i < r1) {
-                goff[i] = (uint16_t)(G + ex);
-                // every candidate gets its group within the position; the group's left id goes to the sentence-wide group table
-                const uint32_t kb = cand_off[i], ke = cand_off[i + 1];
-                for (uint32_t k = kb; k < ke; ++k) {
-                    const uint32_t gid = cgid[k - cbase];
-                    reinterpret_cast<uint16_t*>(&A.g_nd[base + k])[3] = (uint16_t)(gid & 0x7Fu);
-                    if (gid & 0x80u) A.g_gl[base + G + ex + (gid & 0x7Fu)] = cleft[k - cbase];
-                }
-            }
-            G += tot;
-            uint32_t m = ng;
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = __shfl_xor(m, d); m = o > m ? o : m; }
-            ngmax = m > ngmax ? m : ngmax;
-        }
-        __syncthreads();
-        r0 = r1;
     }
-    if (window_small) { route(large_list); return; }
-    if (too_many_groups) { route(fallback); return; }
     __syncthreads();
     // exclusive end-list offset of position p (0 .. n + 1): the cursors now hold the inclusive prefix
     auto eo = [&](uint32_t p) { return p == 0 ? 0u : p == 1 ? 1u : endc[p - 1]; };
-    // passes of the lattice kernel that the step at one position takes: ceil(groups x 2^lg / 64), 2^lg >= predecessors
-    auto step_passes = [](uint32_t ng, uint32_t np) {
+    // passes of the lattice kernel that the step at one position takes: ceil(candidates x 2^lg / 64), 2^lg >= predecessors
+    auto step_passes = [](uint32_t nc, uint32_t np) {
         const uint32_t lg = np <= 1 ? 0u : 32u - (uint32_t)__builtin_clz(np - 1);
-        return (uint32_t)((((uint64_t)ng << lg) + 63) >> 6);
+        return (uint32_t)((((uint64_t)nc << lg) + 63) >> 6);
     };
     uint32_t passes = 0, maxcnt = 1;
     {   // per-character records for the lattice kernel:
-        // {cand_off | goff << 16, end-list offset | pass bound of the position's step << 16 | clean cut << 30 | space << 31,
+        // {cand_off | end-list offset << 16, pass bound of the position's step | clean cut << 30 | space << 31,
         //  length mask (64 bits; for a space position of ignore_space mode its groupable run instead: the sweep never
         //  starts a word there, tokenizer.rs:113-125)}
         // Clean cut before position i: no candidate of an earlier position ends beyond i (with ignore_space, a
@@ -1130,16 +1042,16 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
                 space = (D.space_cateset && (cinfo & D.space_cateset)) ? 0x80000000u : 0u;
                 lm = lens[i];
                 e = lm ? i + 64u - (uint32_t)__builtin_clzll(lm) : i + 1;
-                uint32_t ng = ngp[i];
+                uint32_t nc = cand_off[i + 1] - cand_off[i];
                 if (space) {
                     const uint32_t sw = i + grp[i];
                     const uint64_t lw = sw < n ? lens[sw] : 0ull;
                     const uint32_t e2 = sw < n ? (lw ? sw + 64u - (uint32_t)__builtin_clzll(lw) : sw + 1) : n;
                     e = e2 > e ? e2 : e;
-                    ng = sw < n ? ngp[sw] : 0u;  // the step taken from a space position starts its words behind the run
+                    nc = sw < n ? cand_off[sw + 1] - cand_off[sw] : 0u;  // the step taken from a space position starts its words behind the run
                 }
                 cnt = eo(i + 1) - eo(i);
-                nsl = step_passes(ng, cnt);
+                nsl = step_passes(nc, cnt);
             }
             uint32_t m = e;  // inclusive prefix maximum over the lanes
 #pragma unroll
@@ -1149,8 +1061,7 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
             if (i < n) {
                 const uint32_t cut = (i == 0 || before <= i) ? 0x40000000u : 0u;
                 const uint64_t third = space ? (uint64_t)grp[i] : lm;
-                pc[i] = make_uint4(cand_off[i] | ((uint32_t)goff[i] << 16), eo(i) | ((nsl < 0x3FFFu ? nsl : 0x3FFFu) << 16) | cut | space,
-                                   (uint32_t)third, (uint32_t)(third >> 32));
+                pc[i] = make_uint4(cand_off[i] | (eo(i) << 16), (nsl < 0x3FFFu ? nsl : 0x3FFFu) | cut | space, (uint32_t)third, (uint32_t)(third >> 32));
             }
             const uint32_t top = __shfl(m, 63);
             far = top > far ? top : far;
@@ -1165,14 +1076,14 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
             maxcnt = last > maxcnt ? last : maxcnt;
             passes += step_passes(1u, maxcnt);
         }
-        // terminator: totals (candidates, groups, end-list slots)
-        if (ln == 0) pc[n] = make_uint4(C | (G << 16), eo(n), eo(n + 1), 0);
+        // terminator: totals (candidates, end-list slots)
+        if (ln == 0) pc[n] = make_uint4(C | (eo(n) << 16), 0, eo(n + 1), 0);
     }
     if (ln == 0) {
-        A.s_n[sid] = n; A.s_C[sid] = C; A.s_flags[sid] = G | (ngmax << 16); A.s_passes[sid] = passes;
+        A.s_n[sid] = n; A.s_C[sid] = C; A.s_passes[sid] = passes;
     }
     // smallest tier whose LDS holds the lattice arrays (connection costs are never staged)
-    const uint64_t fixed = lattice_fixed_bytes(C, G, ngmax, passes, 1u);
+    const uint64_t fixed = lattice_fixed_bytes(C, passes, 1u);
     uint32_t tier = fallback;
     for (uint32_t t = 0; t < A.n_tiers; ++t)
         if (fixed <= A.tier_bytes[t]) { tier = t; break; }
@@ -1256,27 +1167,34 @@ __global__ void __launch_bounds__(64) gen_candidates_large(DevDict D, BatchArgs 
     }
 }
 
-// Kernel 2: the lattice sweep of one sentence per wavefront, entirely in LDS.  Persistent waves
-// drain the work list of their tier.  Sentences whose lattice does not fit after all go to the
-// fallback list (fused kernel with global scratch).
+// Kernel 2: the lattice sweep of one sentence per wavefront, entirely in LDS (one list entry per workgroup; the escape
+// tiers run persistent waves).  Sentences whose lattice does not fit after all go to the fallback list (fused kernel
+// with global scratch).
 //
 // What lives in LDS per (segment of a) sentence: per end-list slot the packed key (8 B) and the right id (2 B); per
-// candidate its slot | word cost (4 B) and its left-id group (2 B); per group the left id (2 B); the per-step group
-// minima (8 B x the most groups of a position) and the pass records (16 B each).  Nothing per character: the
-// per-character records of gen_candidates are consumed straight from global memory by the reachability sweep, 64
-// positions at a time, and the end lists were laid out by gen_candidates (every candidate arrives with its slot).
+// candidate {slot | word cost, own sequence field | left id} (8 B); the pass records (32 B each).  Nothing per
+// character: the per-character records of gen_candidates are consumed straight from global memory by the reachability
+// sweep, 64 positions at a time, and the end lists were laid out by gen_candidates (every candidate arrives with its slot).
 //
-// The recurrence runs over PASSES: 64 lanes = 64 (group g, predecessor j) pairs of one sweep step.  A lane adds the
-// connection cost of its pair (loaded kDepth passes ahead into a register ring) to the predecessor's key and
-// folds the sum into the group's minimum with ONE LDS atomic (ds_min_u64 on the packed key: minimum cost, ties to the
-// last inserted predecessor = the `<=` of lattice.rs:141-146); the last pass of a step hands the minima to the
-// step's candidates.  LDS operations of one wave execute in order, so no barrier separates these phases.
+// Key of a node: high word = min_cost biased to unsigned order; low word = (0xFFFE - sequence of the best predecessor) << 16
+// | (0xFFFE - own sequence).  The recurrence runs over PASSES: 64 lanes = 64 (candidate c, predecessor j) pairs of one
+// sweep step.  A lane adds the connection cost of its pair (loaded kDepth passes ahead into a register ring) and c's word
+// cost to j's key; the minimum cost of every candidate is found in registers (DPP ladder over its lanes) and only the lanes
+// that hold it fold their key into the candidate's key with an LDS atomic minimum -- (cost, predecessor field, own field):
+// minimum cost, ties to the last inserted predecessor = the `<=` of lattice.rs:141-146.  Steps of more than 64 pairs simply
+// take several passes; the candidate keys start dead and accumulate.  LDS operations of one wave execute in order, so no
+// barrier separates a pass from the next.
 template <bool kSpaceMode>
 __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, BatchArgs A, uint32_t tier, uint32_t list_id, uint32_t persistent) {
+    typedef __attribute__((address_space(3))) const uint64_t lds_cu64;
+    typedef __attribute__((address_space(3))) uint64_t lds_u64;
+    typedef __attribute__((address_space(3))) const uint16_t lds_cu16;
     const uint32_t ln = threadIdx.x;
     const uint32_t lds_bytes = A.tier_bytes[tier];
     const uint32_t NR = D.num_right;
     constexpr uint32_t kDepth = VBT_DEPTH;  // prefetch distance of the matrix gathers, in passes
+    // absolute LDS address of the dynamic shared memory (records hold absolute addresses: no base add per access)
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)g_smem;
     // long sentences are the critical path of a batch: let their waves win issue arbitration
     if (A.tier_prio && (A.seg_tier < A.n_tiers ? tier >= A.seg_tier : tier + A.tier_prio >= A.n_tiers)) __builtin_amdgcn_s_setprio(2);
     const int src = (int)list_id;  // normally the tier's own list; helper launches sweep the segment tier's list with less LDS
@@ -1307,8 +1225,6 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
         unsigned long long* const pr_ = A.prof ? A.prof + (size_t)(sid & (kProfSlots - 1)) * kProfWords : nullptr;
 #define PROF_MARK(i) do { if (A.prof) { const uint64_t t_ = clock64(); if (ln == 0) atomicAdd(&pr_[i], (unsigned long long)(t_ - prof_t)); prof_t = t_; } } while (0)
         const uint32_t nT = __builtin_amdgcn_readfirstlane(A.s_n[sid]), CT = __builtin_amdgcn_readfirstlane(A.s_C[sid]);
-        const uint32_t sflags = __builtin_amdgcn_readfirstlane(A.s_flags[sid]);
-        const uint32_t GT = sflags & 0xFFFFu, ngmax = sflags >> 16;
         const uint32_t passesT = __builtin_amdgcn_readfirstlane(A.s_passes[sid]);
         const size_t slot0 = sentence_slot(A, uniform64(A.offsets[sid]), sid);
         const size_t node0 = (size_t)A.node_factor * slot0;
@@ -1321,13 +1237,13 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
         // (positions no candidate spans, flagged by gen_candidates): only the nodes ending exactly at the cut
         // -- the interface, carried in registers -- connect a segment to the next.  Sequence numbers, slots and back
         // pointers stay sentence-global; each segment leaves (cost, back pointer) per node in global memory.
-        uint32_t seg_a = 0, seg_c = 0, seg_g = 0, seg_p = 0, seg_s = 0, fail = 0;
+        uint32_t seg_a = 0, seg_c = 0, seg_p = 0, seg_s = 0, fail = 0;
         constexpr uint32_t kCarry = 2;  // interface nodes per lane: up to 128 nodes may end at a cut
         uint64_t carry_key[kCarry];
         uint32_t carry_right[kCarry], m_in = 1;
 #pragma unroll
         for (uint32_t q = 0; q < kCarry; ++q) { carry_key[q] = kDeadKey; carry_right[q] = 0; }
-        if (ln == 0) carry_key[0] = node_key(0x80000000u, 0u, 0u, kBosSeq);  // BOS: cost 0, no predecessor (right id 0)
+        if (ln == 0) carry_key[0] = ((uint64_t)0x80000000u << 32) | (0xFFFEu - kBosSeq);  // BOS: cost 0, no predecessor (right id 0)
         bool multi = false, done = false;
         uint32_t counted = A.lid_count ? __builtin_amdgcn_readfirstlane(A.s_counted[sid]) : 0u;
         uint32_t prof_S = 0, prof_SL = 0;
@@ -1335,7 +1251,7 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
         uint32_t cap_b = nT;          // latest admissible segment end (pulled in when too many nodes end at a cut)
         while (!done) {
         uint32_t seg_b = nT, seg_pass = passesT - seg_p;
-        if (lattice_fixed_bytes(CT - seg_c, GT - seg_g, ngmax, passesT - seg_p, m_in) > budget || cap_b < nT) {
+        if (lattice_fixed_bytes(CT - seg_c, passesT - seg_p, m_in) > budget || cap_b < nT) {
             // furthest clean cut within 256 positions whose segment fits
             uint32_t best = 0, best_pass = 0, run = 0;
             for (uint32_t w0 = 0; w0 < 256 && seg_a + w0 < nT; w0 += 64) {
@@ -1343,7 +1259,7 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
                 uint32_t nsl = 0, cx = 0, cut = 0;
                 if (b <= nT) {
                     const uint4 rp = pcg[b - 1], rb = pcg[b];
-                    nsl = (rp.y >> 16) & 0x3FFFu;
+                    nsl = rp.y & 0x3FFFu;
                     if (nsl == 0x3FFFu) nsl = 1u << 20;  // saturated: unknown, treat as too many
                     cx = rb.x;
                     cut = b == nT ? 1u : (rb.y >> 30) & 1u;
@@ -1351,7 +1267,7 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
                 uint32_t tot;
                 const uint32_t incl = wave_exscan(nsl, tot) + nsl + run;
                 const uint32_t est = b == nT ? passesT - seg_p : incl;  // (the sentence's bound includes the EOS step)
-                const uint64_t bytes = lattice_fixed_bytes(((cx & 0xFFFFu) - seg_c) & 0xFFFFu, ((cx >> 16) - seg_g) & 0xFFFFu, ngmax, est, m_in);
+                const uint64_t bytes = lattice_fixed_bytes(((cx & 0xFFFFu) - seg_c) & 0xFFFFu, est, m_in);
                 const bool fits = b <= cap_b && bytes <= budget;
                 const uint64_t m = __ballot(fits && cut);
                 if (m) {
@@ -1370,17 +1286,15 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
         const uint32_t n = seg_b - seg_a;
         const uint4* __restrict__ pc = pcg + seg_a;
         const uint4 rend = uniform4(pcg[seg_b]);  // record of the segment's end position (the terminator for the last segment)
-        const uint32_t C = ((rend.x & 0xFFFFu) - seg_c) & 0xFFFFu, G = ((rend.x >> 16) - seg_g) & 0xFFFFu;
+        const uint32_t C = ((rend.x & 0xFFFFu) - seg_c) & 0xFFFFu;
         const uint32_t E = m_in + C;  // end-list slots: interface (BOS) + the segment's candidates; slot E is the EOS node's
         const uint32_t sb = seg_s;    // sentence-global slot of local slot 0
         const uint2* __restrict__ nd = ndg + seg_c;
 
         Arena ar{g_smem, lds_bytes, 0, true};
-        uint64_t* g_best = ar.take<uint64_t>(ngmax < 64 ? 64 : ngmax + 1);  // per step: best key of each left-id group (offset 0)
-        uint64_t* e_key = ar.take<uint64_t>(E + 1);       // end-major packed (cost, sequence, back pointer) keys
-        uint2* cnd = ar.take<uint2>(C + 1);               // per candidate: {end-list slot | (u16) word_cost << 16, group * 8 | (0xFFFE - sequence) << 16}
+        uint64_t* e_key = ar.take<uint64_t>(E + 1);  // end-major packed keys
+        uint2* cnd = ar.take<uint2>(C + 1);          // per candidate: {end-list slot | (u16) word_cost << 16, (0xFFFE - sequence) | left_id << 16}
         uint16_t* e_right = ar.take<uint16_t>(E + 1);
-        uint16_t* g_left = ar.take<uint16_t>(G + 1);
         ar.used = (ar.used + 15) & ~15ull;
         LPass* rec = reinterpret_cast<LPass*>(g_smem + ar.used);  // pass records take the rest; afterwards the token path
         const uint32_t sl_cap = ar.ok && lds_bytes > ar.used ? (uint32_t)((lds_bytes - ar.used) / sizeof(LPass)) : 0u;
@@ -1388,10 +1302,10 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
             if (budget > lds_bytes / 3) { budget -= lds_bytes / 4; __syncthreads(); continue; }
             fail = 26; break;
         }
-        const uint32_t offK = (uint32_t)(reinterpret_cast<char*>(e_key) - g_smem), offC = (uint32_t)(reinterpret_cast<char*>(cnd) - g_smem);
-        const uint32_t offR = (uint32_t)(reinterpret_cast<char*>(e_right) - g_smem), offL = (uint32_t)(reinterpret_cast<char*>(g_left) - g_smem);
+        const uint32_t offK = lds0 + (uint32_t)(reinterpret_cast<char*>(e_key) - g_smem), offC = lds0 + (uint32_t)(reinterpret_cast<char*>(cnd) - g_smem);
+        const uint32_t offR = lds0 + (uint32_t)(reinterpret_cast<char*>(e_right) - g_smem);
 
-        // ---- load: candidates from global (every record carries its slot and group); group left ids; interface; EOS ----
+        // ---- load: candidates from global (every record carries its slot); interface; EOS ----
         for (uint32_t c0 = 0; c0 < C; c0 += 64 * 4) {  // 4 independent 8-byte loads per lane in flight
             uint2 r[4];
 #pragma unroll
@@ -1406,21 +1320,16 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
                     const uint32_t es = (r[u].x >> 16) - sb;
                     e_right[es] = (uint16_t)r[u].x;
                     e_key[es] = kDeadKey;  // never inserted until a sweep step reaches its start position
-                    cnd[c] = make_uint2(es | (r[u].y << 16), ((r[u].y >> 16) << 3) | ((0xFFFEu - (seg_c + c)) << 16));
+                    cnd[c] = make_uint2(es | (r[u].y << 16), ((0xFFFEu - (seg_c + c)) & 0xFFFFu) | (r[u].y & 0xFFFF0000u));
                 }
             }
-        }
-        {
-            const uint16_t* __restrict__ gl = A.g_gl + node0 + seg_g;
-            for (uint32_t g = ln; g < G; g += 64) g_left[g] = gl[g];
         }
 #pragma unroll
         for (uint32_t q = 0; q < kCarry; ++q)
             if (q * 64 + ln < m_in) { e_right[q * 64 + ln] = (uint16_t)carry_right[q]; e_key[q * 64 + ln] = carry_key[q]; }
         if (ln == 0) {
-            // EOS pseudo candidate (insert_eos, lattice.rs:85-101): left_id 0, word cost 0, the only member of group G
-            cnd[C] = make_uint2(E, (0xFFFEu - (seg_c + C)) << 16);
-            g_left[G] = 0;
+            // EOS pseudo candidate (insert_eos, lattice.rs:85-101): left_id 0, word cost 0
+            cnd[C] = make_uint2(E, (0xFFFEu - (seg_c + C)) & 0xFFFFu);
             e_key[E] = kDeadKey;
         }
         PROF_MARK(3);
@@ -1432,28 +1341,26 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
         // position p + r and drops the reachability of everything in between (the reference continues from
         // start_word + 1).  The length masks of 64 positions come straight from the per-character records in global
         // memory into one VGPR pair and are read with v_readlane.  The visited positions of a chunk become sweep steps,
-        // every step is cut into passes of 64 padded (group, predecessor) pairs, and the pass records are laid out
+        // every step is cut into passes of 64 padded (candidate, predecessor) pairs, and the pass records are laid out
         // contiguously (exclusive scan of the pass counts).
         uint32_t SL = 0, S = 0, sn_eos = n;
         bool windowed = true, overflow = false;
         // the q-th of the nsl passes of a step (executed by the lane that owns the step)
-        auto make_pass = [&](uint32_t p_beg, uint32_t np, uint32_t g_beg, uint32_t ng, uint32_t c_beg, uint32_t nc, uint32_t lg, uint32_t q, uint32_t nsl) {
+        auto make_pass = [&](uint32_t p_beg, uint32_t np, uint32_t c_beg, uint32_t nc, uint32_t lg, uint32_t q) {
             const uint32_t q0 = q << 6;
             uint64_t mask;
-            if (lg >= 6) {  // one group per pass, 64 of its predecessors at a time
+            if (lg >= 6) {  // one candidate per pass, 64 of its predecessors at a time
                 const uint32_t j0 = q0 & ((1u << lg) - 1u);
                 const uint32_t cnt = np > j0 ? (np - j0 < 64 ? np - j0 : 64u) : 0u;
                 mask = cnt >= 64 ? ~0ull : (1ull << cnt) - 1ull;
-            } else {        // 64 >> lg groups per pass, np of every 2^lg lanes hold a pair
-                const uint32_t g0 = q0 >> lg, gs = ng - g0 < (64u >> lg) ? ng - g0 : (64u >> lg);
+            } else {        // 64 >> lg candidates per pass, np of every 2^lg lanes hold a pair
+                const uint32_t g0 = q0 >> lg, gs = nc - g0 < (64u >> lg) ? nc - g0 : (64u >> lg);
                 const uint64_t one = lg == 0 ? ~0ull : lg == 1 ? 0x5555555555555555ull : lg == 2 ? 0x1111111111111111ull : lg == 3 ? 0x0101010101010101ull
                                    : lg == 4 ? 0x0001000100010001ull : 0x0000000100000001ull;
                 const uint32_t span = gs << lg;
                 mask = (one & (span >= 64 ? ~0ull : (1ull << span) - 1ull)) * (uint64_t)((1ull << np) - 1ull);  // no carries: np <= 2^lg
             }
-            const bool simple = nsl == 1 && nc < 64 && ng <= 64;
-            return LPass{offR + (p_beg << 1), offK + (p_beg << 3), offL + (g_beg << 1), q0, (uint32_t)mask, (uint32_t)(mask >> 32), offC + (c_beg << 3),
-                         lg | (q == 0 ? 32u : 0u) | (q + 1 == nsl ? 64u : 0u) | (simple ? 128u : 0u) | (nc << 8)};
+            return LPass{offR + (p_beg << 1), offK + (p_beg << 3), offC + (c_beg << 3), q0, (uint32_t)mask, (uint32_t)(mask >> 32), lg, np | (nc << 16)};
         };
         {
             uint32_t cur0 = 0;
@@ -1502,36 +1409,37 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
                 const uint64_t any = vis | visp;
                 // lanes = the visited positions of the chunk: step (start_node i, start_word sw)
                 const bool step = (any >> ln) & 1ull;
-                uint32_t xa = rc.x, xb = rn.x;  // candidate / group ranges of the start word
+                uint32_t xa = rc.x, xb = rn.x;  // candidate range of the start word
                 if (kSpaceMode && ((visp >> ln) & 1ull)) {
                     const uint32_t sw = i + gf;  // < n: a run that reaches the end stops the sweep above
                     xa = pc[sw].x; xb = pc[sw + 1].x;
                 }
-                const uint32_t p_beg = (rc.y & 0xFFFFu) - sb, np = ((rn.y & 0xFFFFu) - (rc.y & 0xFFFFu)) & 0xFFFFu;
+                const uint32_t p_beg = (rc.x >> 16) - sb, np = ((rn.x >> 16) - (rc.x >> 16)) & 0xFFFFu;
                 const uint32_t c_beg = ((xa & 0xFFFFu) - seg_c) & 0xFFFFu, nc = ((xb & 0xFFFFu) - (xa & 0xFFFFu)) & 0xFFFFu;
-                const uint32_t g_beg = ((xa >> 16) - seg_g) & 0xFFFFu, ng = ((xb >> 16) - (xa >> 16)) & 0xFFFFu;
                 const uint32_t lg = np <= 1 ? 0u : 32u - (uint32_t)__builtin_clz(np - 1);
-                const uint32_t nsl = step ? (uint32_t)((((uint64_t)ng << lg) + 63) >> 6) : 0u;
+                const uint32_t nsl = step ? (uint32_t)((((uint64_t)nc << lg) + 63) >> 6) : 0u;
                 uint32_t tot;
                 const uint32_t ex = wave_exscan(nsl, tot);
                 if (SL + tot + 2 > sl_cap) overflow = true;
                 if (!overflow)
-                    for (uint32_t q = 0; q < nsl; ++q) rec[SL + ex + q] = make_pass(p_beg, np, g_beg, ng, c_beg, nc, lg, q, nsl);
+                    for (uint32_t q = 0; q < nsl; ++q) rec[SL + ex + q] = make_pass(p_beg, np, c_beg, nc, lg, q);
                 SL += tot;
                 S += (uint32_t)__popcll(any);
             }
         }
         if (!windowed) { fail = 27; break; }  // > 63 skipped spaces in a row: generic pre-pass of the fused kernel
+        uint32_t eos_rec = 0;  // first pass record of the EOS step
         if (last_seg) {
             // + the EOS step (insert_eos(start_node), tokenizer.rs:138): predecessors = ends[sn_eos]
-            const uint32_t y0 = __builtin_amdgcn_readfirstlane(pc[sn_eos].y) & 0xFFFFu;
-            const uint32_t y1 = sn_eos < n ? __builtin_amdgcn_readfirstlane(pc[sn_eos + 1].y) & 0xFFFFu : ET;
+            const uint32_t y0 = __builtin_amdgcn_readfirstlane(pc[sn_eos].x) >> 16;
+            const uint32_t y1 = sn_eos < n ? __builtin_amdgcn_readfirstlane(pc[sn_eos + 1].x) >> 16 : ET;
             const uint32_t p_beg = y0 - sb, np = y1 - y0;
             const uint32_t lg = np <= 1 ? 0u : 32u - (uint32_t)__builtin_clz(np - 1);
             const uint32_t nsl = ((1u << lg) + 63) >> 6;
             if (SL + nsl + 2 > sl_cap) overflow = true;
             if (!overflow)
-                for (uint32_t q = ln; q < nsl; q += 64) rec[SL + q] = make_pass(p_beg, np, G, 1u, C, 1u, lg, q, nsl);
+                for (uint32_t q = ln; q < nsl; q += 64) rec[SL + q] = make_pass(p_beg, np, C, 1u, lg, q);
+            eos_rec = SL;
             SL += nsl;
             ++S;
         } else if (sn_eos != n) { fail = 31; break; }  // cannot happen: a trailing space run spans every later cut
@@ -1541,7 +1449,7 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
             fail = 29; break;
         }
         // one empty pass behind the last one (no lane holds a pair): the software pipeline reads ahead up to it
-        if (ln == 0) rec[SL] = LPass{offR, offK, offL, 0u, 0u, 0u, offC, 0u};
+        if (ln == 0) rec[SL] = LPass{offR, offK, offC, 0u, 0u, 0u, 0u, 0u};
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         PROF_MARK(4);
@@ -1557,101 +1465,79 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
             };
             // Software pipeline, three stages ahead of a pass's execution at iteration p:
             //   A1 (iteration p - kDepth - 2): read its record from LDS (broadcast);
-            //   A2 (iteration p - kDepth - 1): record -> this lane's pair -> LDS addresses; read the pair's two ids;
+            //   A2 (iteration p - kDepth - 1): record -> this lane's pair -> LDS addresses; read the pair's candidate and right id;
             //   B  (iteration p - kDepth)    : gather the pair's connection cost from the matrix (lanes without a pair load cell 0).
             // Every stage consumes what the previous iteration requested, so an iteration issues all its independent LDS
-            // reads up front (next record, next ids, this pass's predecessor keys and candidates) and waits for them once; the
-            // second and last round trip is the read of the group minima behind the atomics.  Pass p lives in ring slot
-            // p % kRing from A2 on; the loop is unrolled kRing times, so slot indices are static and nothing is copied around.
+            // reads up front (next record, next pair, this pass's predecessor keys) and waits for them once.  Pass p lives in
+            // ring slot p % kRing from A2 on; the loop is unrolled kRing times, so slot indices are static.
             constexpr uint32_t kRing = kDepth + 2;
-            uint32_t word[kRing], csh[kRing], keyaddr[kRing], gaddr[kRing];  // VGPRs: cost word in flight, shift that brings the cell down, LDS addresses
-            uint32_t smlo[kRing], smhi[kRing], sbc[kRing], smeta[kRing];      // SGPRs (wave-uniform): lane mask, first candidate, shape
+            uint32_t word[kRing], csh[kRing], keyaddr[kRing], taddr[kRing], cw[kRing];  // VGPRs: cost word in flight, shift that brings the cell
+                                                                                         // down, LDS addresses of the predecessor's and the candidate's key, word cost << 16 | own field
+            uint32_t smlo[kRing], smhi[kRing], slg[kRing];                               // SGPRs (wave-uniform): lane mask, lg
             auto stage_a1 = [&](uint32_t p, uint4& r0, uint4& r1) {
                 const uint4* r = reinterpret_cast<const uint4*>(&rec[p < SL ? p : SL]);  // passes > SL do not exist: they re-read the empty one
                 r0 = r[0]; r1 = r[1];
             };
-            auto stage_a2 = [&](const uint4& r0, const uint4& r1, uint32_t u, uint32_t& left, uint32_t& right) {
-                const uint32_t lg = r1.w & 31u;
-                const uint32_t q = ln + r0.w, gg = q >> lg, j = q & ((1u << lg) - 1u);
-                left = *reinterpret_cast<const uint16_t*>(g_smem + r0.z + (gg << 1));
-                right = *reinterpret_cast<const uint16_t*>(g_smem + r0.x + (j << 1));
+            auto stage_a2 = [&](const uint4& r0, const uint4& r1, uint32_t u, uint2& cd, uint32_t& right) {
+                const uint32_t lg = r1.z & 31u;
+                const uint32_t q = ln + r0.w, cc = q >> lg, j = q & ((1u << lg) - 1u);
+                const uint64_t cdv = *reinterpret_cast<lds_cu64*>(r0.z + (cc << 3));
+                cd = make_uint2((uint32_t)cdv, (uint32_t)(cdv >> 32));
+                right = *reinterpret_cast<lds_cu16*>(r0.x + (j << 1));
                 keyaddr[u] = r0.y + (j << 3);
-                gaddr[u] = gg << 3;
                 smlo[u] = __builtin_amdgcn_readfirstlane(r1.x); smhi[u] = __builtin_amdgcn_readfirstlane(r1.y);
-                sbc[u] = __builtin_amdgcn_readfirstlane(r1.z); smeta[u] = __builtin_amdgcn_readfirstlane(r1.w);
+                slg[u] = __builtin_amdgcn_readfirstlane(r1.z);
             };
-            auto stage_b = [&](uint32_t u, uint32_t left, uint32_t right) {
+            auto stage_b = [&](uint32_t u, const uint2& cd, uint32_t right) {
                 const uint64_t mask = ((uint64_t)smhi[u] << 32) | smlo[u];
-                const uint32_t cell = select_mask(mask, 0u, __umul24(left, NR) + right);  // < 2^32: num_left, num_right <= 65535
+                const uint32_t cell = select_mask(mask, 0u, __umul24(cd.y >> 16, NR) + right);  // < 2^32: num_left, num_right <= 65535
                 word[u] = load_policy<VBT_NT_MATRIX != 0>(&matrix32[cell >> 1]);  // (a 16-bit destination would be packed by the compiler and serialise the loads)
                 csh[u] = cell << 4;  // shift count = its low 5 bits: 16 for an odd cell
+                taddr[u] = offK + ((cd.x & 0xFFFFu) << 3);
+                cw[u] = __builtin_amdgcn_perm(cd.x, cd.y, 0x07060100u);  // word cost (high half of x) << 16 | own field (low half of y)
             };
-            uint4 pr0, pr1;             // record of the pass whose A2 is next
-            uint32_t p_left, p_right;   // ids of the pass whose B is next
+            uint4 pr0, pr1;      // record of the pass whose A2 is next
+            uint2 p_cd;          // candidate and right id of the pass whose B is next
+            uint32_t p_right;
             stage_a1(0, pr0, pr1);
 #pragma unroll
             for (uint32_t p = 0; p <= kDepth; ++p) {
                 uint4 n0, n1;
-                uint32_t nl, nr;
+                uint2 ncd;
+                uint32_t nr;
                 stage_a1(p + 1, n0, n1);
-                stage_a2(pr0, pr1, p, nl, nr);
-                if (p > 0) stage_b(p - 1, p_left, p_right);
-                pr0 = n0; pr1 = n1; p_left = nl; p_right = nr;
+                stage_a2(pr0, pr1, p, ncd, nr);
+                if (p > 0) stage_b(p - 1, p_cd, p_right);
+                pr0 = n0; pr1 = n1; p_cd = ncd; p_right = nr;
             }
             for (uint32_t s0 = 0; s0 < SL; s0 += kRing) {
 #pragma unroll
                 for (uint32_t u = 0; u < kRing; ++u) {
                     const uint32_t si = s0 + u;
-                    const uint32_t bc = sbc[u], meta = smeta[u], nc = meta >> 8;
                     const uint64_t mask = ((uint64_t)smhi[u] << 32) | smlo[u];
                     // ---- all independent LDS reads of the iteration ----
                     uint4 n0, n1;
-                    uint32_t nl, nr;
+                    uint2 ncd;
+                    uint32_t nr;
                     stage_a1(si + kDepth + 2, n0, n1);
-                    stage_a2(pr0, pr1, (u + kRing - 1) % kRing, nl, nr);                       // pass si + kDepth + 1
-                    const uint64_t kb = *reinterpret_cast<const uint64_t*>(g_smem + keyaddr[u]);  // key of this lane's predecessor
-                    const uint2 cd = *reinterpret_cast<const uint2*>(g_smem + bc + (ln << 3));    // candidate this lane may finalise
+                    stage_a2(pr0, pr1, (u + kRing - 1) % kRing, ncd, nr);            // pass si + kDepth + 1
+                    const uint64_t kb = *reinterpret_cast<lds_cu64*>(keyaddr[u]);  // key of this lane's predecessor
                     __builtin_amdgcn_sched_barrier(0);  // (keep these reads together, ahead of their first consumer: one wait for all)
-                    stage_b((u + kDepth) % kRing, p_left, p_right);                           // pass si + kDepth
-                    pr0 = n0; pr1 = n1; p_left = nl; p_right = nr;
+                    stage_b((u + kDepth) % kRing, p_cd, p_right);                  // pass si + kDepth
+                    pr0 = n0; pr1 = n1; p_cd = ncd; p_right = nr;
                     // ---- pass si ----
-                    const uint32_t ga = gaddr[u];
-                    const uint32_t khi = (uint32_t)(kb >> 32) + (uint32_t)(int32_t)(int16_t)(word[u] >> (csh[u] & 31u));  // wrapping i32 add
+                    const uint32_t khi = (uint32_t)(kb >> 32) + (uint32_t)(int32_t)(int16_t)(word[u] >> (csh[u] & 31u))   // wrapping i32 adds:
+                                         + (uint32_t)((int32_t)cw[u] >> 16);                                            // connection + word cost (lattice.rs:125,139)
+                    const uint32_t klo = __builtin_amdgcn_perm((uint32_t)kb, cw[u], 0x05040100u);  // predecessor's own field << 16 | the candidate's
                     const uint64_t live = __ballot((uint32_t)kb != 0xFFFFFFFFu) & mask;
                     // (a lane without a live pair carries the dead key, a no-op for the minimum should it tie with m)
-                    const uint32_t hi = select_mask(live, 0xFFFFFFFFu, khi), lo = select_mask(live, 0xFFFFFFFFu, (uint32_t)kb);
-                    const uint32_t lg = meta & 31u;
-                    // minimum cost of every group in registers; only the lanes that hold it go to LDS, where the atomic on the
+                    const uint32_t hi = select_mask(live, 0xFFFFFFFFu, khi), lo = select_mask(live, 0xFFFFFFFFu, klo);
+                    const uint32_t lg = slg[u];
+                    // minimum cost of every candidate in registers; only the lanes that hold it go to LDS, where the atomic on the
                     // whole key settles ties (rare) towards the last inserted predecessor: no same-address pile-up
-                    const uint32_t m = group_min_u32(hi, lg < 6 ? lg : 6u);  // (more than 64 predecessors: one group per pass)
-                    auto finalise = [&](const uint2& c) {  // the candidate takes its group's minimum (lattice.rs:125)
-                        const uint64_t best = *reinterpret_cast<const uint64_t*>(g_smem + (c.y & 0xFFFFu));
-                        const uint32_t fhi = (uint32_t)(best >> 32) + (uint32_t)(int32_t)(int16_t)(c.x >> 16);
-                        const uint32_t flo = (c.y & 0xFFFF0000u) | (0xFFFEu - ((uint32_t)best >> 16));
-                        *reinterpret_cast<uint64_t*>(g_smem + offK + ((c.x & 0xFFFFu) << 3)) = ((uint64_t)fhi << 32) | flo;
-                    };
-                    if (meta & 128u) {
-                        // the whole step in one pass (the common case): clear the minima, fold the pairs, hand out the results
-                        g_best[ln] = kDeadKey;
-                        if (hi == m)
-                            __hip_atomic_fetch_min(static_cast<uint64_t*>(__builtin_assume_aligned(g_smem + ga, 8)), ((uint64_t)hi << 32) | lo,
-                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                        if (ln < nc) finalise(cd);
-                    } else {
-                        // a step of several passes, or with many candidates / groups
-                        if (meta & 32u) {  // first pass: no minimum yet
-                            const uint32_t ng_hi = ngmax + 1;
-                            for (uint32_t t = ln; t < ng_hi; t += 64) g_best[t] = kDeadKey;
-                        }
-                        if (hi == m)
-                            __hip_atomic_fetch_min(static_cast<uint64_t*>(__builtin_assume_aligned(g_smem + ga, 8)), ((uint64_t)hi << 32) | lo,
-                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                        if (meta & 64u)  // last pass of the step
-                            for (uint32_t cb = 0; cb < nc; cb += 64)
-                                if (cb + ln < nc) finalise(*reinterpret_cast<const uint2*>(g_smem + bc + ((cb + ln) << 3)));
-                    }
+                    const uint32_t m = group_min_u32(hi, lg < 6 ? lg : 6u);  // (more than 64 predecessors: one candidate per pass)
+                    if (hi == m)
+                        __hip_atomic_fetch_min(reinterpret_cast<lds_u64*>(taddr[u]), ((uint64_t)hi << 32) | lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     // LDS operations of one wave execute in order: a compiler-level fence is all the next pass needs
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
@@ -1660,18 +1546,20 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
         }
         PROF_MARK(6);
 
+        // back pointer of a node = sequence of its best predecessor
+        auto key_pred = [](uint64_t k) { return 0xFFFEu - (((uint32_t)k) >> 16); };
         if (multi) {
             // leave (total cost, back pointer) of every node of the segment in the sentence's (dead) hit-staging region
             uint2* __restrict__ nb = reinterpret_cast<uint2*>(A.g_hits + node0 + seg_c);
             for (uint32_t c = ln; c < C; c += 64) {
                 const uint64_t k = e_key[cnd[c].x & 0xFFFFu];
-                nb[2 * c] = make_uint2(key_cost(k), key_back(k));
+                nb[2 * c] = make_uint2(key_cost(k), key_pred(k));
             }
         }
         uint32_t i0 = 0, m_out = 0;
         if (!last_seg) {
             // the interface: nodes ending exactly at the cut
-            i0 = (rend.y & 0xFFFFu) - sb;
+            i0 = (rend.x >> 16) - sb;
             m_out = E - i0;
             if (m_out > 64 * kCarry || m_out == 0) {  // more nodes end here than the carry holds: cut earlier
                 if (seg_b > seg_a + 1 && m_out) { cap_b = seg_b - 1; __syncthreads(); continue; }
@@ -1687,19 +1575,12 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
             const uint32_t c_skip = counted >= nT ? CT : __builtin_amdgcn_readfirstlane(pcg[counted].x) & 0xFFFFu;  // candidates are in start order
             for (uint32_t k = 0; k < SL; ++k) {
                 const uint4 r0 = uniform4(*reinterpret_cast<const uint4*>(&rec[k])), r1 = uniform4(*(reinterpret_cast<const uint4*>(&rec[k]) + 1));
-                if (!(r1.w & 32u)) continue;  // one record per step: its first pass
-                const uint32_t c_beg = (r1.z - offC) >> 3, nc = r1.w >> 8, g_beg = (r0.z - offL) >> 1, lg = r1.w & 31u;
-                const bool eos_step = last_seg && c_beg == C;
+                if (r0.w) continue;  // one record per step: its first pass
+                const uint32_t c_beg = (r0.z - offC) >> 3, nc = r1.w >> 16, np = r1.w & 0xFFFFu;
+                const bool eos_step = last_seg && k == eos_rec;
                 if (eos_step ? counted > nT : seg_c + c_beg < c_skip) continue;
-                // predecessors of the step: the lanes of its first group (spread over 2^(lg-6) passes when there are more than 64)
-                uint32_t np = 0;
-                if (lg < 6) np = (uint32_t)__popcll((((uint64_t)r1.y << 32) | r1.x) & ((1ull << (1u << lg)) - 1ull));
-                else for (uint32_t t = 0; t < (1u << (lg - 6)); ++t) {
-                    const uint4 m = uniform4(*(reinterpret_cast<const uint4*>(&rec[k + t]) + 1));
-                    np += (uint32_t)__popcll(((uint64_t)m.y << 32) | m.x);
-                }
                 uint32_t p_beg = (r0.y - offK) >> 3, p_end = p_beg + np;
-                if (eos_step) { p_beg = (rend.y & 0xFFFFu) - sb; p_end = E; }  // EOS pairs with ends[len_char]
+                if (eos_step) { p_beg = (rend.x >> 16) - sb; p_end = E; }  // EOS pairs with ends[len_char]
                 uint32_t live = 0;
                 for (uint32_t j0 = p_beg; j0 < p_end; j0 += 64) {
                     const uint32_t j = j0 + ln;
@@ -1707,8 +1588,7 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
                     live += (uint32_t)__popcll(__ballot(alive));
                     if (alive) atomicAdd(&A.rid_count[e_right[j]], (unsigned long long)nc);
                 }
-                for (uint32_t c = c_beg + ln; c < c_beg + nc; c += 64)
-                    atomicAdd(&A.lid_count[g_left[g_beg + ((cnd[c].y & 0xFFFFu) >> 3)]], (unsigned long long)live);
+                for (uint32_t c = c_beg + ln; c < c_beg + nc; c += 64) atomicAdd(&A.lid_count[cnd[c].y >> 16], (unsigned long long)live);
             }
             const uint32_t upto = last_seg ? nT + 1 : seg_b;
             if (upto > counted) { counted = upto; if (ln == 0) A.s_counted[sid] = counted; }
@@ -1720,7 +1600,7 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
                 carry_right[q] = q * 64 + ln < m_out ? (uint32_t)e_right[i0 + q * 64 + ln] : 0u;
             }
             m_in = m_out;
-            seg_a = seg_b; seg_c += C; seg_g += G; seg_p += seg_pass; seg_s = rend.y & 0xFFFFu; cap_b = nT;
+            seg_a = seg_b; seg_c += C; seg_p += seg_pass; seg_s = rend.x >> 16; cap_b = nT;
             __syncthreads();
             continue;
         }
@@ -1743,10 +1623,10 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
         if (!multi) {
             uint16_t* path = reinterpret_cast<uint16_t*>(rec);  // the pass records are dead now; tokens <= steps
             if (ln == 0) {
-                uint32_t seq = key_back(e_key[E]);
+                uint32_t seq = key_pred(e_key[E]);
                 while (seq != kBosSeq && T < n) {
                     path[T++] = (uint16_t)seq;
-                    seq = key_back(e_key[cnd[seq].x & 0xFFFFu]);
+                    seq = key_pred(e_key[cnd[seq].x & 0xFFFFu]);
                 }
             }
             T = __shfl(T, 0);
@@ -1766,7 +1646,7 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
             }
         } else {
             // segmented sentence: pull all back pointers into LDS (the arena is free now), walk, emit from global
-            const uint32_t back_eos = key_back(e_key[E]);
+            const uint32_t back_eos = key_pred(e_key[E]);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's own dumps: stores complete
             __syncthreads();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -2110,14 +1990,12 @@ Workspace::Workspace(const Tokenizer& t, uint64_t max_s, uint64_t max_b) : tok(t
     const size_t slots = nbts + ns + 1;
     pipe.s_n = static_cast<uint32_t*>(alloc(ns * 4));
     pipe.s_C = static_cast<uint32_t*>(alloc(ns * 4));
-    pipe.s_flags = static_cast<uint32_t*>(alloc(ns * 4));
     if (!fused) {
         pipe.g_c2b = static_cast<uint16_t*>(alloc(slots * 2));
         pipe.g_pc = static_cast<uint4*>(alloc(slots * 16));
         pipe.node_factor = std::max<uint32_t>(1, env_u32("VBT_NODE_FACTOR", 8));  // candidate slots per input byte
         pipe.g_nd = static_cast<uint2*>(alloc((size_t)pipe.node_factor * slots * 8));
         pipe.g_em = static_cast<uint2*>(alloc((size_t)pipe.node_factor * slots * 8));
-        pipe.g_gl = static_cast<uint16_t*>(alloc((size_t)pipe.node_factor * slots * 2));
         pipe.g_hits = static_cast<uint4*>(alloc((size_t)pipe.node_factor * slots * 16));
         pipe.s_passes = static_cast<uint32_t*>(alloc(ns * 4));
         pipe.s_tier = static_cast<uint8_t*>(alloc(ns));

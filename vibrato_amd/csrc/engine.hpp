@@ -53,20 +53,16 @@ struct BatchArgs {
     // per sentence
     uint32_t* s_n;      // characters
     uint32_t* s_C;      // lattice candidates
-    uint32_t* s_flags;  // left-id groups | max groups of a position << 16
     uint32_t* s_passes; // upper bound of the lattice passes
     // per character slot (sentence s, char i -> slot offsets[s] + s + i; nb + 1 slots per sentence)
     uint16_t* g_c2b;
     uint4* g_pc;        // {cand_off, groupable | is_space << 31, lens lo, lens hi}
     // per candidate (insertion order, contiguous per sentence; sentence s owns the node slots
     // [node_factor * (offsets[s] + s), node_factor * (offsets[s+1] + s + 1)): no allocation atomics).
-    //   g_nd: what the sweep needs, 8 bytes: {right_id | end-list slot << 16, (u16) word_cost | left-id group within the
-    //         start position << 16}
+    //   g_nd: what the sweep needs, 8 bytes: {right_id | end-list slot << 16, (u16) word_cost | left_id << 16}
     //   g_em: what only the tokens of the best path need, 8 bytes: {word_idx, end_char}
-    //   g_gl: left id of every left-id group (sentence-wide group numbering, same region as the candidates)
     uint2* g_nd;
     uint2* g_em;
-    uint16_t* g_gl;
     uint4* g_hits;      // staging of the trie hits of gen_candidates, same per-sentence regions as g_nd
     uint32_t node_factor;
     uint8_t* s_tier;    // LDS tier chosen by gen_candidates (0xFF = none / empty sentence)
