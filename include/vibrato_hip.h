@@ -86,6 +86,17 @@ VBT_API int vbt_dict_from_sources(const char* lex, size_t lex_len, const char* m
 VBT_API int vbt_dict_from_sources_binmatrix(const char* lex, size_t lex_len, const int16_t* matrix,
                                             uint32_t num_right, uint32_t num_left, const char* char_def,
                                             size_t char_len, const char* unk_def, size_t unk_len, vbt_dict** out);
+/* SystemDictionaryBuilder::from_readers_with_bigram_info(lex.csv, bigram.right, bigram.left, bigram.cost, char.def, unk.def,
+ * dual_connector), builder.rs:111-160: the connection costs come from the compact bigram model (RawConnector
+ * connector/raw_connector.rs, DualConnector connector/dual_connector.rs).  `dual` selects a memory layout in the reference;
+ * the cost function is the same.  The device image materialises it as a dense matrix when the tokenizer is created
+ * (VBT_ERR_UNSUPPORTED there if a cost does not fit i16). */
+VBT_API int vbt_dict_from_sources_bigram(const char* lex, size_t lex_len, const char* bigram_right, size_t right_len,
+                                         const char* bigram_left, size_t left_len, const char* bigram_cost, size_t cost_len,
+                                         const char* char_def, size_t char_len, const char* unk_def, size_t unk_len, int dual,
+                                         vbt_dict** out);
+/* ConnectorWrapper variant, connector.rs:30-35: 0 Matrix, 1 Raw, 2 Dual (-1: null / consumed handle) */
+VBT_API int vbt_dict_connector_kind(const vbt_dict* dict);
 /* Dictionary::reset_user_lexicon_from_reader(Some(csv) | None), dictionary.rs:209-229 */
 VBT_API int vbt_dict_set_user_lexicon(vbt_dict* dict, const char* csv, size_t len);
 /* Dictionary::map_connection_ids_from_iter(lmap, rmap), dictionary.rs:245-259: the i-th item (1-origin) is the

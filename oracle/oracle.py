@@ -40,6 +40,23 @@ def lib():
         L.ora_dict_from_sources.argtypes = [u8p, sz, u8p, sz, u8p, sz, u8p, sz, u8p, sz]
         L.ora_dict_from_sources_binmatrix.restype = vp
         L.ora_dict_from_sources_binmatrix.argtypes = [u8p, sz, vp, u32, u32, u8p, sz, u8p, sz, u8p, sz]
+        L.ora_dict_from_sources_bigram.restype = vp
+        L.ora_dict_from_sources_bigram.argtypes = [u8p, sz, u8p, sz, u8p, sz, u8p, sz, u8p, sz, u8p, sz, u8p, sz]
+        L.ora_scorer_new.restype = vp
+        L.ora_scorer_new.argtypes = [vp, u32]
+        L.ora_scorer_free.argtypes = [vp]
+        L.ora_scorer_retrieve.restype = C.c_int
+        L.ora_scorer_retrieve.argtypes = [vp, u32, u32, C.POINTER(i32)]
+        L.ora_scorer_accumulate.restype = i32
+        L.ora_scorer_accumulate.argtypes = [vp, vp, vp, u32]
+        L.ora_raw_connector_new.restype = vp
+        L.ora_raw_connector_new.argtypes = [u8p, sz, u8p, sz, u8p, sz, u8p, sz]
+        L.ora_raw_connector_free.argtypes = [vp]
+        L.ora_raw_connector_cost.restype = i32
+        L.ora_raw_connector_cost.argtypes = [vp, u32, u32]
+        L.ora_raw_connector_num.restype = u32
+        L.ora_raw_connector_num.argtypes = [vp, C.c_int]
+        L.ora_raw_connector_map.argtypes = [vp, vp, vp]
         L.ora_dict_set_user_lexicon.restype = C.c_int
         L.ora_dict_set_user_lexicon.argtypes = [vp, u8p, sz, u8p, sz]
         L.ora_dict_map_connection_ids.restype = C.c_int
@@ -121,6 +138,19 @@ class Dictionary:
         err = C.create_string_buffer(512)
         h = lib().ora_dict_from_sources_binmatrix(lex, len(lex), m.ctypes.data, num_right, num_left,
                                                   char_def, len(char_def), unk, len(unk), err, 512)
+        if not h:
+            raise OracleError(err.value.decode("utf-8", "replace"))
+        return cls(h)
+
+    @classmethod
+    def from_sources_bigram(cls, lex, bigram_right, bigram_left, bigram_cost, char_def, unk):
+        """SystemDictionaryBuilder::from_readers_with_bigram_info (builder.rs:111-160); Raw and Dual share the cost function."""
+        a = [_b(x) for x in (lex, bigram_right, bigram_left, bigram_cost, char_def, unk)]
+        err = C.create_string_buffer(512)
+        args = []
+        for x in a:
+            args += [x, len(x)]
+        h = lib().ora_dict_from_sources_bigram(*args, err, 512)
         if not h:
             raise OracleError(err.value.decode("utf-8", "replace"))
         return cls(h)
@@ -307,3 +337,64 @@ def format_tokens(worker, mode="mecab"):
             f"{t['surface']}\t{t['feature']}\tlex_type={LEX_NAMES[t['lex_type']]}\tleft_id={t['left_id']}\t"
             f"right_id={t['right_id']}\tword_cost={t['word_cost']}\ttotal_cost={t['total_cost']}\n" for t in toks) + "EOS\n"
     raise ValueError(mode)
+
+
+class Scorer:
+    """ScorerBuilder + Scorer (connector/raw_connector/scorer.rs:103-282), for the reference's unit vectors."""
+
+    def __init__(self, triples):
+        t = np.ascontiguousarray(np.array(triples, dtype=np.int64).astype(np.uint32).reshape(-1, 3))
+        self._h = lib().ora_scorer_new(t.ctypes.data, len(t))
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                lib().ora_scorer_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def retrieve_cost(self, key1, key2):
+        out = C.c_int32()
+        return out.value if lib().ora_scorer_retrieve(self._h, key1, key2, C.byref(out)) else None
+
+    def accumulate_cost(self, keys1, keys2):
+        a = np.ascontiguousarray(keys1, dtype=np.uint32)
+        b = np.ascontiguousarray(keys2, dtype=np.uint32)
+        return lib().ora_scorer_accumulate(self._h, a.ctypes.data, b.ctypes.data, len(a))
+
+
+class RawConnector:
+    """RawConnector::from_readers / cost / map_connection_ids (connector/raw_connector.rs:45-161)."""
+
+    def __init__(self, bigram_right, bigram_left, bigram_cost):
+        r, l, c = _b(bigram_right), _b(bigram_left), _b(bigram_cost)
+        err = C.create_string_buffer(512)
+        self._h = lib().ora_raw_connector_new(r, len(r), l, len(l), c, len(c), err, 512)
+        if not self._h:
+            raise OracleError(err.value.decode("utf-8", "replace"))
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                lib().ora_raw_connector_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def cost(self, right_id, left_id):
+        return lib().ora_raw_connector_cost(self._h, right_id, left_id)
+
+    @property
+    def num_left(self):
+        return lib().ora_raw_connector_num(self._h, 1)
+
+    @property
+    def num_right(self):
+        return lib().ora_raw_connector_num(self._h, 0)
+
+    def map_connection_ids(self, left, right):
+        """ConnIdMapper::new(left, right): new id = left[old id] (mapper.rs:14-17)."""
+        l = np.ascontiguousarray(left, dtype=np.uint16)
+        r = np.ascontiguousarray(right, dtype=np.uint16)
+        lib().ora_raw_connector_map(self._h, l.ctypes.data, r.ctypes.data)

@@ -106,6 +106,8 @@ static int parse_int(const char *s, size_t n, int allow_neg, long long lo, long 
     return 1;
 }
 
+#include "raw_connector.c"
+
 /* ------------------------------------------------- lexicon CSV (lexicon.rs) */
 
 typedef struct {
@@ -437,6 +439,7 @@ typedef struct ora_dict {
     unk_entry *unk_entries;
     uint32_t n_unk;
     uint16_t *map_left, *map_right; /* ConnIdMapper, mapper.rs:9-12 (NULL = None) */
+    struct ora_raw_connector *raw;  /* ConnectorWrapper::Raw / ::Dual (connector.rs:30-35): matrix == NULL then */
 } ora_dict;
 
 /* CharInfo bit layout, character.rs:10-24,56-95 */
@@ -818,6 +821,7 @@ ORA_API void ora_dict_free(ora_dict *d) {
     lexicon_free(&d->sys);
     if (d->has_user) lexicon_free(&d->user);
     free(d->matrix);
+    raw_free(d->raw);
     if (d->categories) {
         for (uint32_t i = 0; i < d->n_categories; i++) free(d->categories[i]);
         free(d->categories);
@@ -847,6 +851,8 @@ static ora_dict *dict_build(const char *lex, size_t lex_len, const char *mat, si
         size_t n = (size_t)num_right * num_left;
         d->matrix = (int16_t *)malloc(n ? n * 2 : 2);
         memcpy(d->matrix, matrix_bin, n * 2);
+    } else if (!mat) { /* compact connector: only the id ranges are known here */
+        d->num_right = num_right; d->num_left = num_left;
     } else if (!parse_matrix_def(mat, mat_len, d, err, errcap)) goto fail;
     if (!parse_char_def(chr, chr_len, d, err, errcap)) goto fail;
     if (!parse_unk_def(unk, unk_len, d, err, errcap)) goto fail;
@@ -868,6 +874,18 @@ fail:
 fail2:
     ora_dict_free(d);
     return NULL;
+}
+
+/* SystemDictionaryBuilder::from_readers_with_bigram_info, builder.rs:111-160 (Raw and Dual share the cost function) */
+ORA_API ora_dict *ora_dict_from_sources_bigram(const char *lex, size_t lex_len, const char *right, size_t right_len, const char *left,
+                                               size_t left_len, const char *cost, size_t cost_len, const char *chr, size_t chr_len,
+                                               const char *unk, size_t unk_len, char *err, size_t errcap) {
+    ora_raw_connector *rc = raw_from_sources(right, right_len, left, left_len, cost, cost_len, err, errcap);
+    if (!rc) return NULL;
+    ora_dict *d = dict_build(lex, lex_len, NULL, 0, NULL, rc->num_right, rc->num_left, chr, chr_len, unk, unk_len, err, errcap);
+    if (!d) { raw_free(rc); return NULL; }
+    d->raw = rc;
+    return d;
 }
 
 ORA_API ora_dict *ora_dict_from_sources(const char *lex, size_t lex_len, const char *mat, size_t mat_len,
@@ -954,13 +972,16 @@ ORA_API int ora_dict_map_connection_ids(ora_dict *d, const uint16_t *lmap, size_
             lxs[k]->params[i].right_id = mr[lxs[k]->params[i].right_id];
         }
     }
-    size_t n = (size_t)d->num_left * d->num_right;
-    int16_t *mapped = (int16_t *)malloc(n ? n * 2 : 2);
-    for (uint32_t r = 0; r < d->num_right; r++)
-        for (uint32_t l = 0; l < d->num_left; l++)
-            mapped[(size_t)ml[l] * d->num_right + mr[r]] = d->matrix[(size_t)l * d->num_right + r];
-    free(d->matrix);
-    d->matrix = mapped;
+    if (d->raw) raw_map_ids(d->raw, ml, mr);
+    else {
+        size_t n = (size_t)d->num_left * d->num_right;
+        int16_t *mapped = (int16_t *)malloc(n ? n * 2 : 2);
+        for (uint32_t r = 0; r < d->num_right; r++)
+            for (uint32_t l = 0; l < d->num_left; l++)
+                mapped[(size_t)ml[l] * d->num_right + mr[r]] = d->matrix[(size_t)l * d->num_right + r];
+        free(d->matrix);
+        d->matrix = mapped;
+    }
     for (uint32_t i = 0; i < d->n_unk; i++) {
         d->unk_entries[i].left_id = ml[d->unk_entries[i].left_id];
         d->unk_entries[i].right_id = mr[d->unk_entries[i].right_id];
@@ -979,6 +1000,7 @@ ORA_API uint32_t ora_dict_num_left(const ora_dict *d) { return d->num_left; }
 ORA_API uint32_t ora_dict_num_right(const ora_dict *d) { return d->num_right; }
 /* ConnectorCost::cost(right_id, left_id), matrix_connector.rs:119-125 */
 ORA_API int32_t ora_dict_conn_cost(const ora_dict *d, uint32_t right_id, uint32_t left_id) {
+    if (d->raw) return raw_cost(d->raw, right_id, left_id);
     return (int32_t)d->matrix[(size_t)left_id * d->num_right + right_id];
 }
 /* CharProperty::char_info, character.rs:112-116 */
@@ -1150,11 +1172,11 @@ static void lattice_reset(ora_worker *w, uint32_t len_char) {
 static inline void search_min_node(const ora_worker *w, uint32_t start_node, uint16_t left_id, uint16_t *min_idx, int32_t *min_cost) {
     const ora_dict *d = w->tok->dict;
     const node_vec *e = &w->ends[start_node];
-    const int16_t *row = d->matrix + (size_t)left_id * d->num_right; /* matrix_connector.rs:79-85 */
+    const int16_t *row = d->raw ? NULL : d->matrix + (size_t)left_id * d->num_right; /* matrix_connector.rs:79-85 */
     uint16_t mi = INVALID_IDX;
     int32_t mc = MAX_COST;
     for (uint32_t i = 0; i < e->n; i++) {
-        int32_t conn = (int32_t)row[e->v[i].right_id];
+        int32_t conn = row ? (int32_t)row[e->v[i].right_id] : raw_cost(d->raw, e->v[i].right_id, left_id); /* raw_connector.rs:153-161 */
         int32_t nc = (int32_t)((uint32_t)e->v[i].min_cost + (uint32_t)conn); /* wrapping add (release build) */
         if (nc <= mc) { mi = (uint16_t)i; mc = nc; }
     }

@@ -15,6 +15,8 @@ The Rust reference cannot be executed here (no cargo/rustc), so these vectors ar
   * vibrato/src/tests/lexicon.rs:8-78, dictionary/lexicon.rs:232-272
   * vibrato/src/tests/connector.rs:5-14, connector/matrix_connector.rs:131-183
   * vibrato/src/dictionary/character.rs:288-298
+  * vibrato/src/dictionary/connector/raw_connector/scorer.rs:348-480 (Scorer), raw_connector.rs:324-510,
+    dual_connector.rs:281-360 (compact connectors: builder vectors, cost(), id mapping)
 
 The dictionary text fixtures under vibrato/src/tests/resources/ (lex.csv,
 matrix.def, char.def, unk.def, user.csv; credits in resources/README.md there)
@@ -139,6 +141,92 @@ def parse_sentences(body: str):
     return sents
 
 
+
+def split_fns(src: str):
+    """Yield (name, body) for each `fn <name>_test() { ... }` of a #[cfg(test)] module."""
+    src = src[src.index("#[cfg(test)]"):]
+    for m in re.finditer(r"fn (\w+_test)\(\) \{", src):
+        depth, i = 1, m.end()
+        in_str = False
+        while depth:
+            c = src[i]
+            if in_str:
+                if c == "\\":
+                    i += 1
+                elif c == '"':
+                    in_str = False
+            else:
+                if c == '"':
+                    in_str = True
+                elif c == "{":
+                    depth += 1
+                elif c == "}":
+                    depth -= 1
+            i += 1
+        yield m.group(1), src[m.end():i - 1]
+
+
+U31 = r"(?:U31::new\((\d+)\)\.unwrap\(\)|(INVALID_FEATURE_ID))"
+
+
+def u31_list(text: str):
+    return [0x7FFFFFFF if inv else int(num) for num, inv in re.findall(U31, text)]
+
+
+def connector_vectors():
+    """Scorer / RawConnector / DualConnector known-answer tests, parsed from the reference's test modules."""
+    conn = os.path.join(REF, "dictionary/connector")
+    out = {"scorer": [], "bigram_connector": [], "parse_cost": [], "parse_cost_errors": [], "parse_features": [], "parse_features_errors": []}
+    src = open(os.path.join(conn, "raw_connector/scorer.rs"), encoding="utf-8").read()
+    for name, body in split_fns(src):
+        if name == "u31x8_encode_decode_test":
+            continue
+        ins = [[int(a), int(b), int(c)] for a, b, c in
+               re.findall(r"builder\.insert\(U31::new\((\d+)\)\.unwrap\(\), U31::new\((\d+)\)\.unwrap\(\), (-?\d+)\)", body)]
+        case = {"source": "vibrato/src/dictionary/connector/raw_connector/scorer.rs::" + name, "insert": ins, "retrieve": [], "accumulate": []}
+        for a, b, exp in re.findall(r"scorer\.retrieve_cost\(U31::new\((\d+)\)\.unwrap\(\), U31::new\((\d+)\)\.unwrap\(\)\),\s*(Some\(-?\d+\)|None)", body):
+            case["retrieve"].append([int(a), int(b), None if exp == "None" else int(exp[5:-1])])
+        for k1, k2, exp in re.findall(r"scorer\.accumulate_cost\(\s*&(.*?),\s*&(.*?),?\s*\),\s*(-?\d+),?\s*\)", body, re.S):
+            case["accumulate"].append([u31_list(k1), u31_list(k2), int(exp)])
+        assert case["retrieve"] or case["accumulate"], name
+        out["scorer"].append(case)
+    for fname in ["raw_connector.rs", "dual_connector.rs"]:
+        src = open(os.path.join(conn, fname), encoding="utf-8").read()
+        for name, body in split_fns(src):
+            if name in ("from_readers_test", "mapping_test"):
+                d = {}
+                for var in ["right_rdr", "left_rdr", "cost_rdr"]:
+                    m = re.search(r"let " + var + r" = " + STR, body, re.S)
+                    d[var] = rust_str(m.group(1))
+                mp = re.search(r"ConnIdMapper::new\(vec!\[([^\]]*)\], vec!\[([^\]]*)\]\)", body)
+                out["bigram_connector"].append({
+                    "source": "vibrato/src/dictionary/connector/" + fname + "::" + name,
+                    "dual": fname.startswith("dual"),
+                    "right": d["right_rdr"], "left": d["left_rdr"], "cost": d["cost_rdr"],
+                    "map": [[int(x) for x in mp.group(1).split(",")], [int(x) for x in mp.group(2).split(",")]] if mp else None,
+                    "costs": [[int(r), int(l), int(c)] for r, l, c in re.findall(r"conn\.cost\((\d+), (\d+)\), (-?\d+)\)", body)],
+                })
+            elif name == "parse_cost_test":  # ids handed out in order of first appearance, from EMPTY maps here
+                calls = re.findall(r"parse_cost\(\s*" + STR + r".*?\(U31::new\((\d+)\)\.unwrap\(\), U31::new\((\d+)\)\.unwrap\(\), (-?\d+)\)", body, re.S)
+                out["parse_cost"].append({"source": "vibrato/src/dictionary/connector/raw_connector.rs::" + name,
+                                          "lines": [[rust_str(l), int(r), int(lf), int(c)] for l, r, lf, c in calls]})
+            elif name.startswith("parse_cost_invalid"):
+                out["parse_cost_errors"].append({"source": "vibrato/src/dictionary/connector/raw_connector.rs::" + name,
+                                                 "line": rust_str(re.search(r"parse_cost\(\s*" + STR, body).group(1))})
+            elif name in ("parse_feature_test", "parse_feature_invalid_id_test"):
+                idmap = {rust_str(k): int(v) for k, v in re.findall(STR + r"\.to_string\(\) => U31::new\((\d+)\)", body)}
+                m = re.search(r"parse_features\(\s*" + STR, body)
+                item = {"source": "vibrato/src/dictionary/connector/raw_connector.rs::" + name, "id_map": idmap, "line": rust_str(m.group(1))}
+                if name == "parse_feature_test":
+                    tail = body[m.end():]
+                    item["id"] = int(re.search(r"\(\s*(\d+),\s*vec!", tail).group(1))
+                    item["features"] = u31_list(tail[tail.index("vec!"):])
+                    out["parse_features"].append(item)
+                else:
+                    out["parse_features_errors"].append(item)
+    return out
+
+
 def main():
     res_dst = os.path.join(HERE, "resources")
     os.makedirs(res_dst, exist_ok=True)
@@ -235,6 +323,7 @@ def main():
             {"source": "vibrato/src/dictionary/character.rs:349-353", "char_def": "DEFAULT 0 1 0\n0x0..0xFFFF DEFAULT"}
         ],
     }
+    unit.update(connector_vectors())
     json.dump(unit, open(os.path.join(HERE, "unit_golden.json"), "w"), ensure_ascii=False, indent=1)
     print("unit_golden.json written")
 

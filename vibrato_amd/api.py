@@ -59,6 +59,11 @@ class Dictionary:
         return N.lib().vbt_dict_num_words(self._handle(), lex_type)
 
     @property
+    def connector_kind(self):
+        """"Matrix" | "Raw" | "Dual" (ConnectorWrapper, connector.rs:30-35)."""
+        return ("Matrix", "Raw", "Dual")[N.lib().vbt_dict_connector_kind(self._handle())]
+
+    @property
     def num_left(self):
         return N.lib().vbt_dict_num_left(self._handle())
 
@@ -108,6 +113,17 @@ class SystemDictionaryBuilder:
         lex, matrix, char_def, unk = _b(lex), _b(matrix), _b(char_def), _b(unk)
         h = C.c_void_p()
         N.check(N.lib().vbt_dict_from_sources(lex, len(lex), matrix, len(matrix), char_def, len(char_def), unk, len(unk), C.byref(h)))
+        return Dictionary(h)
+
+    @staticmethod
+    def from_readers_with_bigram_info(lex, bigram_right, bigram_left, bigram_cost, char_def, unk, dual_connector=False):
+        """SystemDictionaryBuilder::from_readers_with_bigram_info (builder.rs:111-160): compact (Raw / Dual) connector."""
+        a = [_b(x) for x in (lex, bigram_right, bigram_left, bigram_cost, char_def, unk)]
+        h = C.c_void_p()
+        args = []
+        for x in a:
+            args += [x, len(x)]
+        N.check(N.lib().vbt_dict_from_sources_bigram(*args, int(dual_connector), C.byref(h)))
         return Dictionary(h)
 
     @staticmethod

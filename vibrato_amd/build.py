@@ -8,7 +8,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 SO = os.path.join(LIBDIR, "libvibrato_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-SOURCES = ["dict.cpp", "engine.hip", "capi.cpp"]
+SOURCES = ["dict.cpp", "connector.cpp", "engine.hip", "capi.cpp"]
 HEADERS = ["dict.hpp", "engine.hpp", "../../include/vibrato_hip.h"]
 
 

@@ -223,6 +223,19 @@ int vbt_dict_from_sources_binmatrix(const char* lex, size_t lex_len, const int16
     });
 }
 
+int vbt_dict_from_sources_bigram(const char* lex, size_t lex_len, const char* bigram_right, size_t right_len, const char* bigram_left,
+                                 size_t left_len, const char* bigram_cost, size_t cost_len, const char* char_def, size_t char_len,
+                                 const char* unk_def, size_t unk_len, int dual, vbt_dict** out) {
+    return guarded([&] {
+        if (!out || !lex || !bigram_right || !bigram_left || !bigram_cost || !char_def || !unk_def) throw Error(VBT_ERR_INVALID_ARGUMENT, "null argument");
+        Dictionary* d = build_dictionary_bigram({lex, lex_len}, {bigram_right, right_len}, {bigram_left, left_len}, {bigram_cost, cost_len},
+                                                {char_def, char_len}, {unk_def, unk_len}, dual != 0);
+        *out = new vbt_dict{d, true};
+    });
+}
+
+int vbt_dict_connector_kind(const vbt_dict* dict) { return dict && dict->d ? dict->d->conn_kind : -1; }
+
 int vbt_dict_set_user_lexicon(vbt_dict* dict, const char* csv, size_t len) {
     return guarded([&] {
         if (!dict || !dict->d) throw Error(VBT_ERR_INVALID_ARGUMENT, "dict: null or consumed");
@@ -286,7 +299,7 @@ int vbt_dict_conn_cost(const vbt_dict* dict, uint32_t right_id, uint32_t left_id
     return guarded([&] {
         const Dictionary& d = dict_of(dict);
         if (right_id >= d.num_right || left_id >= d.num_left) throw Error(VBT_ERR_INVALID_ARGUMENT, "connection id out of range");
-        *out = d.matrix[(size_t)left_id * d.num_right + right_id];
+        *out = conn_cost(d, right_id, left_id);
     });
 }
 

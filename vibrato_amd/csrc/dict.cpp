@@ -527,10 +527,22 @@ void Lexicon::common_prefix(const uint32_t* cps, size_t n, std::vector<std::pair
     }
 }
 
+// lexicon, char.def, unk.def and the id checks of SystemDictionaryBuilder::build (builder.rs:16-47); the connector is set already
+void finish_dictionary(Dictionary& d, std::string_view lex, std::string_view char_def, std::string_view unk_def) {
+    auto rows = parse_lexicon_csv(lex, "lex.csv");
+    parse_char_def(d, char_def);
+    parse_unk_def(d, unk_def);
+    build_lexicon(d.system, rows, "lex.csv");
+    if (!verify_ids(d.system.params, d.num_left, d.num_right))  // builder.rs:24-29
+        fail(VBT_ERR_INVALID_ARGUMENT, "system_lexicon_rdr: system_lexicon_rdr includes invalid connection ids.");
+    for (const Entry& e : d.unk_entries)  // builder.rs:30-35
+        if (d.num_left <= (e.left_right & 0xFFFF) || d.num_right <= (e.left_right >> 16))
+            fail(VBT_ERR_INVALID_ARGUMENT, "unk_handler_rdr: unk_handler_rdr includes invalid connection ids.");
+}
+
 Dictionary* build_dictionary(std::string_view lex, std::string_view matrix_def, const int16_t* matrix_bin, uint32_t num_right,
                              uint32_t num_left, std::string_view char_def, std::string_view unk_def) {
     auto d = std::make_unique<Dictionary>();
-    auto rows = parse_lexicon_csv(lex, "lex.csv");
     if (matrix_bin) {
         if (num_right > 0xFFFF || num_left > 0xFFFF) fail(VBT_ERR_INVALID_ARGUMENT, "matrix: num_right/num_left must fit in u16");
         d->num_right = num_right;
@@ -539,14 +551,7 @@ Dictionary* build_dictionary(std::string_view lex, std::string_view matrix_def, 
     } else {
         parse_matrix_def(*d, matrix_def);
     }
-    parse_char_def(*d, char_def);
-    parse_unk_def(*d, unk_def);
-    build_lexicon(d->system, rows, "lex.csv");
-    if (!verify_ids(d->system.params, d->num_left, d->num_right))  // builder.rs:24-29
-        fail(VBT_ERR_INVALID_ARGUMENT, "system_lexicon_rdr: system_lexicon_rdr includes invalid connection ids.");
-    for (const Entry& e : d->unk_entries)  // builder.rs:30-35
-        if (d->num_left <= (e.left_right & 0xFFFF) || d->num_right <= (e.left_right >> 16))
-            fail(VBT_ERR_INVALID_ARGUMENT, "unk_handler_rdr: unk_handler_rdr includes invalid connection ids.");
+    finish_dictionary(*d, lex, char_def, unk_def);
     return d.release();
 }
 
@@ -584,13 +589,17 @@ void map_connection_ids(Dictionary& d, const uint16_t* lmap, size_t n_lmap, cons
         fail(VBT_ERR_INVALID_ARGUMENT, "map: the mappings must cover every connection id except 0");
     map_lexicon(d.system, ml, mr);
     if (d.has_user) map_lexicon(d.user, ml, mr);
-    std::vector<int16_t> mapped(d.matrix.size());  // matrix_connector.rs:99-116
-    for (uint32_t l = 0; l < d.num_left; ++l) {
-        const int16_t* src = d.matrix.data() + (size_t)l * d.num_right;
-        int16_t* dst = mapped.data() + (size_t)ml[l] * d.num_right;
-        for (uint32_t r = 0; r < d.num_right; ++r) dst[mr[r]] = src[r];
+    if (d.conn_kind == kConnMatrix) {
+        std::vector<int16_t> mapped(d.matrix.size());  // matrix_connector.rs:99-116
+        for (uint32_t l = 0; l < d.num_left; ++l) {
+            const int16_t* src = d.matrix.data() + (size_t)l * d.num_right;
+            int16_t* dst = mapped.data() + (size_t)ml[l] * d.num_right;
+            for (uint32_t r = 0; r < d.num_right; ++r) dst[mr[r]] = src[r];
+        }
+        d.matrix.swap(mapped);
+    } else {
+        map_connector_ids(d, ml, mr);
     }
-    d.matrix.swap(mapped);
     for (Entry& e : d.unk_entries)  // unknown.rs:206-211
         e.left_right = (uint32_t)ml[e.left_right & 0xFFFF] | ((uint32_t)mr[e.left_right >> 16] << 16);
     d.mapper_left = std::move(ml);

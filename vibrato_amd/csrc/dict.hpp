@@ -60,7 +60,36 @@ struct Lexicon {
     void common_prefix(const uint32_t* cps, size_t n, std::vector<std::pair<uint32_t, uint32_t>>& out) const;
 };
 
+// Scorer of the compact connectors (connector/raw_connector/scorer.rs:170-178): a double-array hash from a pair of
+// feature ids to a cost: pos = bases[key1] ^ key2, valid iff checks[pos] == key1.
+struct Scorer {
+    std::vector<uint32_t> bases, checks;
+    std::vector<int32_t> costs;
+};
+
+// RawConnector (connector/raw_connector.rs:22-27): per connection id one row of `width` feature ids (a multiple of 8, the
+// reference's U31x8 vectors flattened; 0x7FFFFFFF = no feature; row 0 = BOS/EOS, all zero).
+struct RawConnector {
+    std::vector<uint32_t> right_feats, left_feats;
+    uint32_t width = 0;
+    Scorer scorer;
+};
+
+// DualConnector (connector/dual_connector.rs:16-23): a small matrix over mapped ids plus one 8-wide raw row per id.
+struct DualConnector {
+    std::vector<int16_t> matrix;  // data[left * m_num_right + right] over the mapped ids
+    uint32_t m_num_right = 0, m_num_left = 0;
+    std::vector<uint16_t> right_map, left_map;
+    std::vector<uint32_t> right_feats, left_feats;  // 8 per id
+    Scorer scorer;
+};
+
+enum ConnKind { kConnMatrix = 0, kConnRaw = 1, kConnDual = 2 };  // ConnectorWrapper, connector.rs:30-35 (bincode variant order)
+
 struct Dictionary {
+    int conn_kind = kConnMatrix;
+    RawConnector raw;
+    DualConnector dual;
     Lexicon system;
     bool has_user = false;
     Lexicon user;
@@ -83,6 +112,22 @@ struct Dictionary {
 Dictionary* build_dictionary(std::string_view lex, std::string_view matrix_def, const int16_t* matrix_bin,
                              uint32_t num_right, uint32_t num_left, std::string_view char_def,
                              std::string_view unk_def);
+
+// SystemDictionaryBuilder::from_readers_with_bigram_info (builder.rs:111-160): the connector comes from bigram.right /
+// bigram.left / bigram.cost.  `dual` only selects the reference's memory layout (Raw vs Dual); both compute the same
+// cost function, and the device materialises either as a dense matrix when the tokenizer is created.
+Dictionary* build_dictionary_bigram(std::string_view lex, std::string_view bigram_right, std::string_view bigram_left,
+                                    std::string_view bigram_cost, std::string_view char_def, std::string_view unk_def, bool dual);
+
+// ConnectorCost::cost(right_id, left_id) (connector.rs:25-28) for any connector kind, on the host.
+int32_t conn_cost(const Dictionary& d, uint32_t right_id, uint32_t left_id);
+// Scorer::accumulate_cost (scorer.rs:327-345, the scalar path): sum of the costs of the (key1[i], key2[i]) pairs present.
+int32_t scorer_accumulate(const Scorer& s, const uint32_t* keys1, const uint32_t* keys2, size_t n);
+// utils::parse_csv_row (utils.rs:40-61)
+std::vector<std::string> parse_csv_row(std::string_view row);
+// helpers shared by dict.cpp and connector.cpp
+void finish_dictionary(Dictionary& d, std::string_view lex, std::string_view char_def, std::string_view unk_def);
+void map_connector_ids(Dictionary& d, const std::vector<uint16_t>& ml, const std::vector<uint16_t>& mr);
 
 // Dictionary::map_connection_ids_from_iter (dictionary.rs:245-259): the i-th item (1-origin) of lmap / rmap
 // is the OLD id that becomes new id i (ConnIdMapper::parse, mapper.rs:49-80).

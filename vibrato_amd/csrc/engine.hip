@@ -1857,6 +1857,38 @@ __global__ void __launch_bounds__(kScanBlock) compact_tokens(BatchArgs A, const 
     }
 }
 
+// Compact connectors (RawConnector / DualConnector) are materialised once, when the tokenizer is created: one thread per
+// (left, right) id pair evaluates the reference's cost function -- Scorer::accumulate_cost over the pair's feature rows
+// (connector/raw_connector/scorer.rs:327-345), plus the small matrix over mapped ids for a dual connector
+// (dual_connector.rs:267-279) -- into the dense i16 matrix the sweep reads.  288 GB of HBM make the reference's memory /
+// speed trade-off moot: the hot path is the MatrixConnector's for every dictionary.
+struct DevConnector {
+    const uint32_t* bases; const uint32_t* checks; const int32_t* costs;
+    uint32_t n_bases, n_checks;
+    const uint32_t* right_feats; const uint32_t* left_feats;
+    uint32_t width;
+    const int16_t* m; const uint16_t* right_map; const uint16_t* left_map;  // dual only (m == nullptr: raw)
+    uint32_t m_num_right;
+};
+__global__ void __launch_bounds__(256) expand_connector(DevConnector c, int16_t* out, uint32_t num_right, uint32_t num_left, uint32_t* range_flag) {
+    const uint32_t right = blockIdx.x * 256 + threadIdx.x, left = blockIdx.y;
+    if (right >= num_right) return;
+    const uint32_t* __restrict__ k1 = c.right_feats + (size_t)right * c.width;
+    const uint32_t* __restrict__ k2 = c.left_feats + (size_t)left * c.width;
+    uint32_t sum = 0;  // wrapping i32
+    for (uint32_t t = 0; t < c.width; ++t) {
+        const uint32_t a = k1[t], b = k2[t];
+        if (a < c.n_bases) {
+            const uint32_t pos = c.bases[a] ^ b;
+            if (pos < c.n_checks && c.checks[pos] == a) sum += (uint32_t)c.costs[pos];
+        }
+    }
+    if (c.m) sum += (uint32_t)(int32_t)c.m[(size_t)c.left_map[left] * c.m_num_right + c.right_map[right]];
+    const int32_t v = (int32_t)sum;
+    if (v < -32768 || v > 32767) atomicOr(range_flag, 1u);
+    out[(size_t)left * num_right + right] = (int16_t)v;
+}
+
 template <typename T>
 T* dev_upload(const std::vector<T>& v, std::vector<void*>& allocs) {
     T* p = nullptr;
@@ -1904,10 +1936,48 @@ Tokenizer::Tokenizer(const Dictionary* dict, bool ignore_space, uint32_t max_gro
         dev_.has_user = dict_->has_user ? 1 : 0;
         if (dict_->has_user) upload_lexicon(dict_->user, dev_.user);
         else dev_.user = dev_.sys;
-        {   // + 1 element: lattice_lds reads the aligned 32-bit word around a cell
+        if (dict_->conn_kind == kConnMatrix) {  // + 1 element: lattice_lds reads the aligned 32-bit word around a cell
             std::vector<int16_t> padded(dict_->matrix);
             padded.push_back(0);
             dev_.matrix = dev_upload(padded, allocs_);
+        } else {
+            const bool is_dual = dict_->conn_kind == kConnDual;
+            const Scorer& sc = is_dual ? dict_->dual.scorer : dict_->raw.scorer;
+            std::vector<void*> tmp;  // the compact structures are only needed by the expansion
+            int16_t* m = nullptr;
+            HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&m), ((size_t)dict_->num_left * dict_->num_right + 1) * 2));
+            allocs_.push_back(m);
+            uint32_t* flag = nullptr;
+            try {
+                HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&flag), 16));
+                tmp.push_back(flag);
+                HIP_CHECK(hipMemset(flag, 0, 16));
+                HIP_CHECK(hipMemset(m + (size_t)dict_->num_left * dict_->num_right, 0, 2));
+                DevConnector c{};
+                c.bases = dev_upload(sc.bases, tmp); c.checks = dev_upload(sc.checks, tmp); c.costs = dev_upload(sc.costs, tmp);
+                c.n_bases = (uint32_t)sc.bases.size(); c.n_checks = (uint32_t)sc.checks.size();
+                c.right_feats = dev_upload(is_dual ? dict_->dual.right_feats : dict_->raw.right_feats, tmp);
+                c.left_feats = dev_upload(is_dual ? dict_->dual.left_feats : dict_->raw.left_feats, tmp);
+                c.width = is_dual ? 8u : dict_->raw.width;
+                if (is_dual) {
+                    c.m = dev_upload(dict_->dual.matrix, tmp);
+                    c.right_map = dev_upload(dict_->dual.right_map, tmp);
+                    c.left_map = dev_upload(dict_->dual.left_map, tmp);
+                    c.m_num_right = dict_->dual.m_num_right;
+                }
+                hipLaunchKernelGGL(expand_connector, dim3((dict_->num_right + 255) / 256, dict_->num_left), dim3(256), 0, nullptr, c, m,
+                                   dict_->num_right, dict_->num_left, flag);
+                uint32_t out_of_range = 0;
+                HIP_CHECK(hipMemcpy(&out_of_range, flag, 4, hipMemcpyDeviceToHost));
+                for (void* p : tmp) (void)hipFree(p);
+                tmp.clear();
+                if (out_of_range)
+                    throw Error(VBT_ERR_UNSUPPORTED, "connector: a connection cost of the compact connector does not fit the i16 matrix of the device image");
+            } catch (...) {
+                for (void* p : tmp) (void)hipFree(p);
+                throw;
+            }
+            dev_.matrix = m;
         }
         dev_.num_right = dict_->num_right;
         dev_.chr2inf = dev_upload(dict_->chr2inf, allocs_);
@@ -2105,8 +2175,9 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
         // many bytes are listed first and generated by the large-LDS generator on a side stream while the bulk
         // runs.  Measured on MI355X it does not pay: the side stream's few wavefronts are slowed by the bulk
         // as much as they save (4.40 vs 4.27 ms per 100k sentences).
-        const uint32_t gen_lds = env_u32("VBT_GEN_LDS", 8192);
-        uint32_t gen_level_lds[kGenLevels] = {32768, 81920, 163840};  // the instances behind the bulk generator (VBT_GEN_LEVELS=a,b,c)
+        // (the bulk generator keeps ~26 bytes of LDS per character: 4 KiB hold ~155 characters and 32+ waves per CU)
+        const uint32_t gen_lds = env_u32("VBT_GEN_LDS", 4096);
+        uint32_t gen_level_lds[kGenLevels] = {16384, 65536, 163840};  // the instances behind the bulk generator (VBT_GEN_LEVELS=a,b,c)
         if (const char* e = std::getenv("VBT_GEN_LEVELS")) {
             unsigned v[3];
             if (std::sscanf(e, "%u,%u,%u", &v[0], &v[1], &v[2]) == 3 && v[0] >= 4096 && v[0] < v[1] && v[1] < v[2] && v[2] <= 163840)
