@@ -221,4 +221,4 @@ def test_compact_connector_cost_outside_i16_is_refused_loudly():
     dv = _dict("product", right, left, cost)
     assert dv.conn_cost(1, 1) == 60000
     with pytest.raises(V.VibratoError):
-        V.Tokenizer(dv, device=0)
+        V.Tokenizer(dv, device=0).new_worker()  # the device image is built at first use
