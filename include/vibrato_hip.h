@@ -95,6 +95,14 @@ VBT_API int vbt_dict_from_sources_bigram(const char* lex, size_t lex_len, const 
                                          const char* bigram_left, size_t left_len, const char* bigram_cost, size_t cost_len,
                                          const char* char_def, size_t char_len, const char* unk_def, size_t unk_len, int dual,
                                          vbt_dict** out);
+/* Dictionary::read(rdr), dictionary.rs:173-197: a dictionary written by Dictionary::write ("VibratoTokenizer 0.5\n" + bincode,
+ * common.rs:5-9).  A zstd frame around it -- the released `system.dic.zst`, which the reference's CLIs unwrap with
+ * zstd::Decoder (tokenize/src/main.rs:59-60) -- is detected by its magic and decompressed first (libzstd.so.1 of the system).
+ * VBT_ERR_INVALID_ARGUMENT: wrong magic (dictionary.rs:188-193); VBT_ERR_INVALID_FORMAT: anything that does not decode. */
+VBT_API int vbt_dict_read(const uint8_t* data, size_t len, vbt_dict** out);
+/* Dictionary::write(wtr), dictionary.rs:142-150.  zstd_level < 0: the plain `system.dic` bytes; otherwise wrapped in a zstd
+ * frame of that level like compile/src/main.rs:98 (level 19 there).  *out is released with vbt_free. */
+VBT_API int vbt_dict_write(const vbt_dict* dict, int zstd_level, uint8_t** out, size_t* len);
 /* ConnectorWrapper variant, connector.rs:30-35: 0 Matrix, 1 Raw, 2 Dual (-1: null / consumed handle) */
 VBT_API int vbt_dict_connector_kind(const vbt_dict* dict);
 /* Dictionary::reset_user_lexicon_from_reader(Some(csv) | None), dictionary.rs:209-229 */

@@ -50,6 +50,8 @@ SIGNATURES = {
     "vbt_dict_from_sources_binmatrix": (_int, [_cp, _sz, _vp, _u32, _u32, _cp, _sz, _cp, _sz, _PP]),
     "vbt_dict_from_sources_bigram": (_int, [_cp, _sz, _cp, _sz, _cp, _sz, _cp, _sz, _cp, _sz, _cp, _sz, _int, _PP]),
     "vbt_dict_connector_kind": (_int, [_vp]),
+    "vbt_dict_read": (_int, [_vp, _sz, _PP]),
+    "vbt_dict_write": (_int, [_vp, _int, _PP, C.POINTER(_sz)]),
     "vbt_dict_set_user_lexicon": (_int, [_vp, _cp, _sz]),
     "vbt_dict_map_connection_ids": (_int, [_vp, _vp, _sz, _vp, _sz]),
     "vbt_dict_free": (None, [_vp]),

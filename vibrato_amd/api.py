@@ -3,6 +3,7 @@
 Token, plus the batched entry points this project adds.  Everything computes on the
 MI355X through libvibrato_hip.so; Python only moves handles and bytes."""
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -38,6 +39,36 @@ class Dictionary:
         if not self._h:
             raise VibratoError(3, "dictionary was moved into a Tokenizer")
         return self._h
+
+    @classmethod
+    def read(cls, rdr):
+        """Dictionary::read (dictionary.rs:173-197).  `rdr`: bytes, a binary file object or a path; `system.dic` as written
+        by Dictionary::write, or the released `system.dic.zst` (a zstd frame around it is unwrapped)."""
+        if isinstance(rdr, (str, os.PathLike)):
+            with open(rdr, "rb") as fh:
+                data = fh.read()
+        elif hasattr(rdr, "read"):
+            data = rdr.read()
+        else:
+            data = bytes(rdr)
+        buf = np.frombuffer(data, dtype=np.uint8)
+        h = C.c_void_p()
+        N.check(N.lib().vbt_dict_read(buf.ctypes.data if len(buf) else None, len(buf), C.byref(h)))
+        return cls(h)
+
+    def write(self, wtr=None, zstd_level=None):
+        """Dictionary::write (dictionary.rs:142-150); zstd_level=19 gives what the reference's `compile` CLI writes
+        (compile/src/main.rs:98).  Returns the bytes (and writes them to `wtr` if given)."""
+        out = C.c_void_p()
+        n = C.c_size_t()
+        N.check(N.lib().vbt_dict_write(self._handle(), -1 if zstd_level is None else int(zstd_level), C.byref(out), C.byref(n)))
+        try:
+            data = C.string_at(out, n.value)
+        finally:
+            N.lib().vbt_free(out)
+        if wtr is not None:
+            wtr.write(data)
+        return data
 
     def reset_user_lexicon_from_reader(self, csv):
         """Dictionary::reset_user_lexicon_from_reader (dictionary.rs:209-229); csv=None clears."""

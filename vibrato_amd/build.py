@@ -8,7 +8,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 SO = os.path.join(LIBDIR, "libvibrato_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-SOURCES = ["dict.cpp", "connector.cpp", "engine.hip", "capi.cpp"]
+SOURCES = ["dict.cpp", "connector.cpp", "dictio.cpp", "engine.hip", "capi.cpp"]
 HEADERS = ["dict.hpp", "engine.hpp", "../../include/vibrato_hip.h"]
 
 
@@ -34,7 +34,7 @@ def build(force=False, verbose=False, variant="", defines=()):
            "-Wall", "-Wno-unused-result", "-x", "hip"]
     cmd += ["-D" + d for d in defines]
     cmd += [os.path.join(CSRC, f) for f in SOURCES]
-    cmd += ["-o", so]
+    cmd += ["-ldl", "-o", so]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -1,10 +1,10 @@
 """`tokenize`-compatible command line (reference: tokenize/src/main.rs:31-132).
 
-    python -m vibrato_amd.cli -i DICT_DIR [-u user.csv] [-O mecab|wakati|detail] [-S] [-M N] < lines.txt
+    python -m vibrato_amd.cli -i system.dic.zst [-u user.csv] [-O mecab|wakati|detail] [-S] [-M N] < lines.txt
 
-DICT_DIR holds MeCab-format sources (lex.csv, matrix.def, char.def, unk.def): the compiled
-`system.dic.zst` container of the reference (zstd + bincode + crawdad blob) is not readable
-offline -- see DESIGN.md "next" rows.  Lines are read with the semantics of BufRead::lines()
+-i takes what the reference's CLI takes -- a dictionary written by Dictionary::write, zstd-compressed or not
+(tokenize/src/main.rs:34,59-60) -- or a directory of MeCab-format sources (lex.csv, matrix.def, char.def, unk.def).
+--compile-to PATH writes the loaded dictionary back out as system.dic.zst (compile/src/main.rs:98).  Lines are read with the semantics of BufRead::lines()
 (`\\n` / `\\r\\n` stripped) and tokenized in blocks of --block lines per GPU batch; the bytes
 written are exactly those of the reference CLI for the same mode.
 """
@@ -25,7 +25,8 @@ def read_sources(d):
 
 def main(argv=None, stdin=None, stdout=None):
     ap = argparse.ArgumentParser(prog="tokenize", description="Predicts morphemes")
-    ap.add_argument("-i", "--sysdic", required=True, help="directory with lex.csv, matrix.def, char.def, unk.def")
+    ap.add_argument("-i", "--sysdic", required=True, help="System dictionary (in zstd), or a directory with lex.csv, matrix.def, char.def, unk.def")
+    ap.add_argument("--compile-to", default=None, help="also write the dictionary as system.dic.zst (zstd level 19) to this path")
     ap.add_argument("-u", "--userlex-csv", default=None, help="User lexicon file.")
     ap.add_argument("-O", "--output-mode", default="mecab", choices=["mecab", "wakati", "detail"])
     ap.add_argument("-S", "--ignore-space", action="store_true", help="Ignores white spaces in input strings.")
@@ -37,7 +38,13 @@ def main(argv=None, stdin=None, stdout=None):
     stdout = stdout or sys.stdout.buffer
 
     print("Loading the dictionary...", file=sys.stderr)
-    d = api.SystemDictionaryBuilder.from_readers(*read_sources(args.sysdic))
+    if os.path.isdir(args.sysdic):
+        d = api.SystemDictionaryBuilder.from_readers(*read_sources(args.sysdic))
+    else:
+        d = api.Dictionary.read(args.sysdic)
+    if args.compile_to:
+        with open(args.compile_to, "wb") as fh:
+            d.write(fh, zstd_level=19)
     if args.userlex_csv:
         with open(args.userlex_csv, "rb") as fh:
             d.reset_user_lexicon_from_reader(fh.read())

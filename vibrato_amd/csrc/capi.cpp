@@ -234,6 +234,26 @@ int vbt_dict_from_sources_bigram(const char* lex, size_t lex_len, const char* bi
     });
 }
 
+int vbt_dict_read(const uint8_t* data, size_t len, vbt_dict** out) {
+    return guarded([&] {
+        if (!out || (!data && len)) throw Error(VBT_ERR_INVALID_ARGUMENT, "null argument");
+        *out = new vbt_dict{read_dictionary(data, len), true};
+    });
+}
+
+int vbt_dict_write(const vbt_dict* dict, int zstd_level, uint8_t** out, size_t* len) {
+    return guarded([&] {
+        if (!out || !len) throw Error(VBT_ERR_INVALID_ARGUMENT, "null argument");
+        std::vector<uint8_t> bytes = write_dictionary(dict_of(dict));
+        if (zstd_level >= 0) bytes = zstd_compress(bytes.data(), bytes.size(), zstd_level);
+        uint8_t* p = static_cast<uint8_t*>(std::malloc(bytes.size() ? bytes.size() : 1));
+        if (!p) throw std::bad_alloc();
+        std::memcpy(p, bytes.data(), bytes.size());
+        *out = p;
+        *len = bytes.size();
+    });
+}
+
 int vbt_dict_connector_kind(const vbt_dict* dict) { return dict && dict->d ? dict->d->conn_kind : -1; }
 
 int vbt_dict_set_user_lexicon(vbt_dict* dict, const char* csv, size_t len) {

@@ -229,13 +229,28 @@ void map_connector_ids(Dictionary& d, const std::vector<uint16_t>& ml, const std
     if (d.conn_kind == kConnRaw) {  // raw_connector.rs:118-146
         permute_rows(d.raw.right_feats, d.raw.width, mr);
         permute_rows(d.raw.left_feats, d.raw.width, ml);
-    } else if (d.conn_kind == kConnDual) {
-        // dual_connector.rs:211-264 also renumbers the small matrix by first use; the cost function only needs the per-id
-        // rows and maps permuted
-        permute_rows(d.dual.right_feats, kSimd, mr);
-        permute_rows(d.dual.left_feats, kSimd, ml);
-        permute_rows(d.dual.right_map, 1, mr);
-        permute_rows(d.dual.left_map, 1, ml);
+    } else if (d.conn_kind == kConnDual) {  // dual_connector.rs:211-264
+        DualConnector& u = d.dual;
+        permute_rows(u.right_feats, kSimd, mr);
+        permute_rows(u.left_feats, kSimd, ml);
+        permute_rows(u.right_map, 1, mr);
+        permute_rows(u.left_map, 1, ml);
+        // the small matrix is renumbered in order of first use by the new connection ids (l.237-262)
+        auto renumber = [](std::vector<uint16_t>& id_map, uint32_t n_old) {
+            std::vector<uint16_t> to_new(n_old, 0xFFFF);
+            uint16_t next = 0;
+            for (uint16_t& i : id_map) {
+                if (to_new[i] == 0xFFFF) to_new[i] = next++;
+                i = to_new[i];
+            }
+            return to_new;
+        };
+        const std::vector<uint16_t> lnew = renumber(u.left_map, u.m_num_left), rnew = renumber(u.right_map, u.m_num_right);
+        std::vector<int16_t> mapped(u.matrix.size());  // matrix_connector.rs:99-116 (ids no connection id uses keep no cell)
+        for (uint32_t l = 0; l < u.m_num_left; ++l)
+            for (uint32_t r = 0; r < u.m_num_right; ++r)
+                if (lnew[l] != 0xFFFF && rnew[r] != 0xFFFF) mapped[(size_t)lnew[l] * u.m_num_right + rnew[r]] = u.matrix[(size_t)l * u.m_num_right + r];
+        u.matrix.swap(mapped);
     }
 }
 

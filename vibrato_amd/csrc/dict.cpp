@@ -12,6 +12,7 @@
 #include "dict.hpp"
 
 #include <algorithm>
+#include <functional>
 #include <charconv>
 #include <cstring>
 #include <memory>
@@ -525,6 +526,60 @@ void Lexicon::common_prefix(const uint32_t* cps, size_t n, std::vector<std::pair
         base = nodes[child].base;
         for (uint32_t k = 0; k < nodes[child].cnt; ++k) out.emplace_back(entries[nodes[child].val + k].word_id, (uint32_t)(i + 1));
     }
+}
+
+// A lexicon from (surface, param, feature) per word id -- the binary dictionary reader's way in (dictio.cpp)
+void lexicon_from_words(Lexicon& lx, const std::function<const std::string&(uint32_t)>& surface, std::vector<WordParam> params,
+                        std::vector<std::string> features, const char* name) {
+    std::vector<LexRow> rows(params.size());
+    for (uint32_t i = 0; i < rows.size(); ++i) {
+        rows[i].surface = surface(i);
+        rows[i].param = params[i];
+        rows[i].feature = features[i];
+    }
+    build_lexicon(lx, rows, name);
+}
+
+// The keys of a lexicon's double array as code points, each with its span of `entries` -- the binary dictionary writer's way out
+void lexicon_keys(const Lexicon& lx, std::vector<std::u32string>& keys, std::vector<std::pair<uint32_t, uint32_t>>& spans) {
+    const uint32_t n = (uint32_t)lx.nodes.size();
+    std::vector<uint32_t> code_to_cp(lx.alphabet + 1, 0);
+    for (uint32_t cp = 0; cp < lx.mapper.size(); ++cp)
+        if (lx.mapper[cp]) code_to_cp[lx.mapper[cp]] = cp;
+    constexpr uint32_t kNone = 0xFFFFFFFFu;
+    std::vector<uint32_t> first(n, kNone), next(n, kNone), parent(n, kNone);
+    for (uint32_t i = n; i-- > 1;) {
+        const uint32_t p = lx.nodes[i].check;
+        if (p >= n) continue;
+        next[i] = first[p];
+        first[p] = i;
+        parent[i] = p;
+    }
+    std::vector<uint32_t> stack;
+    if (n) stack.push_back(0);
+    while (!stack.empty()) {
+        const uint32_t v = stack.back();
+        stack.pop_back();
+        if (lx.nodes[v].cnt) {
+            std::u32string key;
+            for (uint32_t u = v; u != 0; u = parent[u]) key.push_back((char32_t)code_to_cp[lx.nodes[parent[u]].base ^ u]);
+            std::reverse(key.begin(), key.end());
+            keys.push_back(std::move(key));
+            spans.push_back({lx.nodes[v].val, lx.nodes[v].cnt});
+        }
+        for (uint32_t c = first[v]; c != kNone; c = next[c]) stack.push_back(c);
+    }
+}
+
+// the id checks of SystemDictionaryBuilder::build (builder.rs:24-35) and of reset_user_lexicon (dictionary.rs:218-223)
+void verify_dictionary_ids(const Dictionary& d) {
+    if (!verify_ids(d.system.params, d.num_left, d.num_right))
+        fail(VBT_ERR_INVALID_ARGUMENT, "system_lexicon_rdr: system_lexicon_rdr includes invalid connection ids.");
+    if (d.has_user && !verify_ids(d.user.params, d.num_left, d.num_right))
+        fail(VBT_ERR_INVALID_ARGUMENT, "user_lexicon_rdr: includes invalid connection ids.");
+    for (const Entry& e : d.unk_entries)
+        if (d.num_left <= (e.left_right & 0xFFFF) || d.num_right <= (e.left_right >> 16))
+            fail(VBT_ERR_INVALID_ARGUMENT, "unk_handler_rdr: unk_handler_rdr includes invalid connection ids.");
 }
 
 // lexicon, char.def, unk.def and the id checks of SystemDictionaryBuilder::build (builder.rs:16-47); the connector is set already

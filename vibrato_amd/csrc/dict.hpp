@@ -5,6 +5,7 @@
 // the flat arrays the HIP kernels read ("device image").
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <stdexcept>
 #include <string>
 #include <string_view>
@@ -132,6 +133,17 @@ void map_connector_ids(Dictionary& d, const std::vector<uint16_t>& ml, const std
 // Dictionary::map_connection_ids_from_iter (dictionary.rs:245-259): the i-th item (1-origin) of lmap / rmap
 // is the OLD id that becomes new id i (ConnIdMapper::parse, mapper.rs:49-80).
 void map_connection_ids(Dictionary& d, const uint16_t* lmap, size_t n_lmap, const uint16_t* rmap, size_t n_rmap);
+
+// Dictionary::read / Dictionary::write (dictionary.rs:142-197): vibrato's binary `system.dic`, a zstd frame around it is
+// unwrapped on reading (dictio.cpp).
+Dictionary* read_dictionary(const uint8_t* data, size_t len);
+std::vector<uint8_t> write_dictionary(const Dictionary& d);
+std::vector<uint8_t> zstd_compress(const uint8_t* data, size_t len, int level);
+// helpers of the reader / writer that live next to the double-array builder (dict.cpp)
+void lexicon_from_words(Lexicon& lx, const std::function<const std::string&(uint32_t)>& surface, std::vector<WordParam> params,
+                        std::vector<std::string> features, const char* name);
+void lexicon_keys(const Lexicon& lx, std::vector<std::u32string>& keys, std::vector<std::pair<uint32_t, uint32_t>>& spans);
+void verify_dictionary_ids(const Dictionary& d);
 
 // Rust `str` validity (strict UTF-8: no overlongs, surrogates or code points above U+10FFFF).
 bool valid_utf8(const uint8_t* s, size_t n);
