@@ -1,0 +1,134 @@
+//! Viterbi-based tokenizer (reference: `vibrato/src/tokenizer.rs:13-92`).
+pub mod worker;
+
+use std::ptr;
+use std::sync::OnceLock;
+
+use vibrato_hip_sys as sys;
+
+use crate::batch::Batch;
+use crate::dictionary::Dictionary;
+use crate::errors::{check, Result, VibratoError};
+use crate::tokenizer::worker::Worker;
+
+struct Device(*mut sys::vbt_tokenizer);
+// Safety: vbt_tokenizer is immutable after creation apart from its internally locked workspace pool (SURVEY.md 8(b)
+// "threading"): concurrent vbt_worker_new / vbt_tokenize_batch calls on one handle are supported by the library.
+unsafe impl Send for Device {}
+unsafe impl Sync for Device {}
+
+/// Tokenizer. `new`, `ignore_space` and `max_grouping_len` only record options (as in the reference, `tokenizer.rs:26-74`);
+/// the device image (trie, connection matrix, ...) is uploaded once, by the first `new_worker` / `tokenize_batch` call.
+pub struct Tokenizer {
+    dict: Dictionary,
+    ignore_space: bool,
+    max_grouping_len: usize,
+    device_index: i32,
+    device: OnceLock<Device>,
+}
+
+impl Tokenizer {
+    /// Creates a new instance (`tokenizer.rs:26-33`); the dictionary is moved in.
+    pub const fn new(dict: Dictionary) -> Self {
+        Self { dict, ignore_space: false, max_grouping_len: 0, device_index: -1, device: OnceLock::new() }
+    }
+
+    /// Enables MeCab compatible mode: ignores spaces (`tokenizer.rs:42-58`).
+    ///
+    /// # Errors
+    ///
+    /// [`VibratoError`] is returned when category `SPACE` is not defined in the input dictionary.
+    pub fn ignore_space(mut self, yes: bool) -> Result<Self> {
+        if yes && !self.dict.has_category("SPACE") {
+            return Err(VibratoError::invalid_argument("dict", "SPACE is not defined in the input dictionary (i.e., char.def)."));
+        }
+        self.ignore_space = yes;
+        Ok(self)
+    }
+
+    /// Specifies the maximum grouping length for unknown words; `0` = infinity (`tokenizer.rs:67-74`). `24` gives MeCab's results.
+    pub fn max_grouping_len(mut self, max_grouping_len: usize) -> Self {
+        self.max_grouping_len = max_grouping_len;
+        self
+    }
+
+    /// HIP device that will hold the dictionary image (new; default: the current device). One tokenizer per GPU.
+    pub fn device(mut self, index: i32) -> Self {
+        self.device_index = index;
+        self
+    }
+
+    /// Gets the reference to the dictionary (`tokenizer.rs:77-79`).
+    pub const fn dictionary(&self) -> &Dictionary {
+        &self.dict
+    }
+
+    /// Uploads the device image if that has not happened yet. `new_worker` calls this and panics on failure (it is infallible in
+    /// the reference); call it directly to handle a missing device as an error.
+    pub fn build_device_image(&self) -> Result<()> {
+        self.raw().map(|_| ())
+    }
+
+    pub(crate) fn raw(&self) -> Result<*mut sys::vbt_tokenizer> {
+        if let Some(d) = self.device.get() {
+            return Ok(d.0);
+        }
+        // std's OnceLock has no fallible initialiser on stable: serialise the build so that the C handle is consumed once
+        static BUILD: std::sync::Mutex<()> = std::sync::Mutex::new(());
+        let _guard = BUILD.lock().unwrap();
+        if let Some(d) = self.device.get() {
+            return Ok(d.0);
+        }
+        let mgl = u32::try_from(self.max_grouping_len).unwrap_or(0); // lengths beyond u32 never limit anything
+        let mut raw = ptr::null_mut();
+        // Safety: on success the library takes the dictionary handle over (Tokenizer::new moves it); on failure we keep it.
+        check(unsafe { sys::vbt_tokenizer_new(self.dict.raw(), self.ignore_space as i32, mgl, self.device_index, &mut raw) })?;
+        self.dict.rebind_borrowed(unsafe { sys::vbt_tokenizer_dictionary(raw) });
+        let _ = self.device.set(Device(raw));
+        Ok(raw)
+    }
+
+    /// Creates a new worker (`tokenizer.rs:82-84`).
+    ///
+    /// # Panics
+    ///
+    /// When no gfx950 device is available or the upload fails (there is no CPU fallback).
+    pub fn new_worker(&self) -> Worker<'_> {
+        Worker::new(self)
+    }
+
+    /// Tokenizes many sentences in one device batch (new): the loop `reset_sentence; tokenize; token(i)...` of
+    /// `tokenize/src/main.rs:78-82` for every sentence, as a handful of kernel launches. This is the throughput path.
+    pub fn tokenize_batch<I, S>(&self, sentences: I) -> Result<Batch<'_>>
+    where
+        I: IntoIterator<Item = S>,
+        S: AsRef<str>,
+    {
+        let mut text = Vec::new();
+        let mut offsets = vec![0u64];
+        for s in sentences {
+            text.extend_from_slice(s.as_ref().as_bytes());
+            offsets.push(text.len() as u64);
+        }
+        self.tokenize_batch_raw(&text, &offsets)
+    }
+
+    /// The same on concatenated UTF-8 text: sentence `s` is `text[offsets[s]..offsets[s + 1]]`.
+    pub fn tokenize_batch_raw(&self, text: &[u8], offsets: &[u64]) -> Result<Batch<'_>> {
+        if offsets.is_empty() || *offsets.last().unwrap() as usize > text.len() {
+            return Err(VibratoError::invalid_argument("offsets", "offsets must hold n + 1 positions inside text"));
+        }
+        let mut raw = ptr::null_mut();
+        check(unsafe { sys::vbt_tokenize_batch(self.raw()?, text.as_ptr(), offsets.as_ptr(), (offsets.len() - 1) as u64, &mut raw) })?;
+        Ok(Batch::from_raw(raw, self))
+    }
+}
+
+impl Drop for Tokenizer {
+    fn drop(&mut self) {
+        if let Some(d) = self.device.take() {
+            // Safety: workers and batches borrow `self`, so none is alive; the borrowed dictionary view dies with the handle.
+            unsafe { sys::vbt_tokenizer_free(d.0) };
+        }
+    }
+}

@@ -1,0 +1,104 @@
+//! Provider of a routine for tokenization (reference: `vibrato/src/tokenizer/worker.rs:13-103`).
+use std::marker::PhantomData;
+use std::mem::MaybeUninit;
+use std::os::raw::c_char;
+use std::ptr;
+
+use vibrato_hip_sys as sys;
+
+use crate::errors::check;
+use crate::token::{Token, TokenIter};
+use crate::tokenizer::Tokenizer;
+
+/// Occurrence probabilities of connection ids, sorted by probability (`dictionary/mapper.rs:84`).
+pub type ConnIdProbs = Vec<(usize, f64)>;
+
+/// Provider of a routine for tokenization: holds one sentence and its result. One kernel pipeline launch per `tokenize()`
+/// call -- use [`Tokenizer::tokenize_batch`] for throughput.
+pub struct Worker<'t> {
+    raw: *mut sys::vbt_worker,
+    tokenizer: &'t Tokenizer,
+    _not_sync: PhantomData<*mut ()>, // one worker per thread, as in the reference (`&mut self` methods)
+}
+
+impl<'t> Worker<'t> {
+    pub(crate) fn new(tokenizer: &'t Tokenizer) -> Self {
+        let tok = tokenizer.raw().expect("vibrato-hip: cannot create the device tokenizer");
+        let mut raw = ptr::null_mut();
+        check(unsafe { sys::vbt_worker_new(tok, &mut raw) }).expect("vibrato-hip: vbt_worker_new");
+        Self { raw, tokenizer, _not_sync: PhantomData }
+    }
+
+    /// Resets the input sentence to be tokenized (`worker.rs:34-45`).
+    pub fn reset_sentence<S: AsRef<str>>(&mut self, input: S) {
+        let s = input.as_ref();
+        // a &str is valid UTF-8, the only error this call has
+        check(unsafe { sys::vbt_worker_reset_sentence(self.raw, s.as_ptr() as *const c_char, s.len()) }).expect("vbt_worker_reset_sentence");
+    }
+
+    /// Tokenizes the input sentence set in `state` (`worker.rs:49-55`).
+    ///
+    /// # Panics
+    ///
+    /// On a HIP runtime error (the reference is infallible here; there is nothing to fall back to).
+    pub fn tokenize(&mut self) {
+        check(unsafe { sys::vbt_worker_tokenize(self.raw) }).expect("vibrato-hip: device error in tokenize()");
+    }
+
+    /// Gets the number of resultant tokens (`worker.rs:59-61`).
+    #[inline(always)]
+    pub fn num_tokens(&self) -> usize {
+        unsafe { sys::vbt_worker_num_tokens(self.raw) as usize }
+    }
+
+    /// Gets the `i`-th resultant token (`worker.rs:65-68`).
+    #[inline(always)]
+    pub fn token<'w>(&'w self, i: usize) -> Token<'w, 't> {
+        let mut t = MaybeUninit::<sys::vbt_token>::uninit();
+        check(unsafe { sys::vbt_worker_token(self.raw, i as u32, t.as_mut_ptr()) }).expect("token index out of range");
+        // Safety: filled by the library on success; surface points into the worker's copy of the sentence ('w), feature into
+        // dictionary memory owned by the tokenizer ('t)
+        Token::new(unsafe { t.assume_init() })
+    }
+
+    /// Creates an iterator of resultant tokens (`worker.rs:72-74`).
+    #[inline(always)]
+    pub const fn token_iter<'w>(&'w self) -> TokenIter<'w, 't> {
+        TokenIter::new(self, 0)
+    }
+
+    /// Initializes a counter to compute occurrence probabilities of connection ids (`worker.rs:77-84`).
+    pub fn init_connid_counter(&mut self) {
+        check(unsafe { sys::vbt_worker_init_connid_counter(self.raw) }).expect("vbt_worker_init_connid_counter");
+    }
+
+    /// Updates frequencies of connection ids at the last tokenization (`worker.rs:90-93`).
+    ///
+    /// # Panics
+    ///
+    /// It will panic when [`Self::init_connid_counter()`] has never been called.
+    pub fn update_connid_counts(&mut self) {
+        check(unsafe { sys::vbt_worker_update_connid_counts(self.raw) }).expect("init_connid_counter() has never been called");
+    }
+
+    /// Computes the occurrence probabilities of connection ids, for left- and right-ids (`worker.rs:101-103`).
+    ///
+    /// # Panics
+    ///
+    /// It will panic when [`Self::init_connid_counter()`] has never been called.
+    pub fn compute_connid_probs(&self) -> (ConnIdProbs, ConnIdProbs) {
+        let (nl, nr) = self.tokenizer.dictionary().num_connection_ids();
+        let (mut li, mut lp) = (vec![0u32; nl.saturating_sub(1)], vec![0f64; nl.saturating_sub(1)]);
+        let (mut ri, mut rp) = (vec![0u32; nr.saturating_sub(1)], vec![0f64; nr.saturating_sub(1)]);
+        check(unsafe { sys::vbt_worker_compute_connid_probs(self.raw, li.as_mut_ptr(), lp.as_mut_ptr(), ri.as_mut_ptr(), rp.as_mut_ptr()) })
+            .expect("init_connid_counter() has never been called");
+        let zip = |ids: Vec<u32>, ps: Vec<f64>| ids.into_iter().map(|i| i as usize).zip(ps).collect::<ConnIdProbs>();
+        (zip(li, lp), zip(ri, rp))
+    }
+}
+
+impl Drop for Worker<'_> {
+    fn drop(&mut self) {
+        unsafe { sys::vbt_worker_free(self.raw) };
+    }
+}
