@@ -242,7 +242,8 @@ def main():
     # optional: host-to-host pipeline (H2D of batch k+1 and D2H of batch k-1 under the kernels of batch k)
     h2h = None
     if args.host_pipeline and world == 1:
-        h2h = tok.host_pipeline_benchmark(text, offs, n_batches=8)
+        h2h = {"one_call": tok.host_pipeline_benchmark(text, offs, threads=1, rounds=1),
+               "pipelined": tok.host_pipeline_benchmark(text, offs, threads=2, rounds=4)}
 
     result = None
     if rank == 0:

@@ -392,16 +392,17 @@ def test_golden_vectors_through_a_read_dictionary():
         tok = V.Tokenizer(d, device=0).ignore_space(case["ignore_space"]).max_grouping_len(case["max_grouping_len"])
         w = tok.new_worker()
         for s in case["sentences"]:
-            w.reset_sentence(s["input"])
+            w.reset_sentence(s["text"])
             w.tokenize()
-            assert w.num_tokens() == len(s["tokens"]), case["name"]
-            for i, t in enumerate(s["tokens"]):
-                got = w.token(i)
-                assert got.surface == t["surface"], case["name"]
-                if "total_cost" in t:
-                    assert got.total_cost == t["total_cost"], case["name"]
-                if "feature" in t:
-                    assert got.feature == t["feature"], case["name"]
+            assert w.num_tokens() == s["num_tokens"], case["name"]
+            for exp in s["tokens"]:
+                got = w.token(exp["index"])
+                for k in ("surface", "feature", "total_cost"):
+                    if k in exp:
+                        assert getattr(got, k) == exp[k], (case["name"], k)
+                for k in ("range_char", "range_byte"):
+                    if k in exp:
+                        assert list(getattr(got, k)) == exp[k], (case["name"], k)
 
 
 @pytest.mark.gpu

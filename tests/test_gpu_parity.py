@@ -431,3 +431,30 @@ def test_host_batches_reuse_pooled_workspaces():
     _assert_batch_equal(to, tv, text, offs)
     created, reused, idle = tv.pool_stats()
     assert created == 2 and reused == 4 and idle == 2
+
+
+def test_concurrent_host_batches_from_threads_match_oracle():
+    """vbt_tokenize_batch is thread-safe per tokenizer (SURVEY.md 8(b) "threading"): blocks of one corpus pushed by several
+    host threads at once (own pooled workspace, pinned staging and stream each) give the oracle's tokens, and the pools stop
+    growing; the pipeline helper bench.py reports host-to-host throughput with returns the same token total."""
+    from concurrent.futures import ThreadPoolExecutor
+    sd = synth.SynthDict("small")
+    to, tv = _oracle_and_product(sd)
+    text, offs = sd.sentences(6000, "lognormal_40")
+    exp, exp_off = to.new_worker().tokenize_batch(text, offs)
+    bounds = [0, 700, 701, 2500, 2500, 4100, 6000]
+
+    def one(i):
+        lo, hi = bounds[i], bounds[i + 1]
+        got, got_off = tv.tokenize_batch(text=text, offsets=offs[lo:hi + 1]).tokens_in_order()
+        return lo, hi, got, got_off
+
+    for _ in range(3):
+        with ThreadPoolExecutor(4) as ex:
+            for lo, hi, got, got_off in ex.map(one, range(len(bounds) - 1)):
+                assert np.array_equal(got_off, exp_off[lo:hi + 1] - exp_off[lo])
+                assert got.tobytes() == exp[int(exp_off[lo]):int(exp_off[hi])].tobytes()
+    created = tv.pool_stats()[0]
+    r = tv.host_pipeline_benchmark(text, offs, threads=3, rounds=2, repeats=2)
+    assert r["tokens_per_batch"] == len(exp) and r["sentences_per_s"] > 0
+    assert tv.pool_stats()[0] <= created + 3

@@ -36,22 +36,35 @@ struct PooledWorkspace {
     }
 };
 
+// Page-locked host memory recycled between batches: a batch's copy of the text and its results live in pinned blocks, so
+// both directions are true asynchronous DMA on the workspace's stream (pageable copies are staged by the runtime and
+// block), and hipHostMalloc (~ms per block) is off the steady-state path.
+struct PinnedBlock {
+    void* p = nullptr;
+    size_t cap = 0;
+    ~PinnedBlock() { if (p) (void)hipHostFree(p); }
+};
+
 struct vbt_tokenizer {
     std::unique_ptr<Tokenizer> t;
     vbt_dict dict_view;  // borrowed view handed out by vbt_tokenizer_dictionary
     std::mutex pool_mu;
     std::vector<std::unique_ptr<PooledWorkspace>> pool;  // idle workspaces
+    std::vector<std::unique_ptr<PinnedBlock>> host_pool;  // idle pinned blocks
     uint64_t pool_created = 0, pool_reused = 0;
     ~vbt_tokenizer() { pool.clear(); }  // before the Tokenizer (workspaces reference it)
 };
 struct vbt_workspace { std::unique_ptr<Workspace> w; };
 
 struct vbt_batch {
-    const vbt_tokenizer* tok;
-    std::vector<uint8_t> text;
-    std::vector<uint64_t> offsets;
-    std::vector<uint32_t> tok_off, tok_cnt;
-    std::vector<vbt_token_rec> tokens;
+    vbt_tokenizer* tok = nullptr;
+    std::unique_ptr<PinnedBlock> in_blk, out_blk;  // go back to the tokenizer's pool in vbt_batch_free
+    uint64_t n = 0, n_tokens = 0;
+    const uint64_t* offsets = nullptr;  // in_blk: n + 1 rebased offsets, then the text
+    const uint8_t* text = nullptr;
+    const uint32_t* tok_off = nullptr;  // out_blk: tok_off[n], tok_cnt[n], tokens[n_tokens]
+    const uint32_t* tok_cnt = nullptr;
+    const vbt_token_rec* tokens = nullptr;
 };
 
 struct vbt_worker {
@@ -154,7 +167,7 @@ uint64_t round_up_pow2(uint64_t v, uint64_t lo) {
 
 // Smallest idle workspace that holds the request, else a new one (capacities rounded up to powers of two so
 // that batches of similar size share it).  At most kPoolIdle workspaces stay idle; the smallest is dropped first.
-constexpr size_t kPoolIdle = 4;
+constexpr size_t kPoolIdle = 8;
 std::unique_ptr<PooledWorkspace> pool_take(vbt_tokenizer* tok, uint64_t n, uint64_t bytes) {
     {
         std::lock_guard<std::mutex> g(tok->pool_mu);
@@ -179,6 +192,37 @@ std::unique_ptr<PooledWorkspace> pool_take(vbt_tokenizer* tok, uint64_t n, uint6
     HIPX(hipMalloc(reinterpret_cast<void**>(&p->d_off), (p->cap_sentences + 1) * 8));
     HIPX(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
     return p;
+}
+
+constexpr size_t kHostPoolIdle = 8;
+std::unique_ptr<PinnedBlock> host_take(vbt_tokenizer* tok, size_t bytes) {
+    {
+        std::lock_guard<std::mutex> g(tok->pool_mu);
+        size_t best = tok->host_pool.size();
+        for (size_t i = 0; i < tok->host_pool.size(); ++i)
+            if (tok->host_pool[i]->cap >= bytes && (best == tok->host_pool.size() || tok->host_pool[i]->cap < tok->host_pool[best]->cap)) best = i;
+        if (best != tok->host_pool.size()) {
+            auto b = std::move(tok->host_pool[best]);
+            tok->host_pool.erase(tok->host_pool.begin() + (long)best);
+            return b;
+        }
+    }
+    auto b = std::make_unique<PinnedBlock>();
+    b->cap = round_up_pow2(bytes, 1 << 16);
+    HIPX(hipHostMalloc(&b->p, b->cap, hipHostMallocDefault));
+    return b;
+}
+
+void host_give(vbt_tokenizer* tok, std::unique_ptr<PinnedBlock> b) {
+    if (!b) return;
+    std::lock_guard<std::mutex> g(tok->pool_mu);
+    tok->host_pool.push_back(std::move(b));
+    if (tok->host_pool.size() > kHostPoolIdle) {
+        size_t smallest = 0;
+        for (size_t i = 1; i < tok->host_pool.size(); ++i)
+            if (tok->host_pool[i]->cap < tok->host_pool[smallest]->cap) smallest = i;
+        tok->host_pool.erase(tok->host_pool.begin() + (long)smallest);
+    }
 }
 
 void pool_give(vbt_tokenizer* tok, std::unique_ptr<PooledWorkspace> p) {
@@ -483,36 +527,62 @@ int vbt_worker_token(const vbt_worker* w, uint32_t i, vbt_token* out) {
 
 int vbt_tokenize_batch(const vbt_tokenizer* tok_, const uint8_t* text, const uint64_t* offsets, uint64_t n, vbt_batch** out) {
     return guarded([&] {
-        vbt_tokenizer* tok = const_cast<vbt_tokenizer*>(tok_);  // the pool is internally synchronised: the handle stays logically const
+        vbt_tokenizer* tok = const_cast<vbt_tokenizer*>(tok_);  // the pools are internally synchronised: the handle stays logically const
         if (!tok || !offsets || !out || (!text && n && offsets[n] != offsets[0])) throw Error(VBT_ERR_INVALID_ARGUMENT, "null argument");
-        auto b = std::make_unique<vbt_batch>();
-        b->tok = tok;
         const uint64_t lo = offsets[0];
-        b->offsets.resize(n + 1);
-        for (uint64_t i = 0; i <= n; ++i) {
-            if (offsets[i] < lo || (i && offsets[i] < offsets[i - 1])) throw Error(VBT_ERR_INVALID_ARGUMENT, "offsets must be non-decreasing");
-            b->offsets[i] = offsets[i] - lo;
-        }
+        for (uint64_t i = 1; i <= n; ++i)
+            if (offsets[i] < offsets[i - 1]) throw Error(VBT_ERR_INVALID_ARGUMENT, "offsets must be non-decreasing");
         const uint64_t bytes = offsets[n] - lo;
         if (bytes >= 0xFFFFFFFFull || n >= 0xFFFFFFFFull) throw Error(VBT_ERR_INVALID_ARGUMENT, "batch too large (split it)");
-        b->text.assign(text + lo, text + lo + bytes);
-        // every sentence must be a Rust `str` (the reference's callers pass &str; its CLI fails on invalid input lines)
-        for (uint64_t i = 0; i < n; ++i)
-            if (!valid_utf8(b->text.data() + b->offsets[i], b->offsets[i + 1] - b->offsets[i]))
-                throw Error(VBT_ERR_UTF8, "sentence " + std::to_string(i) + " is not valid UTF-8");
         HIPX(hipSetDevice(tok->t->device()));
-        auto p = pool_take(tok, n, bytes);
-        try {
-            if (bytes) HIPX(hipMemcpyAsync(p->d_text, b->text.data(), bytes, hipMemcpyHostToDevice, p->stream));
-            HIPX(hipMemcpyAsync(p->d_off, b->offsets.data(), (n + 1) * 8, hipMemcpyHostToDevice, p->stream));
-            run_and_fetch(*p->ws, static_cast<const uint8_t*>(p->d_text), p->d_off, n, bytes, b->tok_off, b->tok_cnt, b->tokens, p->stream);
-        } catch (...) {
-            (void)hipStreamSynchronize(p->stream);
-            pool_give(tok, std::move(p));
-            throw;
+        // the batch's own copy of the input, in pinned memory: [n + 1 rebased offsets][text]
+        struct Holder {  // blocks and workspace go back to their pools on every path
+            vbt_tokenizer* tok;
+            std::unique_ptr<vbt_batch> b;
+            std::unique_ptr<PooledWorkspace> p;
+            ~Holder() {
+                if (p) { (void)hipStreamSynchronize(p->stream); pool_give(tok, std::move(p)); }
+                if (b) { host_give(tok, std::move(b->in_blk)); host_give(tok, std::move(b->out_blk)); }
+            }
+        } h{tok, std::make_unique<vbt_batch>(), nullptr};
+        vbt_batch& b = *h.b;
+        b.tok = tok;
+        b.n = n;
+        b.in_blk = host_take(tok, (n + 1) * 8 + bytes);
+        uint64_t* offs = static_cast<uint64_t*>(b.in_blk->p);
+        for (uint64_t i = 0; i <= n; ++i) offs[i] = offsets[i] - lo;
+        uint8_t* txt = reinterpret_cast<uint8_t*>(offs + n + 1);
+        if (bytes) std::memcpy(txt, text + lo, bytes);
+        b.offsets = offs;
+        b.text = txt;
+        h.p = pool_take(tok, n, bytes);
+        PooledWorkspace& p = *h.p;
+        if (bytes) HIPX(hipMemcpyAsync(p.d_text, txt, bytes, hipMemcpyHostToDevice, p.stream));
+        HIPX(hipMemcpyAsync(p.d_off, offs, (n + 1) * 8, hipMemcpyHostToDevice, p.stream));
+        p.ws->run(static_cast<const uint8_t*>(p.d_text), p.d_off, n, bytes, p.stream);
+        vbt_call_stats st;
+        p.ws->stats(&st);  // synchronises the stream
+        if (st.error_flags & kErrUtf8) {
+            // every sentence must be a Rust `str` (the reference's callers pass &str; its CLI fails on invalid input lines).  The
+            // device's first kernel validates the text; only this error path walks it again on the host to name the sentence.
+            for (uint64_t i = 0; i < n; ++i)
+                if (!valid_utf8(txt + offs[i], offs[i + 1] - offs[i])) throw Error(VBT_ERR_UTF8, "sentence " + std::to_string(i) + " is not valid UTF-8");
         }
-        pool_give(tok, std::move(p));
-        *out = b.release();
+        check_device_errors(st.error_flags);
+        b.n_tokens = st.n_tokens;
+        b.out_blk = host_take(tok, n * 8 + st.n_tokens * sizeof(vbt_token_rec) + 16);
+        uint32_t* o = static_cast<uint32_t*>(b.out_blk->p);
+        b.tok_off = o;
+        b.tok_cnt = o + n;
+        b.tokens = reinterpret_cast<const vbt_token_rec*>(o + 2 * n);
+        if (n) {
+            HIPX(hipMemcpyAsync(o, p.ws->d_tok_off, n * 4, hipMemcpyDeviceToHost, p.stream));
+            HIPX(hipMemcpyAsync(o + n, p.ws->d_tok_cnt, n * 4, hipMemcpyDeviceToHost, p.stream));
+        }
+        if (st.n_tokens) HIPX(hipMemcpyAsync(o + 2 * n, p.ws->d_tokens, st.n_tokens * sizeof(vbt_token_rec), hipMemcpyDeviceToHost, p.stream));
+        HIPX(hipStreamSynchronize(p.stream));
+        pool_give(tok, std::move(h.p));
+        *out = h.b.release();
     });
 }
 
@@ -528,25 +598,30 @@ int vbt_tokenizer_pool_stats(const vbt_tokenizer* tok_, uint64_t* created, uint6
     });
 }
 
-void vbt_batch_free(vbt_batch* b) { delete b; }
-uint64_t vbt_batch_num_sentences(const vbt_batch* b) { return b->tok_cnt.size(); }
-uint64_t vbt_batch_total_tokens(const vbt_batch* b) { return b->tokens.size(); }
-uint32_t vbt_batch_num_tokens(const vbt_batch* b, uint64_t s) { return s < b->tok_cnt.size() ? b->tok_cnt[s] : 0; }
+void vbt_batch_free(vbt_batch* b) {
+    if (!b) return;
+    host_give(b->tok, std::move(b->in_blk));  // the tokenizer outlives its batches (as it outlives its workers)
+    host_give(b->tok, std::move(b->out_blk));
+    delete b;
+}
+uint64_t vbt_batch_num_sentences(const vbt_batch* b) { return b->n; }
+uint64_t vbt_batch_total_tokens(const vbt_batch* b) { return b->n_tokens; }
+uint32_t vbt_batch_num_tokens(const vbt_batch* b, uint64_t s) { return s < b->n ? b->tok_cnt[s] : 0; }
 const vbt_token_rec* vbt_batch_records(const vbt_batch* b, uint64_t s) {
-    return s < b->tok_cnt.size() && b->tok_cnt[s] ? &b->tokens[b->tok_off[s]] : nullptr;
+    return s < b->n && b->tok_cnt[s] ? &b->tokens[b->tok_off[s]] : nullptr;
 }
 
 int vbt_batch_arrays(const vbt_batch* b, const vbt_token_rec** tokens, const uint32_t** tok_off, const uint32_t** tok_cnt) {
-    if (tokens) *tokens = b->tokens.data();
-    if (tok_off) *tok_off = b->tok_off.data();
-    if (tok_cnt) *tok_cnt = b->tok_cnt.data();
+    if (tokens) *tokens = b->tokens;
+    if (tok_off) *tok_off = b->tok_off;
+    if (tok_cnt) *tok_cnt = b->tok_cnt;
     return VBT_OK;
 }
 
 int vbt_batch_token(const vbt_batch* b, uint64_t s, uint32_t i, vbt_token* out) {
     return guarded([&] {
-        if (s >= b->tok_cnt.size() || i >= b->tok_cnt[s]) throw Error(VBT_ERR_INVALID_ARGUMENT, "token index out of range");
-        fill_token(b->tok->t->dict(), b->text.data() + b->offsets[s], b->tokens[b->tok_off[s] + i], out);
+        if (s >= b->n || i >= b->tok_cnt[s]) throw Error(VBT_ERR_INVALID_ARGUMENT, "token index out of range");
+        fill_token(b->tok->t->dict(), b->text + b->offsets[s], b->tokens[b->tok_off[s] + i], out);
     });
 }
 
@@ -555,11 +630,11 @@ int vbt_batch_format(const vbt_batch* b, int mode, char** out, size_t* len) {
         if (mode < VBT_FORMAT_MECAB || mode > VBT_FORMAT_DETAIL) throw Error(VBT_ERR_INVALID_ARGUMENT, "mode: unknown output mode");
         static const char* kLexNames[3] = {"System", "User", "Unknown"};  // {:?} of LexType
         std::string s;
-        s.reserve(b->tokens.size() * 64 + b->tok_cnt.size() * 4);
+        s.reserve(b->n_tokens * 64 + b->n * 4);
         const Dictionary& d = b->tok->t->dict();
         char num[96];
-        for (size_t si = 0; si < b->tok_cnt.size(); ++si) {
-            const uint8_t* sent = b->text.data() + b->offsets[si];
+        for (size_t si = 0; si < b->n; ++si) {
+            const uint8_t* sent = b->text + b->offsets[si];
             for (uint32_t i = 0; i < b->tok_cnt[si]; ++i) {
                 vbt_token t;
                 fill_token(d, sent, b->tokens[b->tok_off[si] + i], &t);
