@@ -4,6 +4,7 @@ Token, plus the batched entry points this project adds.  Everything computes on 
 MI355X through libvibrato_hip.so; Python only moves handles and bytes."""
 import ctypes as C
 import os
+import threading
 
 import numpy as np
 
@@ -203,6 +204,7 @@ class Tokenizer:
         self._device = device
         self._h = None
         self._dict = None
+        self._build_lock = threading.Lock()
 
     @classmethod
     def new(cls, dictionary, device=-1):
@@ -228,12 +230,14 @@ class Tokenizer:
 
     def _handle(self):
         if not self._h:
-            h = C.c_void_p()
-            N.check(N.lib().vbt_tokenizer_new(self._dict_in._handle(), int(self._ignore_space), self._max_grouping_len,
-                                              self._device, C.byref(h)))
-            self._h = h
-            self._dict_in._h = None  # moved (Tokenizer::new consumes the dictionary)
-            self._dict = C.c_void_p(N.lib().vbt_tokenizer_dictionary(h))
+            with self._build_lock:  # the device image is built once, whichever thread gets here first
+                if not self._h:
+                    h = C.c_void_p()
+                    N.check(N.lib().vbt_tokenizer_new(self._dict_in._handle(), int(self._ignore_space), self._max_grouping_len,
+                                                      self._device, C.byref(h)))
+                    self._dict_in._h = None  # moved (Tokenizer::new consumes the dictionary)
+                    self._dict = C.c_void_p(N.lib().vbt_tokenizer_dictionary(h))
+                    self._h = h
         return self._h
 
     def __del__(self):

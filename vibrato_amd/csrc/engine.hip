@@ -62,7 +62,7 @@ __device__ __forceinline__ uint32_t wave_exscan(uint32_t v, uint32_t& total) {
         uint32_t y = __shfl_up(x, d);
         if ((int)threadIdx.x >= d) x += y;
     }
-    total = __shfl(x, 63);
+    total = (uint32_t)__builtin_amdgcn_readlane((int)x, 63);  // an SGPR: what depends on it stays wave-uniform for the compiler
     return x - v;
 }
 
@@ -74,7 +74,7 @@ __device__ __forceinline__ uint32_t wave_exscan_any(uint32_t v, uint32_t& total)
         uint32_t y = __shfl_up(x, d);
         if (lane >= d) x += y;
     }
-    total = __shfl(x, 63);
+    total = (uint32_t)__builtin_amdgcn_readlane((int)x, 63);  // an SGPR: what depends on it stays wave-uniform for the compiler
     return x - v;
 }
 
@@ -318,7 +318,7 @@ __device__ __forceinline__ uint64_t process_sentence(const DevDict& D, const Bat
             const uint64_t m = brk >> ln;
             const uint32_t g = m ? (uint32_t)__builtin_ctzll(m) + 1 : (64 - ln) + carry;
             if (valid) grp[i] = (IdxT)g;
-            carry = __shfl(g, 0);
+            carry = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
         }
     }
     __syncthreads();
@@ -695,7 +695,7 @@ __device__ __forceinline__ uint64_t process_sentence(const DevDict& D, const Bat
             seq = e_back[nd_eslot[seq]];
         }
     }
-    T = __shfl(T, 0);
+    T = (uint32_t)__builtin_amdgcn_readfirstlane((int)T);
     // tokens go to the sentence's own region of the staging buffer (tokens <= characters <= bytes: it cannot overflow);
     // compact_tokens packs them in sentence order afterwards -- no allocation atomic on a hot counter
     const size_t out_base = sentence_slot(A, b0, sid);
@@ -912,7 +912,7 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
             const uint64_t m = brk >> ln;
             const uint32_t g = m ? (uint32_t)__builtin_ctzll(m) + 1 : (64 - ln) + carry;
             if (valid) grp[i] = (uint16_t)g;
-            carry = __shfl(g, 0);
+            carry = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
         }
     }
     __syncthreads();
@@ -1063,7 +1063,7 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
                 const uint64_t third = space ? (uint64_t)grp[i] : lm;
                 pc[i] = make_uint4(cand_off[i] | (eo(i) << 16), (nsl < 0x3FFFu ? nsl : 0x3FFFu) | cut | space, (uint32_t)third, (uint32_t)(third >> 32));
             }
-            const uint32_t top = __shfl(m, 63);
+            const uint32_t top = (uint32_t)__builtin_amdgcn_readlane((int)m, 63);
             far = top > far ? top : far;
             uint32_t mc = cnt;
 #pragma unroll
@@ -1160,7 +1160,7 @@ __global__ void __launch_bounds__(64) gen_candidates_large(DevDict D, BatchArgs 
     for (;;) {
         uint32_t k = 0;
         if (threadIdx.x == 0) k = atomicAdd(&A.cctrl[2 * t + 1], 1u);
-        k = __shfl(k, 0);
+        k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
         if (k >= count) break;
         gen_one(D, A, A.lists[(size_t)t * A.list_stride + A.list_off + k], lds_bytes, level);
         __syncthreads();
@@ -1273,7 +1273,7 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
                 if (m) {
                     const uint32_t top = 63u - (uint32_t)__builtin_clzll(m);
                     best = seg_a + w0 + top + 1;
-                    best_pass = __shfl(est, (int)top);
+                    best_pass = (uint32_t)__builtin_amdgcn_readlane((int)est, (int)top);  // (top is wave-uniform)
                 }
                 run += tot;
                 if (__ballot(fits) == 0) break;
@@ -1456,7 +1456,10 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
 
         // ---- fused gather + cost recurrence (matrix_connector.rs:79-85, lattice.rs:103-151) ----
         {
-            const uint32_t* __restrict__ matrix32 = reinterpret_cast<const uint32_t*>(D.matrix);
+            // The connection matrix through a buffer resource: buffer_load_sshort returns the sign-extended cell in a full
+            // VGPR (no word extraction), addresses are 32-bit offsets (no 64-bit add per lane), and the hardware range check
+            // makes the garbage offsets of lanes without a pair harmless (out of range reads return 0).
+            const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<int16_t*>(D.matrix), 0, (int)D.matrix_bytes, 0x00020000);
             // lane-wise select by a wave-uniform 64-bit lane mask held in SGPRs: bit ? b : a
             auto select_mask = [](uint64_t mask, uint32_t a, uint32_t b) {
                 uint32_t out;
@@ -1466,13 +1469,13 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
             // Software pipeline, three stages ahead of a pass's execution at iteration p:
             //   A1 (iteration p - kDepth - 2): read its record from LDS (broadcast);
             //   A2 (iteration p - kDepth - 1): record -> this lane's pair -> LDS addresses; read the pair's candidate and right id;
-            //   B  (iteration p - kDepth)    : gather the pair's connection cost from the matrix (lanes without a pair load cell 0).
+            //   B  (iteration p - kDepth)    : gather the pair's connection cost from the matrix.
             // Every stage consumes what the previous iteration requested, so an iteration issues all its independent LDS
             // reads up front (next record, next pair, this pass's predecessor keys) and waits for them once.  Pass p lives in
             // ring slot p % kRing from A2 on; the loop is unrolled kRing times, so slot indices are static.
             constexpr uint32_t kRing = kDepth + 2;
-            uint32_t word[kRing], csh[kRing], keyaddr[kRing], taddr[kRing], cw[kRing];  // VGPRs: cost word in flight, shift that brings the cell
-                                                                                         // down, LDS addresses of the predecessor's and the candidate's key, word cost << 16 | own field
+            uint32_t word[kRing], keyaddr[kRing], taddr[kRing], cw[kRing];  // VGPRs: connection cost in flight (sign-extended), LDS addresses of
+                                                                            // the predecessor's and the candidate's key, word cost << 16 | own field
             uint32_t smlo[kRing], smhi[kRing], slg[kRing];                               // SGPRs (wave-uniform): lane mask, lg
             auto stage_a1 = [&](uint32_t p, uint4& r0, uint4& r1) {
                 const uint4* r = reinterpret_cast<const uint4*>(&rec[p < SL ? p : SL]);  // passes > SL do not exist: they re-read the empty one
@@ -1489,10 +1492,9 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
                 slg[u] = __builtin_amdgcn_readfirstlane(r1.z);
             };
             auto stage_b = [&](uint32_t u, const uint2& cd, uint32_t right) {
-                const uint64_t mask = ((uint64_t)smhi[u] << 32) | smlo[u];
-                const uint32_t cell = select_mask(mask, 0u, __umul24(cd.y >> 16, NR) + right);  // < 2^32: num_left, num_right <= 65535
-                word[u] = load_policy<VBT_NT_MATRIX != 0>(&matrix32[cell >> 1]);  // (a 16-bit destination would be packed by the compiler and serialise the loads)
-                csh[u] = cell << 4;  // shift count = its low 5 bits: 16 for an odd cell
+                // (lanes without a pair hold garbage ids: wherever their offset lands, the load is harmless and its result unused)
+                const uint32_t cell = __umul24(cd.y >> 16, NR) + right;
+                word[u] = (uint32_t)(int32_t)(int16_t)__builtin_amdgcn_raw_buffer_load_b16(mrs, (int)(cell << 1), 0, 0);
                 taddr[u] = offK + ((cd.x & 0xFFFFu) << 3);
                 cw[u] = __builtin_amdgcn_perm(cd.x, cd.y, 0x07060100u);  // word cost (high half of x) << 16 | own field (low half of y)
             };
@@ -1526,7 +1528,7 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
                     stage_b((u + kDepth) % kRing, p_cd, p_right);                  // pass si + kDepth
                     pr0 = n0; pr1 = n1; p_cd = ncd; p_right = nr;
                     // ---- pass si ----
-                    const uint32_t khi = (uint32_t)(kb >> 32) + (uint32_t)(int32_t)(int16_t)(word[u] >> (csh[u] & 31u))   // wrapping i32 adds:
+                    const uint32_t khi = (uint32_t)(kb >> 32) + word[u]                                                   // wrapping i32 adds:
                                          + (uint32_t)((int32_t)cw[u] >> 16);                                            // connection + word cost (lattice.rs:125,139)
                     const uint32_t klo = __builtin_amdgcn_perm((uint32_t)kb, cw[u], 0x05040100u);  // predecessor's own field << 16 | the candidate's
                     const uint64_t live = __ballot((uint32_t)kb != 0xFFFFFFFFu) & mask;
@@ -1629,7 +1631,7 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
                     seq = key_pred(e_key[cnd[seq].x & 0xFFFFu]);
                 }
             }
-            T = __shfl(T, 0);
+            T = (uint32_t)__builtin_amdgcn_readfirstlane((int)T);
             __syncthreads();
             if (ln == 0) A.tok_cnt[sid] = T;
             for (uint32_t t = ln; t < T; t += 64) {
@@ -1682,7 +1684,7 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
                 T = __builtin_amdgcn_readfirstlane(T);
             }
             __syncthreads();
-            T = __shfl(T, 0);
+            T = (uint32_t)__builtin_amdgcn_readfirstlane((int)T);
             __syncthreads();
             if (ln == 0) A.tok_cnt[sid] = T;
             for (uint32_t t = ln; t < T; t += 64) {
@@ -1740,7 +1742,7 @@ __global__ void __launch_bounds__(64) tokenize_lds(DevDict D, BatchArgs A, uint3
     for (;;) {
         uint32_t k = 0;
         if (threadIdx.x == 0) k = atomicAdd(cursor, 1u);
-        k = __shfl(k, 0);
+        k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
         if (k >= count) break;
         const uint32_t sid = in_list[k];
         if (process_sentence<uint16_t, false>(D, A, sid, g_smem, lds_bytes) != 0) push_overflow(out_list, out_count, sid);
@@ -1758,7 +1760,7 @@ __global__ void __launch_bounds__(64) tokenize_global(DevDict D, BatchArgs A, co
     for (;;) {
         uint32_t k = 0;
         if (threadIdx.x == 0) k = atomicAdd(cursor, 1u);
-        k = __shfl(k, 0);
+        k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
         if (k >= count) break;
         const uint32_t sid = in_list[k];
         for (int attempt = 0; attempt < 5; ++attempt) {
@@ -1770,7 +1772,7 @@ __global__ void __launch_bounds__(64) tokenize_global(DevDict D, BatchArgs A, co
                 want = (want + 255) & ~255ull;
                 unsigned long long off = 0;
                 if (threadIdx.x == 0) off = atomicAdd(bump, (unsigned long long)want);
-                off = ((unsigned long long)__shfl((uint32_t)(off >> 32), 0) << 32) | __shfl((uint32_t)off, 0);
+                off = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(off >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)off);
                 if (off + want > A.scratch_bytes) failed = true;
                 else { slab = A.scratch + off; slab_bytes = want; }
             }
@@ -1980,6 +1982,11 @@ Tokenizer::Tokenizer(const Dictionary* dict, bool ignore_space, uint32_t max_gro
             dev_.matrix = m;
         }
         dev_.num_right = dict_->num_right;
+        {   // lattice_lds addresses cells with 32-bit byte offsets through a buffer resource
+            const uint64_t bytes = (uint64_t)dict_->num_left * dict_->num_right * 2;
+            if (bytes >= (1ull << 32)) throw Error(VBT_ERR_UNSUPPORTED, "connector: connection matrices of 4 GiB and more are not supported by the device image");
+            dev_.matrix_bytes = (uint32_t)bytes;
+        }
         dev_.chr2inf = dev_upload(dict_->chr2inf, allocs_);
         dev_.unk_off = dev_upload(dict_->unk_offsets, allocs_);
         dev_.unk_entries = dev_upload(dict_->unk_entries, allocs_);

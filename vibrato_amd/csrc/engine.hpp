@@ -24,6 +24,7 @@ struct DevDict {
     int has_user;
     const int16_t* matrix;  // [num_left][num_right]
     uint32_t num_right;
+    uint32_t matrix_bytes;        // num_left * num_right * 2 (< 2^32: both <= 65535 ... checked at upload)
     const uint32_t* chr2inf;      // 65536 packed CharInfo
     const uint32_t* unk_off;      // n_categories + 1
     const Entry* unk_entries;
