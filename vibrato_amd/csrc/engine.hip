@@ -1089,6 +1089,8 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
         if (fixed <= A.tier_bytes[t]) { tier = t; break; }
     // longer sentences are swept in segments inside the segment tier instead of one huge LDS block
     if (A.seg_tier < A.n_tiers && tier > A.seg_tier) tier = A.seg_tier;
+    // the straggler generators run while the tiers below the segment tier already sweep: their lists are closed
+    if (large && A.early_fork && tier < A.seg_tier) tier = A.seg_tier;
     route(tier);
     PROF_MARK(2);
     if (A.prof && ln == 0) {
@@ -1492,9 +1494,11 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
                 slg[u] = __builtin_amdgcn_readfirstlane(r1.z);
             };
             auto stage_b = [&](uint32_t u, const uint2& cd, uint32_t right) {
-                // (lanes without a pair hold garbage ids: wherever their offset lands, the load is harmless and its result unused)
+                // lanes without a pair hold garbage ids: they all load cell 0 (one cache line; scattered garbage offsets cost the
+                // texture addresser 8 % of the kernel, measured)
+                const uint64_t mask = ((uint64_t)smhi[u] << 32) | smlo[u];
                 const uint32_t cell = __umul24(cd.y >> 16, NR) + right;
-                word[u] = (uint32_t)(int32_t)(int16_t)__builtin_amdgcn_raw_buffer_load_b16(mrs, (int)(cell << 1), 0, 0);
+                word[u] = (uint32_t)(int32_t)(int16_t)__builtin_amdgcn_raw_buffer_load_b16(mrs, (int)select_mask(mask, 0u, cell << 1), 0, 0);
                 taddr[u] = offK + ((cd.x & 0xFFFFu) << 3);
                 cw[u] = __builtin_amdgcn_perm(cd.x, cd.y, 0x07060100u);  // word cost (high half of x) << 16 | own field (low half of y)
             };
@@ -2147,6 +2151,7 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
                 if (tiers[t] >= seg_bytes) { a.seg_tier = (uint32_t)t; break; }
     }
     a.sid0 = 0; a.cctrl = d_cctrl; a.list_off = 0;
+    a.early_fork = (!fused && a.seg_tier < T && a.seg_tier > 0 && env_u32("VBT_LONG_BYTES", 0) == 0 && env_u32("VBT_EARLY_FORK", 0)) ? 1u : 0u;
     a.lid_count = count_connids ? d_connid : nullptr;
     a.rid_count = count_connids ? d_connid + tok.dict().num_left : nullptr;
     a.s_counted = count_connids ? d_counted : nullptr;
@@ -2209,11 +2214,17 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
         hipLaunchKernelGGL(gen_candidates, dim3(cn), dim3(64), gen_lds, stream, D, a, gen_lds);
         if (long_bytes) HIP_CHECK(hipStreamWaitEvent(stream, reinterpret_cast<hipEvent_t>(ev_early), 0));
         hipLaunchKernelGGL(build_lists, dim3(lb), dim3(1024), 0, stream, a, -1);
+        // VBT_EARLY_FORK=1 (off by default): the bulk generator has routed every sentence it could hold and what remains
+        // (longer than ~150 characters) goes to the segment tier at least, so the lists of the tiers below it are final
+        // here and their sweep can fork now, under the straggler generators.  Measured slower on MI355X (2.31 vs 2.26 ms on
+        // the headline batch, 9.8 vs 8.7 ms on config 5): the stragglers then compete with the sweep for the CUs and the
+        // segment tier, the critical path, starts later.
+        if (a.early_fork) { HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_fork), stream)); rec(1); }
         a.direct_push = 1;
         for (uint32_t lv = 1; lv <= kGenLevels; ++lv)  // each level takes what outgrew the one before (the last: a whole CU's LDS, ~5000 characters)
             hipLaunchKernelGGL(gen_candidates_large, dim3(waves_for(gen_level_lds[lv - 1], cn)), dim3(64), gen_level_lds[lv - 1], stream, D, a, gen_level_lds[lv - 1], lv);
         a.direct_push = 0;
-        rec(1);
+        if (!a.early_fork) rec(1);
         // (forking the small tiers before the straggler generators was measured: 3.33 vs 3.2 ms, the stragglers then
         // compete with the sweep and the segment tier starts later)
         HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_fork2), stream));
@@ -2229,7 +2240,7 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
         for (size_t i = 0; i < n_conc; ++i) {
             const size_t t = n_conc - 1 - i;
             hipStream_t side = reinterpret_cast<hipStream_t>(streams[t]);
-            HIP_CHECK(hipStreamWaitEvent(side, reinterpret_cast<hipEvent_t>(ev_fork2), 0));
+            HIP_CHECK(hipStreamWaitEvent(side, reinterpret_cast<hipEvent_t>(a.early_fork && t < a.seg_tier ? ev_fork : ev_fork2), 0));
             // one workgroup per list entry: the lists are built on the device, so the grid covers the whole batch and the
             // workgroups beyond a list's length exit at once (VBT_LAT_PERSIST=1: persistent waves with a work cursor)
             const uint32_t grid = !persist ? cn : (t < tier_waves.size() && tier_waves[t]) ? std::min<uint32_t>(tier_waves[t], waves_for(tiers[t], cn)) : waves_for(tiers[t], cn);

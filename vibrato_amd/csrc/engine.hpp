@@ -75,6 +75,7 @@ struct BatchArgs {
     uint32_t list_stride;
     uint32_t n_tiers;
     uint32_t seg_tier;     // LDS tier that sweeps longer sentences in segments (>= n_tiers: none)
+    uint32_t early_fork;   // the tiers below the segment tier sweep while the straggler generators still run (their lists are final)
     uint32_t direct_push;  // gen_candidates_large: append to the tier lists directly instead of routing through s_tier
     uint32_t tier_prio;  // the top `tier_prio` LDS tiers run at raised wave priority (0 = off)
     // a launch covers sentences [sid0, sid0 + n); cctrl = the list counters it works with (cctrl[2t] = entries of
