@@ -248,6 +248,11 @@ def main():
     result = None
     if rank == 0:
         from oracle import oracle as ora  # checker + cpu_baseline leg only
+        import tempfile
+        native_dir = tempfile.mkdtemp(prefix="vbt_oracle_")
+        native_so = None if args.no_cpu_baseline else ora.build_native(native_dir)  # -march=native for the timed CPU leg
+        if native_so:
+            ora.use_library(native_so)
         do = ora.Dictionary.from_sources_binmatrix(sd.lex, sd.matrix, sd.num_right, sd.num_left, sd.char_def, sd.unk)
         if user_csv is not None:
             do.reset_user_lexicon(user_csv)
@@ -324,7 +329,7 @@ def main():
             mean, lo_t, hi_t = cpu_protocol(lambda: w.tokenize_batch(c_text, c_offs, want_tokens=False))
             sample = (f"first {n_cpu} sentences of the batch ({c_bytes} bytes); 3 trials x 3 runs, min and max run of a trial "
                       f"dropped (benchmark/src/main.rs:53-91); C restatement of vibrato Worker::tokenize (oracle/, gcc -O3 "
-                      f"-march=x86-64-v3: the prebuilt library travels to the GPU box), host has {os.cpu_count()} cores")
+                      f"{'-march=native, compiled on this host' if native_so else '-march=x86-64-v3, prebuilt library'}), host has {os.cpu_count()} cores")
             cpu = {"value": round(n_cpu / mean, 1), "unit": "sentences/s", "cores": 1, "kind": "port", "sample": sample,
                    "range": [round(n_cpu / hi_t, 1), round(n_cpu / lo_t, 1)], "MB_per_s": round(c_bytes / mean / 1e6, 3)}
             # all host cores: one oracle worker per core on contiguous chunks balanced by bytes (ctypes releases the GIL)

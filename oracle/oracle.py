@@ -26,7 +26,29 @@ def build(force=False):
     return _SO
 
 
+def build_native(out_dir):
+    """The same source compiled for the host it runs on (-O3 -march=native), for the cpu_baseline leg of
+    bench.py: the committed Makefile targets x86-64-v3 because its .so travels to other machines.  Returns the path, or None
+    when no compiler is available (the prebuilt library is used then)."""
+    so = os.path.join(out_dir, "libvibrato_oracle_native.so")
+    try:
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-std=gnu11", "-fPIC", "-fvisibility=hidden", "-shared", "-o", so,
+                               os.path.join(_HERE, "vibrato_oracle.c")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    except (OSError, subprocess.CalledProcessError):
+        return None
+    return so
+
+
 _lib = None
+_so_override = None  # set by use_library() before the first lib() call
+
+
+def use_library(path):
+    """Load the oracle from `path` (a build_native() result) instead of the in-tree library."""
+    global _so_override
+    if _lib is not None:
+        raise RuntimeError("the oracle library is already loaded")
+    _so_override = path
 
 
 def lib():
@@ -34,7 +56,7 @@ def lib():
     if _lib is None:
         if not os.path.exists(_SO):
             build()
-        L = C.CDLL(_SO)
+        L = C.CDLL(_so_override or _SO)
         vp, u8p, sz, u32, u64, i32 = C.c_void_p, C.c_char_p, C.c_size_t, C.c_uint32, C.c_uint64, C.c_int32
         L.ora_dict_from_sources.restype = vp
         L.ora_dict_from_sources.argtypes = [u8p, sz, u8p, sz, u8p, sz, u8p, sz, u8p, sz]

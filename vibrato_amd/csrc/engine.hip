@@ -1482,6 +1482,9 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
             auto stage_a1 = [&](uint32_t p, uint4& r0, uint4& r1) {
                 const uint4* r = reinterpret_cast<const uint4*>(&rec[p < SL ? p : SL]);  // passes > SL do not exist: they re-read the empty one
                 r0 = r[0]; r1 = r[1];
+#if defined(VBT_EXP_REC2)
+                { const uint4* rr = reinterpret_cast<const uint4*>(&rec[p + 1 < SL ? p + 1 : SL]); const uint4 x0 = rr[0], x1 = rr[1]; asm volatile("" :: "v"(x0.x), "v"(x1.x)); }
+#endif
             };
             auto stage_a2 = [&](const uint4& r0, const uint4& r1, uint32_t u, uint2& cd, uint32_t& right) {
                 const uint32_t lg = r1.z & 31u;
@@ -1515,6 +1518,9 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
                 stage_a2(pr0, pr1, p, ncd, nr);
                 if (p > 0) stage_b(p - 1, p_cd, p_right);
                 pr0 = n0; pr1 = n1; p_cd = ncd; p_right = nr;
+                // the gathers must be ISSUED in pass order: the wait-count analysis merges this state into the loop header, and a
+                // reordered prologue (the scheduler is free to) makes every iteration's first pass wait for all gathers in flight
+                __builtin_amdgcn_sched_barrier(0);
             }
             for (uint32_t s0 = 0; s0 < SL; s0 += kRing) {
 #pragma unroll
@@ -1525,9 +1531,11 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
                     uint4 n0, n1;
                     uint2 ncd;
                     uint32_t nr;
+                    // (first in the LDS queue: it is the only read this pass's own chain waits for -- lgkmcnt(4) -- the others are
+                    // consumed an iteration later)
+                    const uint64_t kb = *reinterpret_cast<lds_cu64*>(keyaddr[u]);  // key of this lane's predecessor
                     stage_a1(si + kDepth + 2, n0, n1);
                     stage_a2(pr0, pr1, (u + kRing - 1) % kRing, ncd, nr);            // pass si + kDepth + 1
-                    const uint64_t kb = *reinterpret_cast<lds_cu64*>(keyaddr[u]);  // key of this lane's predecessor
                     __builtin_amdgcn_sched_barrier(0);  // (keep these reads together, ahead of their first consumer: one wait for all)
                     stage_b((u + kDepth) % kRing, p_cd, p_right);                  // pass si + kDepth
                     pr0 = n0; pr1 = n1; p_cd = ncd; p_right = nr;
