@@ -18,8 +18,11 @@ pub type ConnIdProbs = Vec<(usize, f64)>;
 pub struct Worker<'t> {
     raw: *mut sys::vbt_worker,
     tokenizer: &'t Tokenizer,
-    _not_sync: PhantomData<*mut ()>, // one worker per thread, as in the reference (`&mut self` methods)
+    _not_sync: PhantomData<std::cell::Cell<()>>, // used from one thread at a time, as in the reference (`&mut self` methods)
 }
+
+// Safety: a worker may move to another thread (the reference's Worker is Send); the library keeps no thread affinity.
+unsafe impl Send for Worker<'_> {}
 
 impl<'t> Worker<'t> {
     pub(crate) fn new(tokenizer: &'t Tokenizer) -> Self {

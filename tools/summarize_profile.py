@@ -19,7 +19,7 @@ if os.path.exists(f"{src}/bench_line.json") and os.path.getsize(f"{src}/bench_li
 stats = glob.glob(f"{src}/stats/**/*kernel_stats.csv", recursive=True)
 if stats:
     shutil.copyfile(stats[0], f"profiles/{tag}_kernel_stats.csv")
-    lines += [f"## `rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline` (profiles/{tag}_kernel_stats.csv)\n",
+    lines += [f"## `rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-pipeline` (profiles/{tag}_kernel_stats.csv)\n",
               "| kernel | calls | total ms | avg us | min us | max us | % |", "|---|---|---|---|---|---|---|"]
     for r in csv.DictReader(open(stats[0])):
         lines.append(f"| `{r['Name'][:70]}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.3f} | {float(r['AverageNs']) / 1e3:.1f} | "
@@ -89,14 +89,46 @@ if pm:
             lines.append(f"L2 hit rate: {d['TCC_HIT_sum'] / (d['TCC_HIT_sum'] + d['TCC_MISS_sum']):.3f}")
         lines.append("")
     json.dump({f"{i}:{k}:{g}": d for (i, k, g), d in pm.items()}, open(f"profiles/{tag}_pmc.json", "w"), indent=1)
+    # calibration of the two counters on known byte counts (tools/calib/fetch_calib.hip, run by tools/profile_round.sh)
+    calib = None
+    try:
+        known = json.loads([l for l in open(f"{src}/calib_bytes.json") if l.startswith("{")][-1])
+        names = list(known)
+        meas = {}
+        for cnt, sub in (("FETCH_SIZE", "calib_r"), ("WRITE_SIZE", "calib_w")):
+            f = glob.glob(f"{src}/{sub}/**/*counter_collection.csv", recursive=True)
+            rows_c = sorted((int(r["Dispatch_Id"]), float(r["Counter_Value"])) for r in csv.DictReader(open(f[0])) if r["Counter_Name"] == cnt and "fillBuffer" not in r["Kernel_Name"])
+            for nm, (_, v) in zip(names, rows_c[-len(names):]):
+                meas.setdefault(nm, {})[cnt] = v * 1024
+        calib = {nm: {"known_bytes": known[nm], "counter_bytes": meas[nm]["FETCH_SIZE" if not nm.startswith("write") else "WRITE_SIZE"],
+                      "bytes_per_counted_byte": round(known[nm] / max(meas[nm]["FETCH_SIZE" if not nm.startswith("write") else "WRITE_SIZE"], 1), 3)} for nm in names}
+        lines += ["## Calibration of FETCH_SIZE / WRITE_SIZE (x 1024 B) on known byte counts over 1 GiB (tools/calib/fetch_calib.hip)\n",
+                  "| pattern | known bytes | counter bytes | true bytes per counted byte |", "|---|---|---|---|"]
+        for nm, c in calib.items():
+            lines.append(f"| {nm} | {c['known_bytes']:,} | {c['counter_bytes']:,.0f} | {c['bytes_per_counted_byte']} |")
+        lines.append("\n(gathers: `known` = useful bytes, so < 1 means whole lines are fetched for a few useful bytes; streaming reads > 1 = the counter under-reports)\n")
+    except Exception as e:  # no calibration run in this profile directory
+        lines.append(f"(no FETCH_SIZE calibration in {src}: {e})\n")
     if all("FETCH_SIZE" in d for d in pm.values()):
         total = sum((d["FETCH_SIZE"] + d.get("WRITE_SIZE", 0)) * 1024 for d in pm.values())
         by_kernel = collections.OrderedDict()
         for (i, k, g), d in pm.items():
             by_kernel[k] = by_kernel.get(k, 0) + int((d["FETCH_SIZE"] + d.get("WRITE_SIZE", 0)) * 1024)
         bench_cfg = json.load(open(f"{src}/bench_line.json"))["config"]["workload"] if os.path.getsize(f"{src}/bench_line.json") else ""
-        json.dump({"workload": bench_cfg, "hbm_bytes_per_step": int(total), "hbm_bytes_by_kernel": by_kernel, "source": f"profiles/{tag}_pmc.json",
-                   "method": "sum over the step's kernels of (FETCH_SIZE + WRITE_SIZE) * 1024, separate rocprofv3 --pmc passes"},
+        insts = collections.OrderedDict()
+        for (i, k, g), d in pm.items():
+            if "SQ_INSTS_VALU" in d:
+                e = insts.setdefault(k, {"valu": 0, "salu": 0, "lds": 0, "vmem_rd": 0, "smem": 0})
+                for key, cn in (("valu", "SQ_INSTS_VALU"), ("salu", "SQ_INSTS_SALU"), ("lds", "SQ_INSTS_LDS"), ("vmem_rd", "SQ_INSTS_VMEM_RD"), ("smem", "SQ_INSTS_SMEM")):
+                    e[key] += int(d.get(cn, 0))
+        # upper bound if every read of the step were a wide streaming read (the calibrated under-report of read16): the
+        # per-char records (16 B/lane) and the sweep records (8 B/lane) are, the trie / matrix gathers are not
+        rf = max((calib or {}).get("read16", {}).get("bytes_per_counted_byte", 1.0), (calib or {}).get("read8", {}).get("bytes_per_counted_byte", 1.0), 1.0)
+        upper = sum((d["FETCH_SIZE"] * rf + d.get("WRITE_SIZE", 0)) * 1024 for d in pm.values())
+        json.dump({"workload": bench_cfg, "hbm_bytes_per_step": int(total), "hbm_bytes_by_kernel": by_kernel, "wave_insts_by_kernel": insts,
+                   "hbm_bytes_per_step_upper_bound": int(upper), "calibration": calib, "source": f"profiles/{tag}_pmc.json",
+                   "method": "sum over the step's kernels of (FETCH_SIZE + WRITE_SIZE) * 1024, separate rocprofv3 --pmc passes; upper bound = "
+                             "every read scaled by the calibrated under-report of wide streaming reads"},
                   open(f"profiles/{tag}_traffic.json", "w"), indent=1)
         lines.append(f"## HBM traffic of one step (all kernels): {total / 1e6:.1f} MB\n")
 open(f"profiles/{tag}_summary.md", "w").write("\n".join(lines) + "\n")
