@@ -817,8 +817,13 @@ __device__ __forceinline__ void list_push(const BatchArgs& A, uint32_t t, uint32
 // candidates in reference insertion order, each tagged with its (start position, left_id) group:
 // search_min_node's result depends only on that pair (lattice.rs:129-151), so the lattice kernel
 // evaluates one row per group instead of one per candidate.
+// kLarge: the instances behind the bulk generator (level 1..3).  They keep the two widest per-character arrays -- the length
+// masks and the candidate offsets, 12 of 26 bytes -- in the sentence's per-character records in global memory instead of LDS
+// (written during the walk, read back in place when the records are finalised: every read there is of a position that has not
+// been finalised yet), so a level holds twice the characters and long sentences run at twice the occupancy.
+template <bool kLarge>
 __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, uint32_t sid, uint32_t lds_bytes, uint32_t level) {
-    const bool large = level != 0;  // level 0: bulk generator; 1, 2: the large- / whole-CU-LDS instances behind it
+    const bool large = kLarge;  // level 0: bulk generator; 1, 2, 3: the large- / whole-CU-LDS instances behind it
     const uint32_t ln = threadIdx.x;
     const uint64_t lt_mask = (1ull << ln) - 1ull;
     uint64_t prof_t = A.prof ? clock64() : 0, prof_acc[3] = {};
@@ -853,9 +858,14 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
         return;
     }
     Arena ar{g_smem, lds_bytes, 0, true};
-    uint64_t* lens = ar.take<uint64_t>(n);
+    uint64_t* lens = kLarge ? nullptr : ar.take<uint64_t>(n);
     uint32_t* ci = ar.take<uint32_t>(n);
-    uint32_t* cand_off = ar.take<uint32_t>(n + 1);
+    uint32_t* cand_off = kLarge ? nullptr : ar.take<uint32_t>(n + 1);
+    uint4* const pcw = A.g_pc + slot0;  // kLarge: .x = candidate offset, .z/.w = length mask until the records are finalised
+    auto set_lens = [&](uint32_t i, uint64_t v) { if constexpr (kLarge) { pcw[i].z = (uint32_t)v; pcw[i].w = (uint32_t)(v >> 32); } else lens[i] = v; };
+    auto get_lens = [&](uint32_t i) -> uint64_t { if constexpr (kLarge) { const uint4 r = pcw[i]; return ((uint64_t)r.w << 32) | r.z; } else return lens[i]; };
+    auto set_co = [&](uint32_t i, uint32_t v) { if constexpr (kLarge) pcw[i].x = v; else cand_off[i] = v; };
+    auto get_co = [&](uint32_t i) -> uint32_t { if constexpr (kLarge) return pcw[i].x & 0xFFFFu; else return cand_off[i]; };  // (a finalised record keeps it in its low half)
     uint16_t* code = ar.take<uint16_t>(n);
     uint16_t* ucode = D.has_user ? ar.take<uint16_t>(n) : code;
     uint16_t* grp = ar.take<uint16_t>(n);
@@ -951,17 +961,17 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
             const uint32_t cinfo = ci[i], cate = (cinfo >> 18) & 0xFFu;
             const uint32_t u0 = D.unk_off[cate], nunk = D.unk_off[cate + 1] - u0;
             unk_spans(cinfo, grp[i], i, matched, D.max_grouping_len, [&](uint32_t e) { seen(u0, nunk, e, 2u); });
-            lens[i] = lmask;
+            set_lens(i, lmask);
         }
         uint32_t tot;
         const uint32_t ex = wave_exscan(cnt, tot);
-        if (i < n) cand_off[i] = C + ex;
+        if (i < n) set_co(i, C + ex);
         C += tot;
         any_long |= __ballot(is_long) != 0;
     }
     // words > 64 chars need the generic pre-pass, > 65531 nodes need u32 indices: fused kernel
     if (C >= 65532 || any_long) { route(fallback); return; }
-    if (ln == 0) cand_off[n] = C;
+    if (ln == 0) set_co(n, C);
     // End lists (`ends[e]` of lattice.rs:39-43) are laid out here once and for all: node slots are numbered by end
     // position (BOS is slot 0, the only node ending at 0), so the lattice kernel reads every candidate with its slot
     // attached and builds no lists.  endc[] turns from counts into running cursors: exclusive prefix now, after the
@@ -998,7 +1008,7 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
             const uint4 hr = hits[h];
             const uint32_t c = hr.y & 0xFFFFu, lex = hr.y >> 16, end = hr.z & 0xFFFFu, pos = hr.z >> 16;
             const Entry* __restrict__ ent = lex == 0 ? D.sys.entries : lex == 1 ? D.user.entries : D.unk_entries;
-            const uint32_t dest = cand_off[pos] + hr.w;
+            const uint32_t dest = get_co(pos) + hr.w;
             const uint32_t slot0 = atomicAdd(&endc[end], c);  // the hit's run of slots in ends[end]
             for (uint32_t t0 = 0; t0 < c; t0 += 4) {
                 Entry e[4];
@@ -1035,20 +1045,21 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
         uint32_t far = 0;  // furthest end of any candidate of the positions before this chunk
         for (uint32_t c0 = 0; c0 < n; c0 += 64) {
             const uint32_t i = c0 + ln;
-            uint32_t e = 0, space = 0, nsl = 0, cnt = 0;
+            uint32_t e = 0, space = 0, nsl = 0, cnt = 0, co_i = 0;
             uint64_t lm = 0;
             if (i < n) {
                 const uint32_t cinfo = ci[i];
                 space = (D.space_cateset && (cinfo & D.space_cateset)) ? 0x80000000u : 0u;
-                lm = lens[i];
+                lm = get_lens(i);
                 e = lm ? i + 64u - (uint32_t)__builtin_clzll(lm) : i + 1;
-                uint32_t nc = cand_off[i + 1] - cand_off[i];
+                co_i = get_co(i);
+                uint32_t nc = get_co(i + 1) - co_i;
                 if (space) {
                     const uint32_t sw = i + grp[i];
-                    const uint64_t lw = sw < n ? lens[sw] : 0ull;
+                    const uint64_t lw = sw < n ? get_lens(sw) : 0ull;
                     const uint32_t e2 = sw < n ? (lw ? sw + 64u - (uint32_t)__builtin_clzll(lw) : sw + 1) : n;
                     e = e2 > e ? e2 : e;
-                    nc = sw < n ? cand_off[sw + 1] - cand_off[sw] : 0u;  // the step taken from a space position starts its words behind the run
+                    nc = sw < n ? get_co(sw + 1) - get_co(sw) : 0u;  // the step taken from a space position starts its words behind the run
                 }
                 cnt = eo(i + 1) - eo(i);
                 nsl = step_passes(nc, cnt);
@@ -1061,7 +1072,7 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
             if (i < n) {
                 const uint32_t cut = (i == 0 || before <= i) ? 0x40000000u : 0u;
                 const uint64_t third = space ? (uint64_t)grp[i] : lm;
-                pc[i] = make_uint4(cand_off[i] | (eo(i) << 16), (nsl < 0x3FFFu ? nsl : 0x3FFFu) | cut | space, (uint32_t)third, (uint32_t)(third >> 32));
+                pc[i] = make_uint4(co_i | (eo(i) << 16), (nsl < 0x3FFFu ? nsl : 0x3FFFu) | cut | space, (uint32_t)third, (uint32_t)(third >> 32));
             }
             const uint32_t top = (uint32_t)__builtin_amdgcn_readlane((int)m, 63);
             far = top > far ? top : far;
@@ -1153,7 +1164,7 @@ __global__ void __launch_bounds__(1024) build_lists(BatchArgs A, int only_list) 
 // Kernel 1: one single-wave workgroup per sentence (small LDS, high occupancy) ...
 __global__ void __launch_bounds__(64) gen_candidates(DevDict D, BatchArgs A, uint32_t lds_bytes) {
     if (batch_rejected(A)) return;  // nothing gets routed: every later kernel finds empty work lists
-    gen_one(D, A, A.sid0 + blockIdx.x, lds_bytes, 0);
+    gen_one<false>(D, A, A.sid0 + blockIdx.x, lds_bytes, 0);
 }
 // ... and persistent waves with a large LDS budget for the sentences that did not fit.
 __global__ void __launch_bounds__(64) gen_candidates_large(DevDict D, BatchArgs A, uint32_t lds_bytes, uint32_t level) {
@@ -1164,7 +1175,7 @@ __global__ void __launch_bounds__(64) gen_candidates_large(DevDict D, BatchArgs 
         if (threadIdx.x == 0) k = atomicAdd(&A.cctrl[2 * t + 1], 1u);
         k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
         if (k >= count) break;
-        gen_one(D, A, A.lists[(size_t)t * A.list_stride + A.list_off + k], lds_bytes, level);
+        gen_one<true>(D, A, A.lists[(size_t)t * A.list_stride + A.list_off + k], lds_bytes, level);
         __syncthreads();
     }
 }
@@ -1718,6 +1729,9 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
             // launched behind this one -- retries; after the last one the fused kernel with the global-memory
             // lattice redoes the sentence.
             const bool escape = list_id == tier && tier >= A.seg_tier && tier + 1 < A.n_tiers && fail != 27;
+#if defined(VBT_DEBUG_ESC)
+            if (ln == 0) printf("esc sid=%u fail=%u nT=%u CT=%u seg_a=%u tier=%u\n", sid, fail, nT, CT, seg_a, tier);
+#endif
             if (ln == 0 && !escape) atomicAdd(&A.ctrl[fail < 32 ? fail : 28], 1u);
             list_push(A, escape ? tier + 1 : A.n_tiers, sid);
             __syncthreads();
@@ -2197,7 +2211,7 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
         // as much as they save (4.40 vs 4.27 ms per 100k sentences).
         // (the bulk generator keeps ~26 bytes of LDS per character: 4 KiB hold ~155 characters and 32+ waves per CU)
         const uint32_t gen_lds = env_u32("VBT_GEN_LDS", 4096);
-        uint32_t gen_level_lds[kGenLevels] = {16384, 65536, 163840};  // the instances behind the bulk generator (VBT_GEN_LEVELS=a,b,c)
+        uint32_t gen_level_lds[kGenLevels] = {16384, 32768, 163840};  // the instances behind the bulk generator (VBT_GEN_LEVELS=a,b,c)
         if (const char* e = std::getenv("VBT_GEN_LEVELS")) {
             unsigned v[3];
             if (std::sscanf(e, "%u,%u,%u", &v[0], &v[1], &v[2]) == 3 && v[0] >= 4096 && v[0] < v[1] && v[1] < v[2] && v[2] <= 163840)
