@@ -1102,6 +1102,53 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
     if (A.seg_tier < A.n_tiers && tier > A.seg_tier) tier = A.seg_tier;
     // the straggler generators run while the tiers below the segment tier already sweep: their lists are closed
     if (large && A.early_fork && tier < A.seg_tier) tier = A.seg_tier;
+    if (tier == A.seg_tier && A.seg_tier + 1 < A.n_tiers && fixed > A.tier_bytes[tier]) {
+        // The sentence has to be swept in segments.  Replay lattice_lds' choice of cuts on the finished records: where some stretch
+        // is too dense for any admissible cut (it would fail there and be re-swept by the escape tier, which only starts when the
+        // whole segment tier has drained), file the sentence for the escape launch that runs NEXT TO the other tiers.  A wrong
+        // guess either way only costs time: lattice_lds still escalates what it cannot sweep.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's own record stores
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const uint4* __restrict__ pcr = A.g_pc + slot0;
+        const uint32_t budget = A.tier_bytes[tier];
+        uint32_t seg_a = 0, seg_c = 0, seg_p = 0, m_in = 1;
+        bool sweepable = true;
+        for (uint32_t guard = 0; guard <= n; ++guard) {
+            if (lattice_fixed_bytes(C - seg_c, passes - seg_p, m_in) <= budget) break;
+            uint32_t best = 0, best_pass = 0, run = 0;
+            for (uint32_t w0 = 0; w0 < 256 && seg_a + w0 < n; w0 += 64) {
+                const uint32_t b = seg_a + w0 + ln + 1;
+                uint32_t nsl = 0, cx = 0, cut = 0;
+                if (b <= n) {
+                    const uint4 rp = pcr[b - 1], rb = pcr[b];
+                    nsl = rp.y & 0x3FFFu;
+                    if (nsl == 0x3FFFu) nsl = 1u << 20;
+                    cx = rb.x;
+                    cut = b == n ? 1u : (rb.y >> 30) & 1u;
+                }
+                uint32_t tot;
+                const uint32_t incl = wave_exscan(nsl, tot) + nsl + run;
+                const uint32_t est = b == n ? passes - seg_p : incl;
+                const bool fits = b <= n && lattice_fixed_bytes(((cx & 0xFFFFu) - seg_c) & 0xFFFFu, est, m_in) <= budget;
+                const uint64_t m = __ballot(fits && cut);
+                if (m) {
+                    const uint32_t top = 63u - (uint32_t)__builtin_clzll(m);
+                    best = seg_a + w0 + top + 1;
+                    best_pass = (uint32_t)__builtin_amdgcn_readlane((int)est, (int)top);
+                }
+                run += tot;
+                if (__ballot(fits) == 0) break;
+            }
+            if (!best) { sweepable = false; break; }
+            if (best >= n) break;
+            const uint32_t xa = __builtin_amdgcn_readfirstlane(pcr[best].x), xb = __builtin_amdgcn_readfirstlane(pcr[best + 1].x);  // (the terminator record at n holds the totals in the same places)
+            const uint32_t m_out = ((xb >> 16) - (xa >> 16)) & 0xFFFFu;  // nodes ending exactly at the cut: the next segment's interface
+            if (m_out == 0 || m_out > 128) { sweepable = false; break; }
+            seg_a = best; seg_c = xa & 0xFFFFu; seg_p += best_pass; m_in = m_out;
+        }
+        if (!sweepable) tier = A.n_tiers + 1 + kGenLevels;  // the pre-routed escape list
+    }
     route(tier);
     PROF_MARK(2);
     if (A.prof && ln == 0) {
@@ -1134,12 +1181,12 @@ __global__ void __launch_bounds__(256) classify_long(BatchArgs A, uint32_t long_
 __global__ void __launch_bounds__(1024) build_lists(BatchArgs A, int only_list) {
     // One global atomic per (workgroup, list): a returning atomic on a hot word costs ~11 ns, so the
     // 16 waves of a workgroup first agree on their shares through LDS.
-    __shared__ uint32_t w_cnt[16][kMaxTiers + 1 + kGenLevels];
-    __shared__ uint32_t l_base[kMaxTiers + 1 + kGenLevels];
+    __shared__ uint32_t w_cnt[16][kMaxTiers + kListsBehindTiers];
+    __shared__ uint32_t l_base[kMaxTiers + kListsBehindTiers];
     const uint32_t rel = blockIdx.x * 1024 + threadIdx.x, sid = A.sid0 + rel;
     const uint32_t t = rel < A.n ? A.s_tier[sid] : 0xFFu;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t n_lists = A.n_tiers + 1 + kGenLevels;
+    const uint32_t n_lists = A.n_tiers + kListsBehindTiers;
     uint32_t my_rank = 0;
     for (uint32_t l = 0; l < n_lists; ++l) {
         const bool mine = t == l && (only_list < 0 || (int)l == only_list);
@@ -2068,7 +2115,7 @@ Workspace::Workspace(const Tokenizer& t, uint64_t max_s, uint64_t max_b) : tok(t
     d_tile_sums = static_cast<uint32_t*>(alloc(((ns + kScanTile - 1) / kScanTile + 1) * 4));
     d_tok_off = static_cast<uint32_t*>(alloc(ns * 4));
     d_tok_cnt = static_cast<uint32_t*>(alloc(ns * 4));
-    d_over = static_cast<uint32_t*>(alloc(2 * ns * 4 * (tiers.size() + 1 + kGenLevels)));  // two regions per list: long-first pass + bulk
+    d_over = static_cast<uint32_t*>(alloc(2 * ns * 4 * (tiers.size() + kListsBehindTiers)));  // two regions per list: long-first pass + bulk
     d_ctrl = static_cast<uint32_t*>(alloc(kCtrlWords * 4));
     d_cctrl = static_cast<uint32_t*>(alloc((size_t)kCtrlBlocks * kBlockCtrlWords * 4));
     if (const char* e = std::getenv("VBT_TIER_WAVES")) {  // experiment: fixed lattice grid per tier
@@ -2276,6 +2323,15 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
                     launch_lattice(dim3(waves_for(tiers[x], std::min<uint32_t>(cn, 4096))), tiers[x], side, (uint32_t)x, (uint32_t)x, 1u);
             HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(tier_events[t]), side));
         }
+        if (a.seg_tier + 1 < T) {
+            // what gen_candidates found too dense to sweep in segments: the first escape tier's LDS, its own stream, next to the others
+            const size_t x = a.seg_tier + 1;
+            hipStream_t side = reinterpret_cast<hipStream_t>(streams[x]);
+            HIP_CHECK(hipStreamWaitEvent(side, reinterpret_cast<hipEvent_t>(ev_fork2), 0));
+            launch_lattice(dim3(waves_for(tiers[x], std::min<uint32_t>(cn, 4096))), tiers[x], side, (uint32_t)x, (uint32_t)(T + 1 + kGenLevels), 1u);
+            HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(tier_events[x]), side));
+            HIP_CHECK(hipStreamWaitEvent(stream, reinterpret_cast<hipEvent_t>(tier_events[x]), 0));
+        }
         for (size_t t = 0; t < n_conc; ++t) HIP_CHECK(hipStreamWaitEvent(stream, reinterpret_cast<hipEvent_t>(tier_events[t]), 0));
         // whatever the pipeline could not take: fused kernel, global-memory lattice
         hipLaunchKernelGGL(tokenize_global, dim3((uint32_t)std::min<uint64_t>(cn, 1024)), dim3(64), 0, stream, D, a,
@@ -2311,13 +2367,14 @@ void Workspace::stats(vbt_call_stats* out) {
             out->n_tier0 += k[0];
             out->n_tier2 += k[2 * T];
             for (size_t t = 1; t < T; ++t) out->n_tier1 += k[2 * t];
+            out->n_tier1 += k[2 * (T + 1 + kGenLevels)];  // pre-routed to the concurrent escape launch
         }
     }
     out->n_tokens = ctrl[kTotal];
     out->error_flags = ctrl[kError];
     if (std::getenv("VBT_DEBUG")) {
         std::fprintf(stderr, "[vbt] lattice fallbacks: arena=%u window=%u passes=%u no-cut=%u space-tail=%u interface/backtrace=%u; lists:", ctrl[26], ctrl[27], ctrl[29], ctrl[30], ctrl[31], ctrl[28]);
-        for (size_t t = 0; t < T + 1 + kGenLevels; ++t) std::fprintf(stderr, " %u", cc[2 * t]);
+        for (size_t t = 0; t < T + kListsBehindTiers; ++t) std::fprintf(stderr, " %u", cc[2 * t]);
         std::fprintf(stderr, "\n");
     }
     if (timing && last_n) {

@@ -70,7 +70,8 @@ struct BatchArgs {
     uint8_t* s_early;   // the same for the early (long-sentence) pipeline
     const uint8_t* s_skip;  // bulk generator: sentences with s_skip[sid] != 0xFF belong to the early pipeline (nullptr = none)
     // work lists: list t (t < n_tiers) feeds LDS tier t, list n_tiers the global-memory fallback (fused kernel),
-    // lists n_tiers + 1 .. n_tiers + kGenLevels the large-LDS instances of gen_candidates
+    // lists n_tiers + 1 .. n_tiers + kGenLevels the large-LDS instances of gen_candidates; list n_tiers + 1 + kGenLevels the sentences
+    // gen_candidates found unsweepable in segments (swept by an escape-tier launch that runs concurrently with the other tiers)
     uint32_t* lists;
     uint32_t list_stride;
     uint32_t n_tiers;
@@ -97,7 +98,8 @@ enum CtrlSlot { kTotal = 0, kError = 1, kBump = 2, kNodeCursor = 4, kTierCtrl = 
 constexpr int kMaxTiers = 8;
 constexpr int kCtrlBlocks = 2;   // list-counter blocks: [0] the batch, [1] the input list of the optional long-first side stream
 constexpr int kGenLevels = 3;  // large-LDS instances of the generator behind the bulk one (32 KiB, 64 KiB, whole CU)
-constexpr int kBlockCtrlWords = 2 * (kMaxTiers + 1 + kGenLevels);
+constexpr int kListsBehindTiers = 1 + kGenLevels + 1;  // fallback, generator levels, pre-routed escapes (see engine.hip `dense_list`)
+constexpr int kBlockCtrlWords = 2 * (kMaxTiers + kListsBehindTiers);
 constexpr int kProfSlots = 256;  // the counters are spread over this many copies (hot-word atomics serialise)
 constexpr int kProfWords = 12;   // kProfPhases cycle totals, sentences, lattice steps, lattice passes, candidates
 constexpr int kProfPhases = 8;  // decode, count, fill, end lists, pre-pass, gather, recurrence, emit
