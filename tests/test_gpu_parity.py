@@ -458,3 +458,25 @@ def test_concurrent_host_batches_from_threads_match_oracle():
     r = tv.host_pipeline_benchmark(text, offs, threads=3, rounds=2, repeats=2)
     assert r["tokens_per_batch"] == len(exp) and r["sentences_per_s"] > 0
     assert tv.pool_stats()[0] <= created + 3
+
+
+@pytest.mark.parametrize("env", [{"VBT_TIERS": "2048,3072,163840", "VBT_SEG_BYTES": "3072"},
+                                 {"VBT_TIERS": "2048,4096,32768,163840", "VBT_SEG_BYTES": "4096", "VBT_GEN_LDS": "2048", "VBT_GEN_LEVELS": "4096,8192,163840"}])
+def test_sentences_too_dense_for_the_segment_tier_are_prerouted_to_a_concurrent_escape_launch(env, monkeypatch):
+    """gen_candidates replays lattice_lds' choice of cuts: with a tiny segment tier on the dense lexicon law many sentences have
+    no admissible cut and must be filed for the escape launch that runs next to the other tiers (none may be lost, none swept
+    twice); the generator levels behind the bulk one keep their length masks / candidate offsets in global memory."""
+    import torch
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    sd = synth.SynthDict("small-dense")
+    to, tv = _oracle_and_product(sd, ignore_space=True, max_grouping_len=24)
+    text, offs = sd.sentences(3000, "mixed", space_p=0.05)
+    _assert_batch_equal(to, tv, text, offs)
+    ws = tv.workspace(3000, len(text))
+    d_text = torch.from_numpy(text.copy()).cuda()
+    d_offs = torch.from_numpy(offs.astype(np.int64)).cuda()
+    ws.run(d_text.data_ptr(), d_offs.data_ptr(), 3000, len(text), torch.cuda.current_stream().cuda_stream)
+    st = ws.stats()
+    assert st["error_flags"] == 0 and st["n_tier0"] + st["n_tier1"] + st["n_tier2"] >= 3000
+    assert st["n_tier1"] > 0
