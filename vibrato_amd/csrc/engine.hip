@@ -1365,6 +1365,9 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
         const uint32_t offK = lds0 + (uint32_t)(reinterpret_cast<char*>(e_key) - g_smem), offC = lds0 + (uint32_t)(reinterpret_cast<char*>(cnd) - g_smem);
         const uint32_t offR = lds0 + (uint32_t)(reinterpret_cast<char*>(e_right) - g_smem);
 
+        // the per-character records of the first 64 positions are requested now, ahead of the candidate loads: by the time the
+        // reachability sweep wants them they have arrived (the sweep of a chunk then prefetches the next chunk's)
+        uint4 rc_next = pc[ln < n ? ln : n], rn_next = pc[ln < n ? ln + 1 : n];
         // ---- load: candidates from global (every record carries its slot); interface; EOS ----
         for (uint32_t c0 = 0; c0 < C; c0 += 64 * 4) {  // 4 independent 8-byte loads per lane in flight
             uint2 r[4];
@@ -1431,7 +1434,8 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
             for (uint32_t chunk = 0; chunk < n && !stop; chunk += 64) {
                 const uint32_t i = chunk + ln;
                 const bool in = i < n;
-                const uint4 rc = pc[in ? i : n], rn = pc[in ? i + 1 : n];  // this position's record and the next one's (n = the end record)
+                const uint4 rc = rc_next, rn = rn_next;  // this position's record and the next one's (n = the end record)
+                if (chunk + 64 < n) { const uint32_t i2 = i + 64; rc_next = pc[i2 < n ? i2 : n]; rn_next = pc[i2 < n ? i2 + 1 : n]; }
                 const bool is_space = kSpaceMode && in && (rc.y >> 31) != 0;
                 const uint32_t l_lo = (in && !is_space) ? rc.z : 0u, l_hi = (in && !is_space) ? rc.w : 0u;
                 const uint32_t gf = is_space ? rc.z : 0u;  // groupable run of a space position
@@ -1694,11 +1698,27 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
         };
         if (!multi) {
             uint16_t* path = reinterpret_cast<uint16_t*>(rec);  // the pass records are dead now; tokens <= steps
+            // The walk along the back pointers is serial (lane 0, one LDS round trip per dependent read).  Where the dead record
+            // area also holds one back pointer per candidate, all lanes resolve key -> predecessor first (candidate -> its slot ->
+            // the slot's key: two reads, 64 candidates at a time), and the walk reads one u16 per token instead of two u64.
+            uint16_t* bp = path + ((n + 2u) & ~1u);
+            const bool flat = (size_t)(reinterpret_cast<char*>(bp + C + 1) - g_smem) <= lds_bytes;
+            if (flat) {
+                for (uint32_t c0 = 0; c0 < C; c0 += 64 * 4) {
+                    uint32_t sl[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { const uint32_t c = c0 + u * 64 + ln; sl[u] = cnd[c < C ? c : 0u].x & 0xFFFFu; }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { const uint32_t c = c0 + u * 64 + ln; if (c < C) bp[c] = (uint16_t)key_pred(e_key[sl[u]]); }
+                }
+                __syncthreads();
+            }
             if (ln == 0) {
                 uint32_t seq = key_pred(e_key[E]);
-                while (seq != kBosSeq && T < n) {
-                    path[T++] = (uint16_t)seq;
-                    seq = key_pred(e_key[cnd[seq].x & 0xFFFFu]);
+                if (flat) {
+                    while (seq != kBosSeq && T < n) { path[T++] = (uint16_t)seq; seq = bp[seq]; }
+                } else {
+                    while (seq != kBosSeq && T < n) { path[T++] = (uint16_t)seq; seq = key_pred(e_key[cnd[seq].x & 0xFFFFu]); }
                 }
             }
             T = (uint32_t)__builtin_amdgcn_readfirstlane((int)T);
