@@ -1072,7 +1072,10 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
             if (i < n) {
                 const uint32_t cut = (i == 0 || before <= i) ? 0x40000000u : 0u;
                 const uint64_t third = space ? (uint64_t)grp[i] : lm;
-                pc[i] = make_uint4(co_i | (eo(i) << 16), (nsl < 0x3FFFu ? nsl : 0x3FFFu) | cut | space, (uint32_t)third, (uint32_t)(third >> 32));
+                const uint32_t yw = (nsl < 0x3FFFu ? nsl : 0x3FFFu) | cut | space;
+                pc[i] = make_uint4(co_i | (eo(i) << 16), yw, (uint32_t)third, (uint32_t)(third >> 32));
+                // (bulk generator: a copy for the routing replay below, over the dead half of lens[] -- positions <= i are consumed)
+                if constexpr (!kLarge) reinterpret_cast<uint32_t*>(lens)[i] = yw;
             }
             const uint32_t top = (uint32_t)__builtin_amdgcn_readlane((int)m, 63);
             far = top > far ? top : far;
@@ -1107,10 +1110,16 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
         // is too dense for any admissible cut (it would fail there and be re-swept by the escape tier, which only starts when the
         // whole segment tier has drained), file the sentence for the escape launch that runs NEXT TO the other tiers.  A wrong
         // guess either way only costs time: lattice_lds still escalates what it cannot sweep.
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's own record stores
+        if constexpr (kLarge) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's own record stores
         __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if constexpr (kLarge) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         const uint4* __restrict__ pcr = A.g_pc + slot0;
+        // what the replay reads per position: the record's second word (pass bound, clean cut), the candidate offset and the
+        // end-list offset -- from LDS in the bulk generator (a global round trip per probe was 5 % of the kernel), from the
+        // records in the levels
+        auto rec_y = [&](uint32_t p) -> uint32_t { if constexpr (kLarge) return pcr[p].y; else return reinterpret_cast<const uint32_t*>(lens)[p]; };
+        auto rec_co = [&](uint32_t p) -> uint32_t { if constexpr (kLarge) return pcr[p].x & 0xFFFFu; else return p < n ? cand_off[p] : C; };
+        auto rec_eo = [&](uint32_t p) -> uint32_t { if constexpr (kLarge) return pcr[p].x >> 16; else return eo(p); };
         const uint32_t budget = A.tier_bytes[tier];
         uint32_t seg_a = 0, seg_c = 0, seg_p = 0, m_in = 1;
         bool sweepable = true;
@@ -1121,16 +1130,15 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
                 const uint32_t b = seg_a + w0 + ln + 1;
                 uint32_t nsl = 0, cx = 0, cut = 0;
                 if (b <= n) {
-                    const uint4 rp = pcr[b - 1], rb = pcr[b];
-                    nsl = rp.y & 0x3FFFu;
+                    nsl = rec_y(b - 1) & 0x3FFFu;
                     if (nsl == 0x3FFFu) nsl = 1u << 20;
-                    cx = rb.x;
-                    cut = b == n ? 1u : (rb.y >> 30) & 1u;
+                    cx = rec_co(b);
+                    cut = b == n ? 1u : (rec_y(b) >> 30) & 1u;
                 }
                 uint32_t tot;
                 const uint32_t incl = wave_exscan(nsl, tot) + nsl + run;
                 const uint32_t est = b == n ? passes - seg_p : incl;
-                const bool fits = b <= n && lattice_fixed_bytes(((cx & 0xFFFFu) - seg_c) & 0xFFFFu, est, m_in) <= budget;
+                const bool fits = b <= n && lattice_fixed_bytes((cx - seg_c) & 0xFFFFu, est, m_in) <= budget;
                 const uint64_t m = __ballot(fits && cut);
                 if (m) {
                     const uint32_t top = 63u - (uint32_t)__builtin_clzll(m);
@@ -1142,10 +1150,9 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
             }
             if (!best) { sweepable = false; break; }
             if (best >= n) break;
-            const uint32_t xa = __builtin_amdgcn_readfirstlane(pcr[best].x), xb = __builtin_amdgcn_readfirstlane(pcr[best + 1].x);  // (the terminator record at n holds the totals in the same places)
-            const uint32_t m_out = ((xb >> 16) - (xa >> 16)) & 0xFFFFu;  // nodes ending exactly at the cut: the next segment's interface
+            const uint32_t m_out = __builtin_amdgcn_readfirstlane((rec_eo(best + 1) - rec_eo(best)) & 0xFFFFu);  // nodes ending exactly at the cut: the next segment's interface
             if (m_out == 0 || m_out > 128) { sweepable = false; break; }
-            seg_a = best; seg_c = xa & 0xFFFFu; seg_p += best_pass; m_in = m_out;
+            seg_a = best; seg_c = __builtin_amdgcn_readfirstlane(rec_co(best)); seg_p += best_pass; m_in = m_out;
         }
         if (!sweepable) tier = A.n_tiers + 1 + kGenLevels;  // the pre-routed escape list
     }
