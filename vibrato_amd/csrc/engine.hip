@@ -771,6 +771,7 @@ __global__ void __launch_bounds__(256) validate_batch(BatchArgs A, uint64_t tota
     if (oN < o0 || oN - o0 > total_bytes) bad |= kErrOffsets;
     for (uint64_t s = tid; s < A.n; s += nthreads) {
         const uint64_t a = A.offsets[s], b = A.offsets[s + 1];
+        if (A.s_tier) A.s_tier[A.sid0 + s] = 0xFF;  // nothing routed yet
         if (b < a || a < o0 || b > oN) bad |= kErrOffsets;
         else if (a < oN && (A.text[a] & 0xC0) == 0x80) bad |= kErrUtf8;  // a sentence starts inside a character
     }
@@ -2143,8 +2144,8 @@ Workspace::Workspace(const Tokenizer& t, uint64_t max_s, uint64_t max_b) : tok(t
     d_tok_off = static_cast<uint32_t*>(alloc(ns * 4));
     d_tok_cnt = static_cast<uint32_t*>(alloc(ns * 4));
     d_over = static_cast<uint32_t*>(alloc(2 * ns * 4 * (tiers.size() + kListsBehindTiers)));  // two regions per list: long-first pass + bulk
-    d_ctrl = static_cast<uint32_t*>(alloc(kCtrlWords * 4));
-    d_cctrl = static_cast<uint32_t*>(alloc((size_t)kCtrlBlocks * kBlockCtrlWords * 4));
+    d_ctrl = static_cast<uint32_t*>(alloc((kCtrlWords + (size_t)kCtrlBlocks * kBlockCtrlWords) * 4));  // one block: cleared by one memset per batch
+    d_cctrl = d_ctrl + kCtrlWords;
     if (const char* e = std::getenv("VBT_TIER_WAVES")) {  // experiment: fixed lattice grid per tier
         std::string spec = e;
         size_t pos = 0;
@@ -2226,8 +2227,7 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
     HIP_CHECK(hipSetDevice(tok.device()));
     last_n = n;
     last_stream = stream_;
-    HIP_CHECK(hipMemsetAsync(d_ctrl, 0, kCtrlWords * 4, stream));
-    HIP_CHECK(hipMemsetAsync(d_cctrl, 0, kCtrlBlocks * kBlockCtrlWords * 4, stream));
+    HIP_CHECK(hipMemsetAsync(d_ctrl, 0, (kCtrlWords + (size_t)kCtrlBlocks * kBlockCtrlWords) * 4, stream));  // ctrl + cctrl
     if (n == 0) return;
     const size_t T = tiers.size();
     const size_t half = std::max<uint64_t>(max_sentences, 1), stride = 2 * half;
@@ -2295,7 +2295,7 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
         const uint32_t cn = (uint32_t)n, lb = (cn + 1023) / 1024;
         a.sid0 = 0; a.n = cn; a.cctrl = d_cctrl; a.list_off = 0; a.direct_push = 0;
         a.s_skip = nullptr;
-        HIP_CHECK(hipMemsetAsync(pipe.s_tier, 0xFF, cn, stream));  // nothing routed yet
+        // (s_tier[] = 0xFF, "nothing routed yet", is written by validate_batch: one launch less per batch)
         if (long_bytes) {
             BatchArgs e = a;  // same routing array, own input list (second counter block / list region)
             e.cctrl = d_cctrl + (size_t)kBlockCtrlWords; e.list_off = (uint32_t)half;
