@@ -446,7 +446,10 @@ std::vector<uint8_t> zstd_decompress(const uint8_t* data, size_t len) {
     ZBuf in{data, len, 0};
     size_t produced = 0;
     for (;;) {
-        if (produced == out.size()) out.resize(out.size() * 2);
+        if (produced == out.size()) {
+            if (out.size() >= (1ull << 34)) { z.freeDStream(ds); throw Error(VBT_ERR_INVALID_FORMAT, "zstd: more than 16 GiB of output (not a dictionary)"); }
+            out.resize(out.size() * 2);
+        }
         struct { void* p; size_t size, pos; } ob{out.data(), out.size(), produced};
         const size_t rc = z.decompressStream(ds, &ob, &in);
         produced = ob.pos;
@@ -536,6 +539,10 @@ Dictionary* read_dictionary(const uint8_t* data, size_t len) {
     d->categories = r.strs();
     if (d->chr2inf.size() != 65536) bad("char_prop: chr2inf must have 65536 entries");
     if (d->categories.empty() || d->categories.size() > 18) bad("char_prop: invalid number of categories");
+    for (uint32_t v : d->chr2inf) {  // CharInfo (character.rs:10-24): the kernels index the unknown-word table with base_id
+        const uint32_t idset = v & 0x3FFFFu, base_id = (v >> 18) & 0xFFu;
+        if (base_id >= d->categories.size() || (idset >> d->categories.size()) != 0) bad("char_prop: a CharInfo names a category that does not exist");
+    }
     {
         const std::vector<uint64_t> offsets = r.vec<uint64_t>();
         const size_t n_entries = r.len(16);
