@@ -999,9 +999,11 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     PROF_MARK(1);
 
-    // expand the hits: lanes = hits, every entry load independent of every other; a candidate becomes an 8-byte sweep record
-    // {right_id | end-list slot << 16, (u16) word_cost | left_id << 16} and an 8-byte token record {word_idx, end_char},
-    // at its place in the reference's insertion order (cand_off[start] + candidates of that start before the hit)
+    // expand the hits: lanes = hits, every entry load independent of every other; a candidate becomes ONE 16-byte record -- the
+    // sweep half {right_id | end-list slot << 16, (u16) word_cost | left_id << 16} and the token half {word_idx, end_char} -- at its
+    // place in the reference's insertion order (cand_off[start] + candidates of that start before the hit).  One scattered store
+    // per candidate: the generator is bound by the number of its scattered store requests (two 8-byte stores into separate arrays
+    // cost 5 % more; the sweep's load phase does not notice the wider record)
     const uint32_t H = *hcount;  // <= C <= region
     for (uint32_t h0 = 0; h0 < H; h0 += 64) {
         const uint32_t h = h0 + ln;
@@ -1019,8 +1021,8 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
                 for (uint32_t q = 0; q < 4; ++q) {
                     if (t0 + q < c) {
                         const uint32_t k = dest + t0 + q;
-                        A.g_nd[base + k] = make_uint2((e[q].left_right >> 16) | ((slot0 + t0 + q) << 16), (e[q].cost & 0xFFFFu) | (e[q].left_right << 16));
-                        A.g_em[base + k] = make_uint2((lex << 30) | e[q].word_id, end);
+                        A.g_cand[base + k] = make_uint4((e[q].left_right >> 16) | ((slot0 + t0 + q) << 16), (e[q].cost & 0xFFFFu) | (e[q].left_right << 16),
+                                                        (lex << 30) | e[q].word_id, end);
                     }
                 }
             }
@@ -1297,8 +1299,8 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
         const size_t slot0 = sentence_slot(A, uniform64(A.offsets[sid]), sid);
         const size_t node0 = (size_t)A.node_factor * slot0;
         const uint4* __restrict__ pcg = A.g_pc + slot0;   // per-character records (+ the terminator at nT)
-        const uint2* __restrict__ ndg = A.g_nd + node0;   // candidate records in insertion order (sweep part)
-        const uint2* __restrict__ em = A.g_em + node0;    // (token part)
+        const uint4* __restrict__ ndg = A.g_cand + node0;  // candidate records in insertion order: .x/.y the sweep half, .z/.w the token half
+        struct TokenHalf { const uint4* p; __device__ __forceinline__ uint2 operator[](uint32_t c) const { const uint4 r = p[c]; return make_uint2(r.z, r.w); } } em{ndg};
         const uint32_t ET = __builtin_amdgcn_readfirstlane(pcg[nT].z);  // end-list slots of the sentence (BOS included)
         const uint32_t kBosSeq = CT + 1;
         // A sentence whose lattice does not fit this tier's LDS is swept in segments that end at clean cuts
@@ -1357,7 +1359,7 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
         const uint32_t C = ((rend.x & 0xFFFFu) - seg_c) & 0xFFFFu;
         const uint32_t E = m_in + C;  // end-list slots: interface (BOS) + the segment's candidates; slot E is the EOS node's
         const uint32_t sb = seg_s;    // sentence-global slot of local slot 0
-        const uint2* __restrict__ nd = ndg + seg_c;
+        const uint4* __restrict__ nd = ndg + seg_c;
 
         Arena ar{g_smem, lds_bytes, 0, true};
         uint64_t* e_key = ar.take<uint64_t>(E + 1);  // end-major packed keys
@@ -1382,7 +1384,7 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const uint32_t c = c0 + u * 64 + ln;
-                r[u] = nd[c < C ? c : 0u];
+                { const uint4 q4 = nd[c < C ? c : 0u]; r[u] = make_uint2(q4.x, q4.y); }
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -2172,8 +2174,7 @@ Workspace::Workspace(const Tokenizer& t, uint64_t max_s, uint64_t max_b) : tok(t
         pipe.g_c2b = static_cast<uint16_t*>(alloc(slots * 2));
         pipe.g_pc = static_cast<uint4*>(alloc(slots * 16));
         pipe.node_factor = std::max<uint32_t>(1, env_u32("VBT_NODE_FACTOR", 8));  // candidate slots per input byte
-        pipe.g_nd = static_cast<uint2*>(alloc((size_t)pipe.node_factor * slots * 8));
-        pipe.g_em = static_cast<uint2*>(alloc((size_t)pipe.node_factor * slots * 8));
+        pipe.g_cand = static_cast<uint4*>(alloc((size_t)pipe.node_factor * slots * 16));
         pipe.g_hits = static_cast<uint4*>(alloc((size_t)pipe.node_factor * slots * 16));
         pipe.s_passes = static_cast<uint32_t*>(alloc(ns * 4));
         pipe.s_tier = static_cast<uint8_t*>(alloc(ns));

@@ -60,11 +60,10 @@ struct BatchArgs {
     uint4* g_pc;        // {cand_off, groupable | is_space << 31, lens lo, lens hi}
     // per candidate (insertion order, contiguous per sentence; sentence s owns the node slots
     // [node_factor * (offsets[s] + s), node_factor * (offsets[s+1] + s + 1)): no allocation atomics).
-    //   g_nd: what the sweep needs, 8 bytes: {right_id | end-list slot << 16, (u16) word_cost | left_id << 16}
-    //   g_em: what only the tokens of the best path need, 8 bytes: {word_idx, end_char}
-    uint2* g_nd;
-    uint2* g_em;
-    uint4* g_hits;      // staging of the trie hits of gen_candidates, same per-sentence regions as g_nd
+    //   g_cand: 16 bytes, one scattered store by the generator: .x/.y what the sweep needs {right_id | end-list slot << 16,
+    //   (u16) word_cost | left_id << 16}, .z/.w what only the tokens of the best path need {word_idx, end_char}
+    uint4* g_cand;
+    uint4* g_hits;      // staging of the trie hits of gen_candidates, same per-sentence regions as g_cand
     uint32_t node_factor;
     uint8_t* s_tier;    // LDS tier chosen by gen_candidates (0xFF = none / empty sentence)
     uint8_t* s_early;   // the same for the early (long-sentence) pipeline
