@@ -2334,10 +2334,14 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
             else hipLaunchKernelGGL(lattice_lds<false>, grid_, dim3(64), lds_, st_, D, a, tier_, list_, persistent_);
         };
         const size_t n_conc = a.seg_tier < T ? a.seg_tier + 1 : T;
+        // The segment tier (the critical path: the longest sentences, then the escape tier behind it) is launched on the launch
+        // stream itself -- no event round trip before it starts nor before what follows it (VBT_MAIN_SEG=0: every tier on a side stream).
+        const bool main_seg = env_u32("VBT_MAIN_SEG", 1) != 0 && a.seg_tier < T;
         for (size_t i = 0; i < n_conc; ++i) {
             const size_t t = n_conc - 1 - i;
-            hipStream_t side = reinterpret_cast<hipStream_t>(streams[t]);
-            HIP_CHECK(hipStreamWaitEvent(side, reinterpret_cast<hipEvent_t>(a.early_fork && t < a.seg_tier ? ev_fork : ev_fork2), 0));
+            const bool on_main = main_seg && t == a.seg_tier;
+            hipStream_t side = on_main ? stream : reinterpret_cast<hipStream_t>(streams[t]);
+            if (!on_main) HIP_CHECK(hipStreamWaitEvent(side, reinterpret_cast<hipEvent_t>(a.early_fork && t < a.seg_tier ? ev_fork : ev_fork2), 0));
             // one workgroup per list entry: the lists are built on the device, so the grid covers the whole batch and the
             // workgroups beyond a list's length exit at once (VBT_LAT_PERSIST=1: persistent waves with a work cursor)
             const uint32_t grid = !persist ? cn : (t < tier_waves.size() && tier_waves[t]) ? std::min<uint32_t>(tier_waves[t], waves_for(tiers[t], cn)) : waves_for(tiers[t], cn);
@@ -2349,7 +2353,7 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
             if (t == a.seg_tier)
                 for (size_t x = t + 1; x < T; ++x)
                     launch_lattice(dim3(waves_for(tiers[x], std::min<uint32_t>(cn, 4096))), tiers[x], side, (uint32_t)x, (uint32_t)x, 1u);
-            HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(tier_events[t]), side));
+            if (!on_main) HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(tier_events[t]), side));
         }
         if (a.seg_tier + 1 < T) {
             // what gen_candidates found too dense to sweep in segments: the first escape tier's LDS, its own stream, next to the others
@@ -2360,7 +2364,8 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
             HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(tier_events[x]), side));
             HIP_CHECK(hipStreamWaitEvent(stream, reinterpret_cast<hipEvent_t>(tier_events[x]), 0));
         }
-        for (size_t t = 0; t < n_conc; ++t) HIP_CHECK(hipStreamWaitEvent(stream, reinterpret_cast<hipEvent_t>(tier_events[t]), 0));
+        for (size_t t = 0; t < n_conc; ++t)
+            if (!(main_seg && t == a.seg_tier)) HIP_CHECK(hipStreamWaitEvent(stream, reinterpret_cast<hipEvent_t>(tier_events[t]), 0));
         // whatever the pipeline could not take: fused kernel, global-memory lattice
         hipLaunchKernelGGL(tokenize_global, dim3((uint32_t)std::min<uint64_t>(cn, 1024)), dim3(64), 0, stream, D, a,
                            (const uint32_t*)over(T), (const uint32_t*)(d_cctrl + 2 * T), d_cctrl + 2 * T + 1);
