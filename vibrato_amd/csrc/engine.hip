@@ -1805,7 +1805,8 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
             // Could not be swept here (no admissible cut, estimates too low, ...): the next escape tier -- more LDS,
             // launched behind this one -- retries; after the last one the fused kernel with the global-memory
             // lattice redoes the sentence.
-            const bool escape = list_id == tier && tier >= A.seg_tier && tier + 1 < A.n_tiers && fail != 27;
+            // (also from the pre-routed launch: the launch stream waits for it before it starts the escape tiers behind the segment tier)
+            const bool escape = tier >= A.seg_tier && tier + 1 < A.n_tiers && fail != 27;
 #if defined(VBT_DEBUG_ESC)
             if (ln == 0) printf("esc sid=%u fail=%u nT=%u CT=%u seg_a=%u tier=%u\n", sid, fail, nT, CT, seg_a, tier);
 #endif
@@ -2121,7 +2122,7 @@ Workspace::Workspace(const Tokenizer& t, uint64_t max_s, uint64_t max_b) : tok(t
     // LDS tiers (bytes per wave), ascending; the global-memory tier always follows
     {
         const char* e = std::getenv("VBT_TIERS");
-        std::string spec = e && *e ? e : (fused ? "16384,32768,65536" : env_u32("VBT_SEG_BYTES", 16384) ? "10240,16384,163840" : "8192,12288,16384,24576,32768,49152,65536,163840");
+        std::string spec = e && *e ? e : (fused ? "16384,32768,65536" : env_u32("VBT_SEG_BYTES", 16384) ? "10240,16384,49152,163840" : "8192,12288,16384,24576,32768,49152,65536,163840");
         size_t pos = 0;
         while (pos < spec.size()) {
             size_t c = spec.find(',', pos);
@@ -2334,6 +2335,17 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
             else hipLaunchKernelGGL(lattice_lds<false>, grid_, dim3(64), lds_, st_, D, a, tier_, list_, persistent_);
         };
         const size_t n_conc = a.seg_tier < T ? a.seg_tier + 1 : T;
+        bool dense_launched = false;
+        if (a.seg_tier + 1 < T) {
+            // what gen_candidates found too dense to sweep in segments of the segment tier: the first escape tier's LDS, its own
+            // stream, next to the others (a 48 KiB workgroup finds room on a busy CU; a whole-CU one would wait for a CU to drain)
+            const size_t x = a.seg_tier + 1;
+            hipStream_t side = reinterpret_cast<hipStream_t>(streams[x]);
+            HIP_CHECK(hipStreamWaitEvent(side, reinterpret_cast<hipEvent_t>(ev_fork2), 0));
+            launch_lattice(dim3(waves_for(tiers[x], std::min<uint32_t>(cn, 4096))), tiers[x], side, (uint32_t)x, (uint32_t)(T + 1 + kGenLevels), 1u);
+            HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(tier_events[x]), side));
+            dense_launched = true;
+        }
         // The segment tier (the critical path: the longest sentences, then the escape tier behind it) is launched on the launch
         // stream itself -- no event round trip before it starts nor before what follows it (VBT_MAIN_SEG=0: every tier on a side stream).
         const bool main_seg = env_u32("VBT_MAIN_SEG", 1) != 0 && a.seg_tier < T;
@@ -2350,20 +2362,15 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
             // too, in shorter segments.  Off by default: measured slower on the headline batch.
             if (a.seg_tier < T && t < a.seg_tier && tiers[t] >= env_u32("VBT_HELP_BYTES", 0xFFFFFFFFu))
                 launch_lattice(dim3(waves_for(tiers[t], cn)), tiers[t], side, (uint32_t)t, a.seg_tier, 1u);
-            if (t == a.seg_tier)
+            if (t == a.seg_tier) {
+                // the escape tiers take what failed here AND in the pre-routed launch: behind both
+                if (dense_launched) HIP_CHECK(hipStreamWaitEvent(side, reinterpret_cast<hipEvent_t>(tier_events[a.seg_tier + 1]), 0));
                 for (size_t x = t + 1; x < T; ++x)
                     launch_lattice(dim3(waves_for(tiers[x], std::min<uint32_t>(cn, 4096))), tiers[x], side, (uint32_t)x, (uint32_t)x, 1u);
+            }
             if (!on_main) HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(tier_events[t]), side));
         }
-        if (a.seg_tier + 1 < T) {
-            // what gen_candidates found too dense to sweep in segments: the first escape tier's LDS, its own stream, next to the others
-            const size_t x = a.seg_tier + 1;
-            hipStream_t side = reinterpret_cast<hipStream_t>(streams[x]);
-            HIP_CHECK(hipStreamWaitEvent(side, reinterpret_cast<hipEvent_t>(ev_fork2), 0));
-            launch_lattice(dim3(waves_for(tiers[x], std::min<uint32_t>(cn, 4096))), tiers[x], side, (uint32_t)x, (uint32_t)(T + 1 + kGenLevels), 1u);
-            HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(tier_events[x]), side));
-            HIP_CHECK(hipStreamWaitEvent(stream, reinterpret_cast<hipEvent_t>(tier_events[x]), 0));
-        }
+        if (dense_launched) HIP_CHECK(hipStreamWaitEvent(stream, reinterpret_cast<hipEvent_t>(tier_events[a.seg_tier + 1]), 0));
         for (size_t t = 0; t < n_conc; ++t)
             if (!(main_seg && t == a.seg_tier)) HIP_CHECK(hipStreamWaitEvent(stream, reinterpret_cast<hipEvent_t>(tier_events[t]), 0));
         // whatever the pipeline could not take: fused kernel, global-memory lattice
