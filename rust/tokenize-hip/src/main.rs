@@ -1,86 +1,91 @@
-//! `tokenize` (reference: `tokenize/src/main.rs:31-132`) on the batched HIP path: same flags, same output bytes.
-//! Lines are read with `BufRead::lines()` and tokenized in blocks of `--block` lines per device batch.
+//! `tokenize` on the batched HIP path: the flags and the output bytes of the reference's command
+//! (`tokenize/src/main.rs:31-132`: `-i/--sysdic`, `-u/--userlex-csv`, `-O/--output-mode mecab|wakati|detail`,
+//! `-S/--ignore-space`, `-M/--max-grouping-len N`), plus `--block LINES` = lines per device batch.
+//!
+//! Standard input is read line by line (`\n` / `\r\n` stripped, as `BufRead::lines` does), collected into blocks and
+//! handed to `Tokenizer::tokenize_batch`; `Batch::format` renders exactly what the reference prints per sentence.
+//! Argument parsing is by hand so that the crate has no dependency to fetch.
 use std::error::Error;
 use std::fs::File;
-use std::io::{BufRead, BufWriter, Write};
-use std::path::PathBuf;
-use std::str::FromStr;
+use std::io::{self, BufRead, BufWriter, Write};
+use std::process::exit;
 
-use clap::Parser;
 use vibrato::batch::OutputMode;
 use vibrato::{Dictionary, Tokenizer};
 
-#[derive(Clone, Debug)]
-struct Mode(OutputMode);
-
-impl FromStr for Mode {
-    type Err = &'static str;
-    fn from_str(mode: &str) -> Result<Self, Self::Err> {
-        match mode {
-            "mecab" => Ok(Self(OutputMode::Mecab)),
-            "wakati" => Ok(Self(OutputMode::Wakati)),
-            "detail" => Ok(Self(OutputMode::Detail)),
-            _ => Err("Could not parse a mode"),
-        }
-    }
-}
-
-#[derive(Parser, Debug)]
-#[clap(name = "tokenize", about = "Predicts morphemes")]
-struct Args {
-    /// System dictionary (in zstd).
-    #[clap(short = 'i', long)]
-    sysdic: PathBuf,
-
-    /// User lexicon file.
-    #[clap(short = 'u', long)]
-    userlex_csv: Option<PathBuf>,
-
-    /// Output mode. Choices are mecab, wakati, and detail.
-    #[clap(short = 'O', long, default_value = "mecab")]
-    output_mode: Mode,
-
-    /// Ignores white spaces in input strings.
-    #[clap(short = 'S', long)]
+struct Options {
+    sysdic: String,
+    userlex_csv: Option<String>,
+    mode: OutputMode,
     ignore_space: bool,
-
-    /// Maximum length of unknown words.
-    #[clap(short = 'M', long)]
-    max_grouping_len: Option<usize>,
-
-    /// Lines per device batch.
-    #[clap(long, default_value = "65536")]
+    max_grouping_len: usize,
     block: usize,
 }
 
-fn main() -> Result<(), Box<dyn Error>> {
-    let args = Args::parse();
+fn usage() -> ! {
+    eprintln!("Predicts morphemes\n\nUsage: tokenize -i <SYSDIC> [-u <USERLEX_CSV>] [-O mecab|wakati|detail] [-S] [-M <N>] [--block <LINES>]");
+    exit(2)
+}
 
-    eprintln!("Loading the dictionary...");
-    let mut dict = Dictionary::read(File::open(args.sysdic)?)?; // the zstd frame is unwrapped by the library
-    if let Some(userlex_csv) = args.userlex_csv {
-        dict = dict.reset_user_lexicon_from_reader(Some(File::open(userlex_csv)?))?;
+fn parse_args() -> Options {
+    let mut o = Options { sysdic: String::new(), userlex_csv: None, mode: OutputMode::Mecab, ignore_space: false, max_grouping_len: 0, block: 1 << 16 };
+    let mut args = std::env::args().skip(1);
+    while let Some(flag) = args.next() {
+        let mut value = |what: &str| args.next().unwrap_or_else(|| { eprintln!("{what} needs a value"); usage() });
+        match flag.as_str() {
+            "-i" | "--sysdic" => o.sysdic = value("--sysdic"),
+            "-u" | "--userlex-csv" => o.userlex_csv = Some(value("--userlex-csv")),
+            "-O" | "--output-mode" => {
+                o.mode = match value("--output-mode").as_str() {
+                    "mecab" => OutputMode::Mecab,
+                    "wakati" => OutputMode::Wakati,
+                    "detail" => OutputMode::Detail,
+                    _ => { eprintln!("Could not parse a mode"); usage() }
+                }
+            }
+            "-S" | "--ignore-space" => o.ignore_space = true,
+            "-M" | "--max-grouping-len" => o.max_grouping_len = value("--max-grouping-len").parse().unwrap_or_else(|_| usage()),
+            "--block" => o.block = value("--block").parse::<usize>().unwrap_or_else(|_| usage()).max(1),
+            _ => usage(),
+        }
     }
-    let tokenizer = Tokenizer::new(dict).ignore_space(args.ignore_space)?.max_grouping_len(args.max_grouping_len.unwrap_or(0));
-    tokenizer.build_device_image()?;
+    if o.sysdic.is_empty() {
+        usage()
+    }
+    o
+}
 
+fn run(o: Options) -> Result<(), Box<dyn Error>> {
+    eprintln!("Loading the dictionary...");
+    // `Dictionary::read` unwraps the zstd frame of a `system.dic.zst` itself
+    let mut dict = Dictionary::read(File::open(&o.sysdic)?)?;
+    if let Some(path) = &o.userlex_csv {
+        dict = dict.reset_user_lexicon_from_reader(Some(File::open(path)?))?;
+    }
+    let tokenizer = Tokenizer::new(dict).ignore_space(o.ignore_space)?.max_grouping_len(o.max_grouping_len);
+    tokenizer.build_device_image()?; // "no MI355X" is an error message here, not a panic in new_worker()
     eprintln!("Ready to tokenize");
-    let out = std::io::stdout();
-    let mut out = BufWriter::new(out.lock());
-    let mut block: Vec<String> = Vec::with_capacity(args.block);
-    let mut flush = |block: &mut Vec<String>| -> Result<(), Box<dyn Error>> {
-        if !block.is_empty() {
-            out.write_all(tokenizer.tokenize_batch(block.iter())?.format(args.output_mode.0)?.as_bytes())?;
+
+    let stdout = io::stdout();
+    let mut out = BufWriter::new(stdout.lock());
+    let mut block: Vec<String> = Vec::with_capacity(o.block);
+    for line in io::stdin().lock().lines() {
+        block.push(line?);
+        if block.len() == o.block {
+            out.write_all(tokenizer.tokenize_batch(&block)?.format(o.mode)?.as_bytes())?;
             block.clear();
         }
-        Ok(())
-    };
-    for line in std::io::stdin().lock().lines() {
-        block.push(line?);
-        if block.len() >= args.block {
-            flush(&mut block)?;
-        }
     }
-    flush(&mut block)?;
+    if !block.is_empty() {
+        out.write_all(tokenizer.tokenize_batch(&block)?.format(o.mode)?.as_bytes())?;
+    }
+    out.flush()?;
     Ok(())
+}
+
+fn main() {
+    if let Err(e) = run(parse_args()) {
+        eprintln!("tokenize: {e}");
+        exit(1)
+    }
 }

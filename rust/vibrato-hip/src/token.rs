@@ -1,4 +1,9 @@
-//! Container of resultant tokens (reference: `vibrato/src/token.rs:8-139`).
+//! Tokens of a finished tokenization.
+//!
+//! API-compatible with `vibrato::token` (`vibrato/src/token.rs:8-139`): the same accessor names and return types, the same two
+//! lifetimes.  A token here is a plain copy of the C ABI's `vbt_token` view -- the device wrote the 24-byte record, the library
+//! resolved `word_idx` against the host-side dictionary -- so every accessor is a field read.
+use std::fmt;
 use std::marker::PhantomData;
 use std::ops::Range;
 
@@ -7,122 +12,122 @@ use vibrato_hip_sys as sys;
 use crate::dictionary::{LexType, WordIdx};
 use crate::tokenizer::worker::Worker;
 
-/// Resultant token. `'w`: the worker (or batch) that holds the sentence text, `'t`: the tokenizer that holds the dictionary.
+/// One token of the best path.
+///
+/// * `'w` -- the holder of the sentence text (a [`Worker`] or a [`crate::batch::Batch`]): `surface()` borrows from it.
+/// * `'t` -- the tokenizer, i.e. the dictionary: `feature()` borrows from it.
+#[derive(Clone, Copy)]
 pub struct Token<'w, 't> {
-    t: sys::vbt_token,
-    _w: PhantomData<&'w ()>,
-    _t: PhantomData<&'t ()>,
+    view: sys::vbt_token,
+    holder: PhantomData<&'w [u8]>,
+    dictionary: PhantomData<&'t [u8]>,
+}
+
+/// `&str` over memory owned by the library.
+///
+/// # Safety
+/// `(p, n)` must describe UTF-8 bytes that outlive `'a`; the library guarantees both for the two pointer pairs of a `vbt_token`
+/// (a slice of a validated sentence cut at character boundaries; a dictionary feature string).
+unsafe fn borrowed_str<'a>(p: *const std::os::raw::c_char, n: usize) -> &'a str {
+    std::str::from_utf8_unchecked(std::slice::from_raw_parts(p as *const u8, n))
 }
 
 impl<'w, 't> Token<'w, 't> {
-    #[inline(always)]
-    pub(crate) fn new(t: sys::vbt_token) -> Self {
-        Self { t, _w: PhantomData, _t: PhantomData }
+    pub(crate) fn new(view: sys::vbt_token) -> Self {
+        Self { view, holder: PhantomData, dictionary: PhantomData }
     }
 
-    /// Gets the position range of the token in characters (`token.rs:21-24`).
-    #[inline(always)]
-    pub fn range_char(&self) -> Range<usize> {
-        self.t.start_char as usize..self.t.end_char as usize
-    }
-
-    /// Gets the position range of the token in bytes (`token.rs:28-32`).
-    #[inline(always)]
-    pub fn range_byte(&self) -> Range<usize> {
-        self.t.start_byte as usize..self.t.end_byte as usize
-    }
-
-    /// Gets the surface string of the token (`token.rs:36-39`).
-    #[inline(always)]
+    /// Surface form: the slice of the input sentence this token covers (skipped spaces belong to no token).
     pub fn surface(&self) -> &'w str {
-        // Safety: a slice of a validated UTF-8 sentence cut at character boundaries, alive for 'w
-        unsafe { std::str::from_utf8_unchecked(std::slice::from_raw_parts(self.t.surface as *const u8, self.t.surface_len)) }
+        unsafe { borrowed_str(self.view.surface, self.view.surface_len) }
     }
 
-    /// Gets the word index of the token (`token.rs:42-45`).
-    #[inline(always)]
-    pub fn word_idx(&self) -> WordIdx {
-        WordIdx::new(self.lex_type(), self.t.word_id)
-    }
-
-    /// Gets the feature string of the token (`token.rs:49-54`).
-    #[inline(always)]
+    /// Feature string of the word, exactly as it stands in the lexicon (or in `unk.def` for an unknown word).
     pub fn feature(&self) -> &'t str {
-        // Safety: dictionary memory, alive for 't
-        unsafe { std::str::from_utf8_unchecked(std::slice::from_raw_parts(self.t.feature as *const u8, self.t.feature_len)) }
+        unsafe { borrowed_str(self.view.feature, self.view.feature_len) }
     }
 
-    /// Gets the lexicon type where the token is from (`token.rs:58-60`).
-    #[inline(always)]
+    /// Half-open range of the token in characters of the sentence.
+    pub fn range_char(&self) -> Range<usize> {
+        (self.view.start_char as usize)..(self.view.end_char as usize)
+    }
+
+    /// Half-open range of the token in bytes of the sentence.
+    pub fn range_byte(&self) -> Range<usize> {
+        (self.view.start_byte as usize)..(self.view.end_byte as usize)
+    }
+
+    /// Which lexicon the word comes from.
     pub fn lex_type(&self) -> LexType {
-        LexType::from_u32(self.t.lex_type)
+        LexType::from_u32(self.view.lex_type)
     }
 
-    /// Gets the left id of the token's node (`token.rs:64-67`).
-    #[inline(always)]
+    /// `(lex_type, word_id)` of the word.
+    pub fn word_idx(&self) -> WordIdx {
+        WordIdx::new(self.lex_type(), self.view.word_id)
+    }
+
+    /// Left connection id of the word.
     pub fn left_id(&self) -> u16 {
-        self.t.left_id
+        self.view.left_id
     }
 
-    /// Gets the right id of the token's node (`token.rs:71-74`).
-    #[inline(always)]
+    /// Right connection id of the word.
     pub fn right_id(&self) -> u16 {
-        self.t.right_id
+        self.view.right_id
     }
 
-    /// Gets the word cost of the token's node (`token.rs:78-87`).
-    #[inline(always)]
+    /// Cost of the word itself.
     pub fn word_cost(&self) -> i16 {
-        self.t.word_cost
+        self.view.word_cost
     }
 
-    /// Gets the total cost from BOS to the token's node (`token.rs:89-92`).
-    #[inline(always)]
+    /// Cost of the best path from BOS up to and including this token (connection to the next token excluded).
     pub fn total_cost(&self) -> i32 {
-        self.t.total_cost
+        self.view.total_cost
     }
 }
 
-impl std::fmt::Debug for Token<'_, '_> {
-    fn fmt(&self, f: &mut std::fmt::Formatter<'_>) -> std::fmt::Result {
-        f.debug_struct("Token")
-            .field("surface", &self.surface())
-            .field("range_char", &self.range_char())
-            .field("range_byte", &self.range_byte())
-            .field("feature", &self.feature())
-            .field("lex_type", &self.lex_type())
-            .field("left_id", &self.left_id())
-            .field("right_id", &self.right_id())
-            .field("word_cost", &self.word_cost())
-            .field("total_cost", &self.total_cost())
-            .finish()
+impl fmt::Debug for Token<'_, '_> {
+    fn fmt(&self, f: &mut fmt::Formatter<'_>) -> fmt::Result {
+        // same field names and order as the reference prints
+        let mut d = f.debug_struct("Token");
+        d.field("surface", &self.surface()).field("range_char", &self.range_char()).field("range_byte", &self.range_byte());
+        d.field("feature", &self.feature()).field("lex_type", &self.lex_type());
+        d.field("left_id", &self.left_id()).field("right_id", &self.right_id());
+        d.field("word_cost", &self.word_cost()).field("total_cost", &self.total_cost());
+        d.finish()
     }
 }
 
-/// Iterator of tokens (`token.rs:112-139`).
+/// Iterator over the tokens of a worker, first token first (`Worker::token_iter`).
 pub struct TokenIter<'w, 't> {
     worker: &'w Worker<'t>,
-    i: usize,
+    pending: Range<usize>,
 }
 
 impl<'w, 't> TokenIter<'w, 't> {
-    #[inline(always)]
-    pub(crate) const fn new(worker: &'w Worker<'t>, i: usize) -> Self {
-        Self { worker, i }
+    pub(crate) fn over(worker: &'w Worker<'t>) -> Self {
+        Self { worker, pending: 0..worker.num_tokens() }
     }
 }
 
 impl<'w, 't> Iterator for TokenIter<'w, 't> {
     type Item = Token<'w, 't>;
 
-    #[inline(always)]
     fn next(&mut self) -> Option<Self::Item> {
-        if self.i < self.worker.num_tokens() {
-            let t = self.worker.token(self.i);
-            self.i += 1;
-            Some(t)
-        } else {
-            None
-        }
+        self.pending.next().map(|i| self.worker.token(i))
+    }
+
+    fn size_hint(&self) -> (usize, Option<usize>) {
+        self.pending.size_hint()
+    }
+}
+
+impl ExactSizeIterator for TokenIter<'_, '_> {}
+
+impl DoubleEndedIterator for TokenIter<'_, '_> {
+    fn next_back(&mut self) -> Option<Self::Item> {
+        self.pending.next_back().map(|i| self.worker.token(i))
     }
 }

@@ -1,4 +1,4 @@
-//! Provider of a routine for tokenization (reference: `vibrato/src/tokenizer/worker.rs:13-103`).
+//! The per-sentence interface: one sentence in, its tokens out (API of `vibrato/src/tokenizer/worker.rs:13-103`).
 use std::marker::PhantomData;
 use std::mem::MaybeUninit;
 use std::os::raw::c_char;
@@ -10,11 +10,11 @@ use crate::errors::check;
 use crate::token::{Token, TokenIter};
 use crate::tokenizer::Tokenizer;
 
-/// Occurrence probabilities of connection ids, sorted by probability (`dictionary/mapper.rs:84`).
+/// `(connection id, probability)` pairs in descending order of probability, id 0 left out (`dictionary/mapper.rs:84`).
 pub type ConnIdProbs = Vec<(usize, f64)>;
 
-/// Provider of a routine for tokenization: holds one sentence and its result. One kernel pipeline launch per `tokenize()`
-/// call -- use [`Tokenizer::tokenize_batch`] for throughput.
+/// Holds one sentence and, after `tokenize()`, its tokens.  Every `tokenize()` call launches the whole kernel pipeline for that
+/// one sentence: fine for interactive use, two orders of magnitude below [`Tokenizer::tokenize_batch`] in throughput.
 pub struct Worker<'t> {
     raw: *mut sys::vbt_worker,
     tokenizer: &'t Tokenizer,
@@ -32,30 +32,28 @@ impl<'t> Worker<'t> {
         Self { raw, tokenizer, _not_sync: PhantomData }
     }
 
-    /// Resets the input sentence to be tokenized (`worker.rs:34-45`).
+    /// Replaces the sentence the worker holds; the previous tokens are gone (`worker.rs:34-45`).
     pub fn reset_sentence<S: AsRef<str>>(&mut self, input: S) {
         let s = input.as_ref();
         // a &str is valid UTF-8, the only error this call has
         check(unsafe { sys::vbt_worker_reset_sentence(self.raw, s.as_ptr() as *const c_char, s.len()) }).expect("vbt_worker_reset_sentence");
     }
 
-    /// Tokenizes the input sentence set in `state` (`worker.rs:49-55`).
+    /// Runs the lattice construction and the Viterbi search for the held sentence on the device (`worker.rs:49-55`).
     ///
     /// # Panics
     ///
-    /// On a HIP runtime error (the reference is infallible here; there is nothing to fall back to).
+    /// If the HIP runtime reports an error: the reference's signature has no error to return, and there is no CPU path.
     pub fn tokenize(&mut self) {
         check(unsafe { sys::vbt_worker_tokenize(self.raw) }).expect("vibrato-hip: device error in tokenize()");
     }
 
-    /// Gets the number of resultant tokens (`worker.rs:59-61`).
-    #[inline(always)]
+    /// How many tokens the last `tokenize()` produced (`worker.rs:59-61`).
     pub fn num_tokens(&self) -> usize {
         unsafe { sys::vbt_worker_num_tokens(self.raw) as usize }
     }
 
-    /// Gets the `i`-th resultant token (`worker.rs:65-68`).
-    #[inline(always)]
+    /// Token number `i` of the sentence, counted from its start (`worker.rs:65-68`).
     pub fn token<'w>(&'w self, i: usize) -> Token<'w, 't> {
         let mut t = MaybeUninit::<sys::vbt_token>::uninit();
         check(unsafe { sys::vbt_worker_token(self.raw, i as u32, t.as_mut_ptr()) }).expect("token index out of range");
@@ -64,31 +62,31 @@ impl<'t> Worker<'t> {
         Token::new(unsafe { t.assume_init() })
     }
 
-    /// Creates an iterator of resultant tokens (`worker.rs:72-74`).
-    #[inline(always)]
-    pub const fn token_iter<'w>(&'w self) -> TokenIter<'w, 't> {
-        TokenIter::new(self, 0)
+    /// All tokens of the last `tokenize()`, in sentence order (`worker.rs:72-74`).
+    pub fn token_iter<'w>(&'w self) -> TokenIter<'w, 't> {
+        TokenIter::over(self)
     }
 
-    /// Initializes a counter to compute occurrence probabilities of connection ids (`worker.rs:77-84`).
+    /// Starts (or restarts) counting how often each connection id is used by the lattices this worker builds (`worker.rs:77-84`).
     pub fn init_connid_counter(&mut self) {
         check(unsafe { sys::vbt_worker_init_connid_counter(self.raw) }).expect("vbt_worker_init_connid_counter");
     }
 
-    /// Updates frequencies of connection ids at the last tokenization (`worker.rs:90-93`).
+    /// Adds the lattice of the last `tokenize()` to the counters (`worker.rs:90-93`).
     ///
     /// # Panics
     ///
-    /// It will panic when [`Self::init_connid_counter()`] has never been called.
+    /// Without a preceding [`Self::init_connid_counter()`], like the reference.
     pub fn update_connid_counts(&mut self) {
         check(unsafe { sys::vbt_worker_update_connid_counts(self.raw) }).expect("init_connid_counter() has never been called");
     }
 
-    /// Computes the occurrence probabilities of connection ids, for left- and right-ids (`worker.rs:101-103`).
+    /// The counters as probabilities: `(left ids, right ids)`, what the reference's `reorder` tool writes to `*.lmap` / `*.rmap`
+    /// (`worker.rs:101-103`).
     ///
     /// # Panics
     ///
-    /// It will panic when [`Self::init_connid_counter()`] has never been called.
+    /// Without a preceding [`Self::init_connid_counter()`], like the reference.
     pub fn compute_connid_probs(&self) -> (ConnIdProbs, ConnIdProbs) {
         let (nl, nr) = self.tokenizer.dictionary().num_connection_ids();
         let (mut li, mut lp) = (vec![0u32; nl.saturating_sub(1)], vec![0f64; nl.saturating_sub(1)]);
