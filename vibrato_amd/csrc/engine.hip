@@ -1,14 +1,15 @@
 // HIP kernels + launch sequence of the MI355X tokenizer (gfx950, wave64).  DESIGN.md section 3 is the map.
 //
-// Pipeline (default): gen_candidates (one wavefront per sentence: UTF-8 decode, char categories and groupable
+// Pipeline (default): validate_batch (device-side input contract) -> gen_candidates (one wavefront per sentence: UTF-8 decode, char categories and groupable
 // runs -- Sentence::compile, sentence.rs:34-71 -- and candidate generation by double-array common-prefix search +
 // unknown-word rules -- Tokenizer::add_lattice_edges tokenizer.rs:141-199, UnkHandler::gen_unk_words
 // unknown.rs:69-137) -> build_lists -> gen_candidates_large (sentences that outgrew the bulk generator's LDS) ->
 // lattice_lds, one launch per LDS tier (one wavefront per sentence: the position sweep with per-node min-cost
 // search over the connection matrix -- build_lattice_inner tokenizer.rs:94-139, Lattice::insert_node /
 // search_min_node lattice.rs:103-151, insert_eos 85-101 -- and the back-trace, append_top_nodes
-// lattice.rs:159-168; the lattice lives in LDS, longer sentences are swept in segments between clean cuts) ->
-// tokenize_global for whatever is left.  The fused single-kernel design (process_sentence: tokenize_lds /
+// lattice.rs:159-168; the lattice lives in LDS, longer sentences are swept in segments between clean cuts; what the
+// generator found too dense for that is swept by a 48 KiB launch next to the tiers) -> tokenize_global for whatever is
+// left -> tok_tile_sums / tok_tile_scan / compact_tokens (tokens from per-sentence staging into sentence order).  The fused single-kernel design (process_sentence: tokenize_lds /
 // tokenize_global) is the fallback with a global-memory lattice and, with VBT_FUSED=1, an A/B reference.
 //
 // Bit-exactness notes: end lists are built with LDS atomics, so their order is arbitrary;
@@ -1379,7 +1380,7 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
         // reachability sweep wants them they have arrived (the sweep of a chunk then prefetches the next chunk's)
         uint4 rc_next = pc[ln < n ? ln : n], rn_next = pc[ln < n ? ln + 1 : n];
         // ---- load: candidates from global (every record carries its slot); interface; EOS ----
-        for (uint32_t c0 = 0; c0 < C; c0 += 64 * 4) {  // 4 independent 8-byte loads per lane in flight
+        for (uint32_t c0 = 0; c0 < C; c0 += 64 * 4) {  // 4 independent 16-byte loads per lane in flight (the sweep half is kept)
             uint2 r[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
