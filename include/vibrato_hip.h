@@ -88,9 +88,10 @@ VBT_API int vbt_dict_from_sources_binmatrix(const char* lex, size_t lex_len, con
                                             size_t char_len, const char* unk_def, size_t unk_len, vbt_dict** out);
 /* SystemDictionaryBuilder::from_readers_with_bigram_info(lex.csv, bigram.right, bigram.left, bigram.cost, char.def, unk.def,
  * dual_connector), builder.rs:111-160: the connection costs come from the compact bigram model (RawConnector
- * connector/raw_connector.rs, DualConnector connector/dual_connector.rs).  `dual` selects a memory layout in the reference;
- * the cost function is the same.  The device image materialises it as a dense matrix when the tokenizer is created
- * (VBT_ERR_UNSUPPORTED there if a cost does not fit i16). */
+ * connector/raw_connector.rs; dual != 0: DualConnector connector/dual_connector.rs, a small matrix over classes of connection
+ * ids + an 8-wide raw part, built as the reference builds it except that ties of its greedy template choice -- which the
+ * reference resolves by hash-set iteration order -- go to the highest template index).  The device image materialises either as
+ * a dense matrix when the tokenizer is created (VBT_ERR_UNSUPPORTED there if a cost does not fit i16). */
 VBT_API int vbt_dict_from_sources_bigram(const char* lex, size_t lex_len, const char* bigram_right, size_t right_len,
                                          const char* bigram_left, size_t left_len, const char* bigram_cost, size_t cost_len,
                                          const char* char_def, size_t char_len, const char* unk_def, size_t unk_len, int dual,

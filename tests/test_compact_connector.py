@@ -54,7 +54,7 @@ def test_from_readers_golden(kind, case):
     for r, l, c in case["costs"]:
         assert d.conn_cost(r, l) == c
     if kind == "product":
-        assert d.connector_kind == "Raw"
+        assert d.connector_kind == ("Dual" if case["dual"] else "Raw")
 
 
 @pytest.mark.parametrize("case", [c for c in GOLD["bigram_connector"] if c["map"] is not None], ids=lambda c: c["source"].split("/")[-1])
@@ -117,7 +117,7 @@ def test_parse_features_golden(kind):
 
 # ------------------------------------------------------------------ synthetic compact model
 
-def synth_bigram(num_right, num_left, seed=7, templates=10, vocab=12, density=0.5, max_abs=300):
+def synth_bigram(num_right, num_left, seed=7, templates=10, vocab=12, density=0.5, max_abs=300, empty_pair=True):
     """bigram.right / bigram.left / bigram.cost of a random compact model: `templates` positions (the builder rounds
     the width up to 16), a small vocabulary per position, '*' and quoted fields, BOS/EOS ("") pairs."""
     rng = random.Random(seed)
@@ -142,7 +142,8 @@ def synth_bigram(num_right, num_left, seed=7, templates=10, vocab=12, density=0.
                     cost.append(f"{ra}/{lb}\t{rng.randint(-max_abs, max_abs)}")
         cost.append(f"/L{t}_1\t{rng.randint(-50, 50)}")   # BOS -> left feature
         cost.append(f"R{t}_2/\t{rng.randint(-50, 50)}")   # right feature -> EOS
-    cost.append("/\t3")  # BOS/EOS pair: counted once per position of the padded width
+    if empty_pair:
+        cost.append("/\t3")  # BOS/EOS pair: counted once per position of the padded width
     rng.shuffle(cost)
     return rows(num_right, "R"), rows(num_left, "L"), "\n".join(cost) + "\n"
 
@@ -169,6 +170,38 @@ def test_product_host_cost_function_matches_oracle_with_mapping():
     assert b != a and sorted(b) == sorted(a)
 
 
+def test_dual_connector_builder_gives_the_raw_cost_function():
+    """DualConnector::from_readers (dual_connector.rs:145-199): matrix over the classes of the kept templates + the eight removed
+    templates through a pruned scorer = the RawConnector's cost for every id pair (what the reference's own dual tests assert on
+    their vectors), as long as no matrix cell is clamped and the model prices no ("" , "") feature pair (the dual matrix counts
+    that pair once per padded position, U31x8::to_simd_vec pads with feature 0)."""
+    sd = synth.SynthDict("tiny")
+    for templates, seed in ((10, 3), (16, 4), (19, 5)):
+        right, left, cost = synth_bigram(sd.num_right, sd.num_left, seed=seed, templates=templates, empty_pair=False)
+        raw = _dict("product", right, left, cost, sd.lex, sd.char_def, sd.unk, dual=False)
+        dual = _dict("product", right, left, cost, sd.lex, sd.char_def, sd.unk, dual=True)
+        ora_d = _dict("oracle", right, left, cost, sd.lex, sd.char_def, sd.unk)
+        assert (raw.connector_kind, dual.connector_kind) == ("Raw", "Dual")
+        for r in range(sd.num_right):
+            for l in range(sd.num_left):
+                c = raw.conn_cost(r, l)
+                assert dual.conn_cost(r, l) == c == ora_d.conn_cost(r, l)
+        # id mapping renumbers the small matrix by first use (dual_connector.rs:211-264) and keeps the function
+        rng = random.Random(seed)
+        lmap = list(range(1, sd.num_left)); rng.shuffle(lmap)
+        rmap = list(range(1, sd.num_right)); rng.shuffle(rmap)
+        raw.map_connection_ids_from_iter(lmap, rmap)
+        dual.map_connection_ids_from_iter(lmap, rmap)
+        assert all(dual.conn_cost(r, l) == raw.conn_cost(r, l) for r in range(sd.num_right) for l in range(sd.num_left))
+        # and the container holds a Dual connector that reads back
+        back = V.Dictionary.read(dual.write())
+        assert back.connector_kind == "Dual"
+        assert all(back.conn_cost(r, l) == raw.conn_cost(r, l) for r in range(0, sd.num_right, 3) for l in range(sd.num_left))
+    with pytest.raises(V.VibratoError):  # fewer than eight templates: nothing to split off (the reference underflows there)
+        right, left, cost = synth_bigram(sd.num_right, sd.num_left, templates=5, empty_pair=False)
+        _dict("product", right, left, cost, sd.lex, sd.char_def, sd.unk, dual=True)
+
+
 # ------------------------------------------------------------------ GPU: tokenization through the expanded matrix
 
 def _assert_same(batch, exp, exp_off):
@@ -182,7 +215,7 @@ def _assert_same(batch, exp, exp_off):
 @pytest.mark.parametrize("dual", [False, True])
 def test_tokenize_with_compact_connector_matches_oracle(dual):
     sd = synth.SynthDict("small")
-    right, left, cost = synth_bigram(sd.num_right, sd.num_left, seed=11)
+    right, left, cost = synth_bigram(sd.num_right, sd.num_left, seed=11, empty_pair=not dual)  # (see the builder test for the pair)
     dv = _dict("product", right, left, cost, sd.lex, sd.char_def, sd.unk, dual=dual)
     do = _dict("oracle", right, left, cost, sd.lex, sd.char_def, sd.unk)
     text, offs = sd.sentences(1500, "lognormal_40")

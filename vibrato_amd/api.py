@@ -149,7 +149,8 @@ class SystemDictionaryBuilder:
 
     @staticmethod
     def from_readers_with_bigram_info(lex, bigram_right, bigram_left, bigram_cost, char_def, unk, dual_connector=False):
-        """SystemDictionaryBuilder::from_readers_with_bigram_info (builder.rs:111-160): compact (Raw / Dual) connector."""
+        """SystemDictionaryBuilder::from_readers_with_bigram_info (builder.rs:111-160): a RawConnector, or with dual_connector=True a
+        DualConnector (small matrix + 8-wide raw part)."""
         a = [_b(x) for x in (lex, bigram_right, bigram_left, bigram_cost, char_def, unk)]
         h = C.c_void_p()
         args = []

@@ -4,10 +4,13 @@
 //   raw_connector/scorer.rs:103-168   ScorerBuilder (two-level trie -> double-array hash)
 //   raw_connector/scorer.rs:257-345   retrieve_cost / accumulate_cost (scalar path; the AVX2 path computes the same sum)
 //   dual_connector.rs:267-279         cost = matrix over mapped ids + one 8-wide raw row per id
+// A dual connector is BUILT like the reference builds it (greedy choice of the eight raw templates, matrix over the classes of
+// the remaining ones, pruned scorer; dual_connector.rs:25-199), with one documented difference: ties of the greedy choice.
 // The device never probes these structures per lattice pair: when a tokenizer is created, one kernel evaluates the cost
 // function for every (left, right) id pair into the dense i16 matrix the sweep kernels read (engine.hip, expand_connector).
 #include <algorithm>
 #include <charconv>
+#include <iterator>
 #include <map>
 #include <memory>
 #include <string>
@@ -206,11 +209,117 @@ int32_t conn_cost(const Dictionary& d, uint32_t right_id, uint32_t left_id) {
     }
 }
 
+namespace {
+
+// U31x8::to_simd_vec (scorer.rs:24-44): chunks of 8, the last one padded with feature id 0 -- NOT with the invalid id, so a
+// bigram.cost line for the pair of empty features ("/") is counted once per padded position, as in the reference
+std::vector<uint32_t> simd_padded(const std::vector<uint32_t>& v) {
+    std::vector<uint32_t> out(v);
+    out.resize((v.size() + kSimd - 1) / kSimd * kSimd, 0u);
+    return out;
+}
+
+uint32_t feat_or_invalid(const std::vector<uint32_t>& row, size_t idx) { return idx < row.size() ? row[idx] : kInvalidFeature; }
+
+// DualConnector::remove_feature_templates_greedy (dual_connector.rs:25-71): eight times, drop the template whose removal leaves
+// the fewest distinct (right rows) x (left rows).  The reference walks a hash set, so which of several equally good templates
+// goes is not reproducible even between two runs of the reference; here candidates are tried in ascending order and, like its
+// `<=`, the last of the best wins.  The cost function does not depend on the choice (only the split between matrix and scorer).
+std::vector<size_t> choose_matrix_templates(const RawBuilder& b) {
+    std::vector<size_t> keep(b.template_size);
+    for (size_t i = 0; i < keep.size(); ++i) keep[i] = i;
+    auto distinct_rows = [&](const std::vector<std::vector<uint32_t>>& rows, size_t without) {
+        std::vector<std::vector<uint32_t>> proj;
+        proj.reserve(rows.size());
+        for (const auto& row : rows) {
+            std::vector<uint32_t> p;
+            for (size_t i : keep)
+                if (i != without && i < row.size()) p.push_back(row[i]);  // (a template a short row does not have is skipped, l.46-50)
+            proj.push_back(std::move(p));
+        }
+        std::sort(proj.begin(), proj.end());
+        return (size_t)(std::unique(proj.begin(), proj.end()) - proj.begin());
+    };
+    for (uint32_t round = 0; round < kSimd; ++round) {
+        size_t best = 0, best_size = b.right_rows.size() * b.left_rows.size();
+        for (size_t trial : keep) {
+            const size_t size = distinct_rows(b.right_rows, trial) * distinct_rows(b.left_rows, trial);
+            if (size <= best_size) { best_size = size; best = trial; }
+        }
+        keep.erase(std::remove(keep.begin(), keep.end(), best), keep.end());
+    }
+    return keep;
+}
+
+// DualConnector::from_readers (dual_connector.rs:145-199)
+void build_dual(Dictionary& d, RawBuilder& b) {
+    if (b.template_size < kSimd) fail(VBT_ERR_INVALID_ARGUMENT, "bigram: a dual connector needs at least 8 feature templates");  // (the reference underflows, l.84)
+    const Scorer full = build_scorer(b.trie);
+    const std::vector<size_t> matrix_idx = choose_matrix_templates(b);
+    std::vector<size_t> raw_idx;
+    for (size_t i = 0; i < b.template_size; ++i)
+        if (!std::binary_search(matrix_idx.begin(), matrix_idx.end(), i)) raw_idx.push_back(i);
+    DualConnector& u = d.dual;
+    // create_matrix_connector (l.73-112): connection ids with equal matrix-template features share a matrix row / column
+    auto classes = [&](const std::vector<std::vector<uint32_t>>& rows, std::vector<uint16_t>& id_map) {
+        std::map<std::vector<uint32_t>, uint32_t> cls;
+        cls.emplace(std::vector<uint32_t>(b.template_size - kSimd, 0u), 0u);  // BOS / EOS
+        id_map.assign(1, 0);
+        for (const auto& row : rows) {
+            std::vector<uint32_t> f;
+            for (size_t i : matrix_idx) f.push_back(feat_or_invalid(row, i));
+            const uint32_t id = cls.emplace(std::move(f), (uint32_t)cls.size()).first->second;
+            if (id > 0xFFFF) fail(VBT_ERR_INVALID_ARGUMENT, "bigram: too many matrix classes");
+            id_map.push_back((uint16_t)id);
+        }
+        std::vector<std::vector<uint32_t>> by_id(cls.size());
+        for (auto& kv : cls) by_id[kv.second] = simd_padded(kv.first);
+        return by_id;
+    };
+    const auto rclass = classes(b.right_rows, u.right_map), lclass = classes(b.left_rows, u.left_map);
+    u.m_num_right = (uint32_t)rclass.size();
+    u.m_num_left = (uint32_t)lclass.size();
+    u.matrix.resize((size_t)u.m_num_right * u.m_num_left);
+    for (uint32_t l = 0; l < u.m_num_left; ++l)
+        for (uint32_t r = 0; r < u.m_num_right; ++r) {
+            const int32_t c = scorer_accumulate(full, rclass[r].data(), lclass[l].data(), rclass[r].size());
+            u.matrix[(size_t)l * u.m_num_right + r] = (int16_t)std::min(32767, std::max(-32768, c));  // clamped, l.101
+        }
+    // create_raw_connector (l.114-143): the eight removed templates per id; scorer entries nobody can reach are dropped
+    auto raw_rows = [&](const std::vector<std::vector<uint32_t>>& rows) {
+        std::vector<uint32_t> out(raw_idx.size(), 0u);  // id 0: zeros
+        for (const auto& row : rows)
+            for (size_t i : raw_idx) out.push_back(feat_or_invalid(row, i));
+        return out;
+    };
+    u.right_feats = raw_rows(b.right_rows);
+    u.left_feats = raw_rows(b.left_rows);
+    std::vector<uint32_t> ru(u.right_feats), lu(u.left_feats);
+    std::sort(ru.begin(), ru.end());
+    std::sort(lu.begin(), lu.end());
+    for (size_t k1 = 0; k1 < b.trie.size(); ++k1) {
+        if (!std::binary_search(ru.begin(), ru.end(), (uint32_t)k1)) { b.trie[k1].clear(); continue; }
+        for (auto it = b.trie[k1].begin(); it != b.trie[k1].end();)
+            it = std::binary_search(lu.begin(), lu.end(), it->first) ? std::next(it) : b.trie[k1].erase(it);
+    }
+    u.scorer = build_scorer(b.trie);
+    d.conn_kind = kConnDual;
+    d.num_right = (uint32_t)u.right_map.size();
+    d.num_left = (uint32_t)u.left_map.size();
+}
+
+}  // namespace
+
 Dictionary* build_dictionary_bigram(std::string_view lex, std::string_view bigram_right, std::string_view bigram_left,
                                     std::string_view bigram_cost, std::string_view char_def, std::string_view unk_def, bool dual) {
-    (void)dual;  // layout choice of the reference only (dual_connector.rs:141-198 splits the same cost function); see dict.hpp
     auto d = std::make_unique<Dictionary>();
     RawBuilder b = parse_bigram(bigram_right, bigram_left, bigram_cost);
+    if (b.right_rows.size() + 1 > 0xFFFF || b.left_rows.size() + 1 > 0xFFFF) fail(VBT_ERR_INVALID_ARGUMENT, "bigram: too many connection ids");
+    if (dual) {
+        build_dual(*d, b);
+        finish_dictionary(*d, lex, char_def, unk_def);
+        return d.release();
+    }
     size_t width = b.template_size;
     if (width) width = ((width - 1) / kSimd + 1) * kSimd;  // raw_connector.rs:58-60
     if (b.right_rows.size() + 1 > 0xFFFF || b.left_rows.size() + 1 > 0xFFFF) fail(VBT_ERR_INVALID_ARGUMENT, "bigram: too many connection ids");

@@ -115,8 +115,8 @@ Dictionary* build_dictionary(std::string_view lex, std::string_view matrix_def, 
                              std::string_view unk_def);
 
 // SystemDictionaryBuilder::from_readers_with_bigram_info (builder.rs:111-160): the connector comes from bigram.right /
-// bigram.left / bigram.cost.  `dual` only selects the reference's memory layout (Raw vs Dual); both compute the same
-// cost function, and the device materialises either as a dense matrix when the tokenizer is created.
+// bigram.left / bigram.cost: a RawConnector, or (dual) a DualConnector built like the reference's (connector.cpp).  The device
+// materialises either as a dense matrix when the tokenizer is created.
 Dictionary* build_dictionary_bigram(std::string_view lex, std::string_view bigram_right, std::string_view bigram_left,
                                     std::string_view bigram_cost, std::string_view char_def, std::string_view unk_def, bool dual);
 
