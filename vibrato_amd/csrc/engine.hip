@@ -1808,9 +1808,6 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
             // lattice redoes the sentence.
             // (also from the pre-routed launch: the launch stream waits for it before it starts the escape tiers behind the segment tier)
             const bool escape = tier >= A.seg_tier && tier + 1 < A.n_tiers && fail != 27;
-#if defined(VBT_DEBUG_ESC)
-            if (ln == 0) printf("esc sid=%u fail=%u nT=%u CT=%u seg_a=%u tier=%u\n", sid, fail, nT, CT, seg_a, tier);
-#endif
             if (ln == 0 && !escape) atomicAdd(&A.ctrl[fail < 32 ? fail : 28], 1u);
             list_push(A, escape ? tier + 1 : A.n_tiers, sid);
             __syncthreads();
