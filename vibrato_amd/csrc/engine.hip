@@ -1555,9 +1555,6 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
             auto stage_a1 = [&](uint32_t p, uint4& r0, uint4& r1) {
                 const uint4* r = reinterpret_cast<const uint4*>(&rec[p < SL ? p : SL]);  // passes > SL do not exist: they re-read the empty one
                 r0 = r[0]; r1 = r[1];
-#if defined(VBT_EXP_REC2)
-                { const uint4* rr = reinterpret_cast<const uint4*>(&rec[p + 1 < SL ? p + 1 : SL]); const uint4 x0 = rr[0], x1 = rr[1]; asm volatile("" :: "v"(x0.x), "v"(x1.x)); }
-#endif
             };
             auto stage_a2 = [&](const uint4& r0, const uint4& r1, uint32_t u, uint2& cd, uint32_t& right) {
                 const uint32_t lg = r1.z & 31u;
