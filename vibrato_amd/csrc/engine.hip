@@ -4,7 +4,7 @@
 // runs -- Sentence::compile, sentence.rs:34-71 -- and candidate generation by double-array common-prefix search +
 // unknown-word rules -- Tokenizer::add_lattice_edges tokenizer.rs:141-199, UnkHandler::gen_unk_words
 // unknown.rs:69-137) -> build_lists -> gen_candidates_large (sentences that outgrew the bulk generator's LDS) ->
-// lattice_lds, one launch per LDS tier (one wavefront per sentence: the position sweep with per-node min-cost
+// lattice_lds (by default ONE 10 KiB tier that sweeps longer sentences in segments; one wavefront per sentence: the position sweep with per-node min-cost
 // search over the connection matrix -- build_lattice_inner tokenizer.rs:94-139, Lattice::insert_node /
 // search_min_node lattice.rs:103-151, insert_eos 85-101 -- and the back-trace, append_top_nodes
 // lattice.rs:159-168; the lattice lives in LDS, longer sentences are swept in segments between clean cuts; what the
@@ -2321,7 +2321,7 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
         // (forking the small tiers before the straggler generators was measured: 3.33 vs 3.2 ms, the stragglers then
         // compete with the sweep and the segment tier starts later)
         HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_fork2), stream));
-        // One lattice_lds launch per LDS tier, each on its own stream.  The tiers above the segment tier are escape
+        // One lattice_lds launch per LDS tier up to the segment tier (default: a single 10 KiB tier).  The tiers above it are escape
         // tiers: nothing is routed to them up front, they take what the tier before them could not sweep, so they are
         // launched on the segment tier's stream, behind it.
         const uint32_t persist = env_u32("VBT_LAT_PERSIST", 0);
