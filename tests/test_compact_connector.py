@@ -202,6 +202,73 @@ def test_dual_connector_builder_gives_the_raw_cost_function():
         _dict("product", right, left, cost, sd.lex, sd.char_def, sd.unk, dual=True)
 
 
+def dual_reference_costs(right, left, cost, num_right, num_left):
+    """Pure-Python restatement of DualConnector::from_readers + cost (dual_connector.rs:25-199, 267-279; small cases only):
+    feature ids in order of first appearance in bigram.cost ("" = 0), greedy removal of eight templates (ties: highest index,
+    the product's documented convention -- the reference's hash-set order is not reproducible), class matrix with cells
+    clamped to i16 and rows padded with feature 0 to a multiple of 8, the removed templates through the pair -> cost table."""
+    import csv as _csv
+    rid, lid, table = {"": 0}, {"": 0}, {}
+    for line in cost.splitlines():
+        feats, c = line.split("\t")
+        a, b = feats.split("/")
+        table[(rid.setdefault(a, len(rid)), lid.setdefault(b, len(lid)))] = int(c)
+    INV = 0x7FFFFFFF
+
+    def rows(text, ids):
+        out = []
+        for line in text.splitlines():
+            out.append([ids.get(f, INV) for f in next(_csv.reader([line.split("\t", 1)[1]]))])
+        return out
+    R, L = rows(right, rid), rows(left, lid)
+    T = max(len(r) for r in R + L)
+    keep = list(range(T))
+
+    def distinct(rws, without):
+        return len({tuple(r[i] for i in keep if i != without and i < len(r)) for r in rws})
+    for _ in range(8):
+        best, best_size = 0, len(R) * len(L)
+        for trial in keep:
+            size = distinct(R, trial) * distinct(L, trial)
+            if size <= best_size:
+                best, best_size = trial, size
+        keep.remove(best)
+    raw_idx = [i for i in range(T) if i not in keep]
+
+    def acc(a, b):
+        return sum(table.get((x, y), 0) for x, y in zip(a, b))
+
+    def pad8(v):
+        return list(v) + [0] * (-len(v) % 8)
+
+    def side(rws):
+        classes, id_map = {tuple([0] * (T - 8)): 0}, [0]
+        for r in rws:
+            id_map.append(classes.setdefault(tuple(r[i] if i < len(r) else INV for i in keep), len(classes)))
+        return [pad8(k) for k in classes], id_map  # dict order = class id order
+    rc, rmap = side(R)
+    lc, lmap = side(L)
+    matrix = [[max(-32768, min(32767, acc(rc[r], lc[l]))) for r in range(len(rc))] for l in range(len(lc))]
+    rraw = [[0] * 8] + [[r[i] if i < len(r) else INV for i in raw_idx] for r in R]
+    lraw = [[0] * 8] + [[r[i] if i < len(r) else INV for i in raw_idx] for r in L]
+    return [[matrix[lmap[l]][rmap[r]] + acc(rraw[r], lraw[l]) for l in range(num_left)] for r in range(num_right)]
+
+
+def test_dual_connector_builder_matches_a_python_restatement_including_its_quirks():
+    """The cases where a Dual connector is NOT the Raw cost function: a priced ("", "") pair is counted once per padded
+    position of the class rows, and class-matrix cells are clamped to i16."""
+    sd = synth.SynthDict("tiny")
+    for templates, seed, max_abs in ((10, 21, 300), (13, 22, 300), (19, 23, 9000)):
+        right, left, cost = synth_bigram(sd.num_right, sd.num_left, seed=seed, templates=templates, max_abs=max_abs, empty_pair=True)
+        dual = _dict("product", right, left, cost, sd.lex, sd.char_def, sd.unk, dual=True)
+        raw = _dict("product", right, left, cost, sd.lex, sd.char_def, sd.unk, dual=False)
+        exp = dual_reference_costs(right, left, cost, sd.num_right, sd.num_left)
+        got = [[dual.conn_cost(r, l) for l in range(sd.num_left)] for r in range(sd.num_right)]
+        assert got == exp
+        differs = sum(got[r][l] != raw.conn_cost(r, l) for r in range(sd.num_right) for l in range(sd.num_left))
+        assert differs > 0  # the quirks are exercised: these models are where Dual and Raw part ways
+
+
 # ------------------------------------------------------------------ GPU: tokenization through the expanded matrix
 
 def _assert_same(batch, exp, exp_off):
