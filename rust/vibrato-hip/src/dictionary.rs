@@ -183,8 +183,9 @@ impl SystemDictionaryBuilder {
     }
 
     /// Creates a new instance from `lex.csv`, `bigram.right`, `bigram.left`, `bigram.cost`, `char.def`, `unk.def`
-    /// (`builder.rs:111-160`): the compact connectors. `dual_connector` selects a memory layout in the reference; on the device
-    /// every connector is expanded into the dense matrix when the tokenizer is created.
+    /// (`builder.rs:111-160`): the compact connectors -- a `RawConnector`, or with `dual_connector` a `DualConnector` (small matrix
+    /// over classes of connection ids + an 8-wide raw part).  On the device every connector is expanded into the dense matrix when
+    /// the tokenizer is created.
     #[allow(clippy::too_many_arguments)]
     pub fn from_readers_with_bigram_info<S, R, L, C, P, U>(system_lexicon_rdr: S, bigram_right_rdr: R, bigram_left_rdr: L,
                                                            bigram_cost_rdr: C, char_prop_rdr: P, unk_handler_rdr: U,
