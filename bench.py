@@ -12,13 +12,20 @@ A "step" is one pass of the tokenize() hot path over one device-resident batch o
                       a communication stream so that it overlaps the next step's kernels).  Fixed total work:
                       "scaling": "strong".
 
-Prints ONE JSON line on rank 0 (contract in the task statement): value = sentences of the whole job per second,
-plus `roofline` (dominant kernel, algorithmic bytes from the oracle's event counters / hipEvent kernel time) and, at
-N = 1, `cpu_baseline` (the C restatement of vibrato's CPU path in oracle/, timed on this host).
+Launching: `python bench.py --gpus N` with no WORLD_SIZE in the environment starts its own N ranks (it re-executes itself
+under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`); started under
+torch.distributed.run it uses the ranks it is given.  Either way rank 0 prints ONE JSON line.
+
+The line (contract in the task statement): value = sentences of the whole job per second, `roofline` (dominant kernel,
+algorithmic bytes from the oracle's event counters / hipEvent kernel time, measured on rank 0's shard), `cpu_baseline` (the C
+restatement of vibrato's CPU path in oracle/, timed on this host: the whole batch at N = 1, a 20k-sentence sample of rank 0's
+shard at N > 1) and, at N = 1, three legs that are never `value`: `suite` (BASELINE config 5 and the dense lexicon law through
+the same timed loop), `worker_loop` (the reference's per-sentence 3-call loop through Worker) and `host_to_host`.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -33,7 +40,8 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "10")
 
 HBM_PEAK_BPS = 8.0e12   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 N_SIMD = 256 * 4        # 256 CUs x 4 SIMDs
-CLOCK_HZ = 2.4e9        # max shader clock; one wave instruction occupies a SIMD's issue port for 4 cycles
+CLOCK_HZ = 2.4e9        # max shader clock
+VALU_CYCLES = 4         # issue cycles one wave64 VALU instruction is charged on its SIMD (the unit SQ_ACTIVE_INST_VALU counts in)
 
 
 def algorithmic_bytes(c):
@@ -73,6 +81,40 @@ def cpu_protocol(run, trials=3, runs=3):
     return sum(means) / len(means), min(means), max(means)
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, as the driver's
+    torch.distributed.run command does) and hand their output through; rank 0 prints the JSON line."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL between processes), see the task's environment notes
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env, cwd=ROOT)
+
+
+def timed_leg(tok, text, offs, steps, warmup, torch):
+    """The timed loop of one single-GPU leg (device-resident input, results left in HBM): returns (seconds, stats)."""
+    n, nbytes = len(offs) - 1, int(len(text))
+    d_text = torch.from_numpy(text).cuda()
+    d_offs = torch.from_numpy(offs.astype(np.int64)).cuda()
+    ws = tok.workspace(n, nbytes)
+    ws.set_timing(True)
+    stream = torch.cuda.current_stream().cuda_stream
+    for _ in range(warmup):
+        ws.run(d_text.data_ptr(), d_offs.data_ptr(), n, nbytes, stream)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ws.run(d_text.data_ptr(), d_offs.data_ptr(), n, nbytes, stream)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return dt, ws.stats()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -89,8 +131,13 @@ def main():
     ap.add_argument("--reorder", action="store_true", help="map the connection ids by usage frequency first (the reference's "
                                                            "`reorder` + `map` tools; statistics from a training batch on the GPU)")
     ap.add_argument("--no-host-pipeline", action="store_true", help="skip the host-to-host leg (vbt_tokenize_batch from host buffers to host "
-                                                                    "results: one call, and two host threads streaming batches); never `value`")
+                                                                    "results: one call, and host threads streaming batches); never `value`")
+    ap.add_argument("--no-suite", action="store_true", help="skip the extra single-GPU legs (BASELINE config 5, dense lexicon law); never `value`")
+    ap.add_argument("--no-worker-loop", action="store_true", help="skip the per-sentence Worker leg (the reference's 3-call loop); never `value`")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
 
     import torch
     import torch.distributed as dist
@@ -99,7 +146,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus} "
+                         f"(or with no launcher at all: bench.py then starts its own ranks)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback")
     # test hooks (tests/test_distributed_gpu.py runs this file with two ranks on a one-GPU box): the collective backend
@@ -107,6 +155,8 @@ def main():
     backend = os.environ.get("VBT_BENCH_BACKEND", "nccl")
     if os.environ.get("VBT_BENCH_SINGLE_DEVICE") == "1":
         local_rank = 0
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: local rank {local_rank} but this node has {torch.cuda.device_count()} GPU(s)")
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -240,12 +290,12 @@ def main():
 
     kernel_ms = st["ms_tier0"] + st["ms_tier12"]
 
-    # host-to-host leg, outside the timed region and never `value`: what a caller of the reference's
-    # 3-call loop pays -- the copy of the text into the batch, H2D, kernels, D2H of the token records into host memory
+    # host-to-host leg, outside the timed region and never `value`: what a caller of the batched entry
+    # point pays -- the copy of the text into the batch, H2D, kernels, D2H of the token records into host memory
     h2h = None
     if not args.no_host_pipeline and world == 1:
         h2h = {"one_call": tok.host_pipeline_benchmark(text, offs, threads=1, rounds=1),
-               "pipelined": tok.host_pipeline_benchmark(text, offs, threads=2, rounds=4)}
+               "pipelined": tok.host_pipeline_benchmark(text, offs, threads=3, rounds=4)}
 
     result = None
     if rank == 0:
@@ -272,14 +322,17 @@ def main():
             n_s, n_t, goff, gcnt, gtok = sharding.unpack_results(gather["out"][(gather["k"] - 1) & 1].view(world, -1)[0], gather["max_s"])
             ordered, ends = sharding.tokens_in_sentence_order(goff[:ns], gcnt[:ns], gtok)
             parity = parity and bool(gathered_ok) and ordered.tobytes() == exp.tobytes()
-        # algorithmic bytes of one launch on this GPU (oracle event counters over rank 0's batch)
+        # algorithmic bytes of one launch on this GPU (oracle event counters over rank 0's batch; at N > 1 extrapolated from the
+        # first 100k sentences of the shard: the counters are sums over sentences drawn from one law)
+        n_cnt = min(n, 100000)
         w.reset_counters()
-        w.tokenize_batch(text, offs, counted=True, want_tokens=False)
+        w.tokenize_batch(text[:int(offs[n_cnt])], offs[:n_cnt + 1], counted=True, want_tokens=False)
         cnt = w.counters()
-        b_alg = algorithmic_bytes(cnt)
+        scale = nbytes / max(int(offs[n_cnt]), 1)
+        b_alg = algorithmic_bytes(cnt) * scale
         # per-kernel split of the SURVEY 8(d) terms: text, char, trie, posting, param and unknown-entry bytes are
         # read by gen_candidates; matrix cells and token records belong to lattice_lds (the dominant kernel)
-        b_lat = 2 * cnt["n_pairs_dedup"] + 24 * cnt["n_tokens"]
+        b_lat = (2 * cnt["n_pairs_dedup"] + 24 * cnt["n_tokens"]) * scale
         b_gen = b_alg - b_lat
         ms_gen, ms_lat = st["ms_tier0"], st["ms_tier12"]
         achieved = b_lat / (ms_lat * 1e-3) if ms_lat > 0 else 0.0
@@ -289,14 +342,26 @@ def main():
         tr = committed_counters(workload) if world == 1 else None
         trk = (tr or {}).get("hbm_bytes_by_kernel", {})
         ins = (tr or {}).get("wave_insts_by_kernel", {})
+        sqk = (tr or {}).get("sq_by_kernel", {})
 
         def issue(kernel, ms):
-            """Instruction-issue ceiling: VALU + SALU wave instructions x 4 cycles / (1024 SIMDs x 2.4 GHz) over the kernel time."""
+            """Instruction-issue view of a kernel from the committed PMC pass: the VALU-only busy time (SALU has its own pipe) at
+            VALU_CYCLES issue cycles per wave64 instruction on 1024 SIMDs, and where the waves' cycles went (SQ counters)."""
             k = ins.get(kernel)
             if not k or ms <= 0:
                 return None
-            floor_ms = (k["valu"] + k["salu"]) * 4 / (N_SIMD * CLOCK_HZ) * 1e3
-            return {"wave_insts": k, "issue_floor_ms": round(floor_ms, 4), "frac_of_kernel_time": round(floor_ms / ms, 4)}
+            floor_ms = k["valu"] * VALU_CYCLES / (N_SIMD * CLOCK_HZ) * 1e3
+            out = {"wave_insts": k, "cycles_per_wave64_valu_assumed": VALU_CYCLES, "valu_busy_ms": round(floor_ms, 4),
+                   "valu_busy_frac_of_kernel_time": round(floor_ms / ms, 4)}
+            q = sqk.get(kernel)
+            if q and q.get("wave_cycles"):
+                out["sq_wave_cycle_shares"] = {"wait_any": round(q.get("wait_any", 0) / q["wave_cycles"], 4),
+                                               "wait_inst_any": round(q.get("wait_inst_any", 0) / q["wave_cycles"], 4),
+                                               "active_inst_any": round(q.get("active_inst_any", 0) / q["wave_cycles"], 4),
+                                               "active_inst_valu": round(q.get("active_inst_valu", 0) / q["wave_cycles"], 4)}
+                if q.get("lds_idx_active"):
+                    out["lds_bank_conflict_share_of_lds_cycles"] = round(q.get("lds_bank_conflict", 0) / q["lds_idx_active"], 4)
+            return out
 
         roofline = {"bound": "hbm",
                     "kernel": "lattice_lds (the per-tier launches of one step run concurrently on side streams; duration = "
@@ -315,25 +380,28 @@ def main():
                                    "frac": round(b_alg / (kernel_ms * 1e-3) / HBM_PEAK_BPS, 6) if kernel_ms > 0 else None,
                                    "algorithmic_bytes_per_step": int(b_alg), "ms": round(kernel_ms, 4),
                                    "traffic": tr["hbm_bytes_per_step"] if tr else None},
-                    "connector_GBps": round(2 * cnt["n_pairs_dedup"] / (kernel_ms * 1e-3) / 1e9, 3) if kernel_ms > 0 else 0.0,
+                    "connector_GBps": round(2 * cnt["n_pairs_dedup"] * scale / (kernel_ms * 1e-3) / 1e9, 3) if kernel_ms > 0 else 0.0,
                     "lattice_density": {"nodes_per_char": round(cnt["n_nodes"] / max(cnt["n_chars"], 1), 2),
                                         "dedup_pairs_per_char": round(cnt["n_pairs_dedup"] / max(cnt["n_chars"], 1), 1)},
-                    "tiers": [st["n_tier0"], st["n_tier1"], st["n_tier2"]], "measured_on": f"rank 0 ({n} sentences, {nbytes} bytes)"}
+                    "tiers": [st["n_tier0"], st["n_tier1"], st["n_tier2"]],
+                    "measured_on": f"rank 0 ({n} sentences, {nbytes} bytes" + (f"; oracle counters of its first {n_cnt} sentences scaled by bytes" if n_cnt < n else "") + ")"}
         cpu = cpu_all = None
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline:
             # vibrato's CPU path restated (oracle/): warm-up, then the protocol of benchmark/src/main.rs:53-91
             # (3 trials x 3 runs, fastest and slowest run of a trial dropped) on a bounded sample of the same batch
-            n_cpu = min(n, 100000)
+            n_cpu = min(n, 100000 if world == 1 else 20000)
             c_offs = offs[:n_cpu + 1]
             c_text = text[:int(c_offs[-1])]
             c_bytes = int(c_offs[-1])
             w.tokenize_batch(sub_text, sub_offs, want_tokens=False)
             mean, lo_t, hi_t = cpu_protocol(lambda: w.tokenize_batch(c_text, c_offs, want_tokens=False))
-            sample = (f"first {n_cpu} sentences of the batch ({c_bytes} bytes); 3 trials x 3 runs, min and max run of a trial "
+            sample = (f"first {n_cpu} sentences of {'the batch' if world == 1 else 'rank 0 shard'} ({c_bytes} bytes); 3 trials x 3 runs, min and max run of a trial "
                       f"dropped (benchmark/src/main.rs:53-91); C restatement of vibrato Worker::tokenize (oracle/, gcc -O3 "
                       f"{'-march=native, compiled on this host' if native_so else '-march=x86-64-v3, prebuilt library'}), host has {os.cpu_count()} cores")
             cpu = {"value": round(n_cpu / mean, 1), "unit": "sentences/s", "cores": 1, "kind": "port", "sample": sample,
-                   "range": [round(n_cpu / hi_t, 1), round(n_cpu / lo_t, 1)], "MB_per_s": round(c_bytes / mean / 1e6, 3)}
+                   "range": [round(n_cpu / hi_t, 1), round(n_cpu / lo_t, 1)], "MB_per_s": round(c_bytes / mean / 1e6, 3),
+                   "us_per_sentence": round(mean / n_cpu * 1e6, 3)}
+        if cpu and world == 1:
             # all host cores: one oracle worker per core on contiguous chunks balanced by bytes (ctypes releases the GIL)
             from concurrent.futures import ThreadPoolExecutor
             cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -351,6 +419,63 @@ def main():
             cpu_all = {"value": round(n_cpu / mean_a, 1), "unit": "sentences/s", "cores": cores, "kind": "port",
                        "sample": "same sample and protocol, one worker thread per host core on contiguous chunks",
                        "range": [round(n_cpu / hi_a, 1), round(n_cpu / lo_a, 1)], "MB_per_s": round(c_bytes / mean_a / 1e6, 3)}
+            del workers, chunks
+
+        # ---- per-sentence leg: the reference's only calling pattern (tokenize/src/main.rs:78-82, benchmark/src/main.rs:57-61) ----
+        worker_loop = None
+        if not args.no_worker_loop and world == 1:
+            n_w = min(n, 10000)
+            w_offs = offs[:n_w + 1]
+            w_text = text[:int(w_offs[-1])]
+            wk = tok.new_worker()
+            wk.loop_benchmark(w_text[:int(w_offs[min(500, n_w)])], w_offs[:min(500, n_w) + 1])  # warm-up: buffers, code, clocks
+            worker_loop = wk.loop_benchmark(w_text, w_offs, rounds=1)
+            fast, slow = wk.path_stats()
+            worker_loop.update({"single_launch_sentences": fast, "batch_pipeline_sentences": slow,
+                                "mean_chars_per_sentence": round(cnt["n_chars"] / max(n_cnt, 1), 1),
+                                "pattern": "reset_sentence -> tokenize -> num_tokens -> token(i) for every token, one Worker, one host thread; "
+                                           "tokenize = ONE kernel launch, text and token records through the worker's pinned host block",
+                                "cpu_us_per_sentence_same_host": cpu["us_per_sentence"] if cpu else None})
+            del wk
+
+        # ---- the other single-GPU BASELINE workloads through the same timed loop (never `value`) ----
+        suite = None
+        if not args.no_suite and world == 1 and args.dict == "unidic" and not args.ignore_space and not args.user_lexicon and not args.reorder:
+            suite = {}
+            legs = [("cfg5", "BASELINE config 5: syn-unidic + user.csv (1000 compounds), -S -M 24, mixed lengths, injected spaces", sd,
+                     dict(user=1000, ignore_space=True, mgl=24, law="mixed", space_p=0.1)),
+                    ("dense", "dense lexicon law (syn-unidic-dense: the upper end of SURVEY 8a's nodes / pairs per character)", None,
+                     dict(user=0, ignore_space=False, mgl=0, law="lognormal_40", space_p=0.0))]
+            for key, what, sdx, o in legs:
+                t_leg = time.time()
+                sdx = sdx or synth.SynthDict("unidic-dense")
+                dvx = V.SystemDictionaryBuilder.from_readers_binmatrix(sdx.lex, sdx.matrix, sdx.num_right, sdx.num_left, sdx.char_def, sdx.unk)
+                dox = ora.Dictionary.from_sources_binmatrix(sdx.lex, sdx.matrix, sdx.num_right, sdx.num_left, sdx.char_def, sdx.unk)
+                if o["user"]:
+                    ucsv = sdx.user_csv(o["user"])
+                    dvx.reset_user_lexicon_from_reader(ucsv)
+                    dox.reset_user_lexicon(ucsv)
+                tokx = V.Tokenizer(dvx, device=local_rank).ignore_space(o["ignore_space"]).max_grouping_len(o["mgl"])
+                tx, ox = sdx.sentences(100000, o["law"], space_p=o["space_p"], seed=synth.SEED)
+                dt_x, stx = timed_leg(tokx, tx, ox, steps=10, warmup=2, torch=torch)
+                wx = ora.Tokenizer(dox, o["ignore_space"], o["mgl"]).new_worker()
+                nsx = 3000
+                g_t, g_o = tokx.tokenize_batch(text=tx[:int(ox[nsx])], offsets=ox[:nsx + 1]).tokens_in_order()
+                wx.reset_counters()
+                e_t, e_o = wx.tokenize_batch(tx[:int(ox[nsx])], ox[:nsx + 1], counted=True)
+                cx = wx.counters()
+                okx = bool(np.array_equal(g_o, e_o) and all(np.array_equal(g_t[f], e_t[f]) for f in V.TOKEN_DTYPE.names))
+                parity = parity and okx
+                suite[key] = {"workload": what, "sentences": 100000, "bytes": int(len(tx)), "steps": 10, "warmup": 2,
+                              "value": round(100000 * 10 / dt_x, 1), "unit": "sentences/s", "ms_per_step": round(dt_x / 10 * 1e3, 4),
+                              "gen_ms": round(stx["ms_tier0"], 4), "lattice_ms": round(stx["ms_tier12"], 4),
+                              "tiers": [stx["n_tier0"], stx["n_tier1"], stx["n_tier2"]], "tokens_per_step": int(stx["n_tokens"]),
+                              "error_flags": int(stx["error_flags"]),
+                              "lattice_density_sample": {"nodes_per_char": round(cx["n_nodes"] / max(cx["n_chars"], 1), 2),
+                                                         "dedup_pairs_per_char": round(cx["n_pairs_dedup"] / max(cx["n_chars"], 1), 1)},
+                              "parity_vs_oracle_sample": okx, "parity_sample_sentences": nsx, "leg_s": round(time.time() - t_leg, 1)}
+                del tokx, dvx, dox, wx, tx, ox
+
         value = n_total * args.steps / elapsed
         par = (f"dp{world}: {n_total}-sentence corpus in {world} contiguous shards balanced by bytes, one process per GPU, no data-path "
                f"collective; final device-resident all_gather of the packed results ({backend}), overlapped with the next step"
@@ -370,10 +495,11 @@ def main():
                         "delivered_all_shards": bool(gathered_ok)} if world > 1 else None),
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all,
             "speedup_vs_cpu_1thread": round(value / cpu["value"], 1) if cpu else None,
+            "suite": suite, "worker_loop": worker_loop,
             "host_to_host": h2h,
             "setup_s": round(t_setup, 1),
         }
-        print(json.dumps(result, ensure_ascii=False))
+        print(json.dumps(result, ensure_ascii=False), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -151,6 +151,17 @@ VBT_API uint32_t vbt_worker_num_tokens(const vbt_worker* w);                    
 VBT_API int vbt_worker_token(const vbt_worker* w, uint32_t i, vbt_token* out);    /* Worker::token(i) */
 /* vbt_worker_reset_sentence fails with VBT_ERR_UTF8 when the bytes are not a Rust `str` (the reference takes &str,
  * worker.rs:34); the worker then holds the empty sentence. */
+/* vbt_worker_tokenize is ONE kernel launch per sentence: the kernel reads the text from the worker's pinned host block and
+ * writes the token records back into it (no copy engine, no allocation in steady state); the call returns when the kernel's
+ * status word has landed.  Sentences a single wavefront cannot take (longer than ~2500 characters, a dictionary word of more
+ * than 64 characters, ...) and workers that count connection ids go through the batch pipeline instead.
+ * vbt_worker_path_stats: sentences served by the single launch / by the batch pipeline so far. */
+VBT_API int vbt_worker_path_stats(const vbt_worker* w, uint64_t* fast, uint64_t* slow);
+/* The reference's calling pattern, timed inside the library (tokenize/src/main.rs:78-82, benchmark/src/main.rs:57-61): for each
+ * of the n sentences reset_sentence -> tokenize -> num_tokens -> token(i) for every token, `rounds` passes; wall seconds and the
+ * number of tokens seen. */
+VBT_API int vbt_worker_loop_benchmark(vbt_worker* w, const uint8_t* text, const uint64_t* offsets, uint64_t n, uint32_t rounds,
+                                      double* seconds, uint64_t* tokens);
 /* Worker::init_connid_counter, worker.rs:77-84 (ConnIdCounter::new, mapper.rs:94-99): zeroed counters */
 VBT_API int vbt_worker_init_connid_counter(vbt_worker* w);
 /* Worker::update_connid_counts, worker.rs:86-93: adds Lattice::add_connid_counts (lattice.rs:170-183) of the last

@@ -71,6 +71,17 @@ def lib():
         L.ora_scorer_retrieve.argtypes = [vp, u32, u32, C.POINTER(i32)]
         L.ora_scorer_accumulate.restype = i32
         L.ora_scorer_accumulate.argtypes = [vp, vp, vp, u32]
+        L.ora_dict_from_sources_bigram2.restype = vp
+        L.ora_dict_from_sources_bigram2.argtypes = [u8p, sz, u8p, sz, u8p, sz, u8p, sz, u8p, sz, u8p, sz, C.c_int, u8p, sz]
+        L.ora_dual_connector_new.restype = vp
+        L.ora_dual_connector_new.argtypes = [u8p, sz, u8p, sz, u8p, sz, u8p, sz]
+        L.ora_dual_connector_free.argtypes = [vp]
+        L.ora_dual_connector_cost.restype = i32
+        L.ora_dual_connector_cost.argtypes = [vp, u32, u32]
+        L.ora_dual_connector_num.restype = u32
+        L.ora_dual_connector_num.argtypes = [vp, C.c_int]
+        L.ora_dual_connector_map.argtypes = [vp, vp, vp]
+        L.ora_dual_connector_matrix_shape.argtypes = [vp, vp, vp]
         L.ora_raw_connector_new.restype = vp
         L.ora_raw_connector_new.argtypes = [u8p, sz, u8p, sz, u8p, sz, u8p, sz]
         L.ora_raw_connector_free.argtypes = [vp]
@@ -165,14 +176,16 @@ class Dictionary:
         return cls(h)
 
     @classmethod
-    def from_sources_bigram(cls, lex, bigram_right, bigram_left, bigram_cost, char_def, unk):
-        """SystemDictionaryBuilder::from_readers_with_bigram_info (builder.rs:111-160); Raw and Dual share the cost function."""
+    def from_sources_bigram(cls, lex, bigram_right, bigram_left, bigram_cost, char_def, unk, dual_connector=False):
+        """SystemDictionaryBuilder::from_readers_with_bigram_info (builder.rs:111-160): a RawConnector, or with dual_connector=True
+        a DualConnector (dual_connector.c: its matrix cells are clamped to i16 and its padded class rows price ("", "") pairs, so
+        the two are NOT the same cost function on every model)."""
         a = [_b(x) for x in (lex, bigram_right, bigram_left, bigram_cost, char_def, unk)]
         err = C.create_string_buffer(512)
         args = []
         for x in a:
             args += [x, len(x)]
-        h = lib().ora_dict_from_sources_bigram(*args, err, 512)
+        h = lib().ora_dict_from_sources_bigram2(*args, int(bool(dual_connector)), err, 512)
         if not h:
             raise OracleError(err.value.decode("utf-8", "replace"))
         return cls(h)
@@ -388,35 +401,48 @@ class Scorer:
 
 class RawConnector:
     """RawConnector::from_readers / cost / map_connection_ids (connector/raw_connector.rs:45-161)."""
+    _kind = "raw"
 
     def __init__(self, bigram_right, bigram_left, bigram_cost):
         r, l, c = _b(bigram_right), _b(bigram_left), _b(bigram_cost)
         err = C.create_string_buffer(512)
-        self._h = lib().ora_raw_connector_new(r, len(r), l, len(l), c, len(c), err, 512)
+        self._h = getattr(lib(), f"ora_{self._kind}_connector_new")(r, len(r), l, len(l), c, len(c), err, 512)
         if not self._h:
             raise OracleError(err.value.decode("utf-8", "replace"))
 
     def __del__(self):
         try:
             if getattr(self, "_h", None):
-                lib().ora_raw_connector_free(self._h)
+                getattr(lib(), f"ora_{self._kind}_connector_free")(self._h)
                 self._h = None
         except Exception:
             pass
 
     def cost(self, right_id, left_id):
-        return lib().ora_raw_connector_cost(self._h, right_id, left_id)
+        return getattr(lib(), f"ora_{self._kind}_connector_cost")(self._h, right_id, left_id)
 
     @property
     def num_left(self):
-        return lib().ora_raw_connector_num(self._h, 1)
+        return getattr(lib(), f"ora_{self._kind}_connector_num")(self._h, 1)
 
     @property
     def num_right(self):
-        return lib().ora_raw_connector_num(self._h, 0)
+        return getattr(lib(), f"ora_{self._kind}_connector_num")(self._h, 0)
 
     def map_connection_ids(self, left, right):
         """ConnIdMapper::new(left, right): new id = left[old id] (mapper.rs:14-17)."""
         l = np.ascontiguousarray(left, dtype=np.uint16)
         r = np.ascontiguousarray(right, dtype=np.uint16)
-        lib().ora_raw_connector_map(self._h, l.ctypes.data, r.ctypes.data)
+        getattr(lib(), f"ora_{self._kind}_connector_map")(self._h, l.ctypes.data, r.ctypes.data)
+
+
+class DualConnector(RawConnector):
+    """DualConnector::from_readers / cost / map_connection_ids (connector/dual_connector.rs:145-279)."""
+    _kind = "dual"
+
+    @property
+    def matrix_shape(self):
+        """(num_right, num_left) of the class matrix"""
+        a, b = C.c_uint32(), C.c_uint32()
+        lib().ora_dual_connector_matrix_shape(self._h, C.byref(a), C.byref(b))
+        return a.value, b.value

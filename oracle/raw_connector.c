@@ -10,9 +10,7 @@
  *   raw_connector/scorer.rs:103-168  ScorerBuilder::insert / build
  *   raw_connector/scorer.rs:257-282  Scorer::retrieve_cost / accumulate_cost (scalar; the AVX2 path of l.284-345 adds the
  *                             same eight lanes)
- *   dual_connector.rs:267-279 DualConnector::cost -- the same cost function split into a matrix and a raw part (its own
- *                             test, l.287-326, holds the values a RawConnector gives on the same input), so the oracle
- *                             evaluates a dual dictionary with the raw restatement.
+ *   (DualConnector: dual_connector.c, built on the RawConnectorBuilder below.)
  *   ../../utils.rs:40-61      parse_csv_row (csv_core defaults)
  * Parity: pinned by the reference's unit vectors (scorer.rs:407-512, raw_connector.rs:331-520, dual_connector.rs:287-384),
  * transcribed by tests/golden/make_golden.py into tests/golden/unit_golden.json.
@@ -223,7 +221,7 @@ static size_t raw_next_line(const char *buf, size_t len, size_t pos, size_t *ls,
     size_t e = pos;
     while (e < len && buf[e] != '\n') e++;
     *ls = pos;
-    *le = (e > pos && buf[e - 1] == '\r') ? e - 1 : e;
+    *le = (e < len && e > pos && buf[e - 1] == '\r') ? e - 1 : e; /* '\r' goes only as part of "\r\n" */
     return e < len ? e + 1 : len;
 }
 
@@ -265,14 +263,27 @@ static uint32_t *raw_feature_matrix(const u32_vec *rows, uint32_t n, uint32_t wi
     return m;
 }
 
-/* RawConnector::from_readers, raw_connector.rs:45-105 */
-static ora_raw_connector *raw_from_sources(const char *right, size_t right_len, const char *left, size_t left_len, const char *cost,
-                                           size_t cost_len, char *err, size_t errcap) {
+/* RawConnectorBuilder (raw_connector.rs:170-253): what from_readers leaves for RawConnector / DualConnector to finish */
+typedef struct {
+    ora_scorer_builder sb;
+    u32_vec *rrows, *lrows; /* right_feat_ids_tmp / left_feat_ids_tmp: one feature-id vector per line */
+    uint32_t nr, nl, tsize; /* rows, feat_template_size (longest row, not rounded) */
+} raw_builder;
+
+static void raw_builder_free(raw_builder *b) {
+    for (uint32_t i = 0; i < b->nr; i++) free(b->rrows[i].v);
+    for (uint32_t i = 0; i < b->nl; i++) free(b->lrows[i].v);
+    free(b->rrows); free(b->lrows);
+    scb_free(&b->sb);
+    memset(b, 0, sizeof(*b));
+}
+
+/* RawConnectorBuilder::from_readers, raw_connector.rs:186-245 */
+static int raw_builder_from_sources(raw_builder *b, const char *right, size_t right_len, const char *left, size_t left_len, const char *cost,
+                                    size_t cost_len, char *err, size_t errcap) {
     str_map rids = {0}, lids = {0};
-    ora_scorer_builder sb = {0};
-    u32_vec *rrows = NULL, *lrows = NULL;
-    uint32_t nr = 0, nl = 0, tsize = 0;
-    ora_raw_connector *c = NULL;
+    int ok = 0;
+    memset(b, 0, sizeof(*b));
     sm_get(&rids, "", 0, 1); /* raw_connector.rs:193-196 */
     sm_get(&lids, "", 0, 1);
     size_t pos = 0;
@@ -289,22 +300,30 @@ static ora_raw_connector *raw_from_sources(const char *right, size_t right_len, 
         if (!slash || memchr(slash + 1, '/', (size_t)(tab - slash - 1))) { set_err(err, errcap, "bigram.cost: The format must be right/left<tab>cost"); goto done; }
         uint32_t rid = sm_get(&rids, line, (uint32_t)(slash - line), 1);
         uint32_t lid = sm_get(&lids, slash + 1, (uint32_t)(tab - slash - 1), 1);
-        scb_insert(&sb, rid, lid, (int32_t)cv);
+        scb_insert(&b->sb, rid, lid, (int32_t)cv);
     }
-    if (!raw_parse_rows(right, right_len, &rids, "bigram.right", &rrows, &nr, &tsize, err, errcap)) goto done;
-    if (!raw_parse_rows(left, left_len, &lids, "bigram.left", &lrows, &nl, &tsize, err, errcap)) goto done;
-    if (tsize) tsize = ((tsize - 1) / RAW_SIMD + 1) * RAW_SIMD; /* raw_connector.rs:58-60 */
-    c = (ora_raw_connector *)calloc(1, sizeof(*c));
-    c->width = tsize; c->num_right = nr + 1; c->num_left = nl + 1;
-    c->right_feats = raw_feature_matrix(rrows, nr, tsize);
-    c->left_feats = raw_feature_matrix(lrows, nl, tsize);
-    scorer_build(&sb, &c->scorer);
+    if (!raw_parse_rows(right, right_len, &rids, "bigram.right", &b->rrows, &b->nr, &b->tsize, err, errcap)) goto done;
+    if (!raw_parse_rows(left, left_len, &lids, "bigram.left", &b->lrows, &b->nl, &b->tsize, err, errcap)) goto done;
+    ok = 1;
 done:
-    for (uint32_t i = 0; i < nr; i++) free(rrows[i].v);
-    for (uint32_t i = 0; i < nl; i++) free(lrows[i].v);
-    free(rrows); free(lrows);
-    scb_free(&sb);
     sm_free(&rids); sm_free(&lids);
+    if (!ok) raw_builder_free(b);
+    return ok;
+}
+
+/* RawConnector::from_readers, raw_connector.rs:45-105 */
+static ora_raw_connector *raw_from_sources(const char *right, size_t right_len, const char *left, size_t left_len, const char *cost,
+                                           size_t cost_len, char *err, size_t errcap) {
+    raw_builder b;
+    if (!raw_builder_from_sources(&b, right, right_len, left, left_len, cost, cost_len, err, errcap)) return NULL;
+    uint32_t tsize = b.tsize;
+    if (tsize) tsize = ((tsize - 1) / RAW_SIMD + 1) * RAW_SIMD; /* raw_connector.rs:58-60 */
+    ora_raw_connector *c = (ora_raw_connector *)calloc(1, sizeof(*c));
+    c->width = tsize; c->num_right = b.nr + 1; c->num_left = b.nl + 1;
+    c->right_feats = raw_feature_matrix(b.rrows, b.nr, tsize);
+    c->left_feats = raw_feature_matrix(b.lrows, b.nl, tsize);
+    scorer_build(&b.sb, &c->scorer);
+    raw_builder_free(&b);
     return c;
 }
 

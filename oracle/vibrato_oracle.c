@@ -107,6 +107,7 @@ static int parse_int(const char *s, size_t n, int allow_neg, long long lo, long 
 }
 
 #include "raw_connector.c"
+#include "dual_connector.c"
 
 /* ------------------------------------------------- lexicon CSV (lexicon.rs) */
 
@@ -439,7 +440,8 @@ typedef struct ora_dict {
     unk_entry *unk_entries;
     uint32_t n_unk;
     uint16_t *map_left, *map_right; /* ConnIdMapper, mapper.rs:9-12 (NULL = None) */
-    struct ora_raw_connector *raw;  /* ConnectorWrapper::Raw / ::Dual (connector.rs:30-35): matrix == NULL then */
+    struct ora_raw_connector *raw;   /* ConnectorWrapper::Raw (connector.rs:30-35): matrix == NULL then */
+    struct ora_dual_connector *dual; /* ConnectorWrapper::Dual: matrix == NULL, raw == NULL */
 } ora_dict;
 
 /* CharInfo bit layout, character.rs:10-24,56-95 */
@@ -822,6 +824,7 @@ ORA_API void ora_dict_free(ora_dict *d) {
     if (d->has_user) lexicon_free(&d->user);
     free(d->matrix);
     raw_free(d->raw);
+    dual_free(d->dual);
     if (d->categories) {
         for (uint32_t i = 0; i < d->n_categories; i++) free(d->categories[i]);
         free(d->categories);
@@ -876,16 +879,30 @@ fail2:
     return NULL;
 }
 
-/* SystemDictionaryBuilder::from_readers_with_bigram_info, builder.rs:111-160 (Raw and Dual share the cost function) */
-ORA_API ora_dict *ora_dict_from_sources_bigram(const char *lex, size_t lex_len, const char *right, size_t right_len, const char *left,
-                                               size_t left_len, const char *cost, size_t cost_len, const char *chr, size_t chr_len,
-                                               const char *unk, size_t unk_len, char *err, size_t errcap) {
+/* SystemDictionaryBuilder::from_readers_with_bigram_info, builder.rs:111-160: a RawConnector, or with dual_connector = true a
+ * DualConnector (builder.rs:134-150) */
+ORA_API ora_dict *ora_dict_from_sources_bigram2(const char *lex, size_t lex_len, const char *right, size_t right_len, const char *left,
+                                                size_t left_len, const char *cost, size_t cost_len, const char *chr, size_t chr_len,
+                                                const char *unk, size_t unk_len, int dual, char *err, size_t errcap) {
+    if (dual) {
+        ora_dual_connector *dc = dual_from_sources(right, right_len, left, left_len, cost, cost_len, err, errcap);
+        if (!dc) return NULL;
+        ora_dict *d = dict_build(lex, lex_len, NULL, 0, NULL, dc->num_right, dc->num_left, chr, chr_len, unk, unk_len, err, errcap);
+        if (!d) { dual_free(dc); return NULL; }
+        d->dual = dc;
+        return d;
+    }
     ora_raw_connector *rc = raw_from_sources(right, right_len, left, left_len, cost, cost_len, err, errcap);
     if (!rc) return NULL;
     ora_dict *d = dict_build(lex, lex_len, NULL, 0, NULL, rc->num_right, rc->num_left, chr, chr_len, unk, unk_len, err, errcap);
     if (!d) { raw_free(rc); return NULL; }
     d->raw = rc;
     return d;
+}
+ORA_API ora_dict *ora_dict_from_sources_bigram(const char *lex, size_t lex_len, const char *right, size_t right_len, const char *left,
+                                               size_t left_len, const char *cost, size_t cost_len, const char *chr, size_t chr_len,
+                                               const char *unk, size_t unk_len, char *err, size_t errcap) {
+    return ora_dict_from_sources_bigram2(lex, lex_len, right, right_len, left, left_len, cost, cost_len, chr, chr_len, unk, unk_len, 0, err, errcap);
 }
 
 ORA_API ora_dict *ora_dict_from_sources(const char *lex, size_t lex_len, const char *mat, size_t mat_len,
@@ -973,6 +990,7 @@ ORA_API int ora_dict_map_connection_ids(ora_dict *d, const uint16_t *lmap, size_
         }
     }
     if (d->raw) raw_map_ids(d->raw, ml, mr);
+    else if (d->dual) dual_map_ids(d->dual, ml, mr);
     else {
         size_t n = (size_t)d->num_left * d->num_right;
         int16_t *mapped = (int16_t *)malloc(n ? n * 2 : 2);
@@ -1001,6 +1019,7 @@ ORA_API uint32_t ora_dict_num_right(const ora_dict *d) { return d->num_right; }
 /* ConnectorCost::cost(right_id, left_id), matrix_connector.rs:119-125 */
 ORA_API int32_t ora_dict_conn_cost(const ora_dict *d, uint32_t right_id, uint32_t left_id) {
     if (d->raw) return raw_cost(d->raw, right_id, left_id);
+    if (d->dual) return dual_cost(d->dual, right_id, left_id);
     return (int32_t)d->matrix[(size_t)left_id * d->num_right + right_id];
 }
 /* CharProperty::char_info, character.rs:112-116 */
@@ -1172,11 +1191,13 @@ static void lattice_reset(ora_worker *w, uint32_t len_char) {
 static inline void search_min_node(const ora_worker *w, uint32_t start_node, uint16_t left_id, uint16_t *min_idx, int32_t *min_cost) {
     const ora_dict *d = w->tok->dict;
     const node_vec *e = &w->ends[start_node];
-    const int16_t *row = d->raw ? NULL : d->matrix + (size_t)left_id * d->num_right; /* matrix_connector.rs:79-85 */
+    const int16_t *row = (d->raw || d->dual) ? NULL : d->matrix + (size_t)left_id * d->num_right; /* matrix_connector.rs:79-85 */
     uint16_t mi = INVALID_IDX;
     int32_t mc = MAX_COST;
     for (uint32_t i = 0; i < e->n; i++) {
-        int32_t conn = row ? (int32_t)row[e->v[i].right_id] : raw_cost(d->raw, e->v[i].right_id, left_id); /* raw_connector.rs:153-161 */
+        int32_t conn = row ? (int32_t)row[e->v[i].right_id]
+                     : d->raw ? raw_cost(d->raw, e->v[i].right_id, left_id)    /* raw_connector.rs:153-161 */
+                              : dual_cost(d->dual, e->v[i].right_id, left_id); /* dual_connector.rs:267-279 */
         int32_t nc = (int32_t)((uint32_t)e->v[i].min_cost + (uint32_t)conn); /* wrapping add (release build) */
         if (nc <= mc) { mi = (uint16_t)i; mc = nc; }
     }

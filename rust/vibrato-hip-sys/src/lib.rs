@@ -115,6 +115,9 @@ extern "C" {
     pub fn vbt_worker_tokenize(w: *mut vbt_worker) -> c_int;
     pub fn vbt_worker_num_tokens(w: *const vbt_worker) -> u32;
     pub fn vbt_worker_token(w: *const vbt_worker, i: u32, out: *mut vbt_token) -> c_int;
+    pub fn vbt_worker_path_stats(w: *const vbt_worker, fast: *mut u64, slow: *mut u64) -> c_int;
+    pub fn vbt_worker_loop_benchmark(w: *mut vbt_worker, text: *const u8, offsets: *const u64, n: u64, rounds: u32, seconds: *mut f64,
+                                     tokens: *mut u64) -> c_int;
     pub fn vbt_worker_init_connid_counter(w: *mut vbt_worker) -> c_int;
     pub fn vbt_worker_update_connid_counts(w: *mut vbt_worker) -> c_int;
     pub fn vbt_worker_connid_counts(w: *const vbt_worker, lid: *mut u64, rid: *mut u64) -> c_int;

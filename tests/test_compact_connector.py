@@ -24,7 +24,7 @@ UNK = "DEFAULT,0,0,0,*"
 
 def _dict(kind, right, left, cost, lex="a,1,1,0,x", char=CHAR, unk=UNK, dual=False):
     if kind == "oracle":
-        return ora.Dictionary.from_sources_bigram(lex, right, left, cost, char, unk)
+        return ora.Dictionary.from_sources_bigram(lex, right, left, cost, char, unk, dual_connector=dual)
     return V.SystemDictionaryBuilder.from_readers_with_bigram_info(lex, right, left, cost, char, unk, dual_connector=dual)
 
 
@@ -47,8 +47,8 @@ def test_oracle_scorer_golden(case):
 @pytest.mark.parametrize("kind", ["oracle", "product"])
 @pytest.mark.parametrize("case", [c for c in GOLD["bigram_connector"] if c["map"] is None], ids=lambda c: c["source"].split("/")[-1])
 def test_from_readers_golden(kind, case):
-    """raw_connector.rs::from_readers_test, dual_connector.rs::from_readers_test (a dual connector gives what a raw
-    one gives on the same input: the product and the oracle evaluate both with the raw cost function)."""
+    """raw_connector.rs::from_readers_test, dual_connector.rs::from_readers_test: product and oracle each build the connector
+    kind the vector names (RawConnector / DualConnector restatement) and answer the reference's costs."""
     d = _dict(kind, case["right"], case["left"], case["cost"], dual=case["dual"])
     assert (d.num_right, d.num_left) == (3, 3)
     for r, l, c in case["costs"]:
@@ -61,7 +61,7 @@ def test_from_readers_golden(kind, case):
 def test_oracle_mapping_golden(case):
     """raw_connector.rs::mapping_test, dual_connector.rs::mapping_test (ConnIdMapper::new moves id 0 too, which
     Dictionary::map_connection_ids_from_iter never does: oracle connector object only)."""
-    c = ora.RawConnector(case["right"], case["left"], case["cost"])
+    c = (ora.DualConnector if case["dual"] else ora.RawConnector)(case["right"], case["left"], case["cost"])
     c.map_connection_ids(case["map"][0], case["map"][1])
     for r, l, exp in case["costs"]:
         assert c.cost(r, l) == exp
@@ -265,6 +265,16 @@ def test_dual_connector_builder_matches_a_python_restatement_including_its_quirk
         exp = dual_reference_costs(right, left, cost, sd.num_right, sd.num_left)
         got = [[dual.conn_cost(r, l) for l in range(sd.num_left)] for r in range(sd.num_right)]
         assert got == exp
+        # ... and the oracle's C restatement of DualConnector (oracle/dual_connector.c), before and after an id mapping
+        od = _dict("oracle", right, left, cost, sd.lex, sd.char_def, sd.unk, dual=True)
+        assert [[od.conn_cost(r, l) for l in range(sd.num_left)] for r in range(sd.num_right)] == exp
+        rng = random.Random(seed)
+        lmap = list(range(1, sd.num_left)); rng.shuffle(lmap)
+        rmap = list(range(1, sd.num_right)); rng.shuffle(rmap)
+        dual2 = _dict("product", right, left, cost, sd.lex, sd.char_def, sd.unk, dual=True)
+        dual2.map_connection_ids_from_iter(lmap, rmap)
+        od.map_connection_ids_from_iter(lmap, rmap)
+        assert all(dual2.conn_cost(r, l) == od.conn_cost(r, l) for r in range(sd.num_right) for l in range(sd.num_left))
         differs = sum(got[r][l] != raw.conn_cost(r, l) for r in range(sd.num_right) for l in range(sd.num_left))
         assert differs > 0  # the quirks are exercised: these models are where Dual and Raw part ways
 
@@ -282,14 +292,35 @@ def _assert_same(batch, exp, exp_off):
 @pytest.mark.parametrize("dual", [False, True])
 def test_tokenize_with_compact_connector_matches_oracle(dual):
     sd = synth.SynthDict("small")
-    right, left, cost = synth_bigram(sd.num_right, sd.num_left, seed=11, empty_pair=not dual)  # (see the builder test for the pair)
+    right, left, cost = synth_bigram(sd.num_right, sd.num_left, seed=11, empty_pair=not dual)
     dv = _dict("product", right, left, cost, sd.lex, sd.char_def, sd.unk, dual=dual)
-    do = _dict("oracle", right, left, cost, sd.lex, sd.char_def, sd.unk)
+    do = _dict("oracle", right, left, cost, sd.lex, sd.char_def, sd.unk, dual=dual)
     text, offs = sd.sentences(1500, "lognormal_40")
     exp, exp_off = ora.Tokenizer(do).new_worker().tokenize_batch(text, offs)
     tok = V.Tokenizer(dv, device=0)
     _assert_same(tok.tokenize_batch(text=text, offsets=offs), exp, exp_off)
     assert len(set(exp["total_cost"].tolist())) > 500
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("templates,seed,max_abs", [(10, 21, 300), (19, 23, 9000)])
+def test_tokenize_with_a_dual_connector_that_is_not_the_raw_cost_function(templates, seed, max_abs):
+    """Models on which DualConnector and RawConnector part ways (a priced ("", "") pair counted per padded class-row position,
+    class-matrix cells clamped to i16 -- dual_connector.rs:103): the GPU sweeps the Dual cost function (expanded into the device
+    matrix) and agrees with the oracle's DualConnector restatement, token for token, while the Raw connector of the same model
+    gives different best paths."""
+    sd = synth.SynthDict("small")
+    right, left, cost = synth_bigram(sd.num_right, sd.num_left, seed=seed, templates=templates, max_abs=max_abs, empty_pair=True)
+    dv = _dict("product", right, left, cost, sd.lex, sd.char_def, sd.unk, dual=True)
+    do = _dict("oracle", right, left, cost, sd.lex, sd.char_def, sd.unk, dual=True)
+    d_raw = _dict("oracle", right, left, cost, sd.lex, sd.char_def, sd.unk, dual=False)
+    assert sum(do.conn_cost(r, l) != d_raw.conn_cost(r, l) for r in range(0, sd.num_right, 7) for l in range(sd.num_left)) > 0
+    text, offs = sd.sentences(1500, "lognormal_40")
+    exp, exp_off = ora.Tokenizer(do).new_worker().tokenize_batch(text, offs)
+    exp_raw, _ = ora.Tokenizer(d_raw).new_worker().tokenize_batch(text, offs)
+    tok = V.Tokenizer(dv, device=0)
+    _assert_same(tok.tokenize_batch(text=text, offsets=offs), exp, exp_off)
+    assert exp.tobytes() != exp_raw.tobytes()
 
 
 @pytest.mark.gpu
@@ -313,12 +344,32 @@ def test_compact_connector_after_id_mapping_and_in_mecab_compat_mode():
 
 
 @pytest.mark.gpu
-def test_compact_connector_cost_outside_i16_is_refused_loudly():
-    """the device image stores i16 cells; a model whose cost function leaves that range must not be truncated silently"""
-    right = "1\tA,B\n"
-    left = "1\ta,b\n"
-    cost = "A/a\t30000\nB/b\t30000\n"
-    dv = _dict("product", right, left, cost)
-    assert dv.conn_cost(1, 1) == 60000
-    with pytest.raises(V.VibratoError):
-        V.Tokenizer(dv, device=0).new_worker()  # the device image is built at first use
+@pytest.mark.parametrize("dual", [False, True])
+@pytest.mark.parametrize("fused", ["0", "1"])
+def test_compact_connector_costs_outside_i16_use_the_i32_device_matrix(dual, fused, monkeypatch):
+    """ConnectorCost::cost of a Raw / Dual connector is an i32 sum (raw_connector.rs:153-161, dual_connector.rs:267-279): a model
+    whose costs leave i16 is expanded into an i32 device matrix and swept by the wide instances of the kernels (batch pipeline,
+    fused fallback, Worker's single launch) -- bit-exact against the oracle, whose search_min_node adds the same i32 costs."""
+    monkeypatch.setenv("VBT_FUSED", fused)
+    sd = synth.SynthDict("small")
+    right, left, cost = synth_bigram(sd.num_right, sd.num_left, seed=31, templates=12, max_abs=30000, empty_pair=not dual)
+    dv = _dict("product", right, left, cost, sd.lex, sd.char_def, sd.unk, dual=dual)
+    do = _dict("oracle", right, left, cost, sd.lex, sd.char_def, sd.unk, dual=dual)
+    wide = [(r, l) for r in range(sd.num_right) for l in range(0, sd.num_left, 5) if not -32768 <= do.conn_cost(r, l) <= 32767]
+    assert wide and dv.conn_cost(*wide[0]) == do.conn_cost(*wide[0])
+    text, offs = sd.sentences(1500, "mixed", space_p=0.05)
+    exp, exp_off = ora.Tokenizer(do, ignore_space=True).new_worker().tokenize_batch(text, offs)
+    tok = V.Tokenizer(dv, device=0).ignore_space(True)
+    _assert_same(tok.tokenize_batch(text=text, offsets=offs), exp, exp_off)
+    assert max(abs(int(c)) for c in exp["total_cost"][:2000]) > 40000  # paths whose costs could not come from i16 cells
+    if fused == "0":  # the per-sentence path on the same dictionary
+        w = tok.new_worker()
+        raw = bytes(text)
+        k = 0
+        for i in range(60):
+            w.reset_sentence(raw[int(offs[i]):int(offs[i + 1])])
+            w.tokenize()
+            n = w.num_tokens()
+            assert n == int(exp_off[i + 1] - exp_off[i])
+            assert [w.token(t).total_cost for t in range(n)] == exp["total_cost"][k:k + n].tolist()
+            k += n

@@ -425,3 +425,138 @@ def test_read_dictionary_matches_oracle_on_synthetic_batch_and_cli_takes_system_
                          cwd=os.path.dirname(HERE), check=True).stdout
     sub_offs = offs[:201]
     assert out.decode("utf-8") == tok.tokenize_batch(text=text[:int(sub_offs[-1])], offsets=sub_offs).format("detail")
+
+
+# ------------------------------------------------------------------ loader hardening (no reference-written file exists offline)
+
+def _split_system_trie(raw):
+    """(prefix, trie blob, suffix) of a written container: the system lexicon's trie is its first field (Vec<u8>)."""
+    at = len(MAGIC)
+    n = struct.unpack_from("<Q", raw, at)[0]
+    return raw[:at], raw[at + 8:at + 8 + n], raw[at + 8 + n:]
+
+
+def test_unbounded_alphabet_field_is_rejected_before_any_allocation():
+    """a u32 alphabet_size of 0xFFFFFFFF used to size a 16 GiB inverse table; it is refused from the field alone."""
+    import resource
+    raw = fixture_dict().write()
+    head, blob, tail = _split_system_trie(raw)
+    table_len = struct.unpack_from("<I", blob, 0)[0]
+    at = 4 + 4 * table_len
+    before = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+    for bogus in (0xFFFFFFFF, 0x7FFFFFFF, table_len + 2):
+        b = bytearray(blob)
+        struct.pack_into("<I", b, at, bogus)
+        with pytest.raises(V.VibratoError, match="alphabet"):
+            V.Dictionary.read(head + struct.pack("<Q", len(b)) + bytes(b) + tail)
+    assert resource.getrusage(resource.RUSAGE_SELF).ru_maxrss - before < 200 * 1024  # KiB: nothing alphabet-sized was allocated
+
+
+def _assemble_crawdad_blob(keys, direct_leaves):
+    """A crawdad 0.3 blob assembled by hand (independent of csrc/dictio.cpp's writer): first-fit XOR double array.
+    direct_leaves=True: a key that is no proper prefix of another key ends AT the node reached by its last character (is_leaf on
+    that node, value in its base); only keys with continuations use the has_leaf flag + a leaf child on the end code 0.
+    direct_leaves=False: every key ends in a leaf child on the end code."""
+    MASK, TOP = 0x7FFFFFFF, 0x80000000
+    chars = sorted({c for k in keys for c in k})
+    code = {c: i + 1 for i, c in enumerate(chars)}  # 0 = end code
+    table = [0xFFFFFFFF] * (max(map(ord, chars)) + 1)
+    for c, v in code.items():
+        table[ord(c)] = v
+    base, check, used = {0: 0}, {0: MASK}, {0}
+    prefixes = {k[:i] for k in keys for i in range(len(k))}  # proper prefixes of some key
+
+    def place(node, prefix):
+        labels = sorted({code[k[len(prefix)]] for k in keys if k.startswith(prefix) and len(k) > len(prefix)})
+        ends_here = prefix in keys
+        if ends_here:
+            labels = [0] + labels
+        if not labels:
+            return
+        b = 0
+        while any((b ^ l) in used for l in labels):
+            b += 1
+        base[node] = b | (base.get(node, 0) & TOP)
+        for l in labels:
+            used.add(b ^ l)
+            check[b ^ l] = node
+            base[b ^ l] = 0
+        if ends_here:
+            base[b] = keys[prefix] | TOP
+            check[node] |= TOP
+        inv = {v: c for c, v in code.items()}
+        for l in labels:
+            if l == 0:
+                continue
+            child, p2 = b ^ l, prefix + inv[l]
+            if direct_leaves and p2 in keys and p2 not in prefixes:
+                base[child] = keys[p2] | TOP  # the key ends at this very node
+            else:
+                place(child, p2)
+
+    place(0, "")
+    n_nodes = max(used) + 1
+    nodes = []
+    for i in range(n_nodes):
+        nodes += [base.get(i, MASK), check.get(i, MASK)]
+    return struct.pack("<I", len(table)) + struct.pack(f"<{len(table)}I", *table) + struct.pack("<II", len(chars) + 1, n_nodes) + \
+        struct.pack(f"<{2 * n_nodes}I", *nodes)
+
+
+@pytest.mark.parametrize("direct_leaves", [False, True])
+def test_reader_accepts_both_terminal_encodings_of_a_hand_assembled_trie(direct_leaves):
+    """crawdad keeps a key's value either in the node its last character reaches (is_leaf) or, when the key has continuations, in
+    a leaf child on the end code (has_leaf): a container whose system trie is assembled by hand in either convention reads back
+    to the same dictionary (every enumeration vector of vibrato/src/tests/lexicon.rs, every word id)."""
+    d0 = fixture_dict()
+    raw = d0.write()
+    head, blob0, tail = _split_system_trie(raw)
+    got = Dec(raw).dictionary()["system"]
+    rows = parse_lex(_src("lex.csv"))
+    by_surface = {}
+    for i, (s, *_r) in enumerate(rows):
+        by_surface.setdefault(s, []).append(i)
+    keys, off = {}, 0
+    for s in sorted(by_surface, key=lambda s: s.encode("utf-8")):
+        keys[s] = off
+        off += 1 + len(by_surface[s])
+    assert off == len(got["postings"])
+    blob = _assemble_crawdad_blob(keys, direct_leaves)
+    for s, v in keys.items():  # the independent search over the hand-assembled blob finds every key
+        assert crawdad_common_prefix_search(blob, s)[-1] == (v, len(s))
+    if direct_leaves:
+        n_direct = sum(1 for s in keys if not any(o != s and o.startswith(s) for o in keys))
+        assert 0 < n_direct < len(keys)  # both encodings occur in one trie
+    d1 = V.Dictionary.read(head + struct.pack("<Q", len(blob)) + blob + tail)
+    for case in GOLD["lexicon_common_prefix"]:
+        if case.get("dict") == "fixture":
+            assert d1.common_prefix(case["input"]) == case["expect"] == d0.common_prefix(case["input"])
+    for s in keys:
+        assert d1.common_prefix(s) == d0.common_prefix(s)
+    assert d1.write() == raw  # re-written by this project's writer: the same bytes as the original
+
+
+@pytest.mark.parametrize("kind", ["matrix", "raw", "dual"])
+def test_verify_dic_tool_walks_and_checks_a_container(kind, tmp_path):
+    """tools/verify_dic.py (the one command that pins the format the day a reference-written file is at hand) passes on
+    containers of every connector kind written here, and fails on a blob whose length field is off."""
+    if kind == "matrix":
+        d = fixture_dict(user=True)
+    else:
+        from test_compact_connector import synth_bigram
+        sd = synth.SynthDict("tiny")
+        right, left, cost = synth_bigram(sd.num_right, sd.num_left, seed=5)
+        d = V.SystemDictionaryBuilder.from_readers_with_bigram_info(sd.lex, right, left, cost, sd.char_def, sd.unk, dual_connector=(kind == "dual"))
+    path = tmp_path / "system.dic.zst"
+    path.write_bytes(d.write(zstd_level=1))
+    tool = os.path.join(os.path.dirname(HERE), "tools", "verify_dic.py")
+    p = subprocess.run([sys.executable, tool, str(path), "東京都"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "ALL CHECKS PASSED" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+    if kind == "matrix":
+        assert "word        6 end_char 3 left 6 right 8 cost 5320" in p.stdout  # vibrato/src/tests/lexicon.rs vector
+        raw = bytearray(d.write())
+        struct.pack_into("<I", raw, len(MAGIC) + 8, struct.unpack_from("<I", raw, len(MAGIC) + 8)[0] + 1)  # table_len + 1
+        bad = tmp_path / "bad.dic"
+        bad.write_bytes(bytes(raw))
+        p = subprocess.run([sys.executable, tool, str(bad)], capture_output=True, text=True, timeout=300)
+        assert p.returncode != 0 and "blob length" in p.stdout

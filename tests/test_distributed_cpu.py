@@ -100,3 +100,17 @@ def test_pack_unpack_round_trip():
     assert (n_s, n_t) == (3, 5) and o.tolist() == [3, 0, 3] and c.tolist() == [2, 3, 0]
     ordered, ends = sharding.tokens_in_sentence_order(o, c, t)
     assert ordered["start_char"].tolist() == [3, 4, 0, 1, 2] and ends.tolist() == [0, 2, 5, 5]
+
+
+def test_bench_py_self_launches_ranks_when_no_launcher_started_it():
+    """`python bench.py --gpus 2` with no WORLD_SIZE: bench.py starts its own two ranks under torch.distributed.run (here, without a
+    GPU, every rank then stops at "needs an MI355X" -- not at the old "launch with torch.distributed.run" refusal)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dict", "tiny", "--sentences", "100"], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0
+    assert p.stderr.count("bench.py needs an MI355X") == 2, p.stderr[-3000:]
+    assert "launch with torch.distributed.run" not in p.stderr

@@ -103,8 +103,128 @@ def test_bench_py_multi_rank_path_runs_config4_shape():
            "--dict", "small", "--sentences", "20000"]
     p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
-    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
-    r = json.loads(line)
+    _check_multi_rank_line(p.stdout)
+
+
+def _check_multi_rank_line(stdout):
+    import json
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines  # ONE JSON line, from rank 0
+    r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["scaling"] == "strong" and r["parity_vs_oracle_sample"] is True
     assert r["gather"]["delivered_all_shards"] is True and r["gather"]["device_resident"] is True
     assert r["value"] > 0 and r["tokens_per_step"] > 20000
+    # rank 0's shard carries the roofline and a bounded CPU baseline at N > 1 as well
+    assert r["roofline"]["frac"] > 0 and r["roofline"]["kernel_ms"] > 0
+    assert r["cpu_baseline"]["value"] > 0 and r["cpu_baseline"]["cores"] == 1
+
+
+def test_bench_py_launches_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (how a driver without torch.distributed.run would start
+    it): bench.py re-executes itself under torch.distributed.run and rank 0 still prints exactly one JSON line."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(VBT_BENCH_BACKEND="gloo", VBT_BENCH_SINGLE_DEVICE="1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dict", "small", "--sentences", "20000"]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    _check_multi_rank_line(p.stdout)
+
+
+def _rccl_worker(port, q):
+    sys.path.insert(0, ROOT)
+    try:
+        import torch
+        import torch.distributed as dist
+        import vibrato_amd as V
+        from tools import synth
+        from vibrato_amd import sharding
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(0)
+        # the real backend: "nccl" IS RCCL on ROCm; one rank is all a one-GPU box admits
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        sd = synth.SynthDict("small")
+        dv = V.SystemDictionaryBuilder.from_readers_binmatrix(sd.lex, sd.matrix, sd.num_right, sd.num_left, sd.char_def, sd.unk)
+        tok = V.Tokenizer(dv, device=0).ignore_space(True).max_grouping_len(24)
+        text, offs = sd.sentences(N_SENT, "mixed", space_p=0.05)
+        ltext, loffs, (lo, hi) = sharding.local_shard(text, offs, 0, 1)
+        n_local, nbytes = hi - lo, len(ltext)
+        d_text = torch.from_numpy(np.ascontiguousarray(ltext)).cuda()
+        d_offs = torch.from_numpy(loffs.astype(np.int64)).cuda()
+        ws = tok.workspace(n_local, nbytes)
+        stream = torch.cuda.current_stream().cuda_stream
+        ws.run(d_text.data_ptr(), d_offs.data_ptr(), n_local, nbytes, stream)
+        st = ws.stats()
+        assert st["error_flags"] == 0
+        ntok = int(st["n_tokens"])
+        max_s = sharding.agree_max(n_local, device="cuda")   # all_reduce(MAX) over RCCL
+        max_t = sharding.agree_max(ntok, device="cuda")
+        assert (max_s, max_t) == (n_local, ntok)
+        v = sharding.workspace_views(ws, n_local, ntok)
+        slot = sharding.packed_bytes(max_s, max_t)
+        send = [torch.empty(slot, dtype=torch.uint8, device="cuda") for _ in range(2)]
+        out = [torch.empty(slot, dtype=torch.uint8, device="cuda") for _ in range(2)]
+        work = [None, None]
+        comm = torch.cuda.Stream()
+        # bench.py's step(): kernels on the launch stream, pack on the launch stream, the collective asynchronously on the
+        # communication stream, double-buffered; three steps so that both buffers are reused once
+        for k in range(4):
+            b = k & 1
+            ws.run(d_text.data_ptr(), d_offs.data_ptr(), n_local, nbytes, stream)
+            if work[b] is not None:
+                work[b].wait()
+            send[b].zero_()
+            sharding.pack_results(send[b], n_local, ntok, v["total"], v["tok_off"], v["tok_cnt"], v["tokens"], max_s)
+            ready = torch.cuda.Event()
+            ready.record()
+            with torch.cuda.stream(comm):
+                comm.wait_event(ready)
+                _, work[b] = sharding.gather_packed(send[b], out[b], async_op=True)
+        for wk in work:
+            wk.wait()
+        torch.cuda.synchronize()
+        tmax = torch.tensor([1.5], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        assert float(tmax.item()) == 1.5
+        dist.barrier()
+        res = []
+        for b in range(2):
+            n_s, n_t, off, cnt, tk = sharding.unpack_results(out[b].view(1, -1)[0], max_s)
+            ordered, _ = sharding.tokens_in_sentence_order(off, cnt, tk)
+            res.append((n_s, n_t, ordered.tobytes()))
+        backend = dist.get_backend()
+        dist.destroy_process_group()
+        q.put(("ok", (backend, res)))
+    except Exception as e:
+        import traceback
+        q.put(("error", f"{e}\n{traceback.format_exc()}"))
+        raise
+
+
+def test_rccl_backend_world_size_one_gather_on_the_communication_stream():
+    """The collective calls bench.py issues at N > 1 -- init_process_group("nccl", device_id=...), all_reduce(MAX) for the slot
+    sizes, pack_results, asynchronous all_gather_into_tensor on the communication stream with the double buffer, barrier --
+    executed on the real RCCL backend (world size 1: what one GPU admits); the gathered records equal the oracle's."""
+    import torch.multiprocessing as mp
+    from oracle import oracle as ora
+    from tools import synth
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + (os.getpid() % 2000)
+    p = ctx.Process(target=_rccl_worker, args=(port, q))
+    p.start()
+    status, payload = q.get(timeout=600)
+    p.join(timeout=120)
+    assert status == "ok", payload
+    assert p.exitcode == 0
+    backend, res = payload
+    assert backend == "nccl"
+    sd = synth.SynthDict("small")
+    d = ora.Dictionary.from_sources_binmatrix(sd.lex, sd.matrix, sd.num_right, sd.num_left, sd.char_def, sd.unk)
+    text, offs = sd.sentences(N_SENT, "mixed", space_p=0.05)
+    toks, _ = ora.Tokenizer(d, True, 24).new_worker().tokenize_batch(text, offs)
+    for n_s, n_t, blob in res:
+        assert n_s == N_SENT and n_t == len(toks)
+        assert blob == toks.tobytes()

@@ -480,3 +480,59 @@ def test_sentences_too_dense_for_the_segment_tier_are_prerouted_to_a_concurrent_
     st = ws.stats()
     assert st["error_flags"] == 0 and st["n_tier0"] + st["n_tier1"] + st["n_tier2"] >= 3000
     assert st["n_tier1"] > 0
+
+
+def _worker_records(worker, text, offs):
+    """Token records of every sentence through the reference's 3-call loop (reset_sentence / tokenize / token(i))."""
+    raw = bytes(text)
+    out = []
+    for i in range(len(offs) - 1):
+        worker.reset_sentence(raw[int(offs[i]):int(offs[i + 1])])
+        worker.tokenize()
+        for k in range(worker.num_tokens()):
+            t = worker.token(k)
+            out.append((t.range_char[0], t.range_char[1], t.range_byte[0], t.range_byte[1], (t.lex_type << 30) | t.word_id, t.total_cost))
+    return np.array(out, dtype=np.int64).reshape(-1, 6)
+
+
+@pytest.mark.parametrize("ignore_space", [False, True])
+def test_worker_single_launch_path_matches_oracle(ignore_space):
+    """Worker::tokenize is ONE launch per sentence (Workspace::run_one): mixed lengths (short ones whole, 150+ characters in
+    segments, 1000+ characters beyond the single wavefront's generator arrays or not), spaces, user lexicon -- every record equal to
+    the oracle's, and the sentences the single launch cannot take come back through the batch pipeline with the same records."""
+    sd = synth.SynthDict("small")
+    to, tv = _oracle_and_product(sd, user_csv=sd.user_csv(300), ignore_space=ignore_space, max_grouping_len=24 if ignore_space else 0)
+    text, offs = sd.sentences(1500, "mixed", space_p=0.08 if ignore_space else 0.0)
+    exp_tok, _ = to.new_worker().tokenize_batch(text, offs)
+    w = tv.new_worker()
+    got = _worker_records(w, text, offs)
+    exp = np.stack([exp_tok[f].astype(np.int64) for f in V.TOKEN_DTYPE.names], axis=1)
+    assert got.shape == exp.shape
+    bad = np.nonzero((got != exp).any(axis=1))[0]
+    assert bad.size == 0, (int(bad[0]), got[bad[0]], exp[bad[0]])
+    fast, slow = w.path_stats()
+    assert fast + slow == sum(1 for i in range(1500) if offs[i + 1] > offs[i])
+    assert fast > 0.9 * (fast + slow), (fast, slow)
+    # empty sentence, then a sentence longer than anything before (the worker's buffers grow), then a short one again
+    w.reset_sentence("")
+    w.tokenize()
+    assert w.num_tokens() == 0
+    big = bytes(text[int(offs[0]):int(offs[400])])
+    for s in (big, bytes(text[int(offs[3]):int(offs[4])])):
+        e, _ = to.new_worker().tokenize_batch(np.frombuffer(s, dtype=np.uint8), np.array([0, len(s)], dtype=np.uint64))
+        g = _worker_records(w, np.frombuffer(s, dtype=np.uint8), np.array([0, len(s)], dtype=np.uint64))
+        assert np.array_equal(g, np.stack([e[f].astype(np.int64) for f in V.TOKEN_DTYPE.names], axis=1))
+
+
+def test_worker_loop_benchmark_counts_tokens():
+    sd = synth.SynthDict("small")
+    to, tv = _oracle_and_product(sd)
+    text, offs = sd.sentences(500, "lognormal_40")
+    exp_tok, _ = to.new_worker().tokenize_batch(text, offs)
+    for spin in ("1", "0"):
+        os.environ["VBT_WORKER_SPIN"] = spin
+        try:
+            r = tv.new_worker().loop_benchmark(text, offs, rounds=2)
+        finally:
+            del os.environ["VBT_WORKER_SPIN"]
+        assert r["tokens"] == 2 * len(exp_tok) and r["us_per_call"] > 0

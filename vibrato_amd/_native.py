@@ -73,6 +73,8 @@ SIGNATURES = {
     "vbt_worker_tokenize": (_int, [_vp]),
     "vbt_worker_num_tokens": (_u32, [_vp]),
     "vbt_worker_token": (_int, [_vp, _u32, C.POINTER(Token)]),
+    "vbt_worker_path_stats": (_int, [_vp, _vp, _vp]),
+    "vbt_worker_loop_benchmark": (_int, [_vp, _vp, _vp, _u64, _u32, _vp, _vp]),
     "vbt_worker_init_connid_counter": (_int, [_vp]),
     "vbt_worker_update_connid_counts": (_int, [_vp]),
     "vbt_worker_connid_counts": (_int, [_vp, _vp, _vp]),

@@ -322,7 +322,8 @@ class Tokenizer:
 
 
 class Worker:
-    """vibrato::tokenizer::worker::Worker (worker.rs:13-75): per-sentence API (one launch per sentence)."""
+    """vibrato::tokenizer::worker::Worker (worker.rs:13-75): per-sentence API -- ONE kernel launch per tokenize(), text and token
+    records through the worker's pinned host block."""
 
     def __init__(self, tokenizer):
         self.tokenizer = tokenizer
@@ -356,6 +357,25 @@ class Worker:
     def token_iter(self):
         """Worker::token_iter (worker.rs:71-75)."""
         return (self.token(i) for i in range(self.num_tokens()))
+
+    def path_stats(self):
+        """(sentences served by the single-launch latency path, sentences handed to the batch pipeline)."""
+        f, s = C.c_uint64(), C.c_uint64()
+        N.check(N.lib().vbt_worker_path_stats(self._h, C.byref(f), C.byref(s)))
+        return f.value, s.value
+
+    def loop_benchmark(self, text, offsets, rounds=1):
+        """The reference's 3-call loop (tokenize/src/main.rs:78-82) over (uint8 text, uint64 offsets[n+1]), timed inside the
+        library: {sentences_per_s, us_per_call, tokens}."""
+        text = np.ascontiguousarray(text, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        sec, ntok = C.c_double(), C.c_uint64()
+        N.check(N.lib().vbt_worker_loop_benchmark(self._h, text.ctypes.data if text.size else None, offsets.ctypes.data, n, int(rounds),
+                                                  C.byref(sec), C.byref(ntok)))
+        calls = n * int(rounds)
+        return {"sentences_per_s": round(calls / sec.value, 1) if sec.value > 0 else None, "us_per_call": round(sec.value / max(calls, 1) * 1e6, 3),
+                "sentences": n, "rounds": int(rounds), "tokens": int(ntok.value)}
 
     def init_connid_counter(self):
         """Worker::init_connid_counter (worker.rs:77-84)."""

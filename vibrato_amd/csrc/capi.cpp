@@ -1,6 +1,7 @@
 // extern "C" boundary of libvibrato_hip.so (see include/vibrato_hip.h).
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -73,11 +74,32 @@ struct vbt_worker {
     std::unique_ptr<Workspace> ws;
     void* d_text = nullptr;
     uint64_t* d_offsets = nullptr;
-    size_t d_text_cap = 0;
+    size_t cap = 0;  // bytes the workspace, d_text and the pinned block below hold
+    // latency path (Workspace::run_one): one pinned host block {text, padded to 16 | status, count | token records}, read and
+    // written by the kernel directly, and the worker's own stream
+    void* h_block = nullptr;
+    uint8_t* h_text = nullptr;
+    uint32_t* h_ctl = nullptr;  // [0] status, [1] token count
+    vbt_token_rec* h_tokens = nullptr;
+    uint8_t* hd_text = nullptr;  // device addresses of the same
+    uint32_t* hd_ctl = nullptr;
+    vbt_token_rec* hd_tokens = nullptr;
+    hipStream_t stream = nullptr;
+    int spin = -1;  // wait for the status word in pinned memory instead of the stream's completion signal (VBT_WORKER_SPIN, default 1)
+    uint64_t n_fast = 0, n_slow = 0;  // sentences served by the single launch / handed to the batch pipeline
     std::vector<vbt_token_rec> tokens;
     // ConnIdCounter of Worker::init_connid_counter (worker.rs:77-84, mapper.rs:87-106); empty = never initialised
     std::vector<uint64_t> lid_count, rid_count;
-    ~vbt_worker() { (void)hipFree(d_text); (void)hipFree(d_offsets); }
+    void release() {
+        ws.reset();
+        (void)hipFree(d_text); (void)hipFree(d_offsets);
+        if (h_block) (void)hipHostFree(h_block);
+        d_text = nullptr; d_offsets = nullptr; h_block = nullptr;
+    }
+    ~vbt_worker() {
+        release();
+        if (stream) (void)hipStreamDestroy(stream);
+    }
 };
 
 namespace {
@@ -426,28 +448,101 @@ int vbt_worker_reset_sentence(vbt_worker* w, const char* utf8, size_t len) {
     });
 }
 
+// Worker::tokenize (worker.rs:49-55).  One launch per sentence (Workspace::run_one): the kernel reads the text from the worker's
+// pinned block and writes the token records back into it; steady state allocates nothing and issues no copy.  Sentences the
+// single wavefront cannot take (status 1) and workers that count connection ids go through the batch pipeline.
 int vbt_worker_tokenize(vbt_worker* w) {
     return guarded([&] {
+        if (!w) throw Error(VBT_ERR_INVALID_ARGUMENT, "null argument");
         w->tokens.clear();
         if (w->text.empty()) return;  // worker.rs:50-52
         const size_t len = w->text.size();
+        if (len >= 0xFFFFFFF0ull) throw Error(VBT_ERR_INVALID_ARGUMENT, "sentence too large");
         HIPX(hipSetDevice(w->tok->t->device()));
-        if (!w->ws || w->ws->max_bytes < len) {
-            const size_t cap = std::max<size_t>(len * 2, 4096);
+        if (!w->ws || w->cap < len) {
+            if (w->stream) HIPX(hipStreamSynchronize(w->stream));
+            w->release();
+            const size_t cap = (std::max<size_t>(len * 2, 4096) + 15) & ~(size_t)15;
             w->ws = std::make_unique<Workspace>(*w->tok->t, 1, cap);
             if (!w->lid_count.empty()) w->ws->enable_connid_counts(true);
-            (void)hipFree(w->d_text); (void)hipFree(w->d_offsets);
-            w->d_text = nullptr; w->d_offsets = nullptr;
-            HIPX(hipMalloc(&w->d_text, cap));
+            HIPX(hipMalloc(&w->d_text, cap + 16));
             HIPX(hipMalloc(reinterpret_cast<void**>(&w->d_offsets), 16));
+            const size_t ctl_off = cap, tok_off = cap + 16;
+            HIPX(hipHostMalloc(&w->h_block, tok_off + (cap + 2) * sizeof(vbt_token_rec), hipHostMallocDefault));
+            void* dev = nullptr;
+            HIPX(hipHostGetDevicePointer(&dev, w->h_block, 0));
+            w->h_text = static_cast<uint8_t*>(w->h_block);
+            w->h_ctl = reinterpret_cast<uint32_t*>(w->h_text + ctl_off);
+            w->h_tokens = reinterpret_cast<vbt_token_rec*>(w->h_text + tok_off);
+            w->hd_text = static_cast<uint8_t*>(dev);
+            w->hd_ctl = reinterpret_cast<uint32_t*>(w->hd_text + ctl_off);
+            w->hd_tokens = reinterpret_cast<vbt_token_rec*>(w->hd_text + tok_off);
+            if (!w->stream) HIPX(hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking));
+            if (w->spin < 0) { const char* e = std::getenv("VBT_WORKER_SPIN"); w->spin = e && *e ? std::atoi(e) : 1; }
+            w->cap = cap;
         }
+        const bool counting = !w->lid_count.empty();
+        if (!counting && !w->ws->fused) {
+            std::memcpy(w->h_text, w->text.data(), len);
+            volatile uint32_t* ctl = w->h_ctl;
+            ctl[0] = 0xFFFFFFFFu; ctl[1] = 0;
+            w->ws->run_one(w->hd_text, (uint32_t)len, static_cast<uint8_t*>(w->d_text), w->d_offsets, w->hd_tokens, w->hd_ctl + 1, w->hd_ctl, w->stream);
+            bool seen = false;
+            if (w->spin) {  // the kernel's last store (system-scope release) is the status word
+                for (uint32_t it = 0; it < (1u << 22) && !seen; ++it) seen = __atomic_load_n(&w->h_ctl[0], __ATOMIC_ACQUIRE) != 0xFFFFFFFFu;
+            }
+            if (!seen) HIPX(hipStreamSynchronize(w->stream));
+            const uint32_t status = __atomic_load_n(&w->h_ctl[0], __ATOMIC_ACQUIRE);
+            if (status == 0) {
+                const uint32_t cnt = w->h_ctl[1];
+                if (cnt > len) throw Error(VBT_ERR_INVALID_STATE, "worker: token count exceeds the sentence");
+                w->tokens.assign(w->h_tokens, w->h_tokens + cnt);
+                ++w->n_fast;
+                return;
+            }
+            if (seen) HIPX(hipStreamSynchronize(w->stream));  // the batch pipeline reuses the workspace's buffers
+            if (status == 0xFFFFFFFFu) throw Error(VBT_ERR_DEVICE, "worker: the tokenize kernel did not report back");
+        }
+        ++w->n_slow;
         const uint64_t offs[2] = {0, len};
         HIPX(hipMemcpy(w->d_text, w->text.data(), len, hipMemcpyHostToDevice));
         HIPX(hipMemcpy(w->d_offsets, offs, 16, hipMemcpyHostToDevice));
         std::vector<uint32_t> off, cnt;
-        if (!w->lid_count.empty()) w->ws->reset_connid_counts();  // the device holds the counts of the last lattice only
-        run_and_fetch(*w->ws, static_cast<const uint8_t*>(w->d_text), w->d_offsets, 1, len, off, cnt, w->tokens);
+        if (counting) w->ws->reset_connid_counts();  // the device holds the counts of the last lattice only
+        run_and_fetch(*w->ws, static_cast<const uint8_t*>(w->d_text), w->d_offsets, 1, len, off, cnt, w->tokens, w->stream);
     });
+}
+
+// Sentences this worker served with the single launch / through the batch pipeline.
+int vbt_worker_path_stats(const vbt_worker* w, uint64_t* fast, uint64_t* slow) {
+    return guarded([&] {
+        if (!w) throw Error(VBT_ERR_INVALID_ARGUMENT, "null argument");
+        if (fast) *fast = w->n_fast;
+        if (slow) *slow = w->n_slow;
+    });
+}
+
+// The reference's calling pattern, timed in C (tokenize/src/main.rs:78-82, benchmark/src/main.rs:57-61): for every sentence
+// reset_sentence -> tokenize -> num_tokens (+ one token() per token), `rounds` passes over the n sentences.
+int vbt_worker_loop_benchmark(vbt_worker* w, const uint8_t* text, const uint64_t* offsets, uint64_t n, uint32_t rounds, double* seconds,
+                              uint64_t* tokens) {
+    if (!w || !offsets || !seconds || !tokens || (!text && n && offsets[n] != offsets[0])) { g_last_error = "null argument"; return VBT_ERR_INVALID_ARGUMENT; }
+    uint64_t total = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t r = 0; r < rounds; ++r) {
+        for (uint64_t i = 0; i < n; ++i) {
+            int rc = vbt_worker_reset_sentence(w, reinterpret_cast<const char*>(text) + offsets[i], offsets[i + 1] - offsets[i]);
+            if (rc == VBT_OK) rc = vbt_worker_tokenize(w);
+            if (rc != VBT_OK) return rc;
+            const uint32_t nt = vbt_worker_num_tokens(w);
+            vbt_token t;
+            for (uint32_t k = 0; k < nt; ++k) { rc = vbt_worker_token(w, k, &t); if (rc != VBT_OK) return rc; }
+            total += nt;
+        }
+    }
+    *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    *tokens = total;
+    return VBT_OK;
 }
 
 // Worker::init_connid_counter (worker.rs:77-84): fresh zeroed counters of num_left / num_right entries.

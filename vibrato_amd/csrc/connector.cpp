@@ -27,15 +27,17 @@ constexpr uint32_t kSimd = 8;                      // SIMD_SIZE, scorer.rs:17
 
 [[noreturn]] void fail(int code, const std::string& msg) { throw Error(code, msg); }
 
-// BufRead::lines(): split at '\n', a trailing '\r' is stripped, no empty line behind a final newline
+// BufRead::lines(): split at '\n'; a '\r' is stripped only as part of a "\r\n" terminator (a last line without '\n' keeps
+// it); no empty line behind a final newline
 std::vector<std::string_view> lines_of(std::string_view buf) {
     std::vector<std::string_view> out;
     size_t pos = 0;
     while (pos < buf.size()) {
         size_t nl = buf.find('\n', pos);
-        if (nl == std::string_view::npos) nl = buf.size();
+        const bool terminated = nl != std::string_view::npos;
+        if (!terminated) nl = buf.size();
         std::string_view line = buf.substr(pos, nl - pos);
-        if (!line.empty() && line.back() == '\r') line.remove_suffix(1);
+        if (terminated && !line.empty() && line.back() == '\r') line.remove_suffix(1);
         out.push_back(line);
         pos = nl + 1;
     }
@@ -92,7 +94,8 @@ std::pair<size_t, std::vector<uint32_t>> parse_features(std::string_view line, c
     if (tab == std::string_view::npos || line.find('\t', tab + 1) != std::string_view::npos)
         fail(VBT_ERR_INVALID_FORMAT, std::string(name) + ": The format must be id<tab>csv_row, " + std::string(line));
     size_t id = 0;
-    const std::string_view id_str = line.substr(0, tab);
+    std::string_view id_str = line.substr(0, tab);
+    if (id_str.size() > 1 && id_str[0] == '+' && id_str[1] != '+' && id_str[1] != '-') id_str.remove_prefix(1);  // usize::from_str takes one '+'
     auto r = std::from_chars(id_str.data(), id_str.data() + id_str.size(), id);
     if (id_str.empty() || r.ec != std::errc() || r.ptr != id_str.data() + id_str.size())
         fail(VBT_ERR_PARSE_INT, std::string(name) + ": invalid id");

@@ -156,6 +156,9 @@ std::vector<CrawdadRecord> crawdad_records(const std::vector<uint8_t>& blob, con
     u32s(n_nodes, 8);
     if (r.pos + (size_t)n_nodes * 8 != r.n) bad(where + "blob length != 12 + 4*table_len + 8*n_nodes");
     if (table_len > 0x110000) bad(where + "code table larger than the Unicode range");
+    // codes are < alphabet and distinct per code point, so a sane alphabet has at most one code per table entry plus the end
+    // marker: an unchecked u32 here would size the inverse table below (16 GiB for 0xFFFFFFFF) before anything else is looked at
+    if ((uint64_t)alphabet > (uint64_t)table_len + 1) bad(where + "alphabet size exceeds the code table");
     std::vector<uint32_t> base(n_nodes), check(n_nodes);
     for (uint32_t i = 0; i < n_nodes; ++i) {
         std::memcpy(&base[i], r.p + r.pos + (size_t)i * 8, 4);
@@ -166,8 +169,12 @@ std::vector<CrawdadRecord> crawdad_records(const std::vector<uint8_t>& blob, con
         const uint32_t c = table[cp];
         if (c == kInvalidCode) continue;
         if (c >= alphabet || code_to_cp[c] != kInvalidCode) bad(where + "the code table is not a bijection onto the alphabet");
+        if (c == 0 && cp != 0) bad(where + "a character shares the end code");
         code_to_cp[c] = cp;
     }
+    // code 0 is the end marker whether or not the table maps U+0000 to it (crawdad's builder does; a table without that entry
+    // describes the same trie)
+    if (alphabet) code_to_cp[0] = 0;
     std::vector<CrawdadRecord> out;
     if (n_nodes == 0) return out;
     // children by inverting `check` (one pass), then a walk from the root; only nodes reached from the root count

@@ -230,9 +230,11 @@ __device__ __forceinline__ void unk_spans(uint32_t cinfo, uint32_t g, uint32_t i
 
 // Tokenizes sentence `sid` inside the arena [abase, abase+acap). Returns 0 when done,
 // otherwise the number of arena bytes it would need (kNoFit: can never fit this tier).
-template <typename IdxT, bool kGlobal>
+// kWide: the connection matrix holds i32 cells (a compact connector whose costs leave i16, raw_connector.rs:153-161).
+template <typename IdxT, bool kGlobal, bool kWide>
 __device__ __forceinline__ uint64_t process_sentence(const DevDict& D, const BatchArgs& A, uint32_t sid, char* abase,
                                                      uint64_t acap) {
+    typedef typename std::conditional<kWide, int32_t, int16_t>::type ConnT;
     const uint32_t ln = threadIdx.x;
     const uint64_t lt_mask = (1ull << ln) - 1ull;
     // optional per-phase cycle accounting (A.prof != nullptr): s_memtime deltas summed per launch
@@ -529,13 +531,13 @@ __device__ __forceinline__ uint64_t process_sentence(const DevDict& D, const Bat
     }
     // connection-cost staging buffer: all pairs if they fit, else as many whole steps as fit
     uint64_t q_cap;
-    int16_t* conn;
+    ConnT* conn;
     {
-        const uint64_t off = (ar.used + 1) & ~1ull;
-        const uint64_t room = ar.cap > off ? (ar.cap - off) / 2 : 0;
-        if (room < max_pairs) return off + 2 * max_pairs;
+        const uint64_t off = (ar.used + sizeof(ConnT) - 1) & ~(uint64_t)(sizeof(ConnT) - 1);
+        const uint64_t room = ar.cap > off ? (ar.cap - off) / sizeof(ConnT) : 0;
+        if (room < max_pairs) return off + sizeof(ConnT) * max_pairs;
         q_cap = room < total_pairs ? room : total_pairs;
-        conn = reinterpret_cast<int16_t*>(ar.base + off);
+        conn = reinterpret_cast<ConnT*>(ar.base + off);
     }
     __syncthreads();
     PROF_MARK(4);
@@ -543,7 +545,7 @@ __device__ __forceinline__ uint64_t process_sentence(const DevDict& D, const Bat
     // ---- P3b/P4: per block of steps: gather the connection costs of every (candidate,
     // predecessor) pair into `conn` with many loads in flight (addresses depend on ids only),
     // then run the cost recurrence of search_min_node/insert_node (lattice.rs:103-151) from LDS.
-    const int16_t* __restrict__ matrix = D.matrix;
+    const ConnT* __restrict__ matrix = reinterpret_cast<const ConnT*>(D.matrix);
     const uint32_t NR = D.num_right;
     for (uint32_t k = 0; k < S;) {
         uint32_t kend = k;
@@ -612,7 +614,7 @@ __device__ __forceinline__ uint64_t process_sentence(const DevDict& D, const Bat
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u)
-                    if (idx[u] != 0xFFFFFFFFu) conn[idx[u]] = (int16_t)val[u];
+                    if (idx[u] != 0xFFFFFFFFu) conn[idx[u]] = (ConnT)val[u];
             }
         }
         __syncthreads();
@@ -635,7 +637,7 @@ __device__ __forceinline__ uint64_t process_sentence(const DevDict& D, const Bat
                         // argmin over packed keys: minimum key = minimum cost, ties -> largest insertion
                         // sequence number, i.e. the `<=` of search_min_node (lattice.rs:141-146)
                         uint64_t best = kDeadKey;
-                        const int16_t* col = conn + soff + ci_;
+                        const ConnT* col = conn + soff + ci_;
                         const uint64_t* pk = e_key + p_beg;
                         for (uint32_t j = 0; j < np; j += 8) {
 #pragma unroll
@@ -1255,8 +1257,8 @@ __global__ void __launch_bounds__(64) gen_candidates_large(DevDict D, BatchArgs 
 // minimum cost, ties to the last inserted predecessor = the `<=` of lattice.rs:141-146.  Steps of more than 64 pairs simply
 // take several passes; the candidate keys start dead and accumulate.  LDS operations of one wave execute in order, so no
 // barrier separates a pass from the next.
-template <bool kSpaceMode>
-__global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, BatchArgs A, uint32_t tier, uint32_t list_id, uint32_t persistent) {
+template <bool kSpaceMode, bool kWide>
+__device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const BatchArgs& A, uint32_t tier, uint32_t sid) {
     typedef __attribute__((address_space(3))) const uint64_t lds_cu64;
     typedef __attribute__((address_space(3))) uint64_t lds_u64;
     typedef __attribute__((address_space(3))) const uint16_t lds_cu16;
@@ -1266,31 +1268,11 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
     constexpr uint32_t kDepth = VBT_DEPTH;  // prefetch distance of the matrix gathers, in passes
     // absolute LDS address of the dynamic shared memory (records hold absolute addresses: no base add per access)
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)g_smem;
-    // long sentences are the critical path of a batch: let their waves win issue arbitration
-    if (A.tier_prio && (A.seg_tier < A.n_tiers ? tier >= A.seg_tier : tier + A.tier_prio >= A.n_tiers)) __builtin_amdgcn_s_setprio(2);
-    const int src = (int)list_id;  // normally the tier's own list; helper launches sweep the segment tier's list with less LDS
-    const uint32_t* list = A.lists + (size_t)src * A.list_stride + A.list_off;
-    const uint32_t count = A.cctrl[2 * src];
-    uint32_t* cursor = &A.cctrl[2 * src + 1];
     auto uniform4 = [](uint4 q) {
         return make_uint4(__builtin_amdgcn_readfirstlane(q.x), __builtin_amdgcn_readfirstlane(q.y),
                           __builtin_amdgcn_readfirstlane(q.z), __builtin_amdgcn_readfirstlane(q.w));
     };
-    // Work distribution: one list entry per workgroup (the grid covers the batch; a returning atomic on a hot word costs
-    // ~11 ns of a serial resource, which bounds a kernel at ~88 M entries/s however fast the waves are), or -- escape tiers,
-    // whose lists are short -- persistent waves that draw entries from a cursor.
-    bool first_item = true;
-    for (;;) {
-        uint32_t item = blockIdx.x;
-        if (persistent) {
-            if (ln == 0) item = atomicAdd(cursor, 1u);
-            item = __builtin_amdgcn_readfirstlane(item);  // lane 0 is always active here; keeps everything below scalar
-        } else if (!first_item) break;
-        first_item = false;
-        if (item >= count) break;
-        // newest entries first: the large-LDS generator levels append their (long, slow) sentences last, level by level,
-        // so reading the list backwards starts the longest sentences first instead of leaving them as the tail
-        const uint32_t sid = __builtin_amdgcn_readfirstlane(list[count - 1 - item]);
+    {
         // profiling adds straight into the spread counters: nothing but the last time stamp lives between marks
         uint64_t prof_t = A.prof ? clock64() : 0;
         unsigned long long* const pr_ = A.prof ? A.prof + (size_t)(sid & (kProfSlots - 1)) * kProfWords : nullptr;
@@ -1571,7 +1553,12 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
                 // texture addresser 8 % of the kernel, measured)
                 const uint64_t mask = ((uint64_t)smhi[u] << 32) | smlo[u];
                 const uint32_t cell = __umul24(cd.y >> 16, NR) + right;
-                word[u] = (uint32_t)(int32_t)(int16_t)__builtin_amdgcn_raw_buffer_load_b16(mrs, (int)select_mask(mask, 0u, cell << 1), 0, 0);
+#ifdef VBT_NO_GATHER  // ceiling experiment (profiles/): the sweep WITHOUT its matrix gather -- wrong results by design, never shipped
+                word[u] = cell & 0xFFu; (void)mrs; (void)mask;
+                if constexpr (false)
+#endif
+                if constexpr (kWide) word[u] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(mrs, (int)select_mask(mask, 0u, cell << 2), 0, 0);  // i32 cells
+                else word[u] = (uint32_t)(int32_t)(int16_t)__builtin_amdgcn_raw_buffer_load_b16(mrs, (int)select_mask(mask, 0u, cell << 1), 0, 0);
                 taddr[u] = offK + ((cd.x & 0xFFFFu) << 3);
                 cw[u] = __builtin_amdgcn_perm(cd.x, cd.y, 0x07060100u);  // word cost (high half of x) << 16 | own field (low half of y)
             };
@@ -1799,6 +1786,43 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
             }
         }
         }  // segments
+        if (fail) return fail;
+        PROF_MARK(7);
+        if (A.prof && ln == 0) {
+            atomicAdd(&pr_[kProfPhases + 1], (unsigned long long)prof_S);
+            atomicAdd(&pr_[kProfPhases + 2], (unsigned long long)prof_SL);
+            atomicAdd(&pr_[kProfPhases + 3], (unsigned long long)CT);
+        }
+#undef PROF_MARK
+    }
+    return 0;
+}
+
+template <bool kSpaceMode, bool kWide>
+__global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, BatchArgs A, uint32_t tier, uint32_t list_id, uint32_t persistent) {
+    const uint32_t ln = threadIdx.x;
+    // long sentences are the critical path of a batch: let their waves win issue arbitration
+    if (A.tier_prio && (A.seg_tier < A.n_tiers ? tier >= A.seg_tier : tier + A.tier_prio >= A.n_tiers)) __builtin_amdgcn_s_setprio(2);
+    const int src = (int)list_id;  // normally the tier's own list; helper launches sweep the segment tier's list with less LDS
+    const uint32_t* list = A.lists + (size_t)src * A.list_stride + A.list_off;
+    const uint32_t count = A.cctrl[2 * src];
+    uint32_t* cursor = &A.cctrl[2 * src + 1];
+    // Work distribution: one list entry per workgroup (the grid covers the batch; a returning atomic on a hot word costs
+    // ~11 ns of a serial resource, which bounds a kernel at ~88 M entries/s however fast the waves are), or -- escape tiers,
+    // whose lists are short -- persistent waves that draw entries from a cursor.
+    bool first_item = true;
+    for (;;) {
+        uint32_t item = blockIdx.x;
+        if (persistent) {
+            if (ln == 0) item = atomicAdd(cursor, 1u);
+            item = __builtin_amdgcn_readfirstlane(item);  // lane 0 is always active here; keeps everything below scalar
+        } else if (!first_item) break;
+        first_item = false;
+        if (item >= count) break;
+        // newest entries first: the large-LDS generator levels append their (long, slow) sentences last, level by level,
+        // so reading the list backwards starts the longest sentences first instead of leaving them as the tail
+        const uint32_t sid = __builtin_amdgcn_readfirstlane(list[count - 1 - item]);
+        const uint32_t fail = lattice_sentence<kSpaceMode, kWide>(D, A, tier, sid);
         if (fail) {
             // Could not be swept here (no admissible cut, estimates too low, ...): the next escape tier -- more LDS,
             // launched behind this one -- retries; after the last one the fused kernel with the global-memory
@@ -1807,18 +1831,45 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
             const bool escape = tier >= A.seg_tier && tier + 1 < A.n_tiers && fail != 27;
             if (ln == 0 && !escape) atomicAdd(&A.ctrl[fail < 32 ? fail : 28], 1u);
             list_push(A, escape ? tier + 1 : A.n_tiers, sid);
-            __syncthreads();
-            continue;
         }
-        PROF_MARK(7);
-        if (A.prof && ln == 0) {
-            atomicAdd(&pr_[kProfPhases + 1], (unsigned long long)prof_S);
-            atomicAdd(&pr_[kProfPhases + 2], (unsigned long long)prof_SL);
-            atomicAdd(&pr_[kProfPhases + 3], (unsigned long long)CT);
-        }
-#undef PROF_MARK
         __syncthreads();
     }
+}
+
+// Worker::tokenize() latency path (worker.rs:49-55; the 3-call loop of tokenize/src/main.rs:78-82): ONE launch, one wavefront, one
+// sentence.  The text comes straight out of the worker's pinned host block (`h_text`, one PCIe round trip: 16 bytes per lane per
+// request into a device copy), the generator and the sweep run back to back in the same wave (what gen_one leaves in global memory is
+// read back by the wave that wrote it: a workgroup-scope fence is all it takes), and the token records, their count and the status
+// word go straight back into pinned host memory (posted writes): no copy engine, no second launch, no allocation.  status: 0 = done,
+// 1 = this sentence needs the batch pipeline (longer than the generator's LDS, unsweepable in segments, a word > 64 characters...).
+template <bool kSpaceMode, bool kWide>
+__global__ void __launch_bounds__(64) tokenize_one(DevDict D, BatchArgs A, uint32_t lds_bytes, const uint8_t* h_text, uint32_t nb, uint32_t* status) {
+    const uint32_t ln = threadIdx.x;
+    {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4* __restrict__ src = reinterpret_cast<const u32x4*>(h_text);  // (the pinned block is padded to 16 bytes)
+        u32x4* dst = reinterpret_cast<u32x4*>(const_cast<uint8_t*>(A.text));
+        for (uint32_t i = ln; i * 16 < nb; i += 64) dst[i] = src[i];
+        uint64_t* offs = const_cast<uint64_t*>(A.offsets);
+        if (ln == 0) { offs[0] = 0; offs[1] = nb; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    gen_one<false>(D, A, 0u, lds_bytes, 0u);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const uint32_t tier = __builtin_amdgcn_readfirstlane((uint32_t)A.s_tier[0]);
+    uint32_t st = 0;
+    if (tier == 0u) st = lattice_sentence<kSpaceMode, kWide>(D, A, 0u, 0u) ? 1u : 0u;
+    else if (tier != 0xFFu) st = 1u;  // 0xFF: an empty sentence, tok_cnt = 0 is already written
+    // every lane's token stores have to be visible to the host before the status word is (the host may spin on it instead of
+    // waiting for the stream): system-scope release by all lanes, then one releasing store
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (ln == 0) __hip_atomic_store(status, st, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 __device__ __forceinline__ void push_overflow(uint32_t* list, uint32_t* counter, uint32_t sid) {
@@ -1828,13 +1879,14 @@ __device__ __forceinline__ void push_overflow(uint32_t* list, uint32_t* counter,
 // LDS tiers: one wavefront per sentence, lattice in `lds_bytes` of LDS.  in_list == nullptr: the
 // grid covers all sentences (block b = sentence b); otherwise persistent waves drain in_list.
 // Sentences that do not fit go to out_list for the next (larger) tier.
+template <bool kWide>
 __global__ void __launch_bounds__(64) tokenize_lds(DevDict D, BatchArgs A, uint32_t lds_bytes, const uint32_t* in_list,
                                                    const uint32_t* in_count, uint32_t* cursor, uint32_t* out_list,
                                                    uint32_t* out_count) {
     if (in_list == nullptr) {
         if (batch_rejected(A)) return;
         const uint32_t sid = blockIdx.x;
-        if (process_sentence<uint16_t, false>(D, A, sid, g_smem, lds_bytes) != 0) push_overflow(out_list, out_count, sid);
+        if (process_sentence<uint16_t, false, kWide>(D, A, sid, g_smem, lds_bytes) != 0) push_overflow(out_list, out_count, sid);
         return;
     }
     const uint32_t count = *in_count;
@@ -1844,12 +1896,13 @@ __global__ void __launch_bounds__(64) tokenize_lds(DevDict D, BatchArgs A, uint3
         k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
         if (k >= count) break;
         const uint32_t sid = in_list[k];
-        if (process_sentence<uint16_t, false>(D, A, sid, g_smem, lds_bytes) != 0) push_overflow(out_list, out_count, sid);
+        if (process_sentence<uint16_t, false, kWide>(D, A, sid, g_smem, lds_bytes) != 0) push_overflow(out_list, out_count, sid);
         __syncthreads();
     }
 }
 
 // Last tier: persistent waves, lattice in a private global-memory slab (any sentence length).
+template <bool kWide>
 __global__ void __launch_bounds__(64) tokenize_global(DevDict D, BatchArgs A, const uint32_t* in_list, const uint32_t* in_count,
                                                       uint32_t* cursor) {
     const uint32_t count = *in_count;
@@ -1863,7 +1916,7 @@ __global__ void __launch_bounds__(64) tokenize_global(DevDict D, BatchArgs A, co
         if (k >= count) break;
         const uint32_t sid = in_list[k];
         for (int attempt = 0; attempt < 5; ++attempt) {
-            const uint64_t need = process_sentence<uint32_t, true>(D, A, sid, slab, slab_bytes);
+            const uint64_t need = process_sentence<uint32_t, true, kWide>(D, A, sid, slab, slab_bytes);
             if (need == 0) break;
             bool failed = need == kNoFit || attempt == 4;
             if (!failed) {  // grow: take a fresh slab from the bump arena
@@ -1971,7 +2024,8 @@ struct DevConnector {
     const int16_t* m; const uint16_t* right_map; const uint16_t* left_map;  // dual only (m == nullptr: raw)
     uint32_t m_num_right;
 };
-__global__ void __launch_bounds__(256) expand_connector(DevConnector c, int16_t* out, uint32_t num_right, uint32_t num_left, uint32_t* range_flag) {
+template <typename CellT>
+__global__ void __launch_bounds__(256) expand_connector(DevConnector c, CellT* out, uint32_t num_right, uint32_t num_left, uint32_t* range_flag) {
     const uint32_t right = blockIdx.x * 256 + threadIdx.x, left = blockIdx.y;
     if (right >= num_right) return;
     const uint32_t* __restrict__ k1 = c.right_feats + (size_t)right * c.width;
@@ -1987,7 +2041,7 @@ __global__ void __launch_bounds__(256) expand_connector(DevConnector c, int16_t*
     if (c.m) sum += (uint32_t)(int32_t)c.m[(size_t)c.left_map[left] * c.m_num_right + c.right_map[right]];
     const int32_t v = (int32_t)sum;
     if (v < -32768 || v > 32767) atomicOr(range_flag, 1u);
-    out[(size_t)left * num_right + right] = (int16_t)v;
+    out[(size_t)left * num_right + right] = (CellT)v;
 }
 
 template <typename T>
@@ -2037,23 +2091,29 @@ Tokenizer::Tokenizer(const Dictionary* dict, bool ignore_space, uint32_t max_gro
         dev_.has_user = dict_->has_user ? 1 : 0;
         if (dict_->has_user) upload_lexicon(dict_->user, dev_.user);
         else dev_.user = dev_.sys;
+        {   // lattice_lds addresses cells with 32-bit byte offsets through a buffer resource (checked before anything is allocated)
+            const uint64_t bytes = (uint64_t)dict_->num_left * dict_->num_right * 2;
+            if (bytes >= (1ull << 32)) throw Error(VBT_ERR_UNSUPPORTED, "connector: connection matrices of 4 GiB and more are not supported by the device image");
+            dev_.matrix_bytes = (uint32_t)bytes;
+        }
         if (dict_->conn_kind == kConnMatrix) {  // + 1 element: lattice_lds reads the aligned 32-bit word around a cell
             std::vector<int16_t> padded(dict_->matrix);
             padded.push_back(0);
             dev_.matrix = dev_upload(padded, allocs_);
         } else {
+            // Compact connectors: evaluated once into a dense matrix (expand_connector).  i16 cells when every cost fits (the
+            // released compact dictionaries: their costs are the matrix.def values of the full ones), else i32 cells -- the
+            // reference's Raw / Dual cost is an i32 sum (raw_connector.rs:153-161, dual_connector.rs:267-279) -- read by the
+            // kWide instances of the sweep kernels.
             const bool is_dual = dict_->conn_kind == kConnDual;
             const Scorer& sc = is_dual ? dict_->dual.scorer : dict_->raw.scorer;
+            const size_t cells = (size_t)dict_->num_left * dict_->num_right;
             std::vector<void*> tmp;  // the compact structures are only needed by the expansion
-            int16_t* m = nullptr;
-            HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&m), ((size_t)dict_->num_left * dict_->num_right + 1) * 2));
-            allocs_.push_back(m);
-            uint32_t* flag = nullptr;
             try {
+                uint32_t* flag = nullptr;
                 HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&flag), 16));
                 tmp.push_back(flag);
                 HIP_CHECK(hipMemset(flag, 0, 16));
-                HIP_CHECK(hipMemset(m + (size_t)dict_->num_left * dict_->num_right, 0, 2));
                 DevConnector c{};
                 c.bases = dev_upload(sc.bases, tmp); c.checks = dev_upload(sc.checks, tmp); c.costs = dev_upload(sc.costs, tmp);
                 c.n_bases = (uint32_t)sc.bases.size(); c.n_checks = (uint32_t)sc.checks.size();
@@ -2066,26 +2126,43 @@ Tokenizer::Tokenizer(const Dictionary* dict, bool ignore_space, uint32_t max_gro
                     c.left_map = dev_upload(dict_->dual.left_map, tmp);
                     c.m_num_right = dict_->dual.m_num_right;
                 }
-                hipLaunchKernelGGL(expand_connector, dim3((dict_->num_right + 255) / 256, dict_->num_left), dim3(256), 0, nullptr, c, m,
-                                   dict_->num_right, dict_->num_left, flag);
+                const dim3 grid((dict_->num_right + 255) / 256, dict_->num_left);
+                int16_t* m = nullptr;
+                HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&m), (cells + 1) * 2));
+                tmp.push_back(m);
+                HIP_CHECK(hipMemset(m + cells, 0, 2));
+                hipLaunchKernelGGL(expand_connector<int16_t>, grid, dim3(256), 0, nullptr, c, m, dict_->num_right, dict_->num_left, flag);
                 uint32_t out_of_range = 0;
                 HIP_CHECK(hipMemcpy(&out_of_range, flag, 4, hipMemcpyDeviceToHost));
+                if (!out_of_range) {
+                    tmp.pop_back();
+                    allocs_.push_back(m);
+                    dev_.matrix = m;
+                } else {
+                    if ((uint64_t)cells * 4 >= (1ull << 32))
+                        throw Error(VBT_ERR_UNSUPPORTED, "connector: i32 connection matrices of 4 GiB and more are not supported by the device image");
+                    (void)hipFree(m);
+                    tmp.pop_back();
+                    int32_t* w = nullptr;
+                    HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&w), (cells + 1) * 4));
+                    tmp.push_back(w);
+                    HIP_CHECK(hipMemset(w + cells, 0, 4));
+                    hipLaunchKernelGGL(expand_connector<int32_t>, grid, dim3(256), 0, nullptr, c, w, dict_->num_right, dict_->num_left, flag);
+                    HIP_CHECK(hipDeviceSynchronize());
+                    tmp.pop_back();
+                    allocs_.push_back(w);
+                    dev_.matrix = reinterpret_cast<const int16_t*>(w);
+                    dev_.matrix_wide = 1;
+                    dev_.matrix_bytes = (uint32_t)(cells * 4);
+                }
                 for (void* p : tmp) (void)hipFree(p);
                 tmp.clear();
-                if (out_of_range)
-                    throw Error(VBT_ERR_UNSUPPORTED, "connector: a connection cost of the compact connector does not fit the i16 matrix of the device image");
             } catch (...) {
                 for (void* p : tmp) (void)hipFree(p);
                 throw;
             }
-            dev_.matrix = m;
         }
         dev_.num_right = dict_->num_right;
-        {   // lattice_lds addresses cells with 32-bit byte offsets through a buffer resource
-            const uint64_t bytes = (uint64_t)dict_->num_left * dict_->num_right * 2;
-            if (bytes >= (1ull << 32)) throw Error(VBT_ERR_UNSUPPORTED, "connector: connection matrices of 4 GiB and more are not supported by the device image");
-            dev_.matrix_bytes = (uint32_t)bytes;
-        }
         dev_.chr2inf = dev_upload(dict_->chr2inf, allocs_);
         dev_.unk_off = dev_upload(dict_->unk_offsets, allocs_);
         dev_.unk_entries = dev_upload(dict_->unk_entries, allocs_);
@@ -2190,8 +2267,10 @@ Workspace::Workspace(const Tokenizer& t, uint64_t max_s, uint64_t max_b) : tok(t
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gen_candidates_large), hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
         if (tiers.back() > 65536)  // a single workgroup may use the CU's whole 160 KiB
         {
-            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lattice_lds<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tiers.back()));
-            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lattice_lds<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tiers.back()));
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lattice_lds<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tiers.back()));
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lattice_lds<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tiers.back()));
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lattice_lds<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tiers.back()));
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lattice_lds<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tiers.back()));
         }
     }
     } catch (...) {  // a failed hipMalloc / stream / event must not leak what was created before it
@@ -2265,13 +2344,14 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
     if (fused) {
         auto count = [&](size_t t) { return d_cctrl + 2 * t; };
         auto cursor = [&](size_t t) { return d_cctrl + 2 * t + 1; };
-        hipLaunchKernelGGL(tokenize_lds, dim3((uint32_t)n), dim3(64), tiers[0], stream, D, a, tiers[0], (const uint32_t*)nullptr,
+        auto fused_lds = D.matrix_wide ? tokenize_lds<true> : tokenize_lds<false>;
+        hipLaunchKernelGGL(fused_lds, dim3((uint32_t)n), dim3(64), tiers[0], stream, D, a, tiers[0], (const uint32_t*)nullptr,
                            (const uint32_t*)nullptr, (uint32_t*)nullptr, over(0), count(0));
         rec(1);
         for (size_t t = 1; t < T; ++t)
-            hipLaunchKernelGGL(tokenize_lds, dim3(waves_for(tiers[t], n)), dim3(64), tiers[t], stream, D, a, tiers[t],
+            hipLaunchKernelGGL(fused_lds, dim3(waves_for(tiers[t], n)), dim3(64), tiers[t], stream, D, a, tiers[t],
                                (const uint32_t*)over(t - 1), (const uint32_t*)count(t - 1), cursor(t), over(t), count(t));
-        hipLaunchKernelGGL(tokenize_global, dim3((uint32_t)std::min<uint64_t>(n, 1024)), dim3(64), 0, stream, D, a,
+        hipLaunchKernelGGL(D.matrix_wide ? tokenize_global<true> : tokenize_global<false>, dim3((uint32_t)std::min<uint64_t>(n, 1024)), dim3(64), 0, stream, D, a,
                            (const uint32_t*)over(T - 1), (const uint32_t*)count(T - 1), cursor(T));
     } else {
         // Stream plan.  The launch stream runs gen_candidates -> build_lists -> gen_candidates_large (stragglers
@@ -2326,8 +2406,9 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
         // launched on the segment tier's stream, behind it.
         const uint32_t persist = env_u32("VBT_LAT_PERSIST", 0);
         auto launch_lattice = [&](dim3 grid_, uint32_t lds_, hipStream_t st_, uint32_t tier_, uint32_t list_, uint32_t persistent_) {
-            if (D.space_cateset) hipLaunchKernelGGL(lattice_lds<true>, grid_, dim3(64), lds_, st_, D, a, tier_, list_, persistent_);
-            else hipLaunchKernelGGL(lattice_lds<false>, grid_, dim3(64), lds_, st_, D, a, tier_, list_, persistent_);
+            auto k = D.space_cateset ? (D.matrix_wide ? lattice_lds<true, true> : lattice_lds<true, false>)
+                                     : (D.matrix_wide ? lattice_lds<false, true> : lattice_lds<false, false>);
+            hipLaunchKernelGGL(k, grid_, dim3(64), lds_, st_, D, a, tier_, list_, persistent_);
         };
         const size_t n_conc = a.seg_tier < T ? a.seg_tier + 1 : T;
         bool dense_launched = false;
@@ -2369,7 +2450,7 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
         for (size_t t = 0; t < n_conc; ++t)
             if (!(main_seg && t == a.seg_tier)) HIP_CHECK(hipStreamWaitEvent(stream, reinterpret_cast<hipEvent_t>(tier_events[t]), 0));
         // whatever the pipeline could not take: fused kernel, global-memory lattice
-        hipLaunchKernelGGL(tokenize_global, dim3((uint32_t)std::min<uint64_t>(cn, 1024)), dim3(64), 0, stream, D, a,
+        hipLaunchKernelGGL(D.matrix_wide ? tokenize_global<true> : tokenize_global<false>, dim3((uint32_t)std::min<uint64_t>(cn, 1024)), dim3(64), 0, stream, D, a,
                            (const uint32_t*)over(T), (const uint32_t*)(d_cctrl + 2 * T), d_cctrl + 2 * T + 1);
     }
     {   // pack the tokens in sentence order (tok_off, total)
@@ -2379,6 +2460,31 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
         hipLaunchKernelGGL(compact_tokens, dim3(n_tiles), dim3(kScanBlock), 0, stream, a, (const uint32_t*)d_tile_sums);
     }
     rec(2);
+    HIP_CHECK(hipGetLastError());
+}
+
+void Workspace::run_one(const uint8_t* h_text_dev, uint32_t nb, uint8_t* d_text, uint64_t* d_offsets, vbt_token_rec* tokens_out, uint32_t* count_out,
+                        uint32_t* status_out, void* stream_) {
+    if (fused) throw Error(VBT_ERR_UNSUPPORTED, "the single-launch path needs the two-kernel pipeline (unset VBT_FUSED)");
+    if (nb > max_bytes) throw Error(VBT_ERR_INVALID_ARGUMENT, "sentence exceeds the workspace capacity");
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    last_n = 1;
+    last_stream = stream_;
+    BatchArgs a = pipe;
+    a.text = d_text; a.offsets = d_offsets; a.n = 1;
+    a.tokens = d_tokens; a.tok_stage = tokens_out; a.tok_cap = (uint32_t)std::max<uint64_t>(max_bytes, 1);
+    a.tok_off = d_tok_off; a.tok_cnt = count_out; a.ctrl = d_ctrl;
+    a.scratch = d_scratch; a.scratch_bytes = scratch_bytes;
+    a.prof = nullptr;
+    a.lists = d_over; a.list_stride = (uint32_t)(2 * std::max<uint64_t>(max_sentences, 1)); a.n_tiers = 1;
+    a.tier_prio = 0; a.seg_tier = 0; a.sid0 = 0; a.cctrl = d_cctrl; a.list_off = 0; a.early_fork = 0; a.direct_push = 0; a.s_skip = nullptr;
+    a.lid_count = nullptr; a.rid_count = nullptr; a.s_counted = nullptr;
+    constexpr uint32_t kOneLds = 65536;  // generator arrays (~26 B per character), then the lattice (whole up to ~400 characters, in segments beyond)
+    a.tier_bytes[0] = kOneLds;
+    const DevDict& D = tok.dev();
+    auto k = D.space_cateset ? (D.matrix_wide ? tokenize_one<true, true> : tokenize_one<true, false>)
+                             : (D.matrix_wide ? tokenize_one<false, true> : tokenize_one<false, false>);
+    hipLaunchKernelGGL(k, dim3(1), dim3(64), kOneLds, stream, D, a, kOneLds, h_text_dev, nb, status_out);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -22,9 +22,10 @@ struct DevLexicon {
 struct DevDict {
     DevLexicon sys, user;
     int has_user;
-    const int16_t* matrix;  // [num_left][num_right]
+    const int16_t* matrix;  // [num_left][num_right]; i32 cells when matrix_wide (a compact connector whose costs leave i16)
     uint32_t num_right;
-    uint32_t matrix_bytes;        // num_left * num_right * 2 (< 2^32: both <= 65535 ... checked at upload)
+    uint32_t matrix_bytes;        // bytes of the matrix (< 2^32: checked at upload)
+    uint32_t matrix_wide;
     const uint32_t* chr2inf;      // 65536 packed CharInfo
     const uint32_t* unk_off;      // n_categories + 1
     const Entry* unk_entries;
@@ -130,6 +131,12 @@ class Workspace {
     ~Workspace();
     void run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n, uint64_t total_bytes, void* stream);
     void stats(vbt_call_stats* out);  // synchronizes the last stream used
+    // Worker::tokenize() latency path: one sentence of `nb` bytes at `h_text_dev` (device address of pinned host memory, padded to
+    // 16 bytes), ONE launch; `d_text` (>= nb + 16 bytes) / `d_offsets` (2 words) are device scratch of the caller; the token records,
+    // their count and a status word (0 = done, 1 = take the batch pipeline) are written through `tokens_out` / `count_out` /
+    // `status_out` (device addresses of pinned host memory).  Asynchronous on `stream`.
+    void run_one(const uint8_t* h_text_dev, uint32_t nb, uint8_t* d_text, uint64_t* d_offsets, vbt_token_rec* tokens_out, uint32_t* count_out,
+                 uint32_t* status_out, void* stream);
 
     const Tokenizer& tok;
     uint64_t max_sentences, max_bytes;
