@@ -121,13 +121,14 @@ def test_all_tiers_agree(tiers, fused, monkeypatch):
     _assert_batch_equal(to, tv, text, offs)
 
 
-@pytest.mark.parametrize("env", [{"VBT_LONG_BYTES": "200"}, {"VBT_GEN_LDS": "2048"}, {"VBT_GEN_LDS": "3072", "VBT_LONG_BYTES": "300"},
+@pytest.mark.parametrize("env", [{"VBT_GEN_LDS": "2048"}, {"VBT_GEN_LDS": "1024", "VBT_GEN_WAVES": "2"}, {"VBT_GEN_LDS": "3072", "VBT_GEN_WAVES": "8"},
+                                 {"VBT_GEN_LDS": "2048", "VBT_GEN_LEVELS": "4096,8192,163840", "VBT_GEN_WAVES": "1"},
                                  {"VBT_SEG_BYTES": "0"}, {"VBT_SEG_BYTES": "8192"}, {"VBT_TIERS": "4096,16384", "VBT_SEG_BYTES": "4096"},
                                  {"VBT_TIERS": "3072", "VBT_SEG_BYTES": "2048"}])
 def test_generator_scheduling_variants_agree(env, monkeypatch):
-    """The optional long-first side stream, a tiny bulk-generator LDS (most sentences become stragglers of the
-    large-LDS generator, which then appends to the work lists directly) and the segmented sweep of sentences
-    that do not fit the segment tier (split at clean cuts, interface carried over) must not change a single token."""
+    """A tiny bulk-generator LDS (most sentences then go through gen_long, the multi-wavefront generator, with 1 / 2 / 4 / 8
+    wavefronts per workgroup and through its small levels) and the segmented sweep of sentences that do not fit the segment tier
+    (split at clean cuts, interface carried over) must not change a single token."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     sd = synth.SynthDict("small")

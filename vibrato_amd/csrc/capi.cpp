@@ -86,6 +86,7 @@ struct vbt_worker {
     vbt_token_rec* hd_tokens = nullptr;
     hipStream_t stream = nullptr;
     int spin = -1;  // wait for the status word in pinned memory instead of the stream's completion signal (VBT_WORKER_SPIN, default 1)
+    int single = 1;  // VBT_WORKER_SINGLE=0: every sentence through the batch pipeline (round-2 behaviour, kept for A/B)
     uint64_t n_fast = 0, n_slow = 0;  // sentences served by the single launch / handed to the batch pipeline
     std::vector<vbt_token_rec> tokens;
     // ConnIdCounter of Worker::init_connid_counter (worker.rs:77-84, mapper.rs:87-106); empty = never initialised
@@ -478,11 +479,16 @@ int vbt_worker_tokenize(vbt_worker* w) {
             w->hd_ctl = reinterpret_cast<uint32_t*>(w->hd_text + ctl_off);
             w->hd_tokens = reinterpret_cast<vbt_token_rec*>(w->hd_text + tok_off);
             if (!w->stream) HIPX(hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking));
-            if (w->spin < 0) { const char* e = std::getenv("VBT_WORKER_SPIN"); w->spin = e && *e ? std::atoi(e) : 1; }
+            if (w->spin < 0) {
+                const char* e = std::getenv("VBT_WORKER_SPIN");
+                w->spin = e && *e ? std::atoi(e) : 1;
+                e = std::getenv("VBT_WORKER_SINGLE");
+                w->single = e && *e ? std::atoi(e) : 1;
+            }
             w->cap = cap;
         }
         const bool counting = !w->lid_count.empty();
-        if (!counting && !w->ws->fused) {
+        if (!counting && !w->ws->fused && w->single) {
             std::memcpy(w->h_text, w->text.data(), len);
             volatile uint32_t* ctl = w->h_ctl;
             ctl[0] = 0xFFFFFFFFu; ctl[1] = 0;

@@ -815,33 +815,33 @@ __device__ __forceinline__ void list_push(const BatchArgs& A, uint32_t t, uint32
     if (threadIdx.x == 0) A.lists[(size_t)t * A.list_stride + A.list_off + atomicAdd(&A.cctrl[2 * t], 1u)] = sid;
 }
 
+// LDS bytes gen_long needs for a sentence of n characters / nb bytes (an over-estimate of its Arena carve: gen_one files a
+// sentence that outgrows it at the smallest level that holds it).
+__host__ __device__ __forceinline__ uint64_t gen_long_bytes(uint32_t n, uint32_t nb, bool has_user) {
+    return 64 + 2 * ((uint64_t)(nb >> 6) + 4) + (uint64_t)(n + 2) * (has_user ? 18u : 16u) + 64;
+}
+
 // Kernel 1 body: Sentence::compile + candidate enumeration of one sentence by one wavefront.
 // Per-character working arrays live in LDS (the vector L1 stalls on hit-under-miss, so nothing
 // is re-read from global while in flight); outputs: per-char records, byte offsets and the
 // candidates in reference insertion order, each tagged with its (start position, left_id) group:
 // search_min_node's result depends only on that pair (lattice.rs:129-151), so the lattice kernel
 // evaluates one row per group instead of one per candidate.
-// kLarge: the instances behind the bulk generator (level 1..3).  They keep the two widest per-character arrays -- the length
-// masks and the candidate offsets, 12 of 26 bytes -- in the sentence's per-character records in global memory instead of LDS
-// (written during the walk, read back in place when the records are finalised: every read there is of a position that has not
-// been finalised yet), so a level holds twice the characters and long sentences run at twice the occupancy.
-template <bool kLarge>
-__device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, uint32_t sid, uint32_t lds_bytes, uint32_t level) {
-    const bool large = kLarge;  // level 0: bulk generator; 1, 2, 3: the large- / whole-CU-LDS instances behind it
+// (Sentences that outgrow this wavefront's LDS -- ~26 bytes per character -- are handed to gen_long: one workgroup per sentence.)
+__device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, uint32_t sid, uint32_t lds_bytes) {
     const uint32_t ln = threadIdx.x;
     const uint64_t lt_mask = (1ull << ln) - 1ull;
     uint64_t prof_t = A.prof ? clock64() : 0, prof_acc[3] = {};
 #define PROF_MARK(i) do { if (A.prof) { const uint64_t t_ = clock64(); prof_acc[i] += t_ - prof_t; prof_t = t_; } } while (0)
     const uint64_t b0 = A.offsets[sid], nb64 = A.offsets[sid + 1] - b0;
-    const uint32_t fallback = A.n_tiers, large_list = level >= kGenLevels ? A.n_tiers : A.n_tiers + 1 + level;  // where a sentence goes that outgrows this instance
+    const uint32_t fallback = A.n_tiers;
     // gen routes a sentence by writing its list index; build_lists turns that into work lists with
     // wave-aggregated atomics (a per-sentence atomic on a hot word caps the kernel at ~88 M/s)
     auto route = [&](uint32_t t) {
-        if (A.direct_push) list_push(A, t, sid);  // the few stragglers behind build_lists
+        if (A.direct_push) list_push(A, t, sid);  // (Worker's single launch: no build_lists behind it)
         else if (ln == 0) A.s_tier[sid] = (uint8_t)t;
     };
-    if (!large && A.s_skip && A.s_skip[sid] != 0xFF) return;  // a long sentence: the early pipeline owns it
-    if (ln == 0 && !large) { A.s_n[sid] = 0; A.s_C[sid] = 0; A.s_tier[sid] = 0xFF; }
+    if (ln == 0) { A.s_n[sid] = 0; A.s_C[sid] = 0; A.s_tier[sid] = 0xFF; }
     if (nb64 == 0) {
         if (ln == 0) A.tok_cnt[sid] = 0;
         return;
@@ -862,20 +862,25 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
         return;
     }
     Arena ar{g_smem, lds_bytes, 0, true};
-    uint64_t* lens = kLarge ? nullptr : ar.take<uint64_t>(n);
+    uint64_t* lens = ar.take<uint64_t>(n);
     uint32_t* ci = ar.take<uint32_t>(n);
-    uint32_t* cand_off = kLarge ? nullptr : ar.take<uint32_t>(n + 1);
-    uint4* const pcw = A.g_pc + slot0;  // kLarge: .x = candidate offset, .z/.w = length mask until the records are finalised
-    auto set_lens = [&](uint32_t i, uint64_t v) { if constexpr (kLarge) { pcw[i].z = (uint32_t)v; pcw[i].w = (uint32_t)(v >> 32); } else lens[i] = v; };
-    auto get_lens = [&](uint32_t i) -> uint64_t { if constexpr (kLarge) { const uint4 r = pcw[i]; return ((uint64_t)r.w << 32) | r.z; } else return lens[i]; };
-    auto set_co = [&](uint32_t i, uint32_t v) { if constexpr (kLarge) pcw[i].x = v; else cand_off[i] = v; };
-    auto get_co = [&](uint32_t i) -> uint32_t { if constexpr (kLarge) return pcw[i].x & 0xFFFFu; else return cand_off[i]; };  // (a finalised record keeps it in its low half)
+    uint32_t* cand_off = ar.take<uint32_t>(n + 1);
+    auto set_lens = [&](uint32_t i, uint64_t v) { lens[i] = v; };
+    auto get_lens = [&](uint32_t i) -> uint64_t { return lens[i]; };
+    auto set_co = [&](uint32_t i, uint32_t v) { cand_off[i] = v; };
+    auto get_co = [&](uint32_t i) -> uint32_t { return cand_off[i]; };
     uint16_t* code = ar.take<uint16_t>(n);
     uint16_t* ucode = D.has_user ? ar.take<uint16_t>(n) : code;
     uint16_t* grp = ar.take<uint16_t>(n);
     uint32_t* endc = ar.take<uint32_t>(n + 1);  // candidates ending at each position (bounds the pass count)
     uint32_t* hcount = ar.take<uint32_t>(1);  // hits staged so far
-    if (!ar.ok) { route(large_list); return; }
+    if (!ar.ok) {  // outgrows this wavefront: gen_long, at the smallest level whose LDS holds it (the levels run concurrently)
+        const uint64_t need = gen_long_bytes(n, nb, D.has_user != 0);
+        uint32_t lv = 0;
+        while (lv + 1 < (uint32_t)kGenLevels && need > A.gen_level_bytes[lv]) ++lv;
+        route(A.n_tiers + 1 + lv);
+        return;
+    }
     for (uint32_t i = ln; i < n + 1; i += 64) endc[i] = i == 0 ? 1u : 0u;  // BOS ends at 0
 
     // decode (Sentence::compute_basic / compute_categories, sentence.rs:40-55); the 3 bytes after a
@@ -1080,8 +1085,8 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
                 const uint64_t third = space ? (uint64_t)grp[i] : lm;
                 const uint32_t yw = (nsl < 0x3FFFu ? nsl : 0x3FFFu) | cut | space;
                 pc[i] = make_uint4(co_i | (eo(i) << 16), yw, (uint32_t)third, (uint32_t)(third >> 32));
-                // (bulk generator: a copy for the routing replay below, over the dead half of lens[] -- positions <= i are consumed)
-                if constexpr (!kLarge) reinterpret_cast<uint32_t*>(lens)[i] = yw;
+                // (a copy for the routing replay below, over the dead half of lens[] -- positions <= i are consumed)
+                reinterpret_cast<uint32_t*>(lens)[i] = yw;
             }
             const uint32_t top = (uint32_t)__builtin_amdgcn_readlane((int)m, 63);
             far = top > far ? top : far;
@@ -1109,23 +1114,17 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
         if (fixed <= A.tier_bytes[t]) { tier = t; break; }
     // longer sentences are swept in segments inside the segment tier instead of one huge LDS block
     if (A.seg_tier < A.n_tiers && tier > A.seg_tier) tier = A.seg_tier;
-    // the straggler generators run while the tiers below the segment tier already sweep: their lists are closed
-    if (large && A.early_fork && tier < A.seg_tier) tier = A.seg_tier;
     if (tier == A.seg_tier && A.seg_tier + 1 < A.n_tiers && fixed > A.tier_bytes[tier]) {
         // The sentence has to be swept in segments.  Replay lattice_lds' choice of cuts on the finished records: where some stretch
         // is too dense for any admissible cut (it would fail there and be re-swept by the escape tier, which only starts when the
         // whole segment tier has drained), file the sentence for the escape launch that runs NEXT TO the other tiers.  A wrong
         // guess either way only costs time: lattice_lds still escalates what it cannot sweep.
-        if constexpr (kLarge) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's own record stores
         __syncthreads();
-        if constexpr (kLarge) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        const uint4* __restrict__ pcr = A.g_pc + slot0;
         // what the replay reads per position: the record's second word (pass bound, clean cut), the candidate offset and the
-        // end-list offset -- from LDS in the bulk generator (a global round trip per probe was 5 % of the kernel), from the
-        // records in the levels
-        auto rec_y = [&](uint32_t p) -> uint32_t { if constexpr (kLarge) return pcr[p].y; else return reinterpret_cast<const uint32_t*>(lens)[p]; };
-        auto rec_co = [&](uint32_t p) -> uint32_t { if constexpr (kLarge) return pcr[p].x & 0xFFFFu; else return p < n ? cand_off[p] : C; };
-        auto rec_eo = [&](uint32_t p) -> uint32_t { if constexpr (kLarge) return pcr[p].x >> 16; else return eo(p); };
+        // end-list offset -- from LDS (a global round trip per probe was 5 % of the kernel)
+        auto rec_y = [&](uint32_t p) -> uint32_t { return reinterpret_cast<const uint32_t*>(lens)[p]; };
+        auto rec_co = [&](uint32_t p) -> uint32_t { return p < n ? cand_off[p] : C; };
+        auto rec_eo = [&](uint32_t p) -> uint32_t { return eo(p); };
         const uint32_t budget = A.tier_bytes[tier];
         uint32_t seg_a = 0, seg_c = 0, seg_p = 0, m_in = 1;
         bool sweepable = true;
@@ -1172,21 +1171,356 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
 #undef PROF_MARK
 }
 
-// Long sentences are the critical path of the generator (one wavefront each): those of >= long_bytes bytes
-// -- which cannot fit the LDS of the bulk generator anyway -- are listed up front, so that the large-LDS
-// generator works on them on a side stream while the bulk runs.  Few qualify: one atomic each is fine.
-__global__ void __launch_bounds__(256) classify_long(BatchArgs A, uint32_t long_bytes) {
-    const uint32_t rel = blockIdx.x * 256 + threadIdx.x;
-    if (rel >= A.n || (A.ctrl[kError] & (uint32_t)kErrFatal)) return;
-    const uint32_t sid = A.sid0 + rel;
-    const uint64_t nb = A.offsets[sid + 1] - A.offsets[sid];
-    const bool is_long = nb >= long_bytes;
-    A.s_early[sid] = is_long ? (uint8_t)1 : (uint8_t)0xFF;
-    if (is_long) {
-        A.s_n[sid] = 0; A.s_C[sid] = 0;
-        const uint32_t t = A.n_tiers + 1;
-        A.lists[(size_t)t * A.list_stride + A.list_off + atomicAdd(&A.cctrl[2 * t], 1u)] = sid;
+// The generator for sentences that outgrew the bulk generator's LDS: ONE WORKGROUP (several wavefronts) per sentence.  Long
+// sentences hold most of the characters of a mixed-length batch (BASELINE config 5: 5 % of the sentences, 55 % of the characters);
+// with one wavefront each their LDS footprint (~16 bytes per character) left 5-10 waves on a CU.  Same phases and the same
+// outputs as gen_one (per-character records, candidates in the reference's insertion order with their end-list slots,
+// routing); the 64-position chunks of every phase are dealt round-robin to the workgroup's waves, and what gen_one carries
+// from chunk to chunk in registers becomes a small scan between two barriers:
+//   characters before a byte chunk (decode)            -> lead bytes per chunk, exclusive prefix
+//   candidates before a position (insertion order)     -> counts per position in LDS (u16), exclusive prefix
+//   furthest end of any earlier candidate (clean cuts) -> maximum per chunk, exclusive prefix maximum
+// The groupable runs (a right-to-left carry) and the prefixes are done by wave 0 in LDS: n / 64 short iterations.
+__device__ __forceinline__ void gen_long(const DevDict& D, const BatchArgs& A, uint32_t sid, uint32_t lds_bytes, uint32_t level) {
+    const uint32_t tid = threadIdx.x, ln = tid & 63u, wv = tid >> 6, nw = blockDim.x >> 6, nthreads = blockDim.x;
+    const uint64_t lt_mask = (1ull << ln) - 1ull;
+    const uint64_t b0 = uniform64(A.offsets[sid]), nb64 = uniform64(A.offsets[sid + 1]) - b0;
+    // (gen_one filed the sentence at a level whose LDS holds it -- gen_long_bytes over-estimates the carve below -- so "does not
+    // fit after all" only happens beyond the last level: the fused kernel takes it)
+    const uint32_t fallback = A.n_tiers, next_level = fallback;
+    (void)level;
+    auto route = [&](uint32_t t) { list_push(A, t, sid); };  // (thread 0 appends: these launches run behind build_lists)
+    if (nb64 == 0) {
+        if (tid == 0) A.tok_cnt[sid] = 0;
+        return;
     }
+    if (nb64 >= 65535) { route(fallback); return; }  // positions are u16 in the LDS lattice
+    const uint32_t nb = (uint32_t)nb64;
+    const uint8_t* __restrict__ txt = A.text + b0;
+    const size_t slot0 = sentence_slot(A, b0, sid);
+    enum { kN = 0, kHits = 1, kLong = 2, kPasses = 3, kMaxCnt = 4, kC = 5 };  // red[]: block-wide scalars
+    Arena ar{g_smem, lds_bytes, 0, true};
+    uint32_t* red = ar.take<uint32_t>(8);
+    const uint32_t nbc = (nb + 63) >> 6;
+    uint16_t* chunk = ar.take<uint16_t>(nbc + 1);  // per byte chunk: characters before it; later per position chunk: furthest end before it
+    if (!ar.ok) { route(next_level); return; }
+    for (uint32_t ch = wv; ch < nbc; ch += nw) {
+        const uint32_t bi = ch * 64 + ln;
+        const bool lead = bi < nb && (txt[bi] & 0xC0) != 0x80;
+        const uint32_t c = (uint32_t)__popcll(__ballot(lead));
+        if (ln == 0) chunk[ch] = (uint16_t)c;
+    }
+    __syncthreads();
+    if (wv == 0) {
+        uint32_t running = 0;
+        for (uint32_t c0 = 0; c0 < nbc; c0 += 64) {
+            const uint32_t i = c0 + ln;
+            const uint32_t v = i < nbc ? chunk[i] : 0u;
+            uint32_t tot;
+            const uint32_t ex = wave_exscan(v, tot);
+            if (i < nbc) chunk[i] = (uint16_t)(running + ex);
+            running += tot;
+        }
+        if (ln == 0) { red[kN] = running; red[kHits] = 0; red[kLong] = 0; red[kPasses] = 0; red[kMaxCnt] = 1; }
+    }
+    __syncthreads();
+    const uint32_t n = __builtin_amdgcn_readfirstlane(red[kN]);
+    if (n == 0) {
+        if (tid == 0) A.tok_cnt[sid] = 0;
+        return;
+    }
+    uint32_t* ci = ar.take<uint32_t>(n);
+    uint16_t* code = ar.take<uint16_t>(n);
+    uint16_t* ucode = D.has_user ? ar.take<uint16_t>(n) : code;
+    uint16_t* grp = ar.take<uint16_t>(n);
+    uint16_t* co = ar.take<uint16_t>(n + 1);    // candidates of a position, then candidates before it (insertion order: CSR offsets)
+    uint32_t* endc = ar.take<uint32_t>(n + 1);  // candidates ending at each position: counts, then running cursors (see gen_one)
+    if (!ar.ok) { route(next_level); return; }
+    uint4* const pcw = A.g_pc + slot0;  // .z/.w = length mask until the records are finalised (as gen_one<kLarge>)
+    for (uint32_t i = tid; i < n + 1; i += nthreads) endc[i] = i == 0 ? 1u : 0u;  // BOS ends at 0
+
+    // decode (sentence.rs:40-55): every chunk loads its 64 bytes and the 64 behind them (the 3 bytes after a lead byte)
+    {
+        uint16_t* c2b = A.g_c2b + slot0;
+        for (uint32_t ch = wv; ch < nbc; ch += nw) {
+            const uint32_t bi = ch * 64 + ln;
+            const uint32_t cur = bi < nb ? txt[bi] : 0x80u, nxt = bi + 64 < nb ? txt[bi + 64] : 0x80u;
+            const uint32_t b = cur;
+            uint32_t t[3];
+#pragma unroll
+            for (int k = 1; k <= 3; ++k) {
+                const uint32_t src = (ln + k) & 63u;
+                const uint32_t a = __shfl(cur, src), c = __shfl(nxt, src);
+                t[k - 1] = ((ln + k < 64) ? a : c) & 0x3Fu;
+            }
+            const bool lead = bi < nb && (b & 0xC0) != 0x80;
+            const uint64_t m = __ballot(lead);
+            if (lead) {
+                const uint32_t idx = chunk[ch] + (uint32_t)__popcll(m & lt_mask);
+                uint32_t cp;
+                if (b < 0x80) cp = b;
+                else if (b < 0xE0) cp = ((b & 0x1F) << 6) | t[0];
+                else if (b < 0xF0) cp = ((b & 0x0F) << 12) | (t[0] << 6) | t[1];
+                else cp = ((b & 0x07) << 18) | (t[0] << 12) | (t[1] << 6) | t[2];
+                ci[idx] = D.chr2inf[cp < 65536u ? cp : 0u];  // character.rs:112-116
+                code[idx] = cp < D.sys.mapper_len ? D.sys.mapper[cp] : (uint16_t)0;
+                if (D.has_user) ucode[idx] = cp < D.user.mapper_len ? D.user.mapper[cp] : (uint16_t)0;
+                c2b[idx] = (uint16_t)bi;
+            }
+        }
+        if (tid == 0) c2b[n] = (uint16_t)nb;
+    }
+    __syncthreads();
+    if (wv == 0) {  // groupable (sentence.rs:57-71): right to left, the run length carried across chunks
+        uint32_t carry = 0;
+        for (int ch = (int)((n - 1) / 64); ch >= 0; --ch) {
+            const uint32_t i = (uint32_t)ch * 64 + ln;
+            const bool valid = i < n;
+            bool link = false;
+            if (valid && i + 1 < n) link = ((ci[i] & ci[i + 1]) & 0x3FFFFu) != 0;
+            const uint64_t brk = __ballot(valid && !link);
+            const uint64_t m = brk >> ln;
+            const uint32_t g = m ? (uint32_t)__builtin_ctzll(m) + 1 : (64 - ln) + carry;
+            if (valid) grp[i] = (uint16_t)g;
+            carry = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
+        }
+    }
+    __syncthreads();
+
+    // one trie walk per start position (tokenizer.rs:155-198, unknown.rs:69-116): hits staged in global memory exactly as in gen_one
+    const uint64_t base = (uint64_t)A.node_factor * slot0;
+    const uint64_t region = (uint64_t)A.node_factor * (nb + 1);
+    uint4* __restrict__ hits = A.g_hits + base;
+    for (uint32_t c0 = wv * 64; c0 < n; c0 += nw * 64) {
+        const uint32_t i = c0 + ln;
+        bool is_long = false;
+        if (i < n) {
+            uint32_t cnt = 0;
+            uint64_t lmask = 0;
+            auto seen = [&](uint32_t v, uint32_t c, uint32_t end, uint32_t lex) {
+                if (c == 0) return;  // a category without unknown-word entries contributes nothing (unknown.rs:118-130)
+                const uint32_t h = atomicAdd(&red[kHits], 1u);
+                if (h < region) hits[h] = make_uint4(v, c | (lex << 16), end | (i << 16), cnt);
+                cnt += c;
+                const uint32_t len = end - i;
+                if (len <= 64) lmask |= 1ull << (len - 1); else is_long = true;
+                atomicAdd(&endc[end], c);
+            };
+            bool matched = false;
+            if (D.has_user) matched |= walk_trie(D.user, ucode, i, n, [&](uint32_t v, uint32_t c, uint32_t e) { seen(v, c, e, 1u); });
+            matched |= walk_trie(D.sys, code, i, n, [&](uint32_t v, uint32_t c, uint32_t e) { seen(v, c, e, 0u); });
+            const uint32_t cinfo = ci[i], cate = (cinfo >> 18) & 0xFFu;
+            const uint32_t u0 = D.unk_off[cate], nunk = D.unk_off[cate + 1] - u0;
+            unk_spans(cinfo, grp[i], i, matched, D.max_grouping_len, [&](uint32_t e) { seen(u0, nunk, e, 2u); });
+            pcw[i].z = (uint32_t)lmask; pcw[i].w = (uint32_t)(lmask >> 32);
+            co[i] = (uint16_t)(cnt < 0xFFFFu ? cnt : 0xFFFFu);
+            if (cnt >= 0xFFFFu) is_long = true;  // (more candidates at one position than the u16 arrays hold: fused kernel)
+        }
+        if (__ballot(is_long) != 0 && ln == 0) atomicOr(&red[kLong], 1u);
+    }
+    __syncthreads();
+    if (wv == 0) {  // candidates before a position (CSR offsets), then the end-list offsets
+        uint32_t running = 0;
+        for (uint32_t c0 = 0; c0 < n; c0 += 64) {
+            const uint32_t i = c0 + ln;
+            const uint32_t v = i < n ? co[i] : 0u;
+            uint32_t tot;
+            const uint32_t ex = wave_exscan(v, tot);
+            if (i < n && running + ex < 0xFFFFu) co[i] = (uint16_t)(running + ex);
+            running += tot;
+            if (running >= 65532u) { running = 65532u; break; }  // (wave-uniform) too many nodes for u16 indices: fused kernel, see below
+        }
+        if (ln == 0) { red[kC] = running; if (running < 65532u) co[n] = (uint16_t)running; }
+        uint32_t run2 = 0;
+        for (uint32_t c0 = 0; c0 < n + 1; c0 += 64) {
+            const uint32_t p = c0 + ln;
+            const uint32_t cnt = p < n + 1 ? endc[p] : 0u;
+            uint32_t tot;
+            const uint32_t ex = wave_exscan(cnt, tot);
+            if (p < n + 1) endc[p] = run2 + ex;
+            run2 += tot;
+        }
+    }
+    __syncthreads();
+    const uint32_t C = __builtin_amdgcn_readfirstlane(red[kC]), H = __builtin_amdgcn_readfirstlane(red[kHits]);
+    // words > 64 chars need the generic pre-pass, > 65531 nodes need u32 indices, denser than the region: fused kernel
+    if (C >= 65532 || __builtin_amdgcn_readfirstlane(red[kLong]) || C > region) { route(fallback); return; }
+    // the staged hits (and the length masks) are read back by other waves of this workgroup: stores complete, workgroup scope
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+    // expand the hits: threads = hits (see gen_one)
+    for (uint32_t h = tid; h < H; h += nthreads) {
+        const uint4 hr = hits[h];
+        const uint32_t c = hr.y & 0xFFFFu, lex = hr.y >> 16, end = hr.z & 0xFFFFu, pos = hr.z >> 16;
+        const Entry* __restrict__ ent = lex == 0 ? D.sys.entries : lex == 1 ? D.user.entries : D.unk_entries;
+        const uint32_t dest = (uint32_t)co[pos] + hr.w;
+        const uint32_t es0 = atomicAdd(&endc[end], c);  // the hit's run of slots in ends[end]
+        for (uint32_t t0 = 0; t0 < c; t0 += 4) {
+            Entry e[4];
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q) e[q] = ent[hr.x + (t0 + q < c ? t0 + q : t0)];
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q) {
+                if (t0 + q < c) {
+                    const uint32_t k = dest + t0 + q;
+                    A.g_cand[base + k] = make_uint4((e[q].left_right >> 16) | ((es0 + t0 + q) << 16), (e[q].cost & 0xFFFFu) | (e[q].left_right << 16),
+                                                    (lex << 30) | e[q].word_id, end);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    auto eo = [&](uint32_t p) { return p == 0 ? 0u : p == 1 ? 1u : endc[p - 1]; };  // exclusive end-list offset: the cursors hold the inclusive prefix now
+    auto step_passes = [](uint32_t nc, uint32_t np) {
+        const uint32_t lg = np <= 1 ? 0u : 32u - (uint32_t)__builtin_clz(np - 1);
+        return (uint32_t)((((uint64_t)nc << lg) + 63) >> 6);
+    };
+    auto get_lens = [&](uint32_t i) -> uint64_t { const uint4 r = pcw[i]; return ((uint64_t)r.w << 32) | r.z; };
+    // per-character records (layout and meaning: gen_one).  Per position: e = the furthest end of its candidates (for a space
+    // position of ignore_space mode: of the position behind the run); first the maximum per chunk, then its exclusive prefix
+    // maximum (`far` of gen_one), then the records.
+    struct PosInfo { uint32_t e, space, nsl, cnt, co_i; uint64_t lm; };
+    auto pos_info = [&](uint32_t i) {
+        PosInfo r{0, 0, 0, 0, 0, 0};
+        if (i < n) {
+            const uint32_t cinfo = ci[i];
+            r.space = (D.space_cateset && (cinfo & D.space_cateset)) ? 0x80000000u : 0u;
+            r.lm = get_lens(i);
+            r.e = r.lm ? i + 64u - (uint32_t)__builtin_clzll(r.lm) : i + 1;
+            r.co_i = co[i];
+            uint32_t nc = (uint32_t)co[i + 1] - r.co_i;
+            if (r.space) {
+                const uint32_t sw = i + grp[i];
+                const uint64_t lw = sw < n ? get_lens(sw) : 0ull;
+                const uint32_t e2 = sw < n ? (lw ? sw + 64u - (uint32_t)__builtin_clzll(lw) : sw + 1) : n;
+                r.e = e2 > r.e ? e2 : r.e;
+                nc = sw < n ? (uint32_t)co[sw + 1] - co[sw] : 0u;  // the step taken from a space position starts its words behind the run
+            }
+            r.cnt = eo(i + 1) - eo(i);
+            r.nsl = step_passes(nc, r.cnt);
+        }
+        return r;
+    };
+    auto wave_max = [&](uint32_t v) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = __shfl_xor(v, d); v = o > v ? o : v; }
+        return v;
+    };
+    // (the furthest ends are kept per position over the dead trie codes: the second pass must not read another position's length
+    // mask again -- a wave may have finalised that record already, and a finalised space position keeps its run length there)
+    uint16_t* const far_end = code;
+    const uint32_t npc = (n + 63) >> 6;
+    for (uint32_t ch = wv; ch < npc; ch += nw) {
+        const uint32_t i = ch * 64 + ln;
+        const uint32_t e = pos_info(i).e;
+        if (i < n) far_end[i] = (uint16_t)e;  // (<= n < 65535)
+        const uint32_t top = wave_max(e);
+        if (ln == 0) chunk[ch] = (uint16_t)top;
+    }
+    __syncthreads();
+    if (wv == 0) {
+        uint32_t far = 0;
+        for (uint32_t c0 = 0; c0 < npc; c0 += 64) {
+            const uint32_t i = c0 + ln;
+            uint32_t m = i < npc ? chunk[i] : 0u;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(m, d); if ((int)ln >= d) m = o > m ? o : m; }
+            uint32_t before = __shfl_up(m, 1);
+            before = ln == 0 ? far : (before > far ? before : far);
+            const uint32_t top = (uint32_t)__builtin_amdgcn_readlane((int)m, 63);
+            if (i < npc) chunk[i] = (uint16_t)before;
+            far = top > far ? top : far;
+        }
+    }
+    __syncthreads();
+    {
+        uint4* pc = A.g_pc + slot0;
+        for (uint32_t ch = wv; ch < npc; ch += nw) {
+            const uint32_t i = ch * 64 + ln;
+            PosInfo r = pos_info(i);
+            r.e = i < n ? (uint32_t)far_end[i] : 0u;
+            const uint32_t far = chunk[ch];
+            uint32_t m = r.e;  // inclusive prefix maximum over the lanes
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(m, d); if ((int)ln >= d) m = o > m ? o : m; }
+            uint32_t before = __shfl_up(m, 1);
+            before = ln == 0 ? far : (before > far ? before : far);
+            if (i < n) {
+                const uint32_t cut = (i == 0 || before <= i) ? 0x40000000u : 0u;
+                const uint64_t third = r.space ? (uint64_t)grp[i] : r.lm;
+                const uint32_t yw = (r.nsl < 0x3FFFu ? r.nsl : 0x3FFFu) | cut | r.space;
+                pc[i] = make_uint4(r.co_i | (eo(i) << 16), yw, (uint32_t)third, (uint32_t)(third >> 32));
+            }
+            uint32_t nsl = r.nsl;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) nsl += __shfl_xor(nsl, d);
+            const uint32_t mc = wave_max(r.cnt);
+            if (ln == 0) { atomicAdd(&red[kPasses], nsl); atomicMax(&red[kMaxCnt], mc); }
+        }
+    }
+    __syncthreads();
+    uint32_t passes = __builtin_amdgcn_readfirstlane(red[kPasses]), maxcnt = __builtin_amdgcn_readfirstlane(red[kMaxCnt]);
+    {   // EOS connects to the end list of the last visited position: bounded by the longest list
+        const uint32_t last = eo(n + 1) - eo(n);
+        maxcnt = last > maxcnt ? last : maxcnt;
+        passes += step_passes(1u, maxcnt);
+    }
+    if (tid == 0) {
+        A.g_pc[slot0 + n] = make_uint4(C | (eo(n) << 16), 0, eo(n + 1), 0);  // terminator: totals (candidates, end-list slots)
+        A.s_n[sid] = n; A.s_C[sid] = C; A.s_passes[sid] = passes;
+    }
+    // smallest tier whose LDS holds the lattice arrays, else the segment tier (see gen_one)
+    const uint64_t fixed = lattice_fixed_bytes(C, passes, 1u);
+    uint32_t tier = fallback;
+    for (uint32_t t = 0; t < A.n_tiers; ++t)
+        if (fixed <= A.tier_bytes[t]) { tier = t; break; }
+    if (A.seg_tier < A.n_tiers && tier > A.seg_tier) tier = A.seg_tier;
+    if (tier == A.seg_tier && A.seg_tier + 1 < A.n_tiers && fixed > A.tier_bytes[tier]) {
+        // replay lattice_lds' choice of cuts on the finished records (wave 0; see gen_one): unsweepable -> the pre-routed escape list
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (wv != 0) return;
+        const uint4* __restrict__ pcr = A.g_pc + slot0;
+        const uint32_t budget = A.tier_bytes[tier];
+        uint32_t seg_a = 0, seg_c = 0, seg_p = 0, m_in = 1;
+        bool sweepable = true;
+        for (uint32_t guard = 0; guard <= n; ++guard) {
+            if (lattice_fixed_bytes(C - seg_c, passes - seg_p, m_in) <= budget) break;
+            uint32_t best = 0, best_pass = 0, run = 0;
+            for (uint32_t w0 = 0; w0 < 256 && seg_a + w0 < n; w0 += 64) {
+                const uint32_t b = seg_a + w0 + ln + 1;
+                uint32_t nsl = 0, cx = 0, cut = 0;
+                if (b <= n) {
+                    nsl = pcr[b - 1].y & 0x3FFFu;
+                    if (nsl == 0x3FFFu) nsl = 1u << 20;
+                    cx = pcr[b].x & 0xFFFFu;
+                    cut = b == n ? 1u : (pcr[b].y >> 30) & 1u;
+                }
+                uint32_t tot;
+                const uint32_t incl = wave_exscan(nsl, tot) + nsl + run;
+                const uint32_t est = b == n ? passes - seg_p : incl;
+                const bool fits = b <= n && lattice_fixed_bytes((cx - seg_c) & 0xFFFFu, est, m_in) <= budget;
+                const uint64_t m = __ballot(fits && cut);
+                if (m) {
+                    const uint32_t top = 63u - (uint32_t)__builtin_clzll(m);
+                    best = seg_a + w0 + top + 1;
+                    best_pass = (uint32_t)__builtin_amdgcn_readlane((int)est, (int)top);
+                }
+                run += tot;
+                if (__ballot(fits) == 0) break;
+            }
+            if (!best) { sweepable = false; break; }
+            if (best >= n) break;
+            const uint32_t m_out = __builtin_amdgcn_readfirstlane(((pcr[best + 1].x >> 16) - (pcr[best].x >> 16)) & 0xFFFFu);  // nodes ending exactly at the cut
+            if (m_out == 0 || m_out > 128) { sweepable = false; break; }
+            seg_a = best; seg_c = __builtin_amdgcn_readfirstlane(pcr[best].x & 0xFFFFu); seg_p += best_pass; m_in = m_out;
+        }
+        if (!sweepable) tier = A.n_tiers + 1 + kGenLevels;  // the pre-routed escape list
+    }
+    route(tier);
 }
 
 // Turns the per-sentence routing decisions into work lists: one atomic per (wave, list) instead of
@@ -1224,19 +1558,20 @@ __global__ void __launch_bounds__(1024) build_lists(BatchArgs A, int only_list) 
 // Kernel 1: one single-wave workgroup per sentence (small LDS, high occupancy) ...
 __global__ void __launch_bounds__(64) gen_candidates(DevDict D, BatchArgs A, uint32_t lds_bytes) {
     if (batch_rejected(A)) return;  // nothing gets routed: every later kernel finds empty work lists
-    gen_one<false>(D, A, A.sid0 + blockIdx.x, lds_bytes, 0);
+    gen_one(D, A, A.sid0 + blockIdx.x, lds_bytes);
 }
-// ... and persistent waves with a large LDS budget for the sentences that did not fit.
-__global__ void __launch_bounds__(64) gen_candidates_large(DevDict D, BatchArgs A, uint32_t lds_bytes, uint32_t level) {
+// ... and persistent workgroups (several wavefronts, a large LDS budget) for the sentences that did not fit: gen_long.
+__global__ void __launch_bounds__(1024) gen_candidates_large(DevDict D, BatchArgs A, uint32_t lds_bytes, uint32_t level) {
+    uint32_t* const next_item = reinterpret_cast<uint32_t*>(g_smem + lds_bytes - 16);  // (the last 16 bytes stay out of gen_long's arena)
     const uint32_t t = A.n_tiers + level;
     const uint32_t count = A.cctrl[2 * t];
     for (;;) {
-        uint32_t k = 0;
-        if (threadIdx.x == 0) k = atomicAdd(&A.cctrl[2 * t + 1], 1u);
-        k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
-        if (k >= count) break;
-        gen_one<true>(D, A, A.lists[(size_t)t * A.list_stride + A.list_off + k], lds_bytes, level);
+        if (threadIdx.x == 0) *next_item = atomicAdd(&A.cctrl[2 * t + 1], 1u);
         __syncthreads();
+        const uint32_t k = __builtin_amdgcn_readfirstlane(*next_item);
+        if (k >= count) break;
+        gen_long(D, A, A.lists[(size_t)t * A.list_stride + A.list_off + k], lds_bytes - 16, level);
+        __syncthreads();  // (also: next_item is read by every wave before thread 0 draws the next one)
     }
 }
 
@@ -1856,7 +2191,7 @@ __global__ void __launch_bounds__(64) tokenize_one(DevDict D, BatchArgs A, uint3
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    gen_one<false>(D, A, 0u, lds_bytes, 0u);
+    gen_one(D, A, 0u, lds_bytes);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -2251,7 +2586,6 @@ Workspace::Workspace(const Tokenizer& t, uint64_t max_s, uint64_t max_b) : tok(t
         pipe.g_hits = static_cast<uint4*>(alloc((size_t)pipe.node_factor * slots * 16));
         pipe.s_passes = static_cast<uint32_t*>(alloc(ns * 4));
         pipe.s_tier = static_cast<uint8_t*>(alloc(ns));
-        pipe.s_early = static_cast<uint8_t*>(alloc(ns));
         for (size_t t = 0; t < tiers.size(); ++t) {
             hipStream_t st;
             HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
@@ -2260,10 +2594,11 @@ Workspace::Workspace(const Tokenizer& t, uint64_t max_s, uint64_t max_b) : tok(t
             HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             tier_events.push_back(e);
         }
-        HIP_CHECK(hipEventCreateWithFlags(reinterpret_cast<hipEvent_t*>(&ev_fork), hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(reinterpret_cast<hipEvent_t*>(&ev_fork2), hipEventDisableTiming));
-        HIP_CHECK(hipEventCreateWithFlags(reinterpret_cast<hipEvent_t*>(&ev_early), hipEventDisableTiming));
-        HIP_CHECK(hipStreamCreateWithFlags(reinterpret_cast<hipStream_t*>(&early_stream), hipStreamNonBlocking));
+        for (int q = 0; q + 1 < kGenLevels; ++q) {
+            HIP_CHECK(hipStreamCreateWithFlags(reinterpret_cast<hipStream_t*>(&gen_streams[q]), hipStreamNonBlocking));
+            HIP_CHECK(hipEventCreateWithFlags(reinterpret_cast<hipEvent_t*>(&gen_events[q]), hipEventDisableTiming));
+        }
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gen_candidates_large), hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
         if (tiers.back() > 65536)  // a single workgroup may use the CU's whole 160 KiB
         {
@@ -2285,12 +2620,13 @@ void Workspace::release() {
     for (auto& e : ev) if (e) { (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(e)); e = nullptr; }
     for (void* e : tier_events) (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(e));
     tier_events.clear();
-    if (ev_fork) (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(ev_fork));
     if (ev_fork2) (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(ev_fork2));
-    if (ev_early) (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(ev_early));
-    ev_fork = ev_fork2 = ev_early = nullptr;
-    if (early_stream) (void)hipStreamDestroy(reinterpret_cast<hipStream_t>(early_stream));
-    early_stream = nullptr;
+    ev_fork2 = nullptr;
+    for (int q = 0; q + 1 < kGenLevels; ++q) {
+        if (gen_events[q]) (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(gen_events[q]));
+        if (gen_streams[q]) (void)hipStreamDestroy(reinterpret_cast<hipStream_t>(gen_streams[q]));
+        gen_events[q] = gen_streams[q] = nullptr;
+    }
     for (void* st : streams) (void)hipStreamDestroy(reinterpret_cast<hipStream_t>(st));
     streams.clear();
 }
@@ -2323,7 +2659,6 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
                 if (tiers[t] >= seg_bytes) { a.seg_tier = (uint32_t)t; break; }
     }
     a.sid0 = 0; a.cctrl = d_cctrl; a.list_off = 0;
-    a.early_fork = (!fused && a.seg_tier < T && a.seg_tier > 0 && env_u32("VBT_LONG_BYTES", 0) == 0 && env_u32("VBT_EARLY_FORK", 0)) ? 1u : 0u;
     a.lid_count = count_connids ? d_connid : nullptr;
     a.rid_count = count_connids ? d_connid + tok.dict().num_left : nullptr;
     a.s_counted = count_connids ? d_counted : nullptr;
@@ -2354,50 +2689,41 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
         hipLaunchKernelGGL(D.matrix_wide ? tokenize_global<true> : tokenize_global<false>, dim3((uint32_t)std::min<uint64_t>(n, 1024)), dim3(64), 0, stream, D, a,
                            (const uint32_t*)over(T - 1), (const uint32_t*)count(T - 1), cursor(T));
     } else {
-        // Stream plan.  The launch stream runs gen_candidates -> build_lists -> gen_candidates_large (stragglers
-        // that outgrew the bulk generator's LDS) and then forks one lattice_lds launch per LDS tier onto the
-        // tier streams and joins them.  Optional (VBT_LONG_BYTES > 0, off by default): sentences of at least that
-        // many bytes are listed first and generated by the large-LDS generator on a side stream while the bulk
-        // runs.  Measured on MI355X it does not pay: the side stream's few wavefronts are slowed by the bulk
-        // as much as they save (4.40 vs 4.27 ms per 100k sentences).
+        // Stream plan.  The launch stream runs gen_candidates -> build_lists -> gen_candidates_large (gen_long: the sentences
+        // that outgrew the bulk generator's LDS, one workgroup of several wavefronts each) and then forks one lattice_lds launch
+        // per LDS tier onto the tier streams and joins them.
         // (the bulk generator keeps ~26 bytes of LDS per character: 4 KiB hold ~155 characters and 32+ waves per CU)
         const uint32_t gen_lds = env_u32("VBT_GEN_LDS", 4096);
-        uint32_t gen_level_lds[kGenLevels] = {16384, 32768, 163840};  // the instances behind the bulk generator (VBT_GEN_LEVELS=a,b,c)
+        uint32_t gen_level_lds[kGenLevels] = {16384, 32768, 163840};  // the levels of gen_long (VBT_GEN_LEVELS=a,b,c): ~16 bytes per character
         if (const char* e = std::getenv("VBT_GEN_LEVELS")) {
             unsigned v[3];
             if (std::sscanf(e, "%u,%u,%u", &v[0], &v[1], &v[2]) == 3 && v[0] >= 4096 && v[0] < v[1] && v[1] < v[2] && v[2] <= 163840)
                 for (int q = 0; q < 3; ++q) gen_level_lds[q] = v[q];
         }
-        const uint32_t long_bytes = env_u32("VBT_LONG_BYTES", 0);
         const uint32_t cn = (uint32_t)n, lb = (cn + 1023) / 1024;
         a.sid0 = 0; a.n = cn; a.cctrl = d_cctrl; a.list_off = 0; a.direct_push = 0;
-        a.s_skip = nullptr;
+        for (int q = 0; q < kGenLevels; ++q) a.gen_level_bytes[q] = gen_level_lds[q] - 16;
         // (s_tier[] = 0xFF, "nothing routed yet", is written by validate_batch: one launch less per batch)
-        if (long_bytes) {
-            BatchArgs e = a;  // same routing array, own input list (second counter block / list region)
-            e.cctrl = d_cctrl + (size_t)kBlockCtrlWords; e.list_off = (uint32_t)half;
-            hipLaunchKernelGGL(classify_long, dim3((cn + 255) / 256), dim3(256), 0, stream, e, long_bytes);
-            HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_fork), stream));
-            hipStream_t es = reinterpret_cast<hipStream_t>(early_stream);
-            HIP_CHECK(hipStreamWaitEvent(es, reinterpret_cast<hipEvent_t>(ev_fork), 0));
-            hipLaunchKernelGGL(gen_candidates_large, dim3(waves_for(gen_level_lds[0], cn)), dim3(64), gen_level_lds[0], es, D, e, gen_level_lds[0], 1u);
-            HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_early), es));
-            a.s_skip = pipe.s_early;  // the bulk generator leaves these alone
-        }
         hipLaunchKernelGGL(gen_candidates, dim3(cn), dim3(64), gen_lds, stream, D, a, gen_lds);
-        if (long_bytes) HIP_CHECK(hipStreamWaitEvent(stream, reinterpret_cast<hipEvent_t>(ev_early), 0));
         hipLaunchKernelGGL(build_lists, dim3(lb), dim3(1024), 0, stream, a, -1);
-        // VBT_EARLY_FORK=1 (off by default): the bulk generator has routed every sentence it could hold and what remains
-        // (longer than ~150 characters) goes to the segment tier at least, so the lists of the tiers below it are final
-        // here and their sweep can fork now, under the straggler generators.  Measured slower on MI355X (2.31 vs 2.26 ms on
-        // the headline batch, 9.8 vs 8.7 ms on config 5): the stragglers then compete with the sweep for the CUs and the
-        // segment tier, the critical path, starts later.
-        if (a.early_fork) { HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_fork), stream)); rec(1); }
-        a.direct_push = 1;
-        for (uint32_t lv = 1; lv <= kGenLevels; ++lv)  // each level takes what outgrew the one before (the last: a whole CU's LDS, ~5000 characters)
-            hipLaunchKernelGGL(gen_candidates_large, dim3(waves_for(gen_level_lds[lv - 1], cn)), dim3(64), gen_level_lds[lv - 1], stream, D, a, gen_level_lds[lv - 1], lv);
-        a.direct_push = 0;
-        if (!a.early_fork) rec(1);
+        // gen_one filed every sentence that outgrew it at the smallest level of gen_long that holds it, so the levels are
+        // independent: each on its own stream, side by side.  Workgroups of 4 wavefronts (16 at the last level, which has a CU
+        // to itself), as many as a CU's LDS and its 32 wave slots admit.
+        auto launch_level = [&](uint32_t lv, hipStream_t st_) {
+            const uint32_t lds = gen_level_lds[lv - 1], nw = lds > 65536 ? 16u : std::max<uint32_t>(1, std::min<uint32_t>(16, env_u32("VBT_GEN_WAVES", 4)));
+            const uint32_t per_cu = std::max<uint32_t>(1, std::min<uint32_t>(32 / nw, 163840 / lds));
+            hipLaunchKernelGGL(gen_candidates_large, dim3(std::max<uint32_t>(1, std::min<uint32_t>(cn, per_cu * 256))), dim3(nw * 64), lds, st_, D, a, lds, lv);
+        };
+        HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_fork2), stream));
+        for (uint32_t lv = 2; lv <= kGenLevels; ++lv) {
+            hipStream_t side = reinterpret_cast<hipStream_t>(gen_streams[lv - 2]);
+            HIP_CHECK(hipStreamWaitEvent(side, reinterpret_cast<hipEvent_t>(ev_fork2), 0));
+            launch_level(lv, side);
+            HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(gen_events[lv - 2]), side));
+        }
+        launch_level(1, stream);
+        for (uint32_t lv = 2; lv <= kGenLevels; ++lv) HIP_CHECK(hipStreamWaitEvent(stream, reinterpret_cast<hipEvent_t>(gen_events[lv - 2]), 0));
+        rec(1);
         // (forking the small tiers before the straggler generators was measured: 3.33 vs 3.2 ms, the stragglers then
         // compete with the sweep and the segment tier starts later)
         HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_fork2), stream));
@@ -2429,7 +2755,7 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
             const size_t t = n_conc - 1 - i;
             const bool on_main = main_seg && t == a.seg_tier;
             hipStream_t side = on_main ? stream : reinterpret_cast<hipStream_t>(streams[t]);
-            if (!on_main) HIP_CHECK(hipStreamWaitEvent(side, reinterpret_cast<hipEvent_t>(a.early_fork && t < a.seg_tier ? ev_fork : ev_fork2), 0));
+            if (!on_main) HIP_CHECK(hipStreamWaitEvent(side, reinterpret_cast<hipEvent_t>(ev_fork2), 0));
             // one workgroup per list entry: the lists are built on the device, so the grid covers the whole batch and the
             // workgroups beyond a list's length exit at once (VBT_LAT_PERSIST=1: persistent waves with a work cursor)
             const uint32_t grid = !persist ? cn : (t < tier_waves.size() && tier_waves[t]) ? std::min<uint32_t>(tier_waves[t], waves_for(tiers[t], cn)) : waves_for(tiers[t], cn);
@@ -2477,7 +2803,7 @@ void Workspace::run_one(const uint8_t* h_text_dev, uint32_t nb, uint8_t* d_text,
     a.scratch = d_scratch; a.scratch_bytes = scratch_bytes;
     a.prof = nullptr;
     a.lists = d_over; a.list_stride = (uint32_t)(2 * std::max<uint64_t>(max_sentences, 1)); a.n_tiers = 1;
-    a.tier_prio = 0; a.seg_tier = 0; a.sid0 = 0; a.cctrl = d_cctrl; a.list_off = 0; a.early_fork = 0; a.direct_push = 0; a.s_skip = nullptr;
+    a.tier_prio = 0; a.seg_tier = 0; a.sid0 = 0; a.cctrl = d_cctrl; a.list_off = 0; a.direct_push = 0;
     a.lid_count = nullptr; a.rid_count = nullptr; a.s_counted = nullptr;
     constexpr uint32_t kOneLds = 65536;  // generator arrays (~26 B per character), then the lattice (whole up to ~400 characters, in segments beyond)
     a.tier_bytes[0] = kOneLds;

@@ -67,8 +67,6 @@ struct BatchArgs {
     uint4* g_hits;      // staging of the trie hits of gen_candidates, same per-sentence regions as g_cand
     uint32_t node_factor;
     uint8_t* s_tier;    // LDS tier chosen by gen_candidates (0xFF = none / empty sentence)
-    uint8_t* s_early;   // the same for the early (long-sentence) pipeline
-    const uint8_t* s_skip;  // bulk generator: sentences with s_skip[sid] != 0xFF belong to the early pipeline (nullptr = none)
     // work lists: list t (t < n_tiers) feeds LDS tier t, list n_tiers the global-memory fallback (fused kernel),
     // lists n_tiers + 1 .. n_tiers + kGenLevels the large-LDS instances of gen_candidates; list n_tiers + 1 + kGenLevels the sentences
     // gen_candidates found unsweepable in segments (swept by an escape-tier launch that runs concurrently with the other tiers)
@@ -76,8 +74,7 @@ struct BatchArgs {
     uint32_t list_stride;
     uint32_t n_tiers;
     uint32_t seg_tier;     // LDS tier that sweeps longer sentences in segments (>= n_tiers: none)
-    uint32_t early_fork;   // the tiers below the segment tier sweep while the straggler generators still run (their lists are final)
-    uint32_t direct_push;  // gen_candidates_large: append to the tier lists directly instead of routing through s_tier
+    uint32_t direct_push;  // gen_one appends to the work lists directly instead of routing through s_tier (no build_lists behind it)
     uint32_t tier_prio;  // the top `tier_prio` LDS tiers run at raised wave priority (0 = off)
     // a launch covers sentences [sid0, sid0 + n); cctrl = the list counters it works with (cctrl[2t] = entries of
     // list t, cctrl[2t+1] = its work cursor); list t starts at lists[t * list_stride + list_off]
@@ -89,6 +86,7 @@ struct BatchArgs {
     unsigned long long* rid_count;
     uint32_t* s_counted;  // per sentence: the steps of positions below this are already counted (a retry must not count them again)
     uint32_t tier_bytes[8];
+    uint32_t gen_level_bytes[3];  // LDS of the levels of gen_long (gen_one files what outgrows it at the smallest level that holds it)
 };
 
 // ctrl[kTotal] total tokens; ctrl[kError] DevError flags; ctrl[kBump..+1] u64 scratch bump pointer;
@@ -148,10 +146,9 @@ class Workspace {
     BatchArgs pipe{};                // device pointers of those buffers
     std::vector<void*> streams;      // one side stream per LDS tier
     std::vector<void*> tier_events;
-    void* ev_fork = nullptr;
     void* ev_fork2 = nullptr;
-    void* ev_early = nullptr;
-    void* early_stream = nullptr;  // generator + list building of the long sentences
+    void* gen_streams[2] = {nullptr, nullptr};  // gen_long levels 2 and 3 run next to level 1
+    void* gen_events[2] = {nullptr, nullptr};
     bool fused = false;              // VBT_FUSED=1: the single fused kernel per sentence (A/B reference)
     unsigned long long* d_connid = nullptr;  // [num_left + num_right] usage counters, allocated on first use
     uint32_t* d_counted = nullptr;           // per-sentence watermark of the counted steps
