@@ -649,7 +649,7 @@ int vbt_tokenize_batch(const vbt_tokenizer* tok_, const uint8_t* text, const uin
         vbt_batch& b = *h.b;
         b.tok = tok;
         b.n = n;
-        b.in_blk = host_take(tok, (n + 1) * 8 + bytes);
+        b.in_blk = host_take(tok, (n + 1) * 8 + bytes + 24);
         uint64_t* offs = static_cast<uint64_t*>(b.in_blk->p);
         for (uint64_t i = 0; i <= n; ++i) offs[i] = offsets[i] - lo;
         uint8_t* txt = reinterpret_cast<uint8_t*>(offs + n + 1);
@@ -660,28 +660,34 @@ int vbt_tokenize_batch(const vbt_tokenizer* tok_, const uint8_t* text, const uin
         PooledWorkspace& p = *h.p;
         if (bytes) HIPX(hipMemcpyAsync(p.d_text, txt, bytes, hipMemcpyHostToDevice, p.stream));
         HIPX(hipMemcpyAsync(p.d_off, offs, (n + 1) * 8, hipMemcpyHostToDevice, p.stream));
-        p.ws->run(static_cast<const uint8_t*>(p.d_text), p.d_off, n, bytes, p.stream);
-        vbt_call_stats st;
-        p.ws->stats(&st);  // synchronises the stream
-        if (st.error_flags & kErrUtf8) {
+        // kernels up to the token-offset scan; the total and the error flags come back in 8 bytes, then the packing kernel writes
+        // the results straight into this batch's pinned block (no copy command behind the kernels)
+        p.ws->run(static_cast<const uint8_t*>(p.d_text), p.d_off, n, bytes, p.stream, /*defer_pack=*/true);
+        uint32_t* tail = reinterpret_cast<uint32_t*>(txt + ((bytes + 7) & ~(uint64_t)7));  // {n_tokens, error flags}
+        tail[0] = tail[1] = 0;
+        HIPX(hipMemcpyAsync(tail, p.ws->d_ctrl, 8, hipMemcpyDeviceToHost, p.stream));
+        HIPX(hipStreamSynchronize(p.stream));
+        const uint32_t error_flags = tail[1];
+        if (error_flags & kErrUtf8) {
             // every sentence must be a Rust `str` (the reference's callers pass &str; its CLI fails on invalid input lines).  The
             // device's first kernel validates the text; only this error path walks it again on the host to name the sentence.
             for (uint64_t i = 0; i < n; ++i)
                 if (!valid_utf8(txt + offs[i], offs[i + 1] - offs[i])) throw Error(VBT_ERR_UTF8, "sentence " + std::to_string(i) + " is not valid UTF-8");
         }
-        check_device_errors(st.error_flags);
-        b.n_tokens = st.n_tokens;
-        b.out_blk = host_take(tok, n * 8 + st.n_tokens * sizeof(vbt_token_rec) + 16);
+        check_device_errors(error_flags);
+        b.n_tokens = tail[0];
+        b.out_blk = host_take(tok, n * 8 + (size_t)b.n_tokens * sizeof(vbt_token_rec) + 16);
         uint32_t* o = static_cast<uint32_t*>(b.out_blk->p);
         b.tok_off = o;
         b.tok_cnt = o + n;
         b.tokens = reinterpret_cast<const vbt_token_rec*>(o + 2 * n);
         if (n) {
-            HIPX(hipMemcpyAsync(o, p.ws->d_tok_off, n * 4, hipMemcpyDeviceToHost, p.stream));
-            HIPX(hipMemcpyAsync(o + n, p.ws->d_tok_cnt, n * 4, hipMemcpyDeviceToHost, p.stream));
+            void* dev = nullptr;
+            HIPX(hipHostGetDevicePointer(&dev, o, 0));
+            uint32_t* od = static_cast<uint32_t*>(dev);
+            p.ws->pack_to(reinterpret_cast<vbt_token_rec*>(od + 2 * n), od, od + n, p.stream);
+            HIPX(hipStreamSynchronize(p.stream));
         }
-        if (st.n_tokens) HIPX(hipMemcpyAsync(o + 2 * n, p.ws->d_tokens, st.n_tokens * sizeof(vbt_token_rec), hipMemcpyDeviceToHost, p.stream));
-        HIPX(hipStreamSynchronize(p.stream));
         pool_give(tok, std::move(h.p));
         *out = h.b.release();
     });

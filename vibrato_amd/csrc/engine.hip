@@ -741,10 +741,10 @@ __device__ __forceinline__ uint64_t process_sentence(const DevDict& D, const Bat
 #endif
 // One pass of the fused gather+recurrence loop of lattice_lds: 64 lanes = 64 padded (candidate c, predecessor j) pairs
 // of one sweep step, pair q = q0 + lane, c = q >> lg, j = q & (2^lg - 1), 2^lg >= the number of predecessors.  The
-// record is built once per pass by the lane that owns the step, so everything a pass needs is precomputed: absolute LDS
-// byte addresses (of the first predecessor's right id and key, of the first candidate) and the mask of the lanes that
-// hold a real pair.
-struct alignas(16) LPass { uint32_t baseR, baseK, baseC, q0, mlo, mhi, lg, pad; };
+// record is built once per pass by the lane that owns the step: absolute LDS byte addresses (of the first predecessor's right
+// id and key, of the first candidate), q0, lg and the step's np / nc -- a lane holds a real pair iff j < np && c < nc (two
+// compares at consumption; a precomputed 64-bit lane mask cost the record builder ~30 VALU instructions per pass).
+struct alignas(16) LPass { uint32_t baseR, baseK, baseC, q0, np, nc, lg, pad; };
 
 // LDS bytes of the lattice arrays of lattice_lds for a (segment of a) sentence with C candidates, `passes` passes and
 // m_in nodes ending at its first position.  Must over-estimate the Arena carve there; gen_candidates routes sentences
@@ -1681,7 +1681,7 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
 
         Arena ar{g_smem, lds_bytes, 0, true};
         uint64_t* e_key = ar.take<uint64_t>(E + 1);  // end-major packed keys
-        uint2* cnd = ar.take<uint2>(C + 1);          // per candidate: {end-list slot | (u16) word_cost << 16, (0xFFFE - sequence) | left_id << 16}
+        uint2* cnd = ar.take<uint2>(C + 1);          // per candidate: {byte offset of its key (end-list slot * 8) | (u16) word_cost << 16, (0xFFFE - sequence) | left_id << 16}
         uint16_t* e_right = ar.take<uint16_t>(E + 1);
         ar.used = (ar.used + 15) & ~15ull;
         LPass* rec = reinterpret_cast<LPass*>(g_smem + ar.used);  // pass records take the rest; afterwards the token path
@@ -1711,7 +1711,7 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
                     const uint32_t es = (r[u].x >> 16) - sb;
                     e_right[es] = (uint16_t)r[u].x;
                     e_key[es] = kDeadKey;  // never inserted until a sweep step reaches its start position
-                    cnd[c] = make_uint2(es | (r[u].y << 16), ((0xFFFEu - (seg_c + c)) & 0xFFFFu) | (r[u].y & 0xFFFF0000u));
+                    cnd[c] = make_uint2((es << 3) | (r[u].y << 16), ((0xFFFEu - (seg_c + c)) & 0xFFFFu) | (r[u].y & 0xFFFF0000u));
                 }
             }
         }
@@ -1720,7 +1720,7 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
             if (q * 64 + ln < m_in) { e_right[q * 64 + ln] = (uint16_t)carry_right[q]; e_key[q * 64 + ln] = carry_key[q]; }
         if (ln == 0) {
             // EOS pseudo candidate (insert_eos, lattice.rs:85-101): left_id 0, word cost 0
-            cnd[C] = make_uint2(E, (0xFFFEu - (seg_c + C)) & 0xFFFFu);
+            cnd[C] = make_uint2(E << 3, (0xFFFEu - (seg_c + C)) & 0xFFFFu);
             e_key[E] = kDeadKey;
         }
         PROF_MARK(3);
@@ -1738,20 +1738,7 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
         bool windowed = true, overflow = false;
         // the q-th of the nsl passes of a step (executed by the lane that owns the step)
         auto make_pass = [&](uint32_t p_beg, uint32_t np, uint32_t c_beg, uint32_t nc, uint32_t lg, uint32_t q) {
-            const uint32_t q0 = q << 6;
-            uint64_t mask;
-            if (lg >= 6) {  // one candidate per pass, 64 of its predecessors at a time
-                const uint32_t j0 = q0 & ((1u << lg) - 1u);
-                const uint32_t cnt = np > j0 ? (np - j0 < 64 ? np - j0 : 64u) : 0u;
-                mask = cnt >= 64 ? ~0ull : (1ull << cnt) - 1ull;
-            } else {        // 64 >> lg candidates per pass, np of every 2^lg lanes hold a pair
-                const uint32_t g0 = q0 >> lg, gs = nc - g0 < (64u >> lg) ? nc - g0 : (64u >> lg);
-                const uint64_t one = lg == 0 ? ~0ull : lg == 1 ? 0x5555555555555555ull : lg == 2 ? 0x1111111111111111ull : lg == 3 ? 0x0101010101010101ull
-                                   : lg == 4 ? 0x0001000100010001ull : 0x0000000100000001ull;
-                const uint32_t span = gs << lg;
-                mask = (one & (span >= 64 ? ~0ull : (1ull << span) - 1ull)) * (uint64_t)((1ull << np) - 1ull);  // no carries: np <= 2^lg
-            }
-            return LPass{offR + (p_beg << 1), offK + (p_beg << 3), offC + (c_beg << 3), q0, (uint32_t)mask, (uint32_t)(mask >> 32), lg, np | (nc << 16)};
+            return LPass{offR + (p_beg << 1), offK + (p_beg << 3), offC + (c_beg << 3), q << 6, np, nc, lg, 0u};
         };
         {
             uint32_t cur0 = 0;
@@ -1841,7 +1828,7 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
             fail = 29; break;
         }
         // one empty pass behind the last one (no lane holds a pair): the software pipeline reads ahead up to it
-        if (ln == 0) rec[SL] = LPass{offR, offK, offC, 0u, 0u, 0u, 0u, 0u};
+        if (ln == 0) rec[SL] = LPass{offR, offK, offC, 0u, 0u, 0u, 0u, 0u};  // np = nc = 0: no lane holds a pair
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         PROF_MARK(4);
@@ -1866,22 +1853,24 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
             // reads up front (next record, next pair, this pass's predecessor keys) and waits for them once.  Pass p lives in
             // ring slot p % kRing from A2 on; the loop is unrolled kRing times, so slot indices are static.
             constexpr uint32_t kRing = kDepth + 2;
-            uint32_t word[kRing], keyaddr[kRing], taddr[kRing], cw[kRing];  // VGPRs: connection cost in flight (sign-extended), LDS addresses of
-                                                                            // the predecessor's and the candidate's key, word cost << 16 | own field
+            uint32_t word[kRing], keyaddr[kRing], taddr[kRing], wc[kRing], cy[kRing];  // VGPRs: connection cost in flight (sign-extended), LDS addresses of
+                                                                                       // the predecessor's and the candidate's key, word cost, {own field, left id}
             uint32_t smlo[kRing], smhi[kRing], slg[kRing];                               // SGPRs (wave-uniform): lane mask, lg
             auto stage_a1 = [&](uint32_t p, uint4& r0, uint4& r1) {
                 const uint4* r = reinterpret_cast<const uint4*>(&rec[p < SL ? p : SL]);  // passes > SL do not exist: they re-read the empty one
                 r0 = r[0]; r1 = r[1];
             };
             auto stage_a2 = [&](const uint4& r0, const uint4& r1, uint32_t u, uint2& cd, uint32_t& right) {
-                const uint32_t lg = r1.z & 31u;
+                const uint32_t lg = __builtin_amdgcn_readfirstlane(r1.z);  // (< 32)
                 const uint32_t q = ln + r0.w, cc = q >> lg, j = q & ((1u << lg) - 1u);
                 const uint64_t cdv = *reinterpret_cast<lds_cu64*>(r0.z + (cc << 3));
                 cd = make_uint2((uint32_t)cdv, (uint32_t)(cdv >> 32));
                 right = *reinterpret_cast<lds_cu16*>(r0.x + (j << 1));
+                asm volatile("" : "+v"(right));  // (a 32-bit value from here on: carried as i16 through the pipeline's phi it is masked again at its use)
                 keyaddr[u] = r0.y + (j << 3);
-                smlo[u] = __builtin_amdgcn_readfirstlane(r1.x); smhi[u] = __builtin_amdgcn_readfirstlane(r1.y);
-                slg[u] = __builtin_amdgcn_readfirstlane(r1.z);
+                const uint64_t mask = __builtin_amdgcn_ballot_w64(j < r1.x) & __builtin_amdgcn_ballot_w64(cc < r1.y);  // the lanes that hold a real pair (np, nc of the step)
+                smlo[u] = (uint32_t)mask; smhi[u] = (uint32_t)(mask >> 32);
+                slg[u] = lg;
             };
             auto stage_b = [&](uint32_t u, const uint2& cd, uint32_t right) {
                 // lanes without a pair hold garbage ids: they all load cell 0 (one cache line; scattered garbage offsets cost the
@@ -1894,8 +1883,9 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
 #endif
                 if constexpr (kWide) word[u] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(mrs, (int)select_mask(mask, 0u, cell << 2), 0, 0);  // i32 cells
                 else word[u] = (uint32_t)(int32_t)(int16_t)__builtin_amdgcn_raw_buffer_load_b16(mrs, (int)select_mask(mask, 0u, cell << 1), 0, 0);
-                taddr[u] = offK + ((cd.x & 0xFFFFu) << 3);
-                cw[u] = __builtin_amdgcn_perm(cd.x, cd.y, 0x07060100u);  // word cost (high half of x) << 16 | own field (low half of y)
+                taddr[u] = offK + (cd.x & 0xFFFFu);          // the candidate's key (its record holds the byte offset)
+                wc[u] = (uint32_t)((int32_t)cd.x >> 16);     // word cost, sign-extended
+                cy[u] = cd.y;                                // low half: the candidate's own sequence field
             };
             uint4 pr0, pr1;      // record of the pass whose A2 is next
             uint2 p_cd;          // candidate and right id of the pass whose B is next
@@ -1932,9 +1922,8 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
                     stage_b((u + kDepth) % kRing, p_cd, p_right);                  // pass si + kDepth
                     pr0 = n0; pr1 = n1; p_cd = ncd; p_right = nr;
                     // ---- pass si ----
-                    const uint32_t khi = (uint32_t)(kb >> 32) + word[u]                                                   // wrapping i32 adds:
-                                         + (uint32_t)((int32_t)cw[u] >> 16);                                            // connection + word cost (lattice.rs:125,139)
-                    const uint32_t klo = __builtin_amdgcn_perm((uint32_t)kb, cw[u], 0x05040100u);  // predecessor's own field << 16 | the candidate's
+                    const uint32_t khi = (uint32_t)(kb >> 32) + word[u] + wc[u];                 // wrapping i32 adds: connection + word cost (lattice.rs:125,139)
+                    const uint32_t klo = __builtin_amdgcn_perm((uint32_t)kb, cy[u], 0x05040100u);  // predecessor's own field << 16 | the candidate's
                     const uint64_t live = __ballot((uint32_t)kb != 0xFFFFFFFFu) & mask;
                     // (a lane without a live pair carries the dead key, a no-op for the minimum should it tie with m)
                     const uint32_t hi = select_mask(live, 0xFFFFFFFFu, khi), lo = select_mask(live, 0xFFFFFFFFu, klo);
@@ -1942,7 +1931,9 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
                     // minimum cost of every candidate in registers; only the lanes that hold it go to LDS, where the atomic on the
                     // whole key settles ties (rare) towards the last inserted predecessor: no same-address pile-up
                     const uint32_t m = group_min_u32(hi, lg < 6 ? lg : 6u);  // (more than 64 predecessors: one candidate per pass)
-                    if (hi == m)
+                    // (only lanes with a live pair: a lane without one holds whatever its garbage candidate address read, and a
+                    // misaligned 64-bit LDS atomic is a memory violation)
+                    if (__builtin_amdgcn_inverse_ballot_w64(__builtin_amdgcn_ballot_w64(hi == m) & live))
                         __hip_atomic_fetch_min(reinterpret_cast<lds_u64*>(taddr[u]), ((uint64_t)hi << 32) | lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     // LDS operations of one wave execute in order: a compiler-level fence is all the next pass needs
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1958,7 +1949,7 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
             // leave (total cost, back pointer) of every node of the segment in the sentence's (dead) hit-staging region
             uint2* __restrict__ nb = reinterpret_cast<uint2*>(A.g_hits + node0 + seg_c);
             for (uint32_t c = ln; c < C; c += 64) {
-                const uint64_t k = e_key[cnd[c].x & 0xFFFFu];
+                const uint64_t k = e_key[(cnd[c].x & 0xFFFFu) >> 3];
                 nb[2 * c] = make_uint2(key_cost(k), key_pred(k));
             }
         }
@@ -1982,7 +1973,7 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
             for (uint32_t k = 0; k < SL; ++k) {
                 const uint4 r0 = uniform4(*reinterpret_cast<const uint4*>(&rec[k])), r1 = uniform4(*(reinterpret_cast<const uint4*>(&rec[k]) + 1));
                 if (r0.w) continue;  // one record per step: its first pass
-                const uint32_t c_beg = (r0.z - offC) >> 3, nc = r1.w >> 16, np = r1.w & 0xFFFFu;
+                const uint32_t c_beg = (r0.z - offC) >> 3, nc = r1.y, np = r1.x;
                 const bool eos_step = last_seg && k == eos_rec;
                 if (eos_step ? counted > nT : seg_c + c_beg < c_skip) continue;
                 uint32_t p_beg = (r0.y - offK) >> 3, p_end = p_beg + np;
@@ -2037,7 +2028,7 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
                 for (uint32_t c0 = 0; c0 < C; c0 += 64 * 4) {
                     uint32_t sl[4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) { const uint32_t c = c0 + u * 64 + ln; sl[u] = cnd[c < C ? c : 0u].x & 0xFFFFu; }
+                    for (int u = 0; u < 4; ++u) { const uint32_t c = c0 + u * 64 + ln; sl[u] = (cnd[c < C ? c : 0u].x & 0xFFFFu) >> 3; }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) { const uint32_t c = c0 + u * 64 + ln; if (c < C) bp[c] = (uint16_t)key_pred(e_key[sl[u]]); }
                 }
@@ -2048,7 +2039,7 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
                 if (flat) {
                     while (seq != kBosSeq && T < n) { path[T++] = (uint16_t)seq; seq = bp[seq]; }
                 } else {
-                    while (seq != kBosSeq && T < n) { path[T++] = (uint16_t)seq; seq = key_pred(e_key[cnd[seq].x & 0xFFFFu]); }
+                    while (seq != kBosSeq && T < n) { path[T++] = (uint16_t)seq; seq = key_pred(e_key[(cnd[seq].x & 0xFFFFu) >> 3]); }
                 }
             }
             T = (uint32_t)__builtin_amdgcn_readfirstlane((int)T);
@@ -2063,7 +2054,7 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
                 o.start_char = stp; o.end_char = en;
                 o.start_byte = c2b[stp]; o.end_byte = c2b[en];
                 o.word_idx = r.x;
-                o.total_cost = (int32_t)key_cost(e_key[cnd[c].x & 0xFFFFu]);
+                o.total_cost = (int32_t)key_cost(e_key[(cnd[c].x & 0xFFFFu) >> 3]);
                 A.tok_stage[slot0 + t] = o;  // the sentence's own staging region: no allocation atomic (compact_tokens packs them)
             }
         } else {
@@ -2346,6 +2337,37 @@ __global__ void __launch_bounds__(kScanBlock) compact_tokens(BatchArgs A, const 
     }
 }
 
+// The same packing, written straight into the caller's (pinned, device-mapped) host block: tok_off, tok_cnt and the token
+// records leave the GPU as the kernel's own stores -- posted PCIe writes, one fully coalesced 8-byte word per lane -- instead
+// of a copy command behind the kernels (the runtime serves a device -> pinned-host hipMemcpyAsync with a copy KERNEL of
+// ~1.3 ms for the 68 MB of the headline batch, serialised behind the batch's kernels: profiles/r03_h2h_timeline.md).
+__global__ void __launch_bounds__(kScanBlock) compact_tokens_out(BatchArgs A, const uint32_t* tile_sums, vbt_token_rec* out_tokens, uint32_t* out_off,
+                                                                 uint32_t* out_cnt) {
+    __shared__ uint32_t ws[kScanBlock / 64];
+    __shared__ uint32_t offs[kScanTile + 1];
+    if (A.ctrl[kError] & (uint32_t)kErrFatal) return;
+    const uint32_t tile0 = blockIdx.x * kScanTile, s = tile0 + threadIdx.x;
+    const uint32_t c = s < A.n ? A.tok_cnt[s] : 0u;
+    uint32_t tot;
+    const uint32_t ex = block_exscan(c, ws, tot);
+    const uint32_t base = tile_sums[blockIdx.x];
+    offs[threadIdx.x] = ex;
+    if (s < A.n) { out_off[s] = base + ex; out_cnt[s] = c; }
+    if (threadIdx.x == 0) offs[kScanTile] = tot;
+    __syncthreads();
+    const uint64_t o0 = A.offsets[0];
+    const uint64_t* __restrict__ src = reinterpret_cast<const uint64_t*>(A.tok_stage);
+    uint64_t* __restrict__ dst = reinterpret_cast<uint64_t*>(out_tokens) + 3 * (size_t)base;
+    for (uint32_t w = threadIdx.x; w < 3 * tot; w += kScanBlock) {  // word w of the tile's packed records: token w / 3, part w % 3
+        const uint32_t k = w / 3, part = w - 3 * k;
+        uint32_t lo = 0, hi = kScanTile;  // last sentence of the tile whose offset is <= k
+        while (lo + 1 < hi) { const uint32_t mid = (lo + hi) >> 1; if (offs[mid] <= k) lo = mid; else hi = mid; }
+        const uint32_t sn = tile0 + lo;
+        const size_t from = (size_t)(A.offsets[sn] - o0) + sn + (k - offs[lo]);
+        dst[w] = src[3 * from + part];
+    }
+}
+
 // Compact connectors (RawConnector / DualConnector) are materialised once, when the tokenizer is created: one thread per
 // (left, right) id pair evaluates the reference's cost function -- Scorer::accumulate_cost over the pair's feature rows
 // (connector/raw_connector/scorer.rs:327-345), plus the small matrix over mapped ids for a dual connector
@@ -2595,10 +2617,7 @@ Workspace::Workspace(const Tokenizer& t, uint64_t max_s, uint64_t max_b) : tok(t
             tier_events.push_back(e);
         }
         HIP_CHECK(hipEventCreateWithFlags(reinterpret_cast<hipEvent_t*>(&ev_fork2), hipEventDisableTiming));
-        for (int q = 0; q + 1 < kGenLevels; ++q) {
-            HIP_CHECK(hipStreamCreateWithFlags(reinterpret_cast<hipStream_t*>(&gen_streams[q]), hipStreamNonBlocking));
-            HIP_CHECK(hipEventCreateWithFlags(reinterpret_cast<hipEvent_t*>(&gen_events[q]), hipEventDisableTiming));
-        }
+
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gen_candidates_large), hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
         if (tiers.back() > 65536)  // a single workgroup may use the CU's whole 160 KiB
         {
@@ -2622,18 +2641,13 @@ void Workspace::release() {
     tier_events.clear();
     if (ev_fork2) (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(ev_fork2));
     ev_fork2 = nullptr;
-    for (int q = 0; q + 1 < kGenLevels; ++q) {
-        if (gen_events[q]) (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(gen_events[q]));
-        if (gen_streams[q]) (void)hipStreamDestroy(reinterpret_cast<hipStream_t>(gen_streams[q]));
-        gen_events[q] = gen_streams[q] = nullptr;
-    }
     for (void* st : streams) (void)hipStreamDestroy(reinterpret_cast<hipStream_t>(st));
     streams.clear();
 }
 
 Workspace::~Workspace() { release(); }
 
-void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n, uint64_t total_bytes, void* stream_) {
+void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n, uint64_t total_bytes, void* stream_, bool defer_pack) {
     if (n > max_sentences || total_bytes > max_bytes) throw Error(VBT_ERR_INVALID_ARGUMENT, "batch exceeds the workspace capacity");
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     HIP_CHECK(hipSetDevice(tok.device()));
@@ -2706,23 +2720,15 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
         // (s_tier[] = 0xFF, "nothing routed yet", is written by validate_batch: one launch less per batch)
         hipLaunchKernelGGL(gen_candidates, dim3(cn), dim3(64), gen_lds, stream, D, a, gen_lds);
         hipLaunchKernelGGL(build_lists, dim3(lb), dim3(1024), 0, stream, a, -1);
-        // gen_one filed every sentence that outgrew it at the smallest level of gen_long that holds it, so the levels are
-        // independent: each on its own stream, side by side.  Workgroups of 4 wavefronts (16 at the last level, which has a CU
-        // to itself), as many as a CU's LDS and its 32 wave slots admit.
-        auto launch_level = [&](uint32_t lv, hipStream_t st_) {
+        // gen_one filed every sentence that outgrew it at the smallest level of gen_long that holds it.  The levels run one after
+        // the other on the launch stream: side by side on their own streams was measured and costs more in event round trips
+        // (+0.35 ms per step on the headline batch, whose upper levels are empty) than config 5 gains from the overlap.
+        // Workgroups of 4 wavefronts (16 at the last level, which has a CU to itself), as many as a CU's LDS and its 32 wave slots admit.
+        for (uint32_t lv = 1; lv <= kGenLevels; ++lv) {
             const uint32_t lds = gen_level_lds[lv - 1], nw = lds > 65536 ? 16u : std::max<uint32_t>(1, std::min<uint32_t>(16, env_u32("VBT_GEN_WAVES", 4)));
             const uint32_t per_cu = std::max<uint32_t>(1, std::min<uint32_t>(32 / nw, 163840 / lds));
-            hipLaunchKernelGGL(gen_candidates_large, dim3(std::max<uint32_t>(1, std::min<uint32_t>(cn, per_cu * 256))), dim3(nw * 64), lds, st_, D, a, lds, lv);
-        };
-        HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_fork2), stream));
-        for (uint32_t lv = 2; lv <= kGenLevels; ++lv) {
-            hipStream_t side = reinterpret_cast<hipStream_t>(gen_streams[lv - 2]);
-            HIP_CHECK(hipStreamWaitEvent(side, reinterpret_cast<hipEvent_t>(ev_fork2), 0));
-            launch_level(lv, side);
-            HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(gen_events[lv - 2]), side));
+            hipLaunchKernelGGL(gen_candidates_large, dim3(std::max<uint32_t>(1, std::min<uint32_t>(cn, per_cu * 256))), dim3(nw * 64), lds, stream, D, a, lds, lv);
         }
-        launch_level(1, stream);
-        for (uint32_t lv = 2; lv <= kGenLevels; ++lv) HIP_CHECK(hipStreamWaitEvent(stream, reinterpret_cast<hipEvent_t>(gen_events[lv - 2]), 0));
         rec(1);
         // (forking the small tiers before the straggler generators was measured: 3.33 vs 3.2 ms, the stragglers then
         // compete with the sweep and the segment tier starts later)
@@ -2783,7 +2789,8 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
         const uint32_t n_tiles = (uint32_t)((n + kScanTile - 1) / kScanTile);
         hipLaunchKernelGGL(tok_tile_sums, dim3(n_tiles), dim3(kScanBlock), 0, stream, a, d_tile_sums);
         hipLaunchKernelGGL(tok_tile_scan, dim3(1), dim3(1024), 0, stream, a, d_tile_sums, n_tiles);
-        hipLaunchKernelGGL(compact_tokens, dim3(n_tiles), dim3(kScanBlock), 0, stream, a, (const uint32_t*)d_tile_sums);
+        if (!defer_pack) hipLaunchKernelGGL(compact_tokens, dim3(n_tiles), dim3(kScanBlock), 0, stream, a, (const uint32_t*)d_tile_sums);
+        last_args = a;
     }
     rec(2);
     HIP_CHECK(hipGetLastError());
@@ -2811,6 +2818,14 @@ void Workspace::run_one(const uint8_t* h_text_dev, uint32_t nb, uint8_t* d_text,
     auto k = D.space_cateset ? (D.matrix_wide ? tokenize_one<true, true> : tokenize_one<true, false>)
                              : (D.matrix_wide ? tokenize_one<false, true> : tokenize_one<false, false>);
     hipLaunchKernelGGL(k, dim3(1), dim3(64), kOneLds, stream, D, a, kOneLds, h_text_dev, nb, status_out);
+    HIP_CHECK(hipGetLastError());
+}
+
+void Workspace::pack_to(vbt_token_rec* out_tokens, uint32_t* out_off, uint32_t* out_cnt, void* stream_) {
+    if (last_n == 0) return;
+    const uint32_t n_tiles = (uint32_t)((last_n + kScanTile - 1) / kScanTile);
+    hipLaunchKernelGGL(compact_tokens_out, dim3(n_tiles), dim3(kScanBlock), 0, reinterpret_cast<hipStream_t>(stream_), last_args, (const uint32_t*)d_tile_sums,
+                       out_tokens, out_off, out_cnt);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -127,7 +127,10 @@ class Workspace {
   public:
     Workspace(const Tokenizer& tok, uint64_t max_sentences, uint64_t max_bytes);
     ~Workspace();
-    void run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n, uint64_t total_bytes, void* stream);
+    // defer_pack: stop behind the token-offset scan (the total is in d_ctrl[kTotal]); pack_to() then writes tok_off, tok_cnt and
+    // the packed records wherever the caller wants them (vbt_tokenize_batch: straight into its pinned host block)
+    void run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n, uint64_t total_bytes, void* stream, bool defer_pack = false);
+    void pack_to(vbt_token_rec* out_tokens, uint32_t* out_off, uint32_t* out_cnt, void* stream);
     void stats(vbt_call_stats* out);  // synchronizes the last stream used
     // Worker::tokenize() latency path: one sentence of `nb` bytes at `h_text_dev` (device address of pinned host memory, padded to
     // 16 bytes), ONE launch; `d_text` (>= nb + 16 bytes) / `d_offsets` (2 words) are device scratch of the caller; the token records,
@@ -147,8 +150,6 @@ class Workspace {
     std::vector<void*> streams;      // one side stream per LDS tier
     std::vector<void*> tier_events;
     void* ev_fork2 = nullptr;
-    void* gen_streams[2] = {nullptr, nullptr};  // gen_long levels 2 and 3 run next to level 1
-    void* gen_events[2] = {nullptr, nullptr};
     bool fused = false;              // VBT_FUSED=1: the single fused kernel per sentence (A/B reference)
     unsigned long long* d_connid = nullptr;  // [num_left + num_right] usage counters, allocated on first use
     uint32_t* d_counted = nullptr;           // per-sentence watermark of the counted steps
@@ -164,6 +165,7 @@ class Workspace {
     bool timing = false, profile = false;
     void read_profile(uint64_t* out, bool reset);  // kProfWords values
     uint64_t last_n = 0;
+    BatchArgs last_args{};  // of the last run(): what pack_to() packs
     void* last_stream = nullptr;
     void* ev[4] = {nullptr, nullptr, nullptr, nullptr};
 
