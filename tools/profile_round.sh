@@ -9,7 +9,7 @@ TAG=${1:-r01}; shift
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-BENCH="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-pipeline $@"
+BENCH="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-pipeline --no-suite --no-worker-loop $@"
 timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- $BENCH > $OUT/stats.log 2>&1
 grep '^{' $OUT/stats.log | tail -1 > $OUT/bench_line.json
 i=0
@@ -17,7 +17,7 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU S
            "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
            "FETCH_SIZE TCC_HIT_sum" "WRITE_SIZE TCC_MISS_sum TCC_REQ_sum"; do
   i=$((i+1))
-  timeout 150 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/pmc$i -o pmc$i -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-host-pipeline $@ > $OUT/pmc$i.log 2>&1
+  timeout 150 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/pmc$i -o pmc$i -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-host-pipeline --no-suite --no-worker-loop $@ > $OUT/pmc$i.log 2>&1
 done
 # 3. calibration of FETCH_SIZE / WRITE_SIZE on known byte counts in the kernels' access patterns (tools/calib/fetch_calib.hip)
 if [ -x tools/calib/fetch_calib ]; then

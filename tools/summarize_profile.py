@@ -121,11 +121,21 @@ if pm:
                 e = insts.setdefault(k, {"valu": 0, "salu": 0, "lds": 0, "vmem_rd": 0, "smem": 0})
                 for key, cn in (("valu", "SQ_INSTS_VALU"), ("salu", "SQ_INSTS_SALU"), ("lds", "SQ_INSTS_LDS"), ("vmem_rd", "SQ_INSTS_VMEM_RD"), ("smem", "SQ_INSTS_SMEM")):
                     e[key] += int(d.get(cn, 0))
+        # where the waves' cycles went (SQ counters of the second PMC pass), per kernel: bench.py reports the shares
+        sq = collections.OrderedDict()
+        for (i, k, g), d in pm.items():
+            if "SQ_WAVE_CYCLES" in d:
+                e = sq.setdefault(k, {"wave_cycles": 0, "busy_cycles": 0, "wait_any": 0, "wait_inst_any": 0, "active_inst_any": 0, "active_inst_valu": 0,
+                                      "active_inst_lds": 0, "lds_bank_conflict": 0, "lds_idx_active": 0})
+                for key, cn in (("wave_cycles", "SQ_WAVE_CYCLES"), ("busy_cycles", "SQ_BUSY_CYCLES"), ("wait_any", "SQ_WAIT_ANY"), ("wait_inst_any", "SQ_WAIT_INST_ANY"),
+                                ("active_inst_any", "SQ_ACTIVE_INST_ANY"), ("active_inst_valu", "SQ_ACTIVE_INST_VALU"), ("active_inst_lds", "SQ_ACTIVE_INST_LDS"),
+                                ("lds_bank_conflict", "SQ_LDS_BANK_CONFLICT"), ("lds_idx_active", "SQ_LDS_IDX_ACTIVE")):
+                    e[key] += int(d.get(cn, 0))
         # upper bound if every read of the step were a wide streaming read (the calibrated under-report of read16): the
         # per-char records (16 B/lane) and the sweep records (8 B/lane) are, the trie / matrix gathers are not
         rf = max((calib or {}).get("read16", {}).get("bytes_per_counted_byte", 1.0), (calib or {}).get("read8", {}).get("bytes_per_counted_byte", 1.0), 1.0)
         upper = sum((d["FETCH_SIZE"] * rf + d.get("WRITE_SIZE", 0)) * 1024 for d in pm.values())
-        json.dump({"workload": bench_cfg, "hbm_bytes_per_step": int(total), "hbm_bytes_by_kernel": by_kernel, "wave_insts_by_kernel": insts,
+        json.dump({"workload": bench_cfg, "hbm_bytes_per_step": int(total), "hbm_bytes_by_kernel": by_kernel, "wave_insts_by_kernel": insts, "sq_by_kernel": sq,
                    "hbm_bytes_per_step_upper_bound": int(upper), "calibration": calib, "source": f"profiles/{tag}_pmc.json",
                    "method": "sum over the step's kernels of (FETCH_SIZE + WRITE_SIZE) * 1024, separate rocprofv3 --pmc passes; upper bound = "
                              "every read scaled by the calibrated under-report of wide streaming reads"},

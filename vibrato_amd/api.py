@@ -282,7 +282,7 @@ class Tokenizer:
     def host_pipeline_benchmark(self, text, offsets, threads=2, rounds=4, repeats=3):
         """Host-to-host streaming throughput of vbt_tokenize_batch: `threads` host threads each push the whole batch through
         the thread-safe entry point `rounds` times, concurrently -- every call owns a pooled workspace, pinned staging and a
-        stream, so the H2D copy and the D2H copy of one batch run under the kernels of another.  Includes everything a
+        stream, so the H2D copy and the D2H copy (SDMA engines) of one batch run under the kernels of another.  Includes everything a
         caller of the reference's 3-call loop pays: the copy of the text into the batch, both PCIe directions and the result
         arrays landing in (pinned) host memory.  threads=1, rounds=1 is the latency of one unpipelined call."""
         import time

@@ -34,7 +34,7 @@ def build(force=False, verbose=False, variant="", defines=()):
            "-Wall", "-Wno-unused-result", "-x", "hip"]
     cmd += ["-D" + d for d in defines]
     cmd += [os.path.join(CSRC, f) for f in SOURCES]
-    cmd += ["-ldl", "-o", so]
+    cmd += ["-ldl", "-lhsa-runtime64", "-o", so]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -11,6 +11,9 @@
 #include <string>
 #include <vector>
 
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
+
 #include "engine.hpp"
 
 using namespace vbt;
@@ -46,6 +49,58 @@ struct PinnedBlock {
     ~PinnedBlock() { if (p) (void)hipHostFree(p); }
 };
 
+// Device -> pinned-host copies on the GPU's SDMA engines (hsa_amd_memory_async_copy), next to the HIP runtime: hipMemcpyAsync
+// serves a device -> pinned-host copy of this size with a copy KERNEL (and so does a kernel that stores to the mapped block
+// itself); either way the 69 MB of token records of a headline batch occupy the shader memory pipes for ~1.3 ms during which
+// the kernels of the other batches in flight do not advance (profiles/r03_h2h_timeline.md).  The DMA engines do not.
+struct Sdma {
+    hsa_agent_t gpu{}, cpu{};
+    bool ok = false;
+    struct Find { uint32_t bdf; uint32_t domain; hsa_agent_t gpu{}, cpu{}; bool has_gpu = false, has_cpu = false; };
+    static hsa_status_t visit(hsa_agent_t a, void* data) {
+        Find* f = static_cast<Find*>(data);
+        hsa_device_type_t type;
+        if (hsa_agent_get_info(a, HSA_AGENT_INFO_DEVICE, &type) != HSA_STATUS_SUCCESS) return HSA_STATUS_SUCCESS;
+        if (type == HSA_DEVICE_TYPE_CPU) {
+            if (!f->has_cpu) { f->cpu = a; f->has_cpu = true; }
+        } else if (type == HSA_DEVICE_TYPE_GPU) {
+            uint32_t bdf = 0, domain = 0;
+            (void)hsa_agent_get_info(a, static_cast<hsa_agent_info_t>(HSA_AMD_AGENT_INFO_BDFID), &bdf);
+            (void)hsa_agent_get_info(a, static_cast<hsa_agent_info_t>(HSA_AMD_AGENT_INFO_DOMAIN), &domain);
+            if (!f->has_gpu && bdf == f->bdf && domain == f->domain) { f->gpu = a; f->has_gpu = true; }
+        }
+        return HSA_STATUS_SUCCESS;
+    }
+    explicit Sdma(int device) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) != hipSuccess) return;
+        if (hsa_init() != HSA_STATUS_SUCCESS) return;  // (reference counted: the HIP runtime holds it already)
+        Find f{(uint32_t)((prop.pciBusID << 8) | (prop.pciDeviceID << 3)), (uint32_t)prop.pciDomainID};
+        if (hsa_iterate_agents(visit, &f) != HSA_STATUS_SUCCESS || !f.has_gpu || !f.has_cpu) return;
+        gpu = f.gpu; cpu = f.cpu; ok = true;
+    }
+    // copies[k] = {dst (pinned host), src (device), bytes}; returns when all have landed
+    bool d2h(const void* const* src, void* const* dst, const size_t* bytes, int n) const {
+        hsa_signal_t sig;
+        int live = 0;
+        for (int k = 0; k < n; ++k) live += bytes[k] ? 1 : 0;
+        if (!live) return true;
+        if (hsa_signal_create(live, 0, nullptr, &sig) != HSA_STATUS_SUCCESS) return false;
+        bool good = true;
+        int issued = 0;
+        for (int k = 0; k < n && good; ++k)
+            if (bytes[k]) { good = hsa_amd_memory_async_copy(dst[k], cpu, src[k], gpu, bytes[k], 0, nullptr, sig) == HSA_STATUS_SUCCESS; issued += good ? 1 : 0; }
+        if (issued) {
+            // (a failed issue leaves the count above zero: wait only for what was issued)
+            const hsa_signal_value_t target = live - issued + 1;
+            while (hsa_signal_wait_scacquire(sig, HSA_SIGNAL_CONDITION_LT, target, UINT64_MAX, HSA_WAIT_STATE_ACTIVE) >= target) {}
+            if (hsa_signal_load_relaxed(sig) < 0) good = false;
+        }
+        (void)hsa_signal_destroy(sig);
+        return good;
+    }
+};
+
 struct vbt_tokenizer {
     std::unique_ptr<Tokenizer> t;
     vbt_dict dict_view;  // borrowed view handed out by vbt_tokenizer_dictionary
@@ -53,6 +108,8 @@ struct vbt_tokenizer {
     std::vector<std::unique_ptr<PooledWorkspace>> pool;  // idle workspaces
     std::vector<std::unique_ptr<PinnedBlock>> host_pool;  // idle pinned blocks
     uint64_t pool_created = 0, pool_reused = 0;
+    std::unique_ptr<Sdma> sdma;  // device -> pinned-host copies on the DMA engines (created at the first host batch)
+    int out_mode = -1;                  // VBT_H2H_OUT: 0 = the packing kernel stores into the pinned block, 1 = SDMA copies (default)
     ~vbt_tokenizer() { pool.clear(); }  // before the Tokenizer (workspaces reference it)
 };
 struct vbt_workspace { std::unique_ptr<Workspace> w; };
@@ -660,9 +717,23 @@ int vbt_tokenize_batch(const vbt_tokenizer* tok_, const uint8_t* text, const uin
         PooledWorkspace& p = *h.p;
         if (bytes) HIPX(hipMemcpyAsync(p.d_text, txt, bytes, hipMemcpyHostToDevice, p.stream));
         HIPX(hipMemcpyAsync(p.d_off, offs, (n + 1) * 8, hipMemcpyHostToDevice, p.stream));
-        // kernels up to the token-offset scan; the total and the error flags come back in 8 bytes, then the packing kernel writes
-        // the results straight into this batch's pinned block (no copy command behind the kernels)
-        p.ws->run(static_cast<const uint8_t*>(p.d_text), p.d_off, n, bytes, p.stream, /*defer_pack=*/true);
+        // How the results reach the host (VBT_H2H_OUT): 1 (default) = packed on the device, then copied by the GPU's SDMA engines
+        // (Sdma above); 0 = the packing kernel stores them straight into this batch's pinned block.  Either way the total and the
+        // error flags come back first, in 8 bytes, so that the pinned block is sized exactly.
+        if (tok->out_mode < 0) {
+            std::lock_guard<std::mutex> g(tok->pool_mu);
+            if (tok->out_mode < 0) {
+                const char* e = std::getenv("VBT_H2H_OUT");
+                int mode = e && *e ? std::atoi(e) : 1;
+                if (mode == 1) {
+                    tok->sdma = std::make_unique<Sdma>(tok->t->device());
+                    if (!tok->sdma->ok) mode = 0;
+                }
+                tok->out_mode = mode;
+            }
+        }
+        const bool use_sdma = tok->out_mode == 1;
+        p.ws->run(static_cast<const uint8_t*>(p.d_text), p.d_off, n, bytes, p.stream, /*defer_pack=*/!use_sdma);
         uint32_t* tail = reinterpret_cast<uint32_t*>(txt + ((bytes + 7) & ~(uint64_t)7));  // {n_tokens, error flags}
         tail[0] = tail[1] = 0;
         HIPX(hipMemcpyAsync(tail, p.ws->d_ctrl, 8, hipMemcpyDeviceToHost, p.stream));
@@ -681,11 +752,17 @@ int vbt_tokenize_batch(const vbt_tokenizer* tok_, const uint8_t* text, const uin
         b.tok_off = o;
         b.tok_cnt = o + n;
         b.tokens = reinterpret_cast<const vbt_token_rec*>(o + 2 * n);
-        if (n) {
+        if (n && use_sdma) {
+            const void* src[3] = {p.ws->d_tok_off, p.ws->d_tok_cnt, p.ws->d_tokens};
+            void* dst[3] = {o, o + n, o + 2 * n};
+            const size_t len[3] = {(size_t)n * 4, (size_t)n * 4, (size_t)b.n_tokens * sizeof(vbt_token_rec)};
+            if (!tok->sdma->d2h(src, dst, len, 3)) throw Error(VBT_ERR_DEVICE, "device -> host copy of the results failed (hsa_amd_memory_async_copy)");
+        } else if (n) {
             void* dev = nullptr;
             HIPX(hipHostGetDevicePointer(&dev, o, 0));
             uint32_t* od = static_cast<uint32_t*>(dev);
-            p.ws->pack_to(reinterpret_cast<vbt_token_rec*>(od + 2 * n), od, od + n, p.stream);
+            static const bool no_pack = std::getenv("VBT_H2H_NO_PACK") != nullptr;  // timing experiment only: results stay on the device
+            if (!no_pack) p.ws->pack_to(reinterpret_cast<vbt_token_rec*>(od + 2 * n), od, od + n, p.stream);
             HIPX(hipStreamSynchronize(p.stream));
         }
         pool_give(tok, std::move(h.p));

@@ -2341,30 +2341,33 @@ __global__ void __launch_bounds__(kScanBlock) compact_tokens(BatchArgs A, const 
 // records leave the GPU as the kernel's own stores -- posted PCIe writes, one fully coalesced 8-byte word per lane -- instead
 // of a copy command behind the kernels (the runtime serves a device -> pinned-host hipMemcpyAsync with a copy KERNEL of
 // ~1.3 ms for the 68 MB of the headline batch, serialised behind the batch's kernels: profiles/r03_h2h_timeline.md).
-__global__ void __launch_bounds__(kScanBlock) compact_tokens_out(BatchArgs A, const uint32_t* tile_sums, vbt_token_rec* out_tokens, uint32_t* out_off,
+__global__ void __launch_bounds__(kScanBlock) compact_tokens_out(BatchArgs A, const uint32_t* tile_sums, uint32_t n_tiles, vbt_token_rec* out_tokens, uint32_t* out_off,
                                                                  uint32_t* out_cnt) {
     __shared__ uint32_t ws[kScanBlock / 64];
     __shared__ uint32_t offs[kScanTile + 1];
     if (A.ctrl[kError] & (uint32_t)kErrFatal) return;
-    const uint32_t tile0 = blockIdx.x * kScanTile, s = tile0 + threadIdx.x;
-    const uint32_t c = s < A.n ? A.tok_cnt[s] : 0u;
-    uint32_t tot;
-    const uint32_t ex = block_exscan(c, ws, tot);
-    const uint32_t base = tile_sums[blockIdx.x];
-    offs[threadIdx.x] = ex;
-    if (s < A.n) { out_off[s] = base + ex; out_cnt[s] = c; }
-    if (threadIdx.x == 0) offs[kScanTile] = tot;
-    __syncthreads();
-    const uint64_t o0 = A.offsets[0];
-    const uint64_t* __restrict__ src = reinterpret_cast<const uint64_t*>(A.tok_stage);
-    uint64_t* __restrict__ dst = reinterpret_cast<uint64_t*>(out_tokens) + 3 * (size_t)base;
-    for (uint32_t w = threadIdx.x; w < 3 * tot; w += kScanBlock) {  // word w of the tile's packed records: token w / 3, part w % 3
-        const uint32_t k = w / 3, part = w - 3 * k;
-        uint32_t lo = 0, hi = kScanTile;  // last sentence of the tile whose offset is <= k
-        while (lo + 1 < hi) { const uint32_t mid = (lo + hi) >> 1; if (offs[mid] <= k) lo = mid; else hi = mid; }
-        const uint32_t sn = tile0 + lo;
-        const size_t from = (size_t)(A.offsets[sn] - o0) + sn + (k - offs[lo]);
-        dst[w] = src[3 * from + part];
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {  // (the grid may be smaller than the tile count: VBT_PACK_WGS)
+        const uint32_t tile0 = tile * kScanTile, s = tile0 + threadIdx.x;
+        const uint32_t c = s < A.n ? A.tok_cnt[s] : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_exscan(c, ws, tot);
+        const uint32_t base = tile_sums[tile];
+        offs[threadIdx.x] = ex;
+        if (s < A.n) { out_off[s] = base + ex; out_cnt[s] = c; }
+        if (threadIdx.x == 0) offs[kScanTile] = tot;
+        __syncthreads();
+        const uint64_t o0 = A.offsets[0];
+        const uint64_t* __restrict__ src = reinterpret_cast<const uint64_t*>(A.tok_stage);
+        uint64_t* __restrict__ dst = reinterpret_cast<uint64_t*>(out_tokens) + 3 * (size_t)base;
+        for (uint32_t w = threadIdx.x; w < 3 * tot; w += kScanBlock) {  // word w of the tile's packed records: token w / 3, part w % 3
+            const uint32_t k = w / 3, part = w - 3 * k;
+            uint32_t lo = 0, hi = kScanTile;  // last sentence of the tile whose offset is <= k
+            while (lo + 1 < hi) { const uint32_t mid = (lo + hi) >> 1; if (offs[mid] <= k) lo = mid; else hi = mid; }
+            const uint32_t sn = tile0 + lo;
+            const size_t from = (size_t)(A.offsets[sn] - o0) + sn + (k - offs[lo]);
+            dst[w] = src[3 * from + part];
+        }
+        __syncthreads();  // offs[] is rewritten by the next tile
     }
 }
 
@@ -2824,7 +2827,8 @@ void Workspace::run_one(const uint8_t* h_text_dev, uint32_t nb, uint8_t* d_text,
 void Workspace::pack_to(vbt_token_rec* out_tokens, uint32_t* out_off, uint32_t* out_cnt, void* stream_) {
     if (last_n == 0) return;
     const uint32_t n_tiles = (uint32_t)((last_n + kScanTile - 1) / kScanTile);
-    hipLaunchKernelGGL(compact_tokens_out, dim3(n_tiles), dim3(kScanBlock), 0, reinterpret_cast<hipStream_t>(stream_), last_args, (const uint32_t*)d_tile_sums,
+    const uint32_t wgs = std::max<uint32_t>(1, std::min<uint32_t>(n_tiles, env_u32("VBT_PACK_WGS", n_tiles)));
+    hipLaunchKernelGGL(compact_tokens_out, dim3(wgs), dim3(kScanBlock), 0, reinterpret_cast<hipStream_t>(stream_), last_args, (const uint32_t*)d_tile_sums, n_tiles,
                        out_tokens, out_off, out_cnt);
     HIP_CHECK(hipGetLastError());
 }
