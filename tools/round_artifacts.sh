@@ -1,17 +1,28 @@
 #!/bin/bash
-# Everything the round's committed artefacts come from, in one GPU call: tools/round_artifacts.sh r02
-#   parity suite, default bench line (CPU legs + host-to-host leg), rocprofv3 evidence, the other BASELINE configurations
-TAG=${1:-r02}; OUT=gpurun_out/art_$TAG; mkdir -p $OUT
+# Everything the round's committed artefacts come from, in one GPU call: tools/round_artifacts.sh r03
+#   parity suite, default bench line (CPU legs, suite, Worker loop, host-to-host), rocprofv3 evidence, the other BASELINE
+#   configurations, config-5 kernel timeline, phase profile, host-to-host timeline, the self-launched 2-rank bench line
+TAG=${1:-r03}; OUT=gpurun_out/art_$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log; tail -3 $OUT/pytest_gpu.log
-timeout 600 python bench.py > $OUT/bench_default.json 2>$OUT/bench_default.err; tail -c 300 $OUT/bench_default.err
+timeout 1200 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log; tail -3 $OUT/pytest_gpu.log
+timeout 900 python bench.py > $OUT/bench_default.json 2>$OUT/bench_default.err; tail -c 300 $OUT/bench_default.err
 bash tools/profile_round.sh $TAG > $OUT/profile.log 2>&1
-run() { name=$1; shift; timeout 300 python bench.py --no-cpu-baseline --no-host-pipeline --steps 10 "$@" 2>/dev/null | grep '^{' | tail -1 > $OUT/$name.json; python -c "
+run() { name=$1; shift; timeout 300 python bench.py --no-cpu-baseline --no-host-pipeline --no-suite --no-worker-loop --steps 10 "$@" 2>/dev/null | grep '^{' | tail -1 > $OUT/$name.json; python -c "
 import json; d=json.load(open('$OUT/$name.json')); r=d['roofline']; print('$name', d['value'], d['ms_per_step'], 'gen', r['gen_candidates']['kernel_ms'], 'lat', r['kernel_ms'], d['parity_vs_oracle_sample'], r['tiers'])"; }
+CFG5="--law mixed --ignore-space --max-grouping-len 24 --user-lexicon 1000"
 run cfg2_ipadic --dict ipadic
 run cfg3_unidic
-run cfg5_unidic_user_S_M24_mixed --law mixed --ignore-space --max-grouping-len 24 --user-lexicon 1000
+run cfg5_unidic_user_S_M24_mixed $CFG5
 run dense_unidic --dict unidic-dense
 run unidic_short_uniform_5_20 --law uniform_5_20
-run cfg3_unidic_reordered --reorder
 timeout 200 python tools/phase_profile.py > $OUT/phase.txt 2>&1; tail -12 $OUT/phase.txt
+# config 5, kernel by kernel
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/cfg5_stats -o stats -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-pipeline --no-suite --no-worker-loop $CFG5 > $OUT/cfg5_stats.log 2>&1
+# host-to-host pipeline: hip + memory-copy + kernel trace (no counters)
+timeout 300 rocprofv3 --hip-trace --memory-copy-trace --kernel-trace --output-format csv -d $OUT/h2h_trace -o h2h -- python tools/h2h_bench.py 1 1 4 4 > $OUT/h2h_trace.log 2>&1
+rm -f $OUT/h2h_trace/*hip_api_trace.csv   # (7 MB of API calls: not needed for the timeline)
+TAG=sdma python tools/h2h_bench.py 1 1 3 4 4 4 4 4 2>&1 | grep -v amdgpu > $OUT/h2h_modes.txt
+TAG=kernel_stores VBT_H2H_OUT=0 python tools/h2h_bench.py 1 1 3 4 4 4 2>&1 | grep -v amdgpu >> $OUT/h2h_modes.txt
+cat $OUT/h2h_modes.txt
+# bench.py --gpus 2 started WITHOUT a launcher (it starts its own ranks); one GPU on this box: both ranks on device 0, gloo instead of RCCL
+VBT_BENCH_BACKEND=gloo VBT_BENCH_SINGLE_DEVICE=1 timeout 600 python bench.py --gpus 2 --steps 5 --warmup 2 --sentences 200000 > $OUT/bench_gpus2_selflaunch_gloo.json 2>$OUT/bench_gpus2.err; tail -c 300 $OUT/bench_gpus2_selflaunch_gloo.json

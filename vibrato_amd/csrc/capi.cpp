@@ -79,24 +79,28 @@ struct Sdma {
         if (hsa_iterate_agents(visit, &f) != HSA_STATUS_SUCCESS || !f.has_gpu || !f.has_cpu) return;
         gpu = f.gpu; cpu = f.cpu; ok = true;
     }
-    // copies[k] = {dst (pinned host), src (device), bytes}; returns when all have landed
+    // dst[k] (pinned host) <- src[k] (device), bytes[k]; returns when all have landed.  One completion signal per copy, initial
+    // value 1: what rocprofv3's memory-copy tracing expects of a caller (it aborts on a shared, counted signal).
     bool d2h(const void* const* src, void* const* dst, const size_t* bytes, int n) const {
-        hsa_signal_t sig;
-        int live = 0;
-        for (int k = 0; k < n; ++k) live += bytes[k] ? 1 : 0;
-        if (!live) return true;
-        if (hsa_signal_create(live, 0, nullptr, &sig) != HSA_STATUS_SUCCESS) return false;
-        bool good = true;
+        constexpr int kMax = 4;
+        hsa_signal_t sig[kMax];
         int issued = 0;
-        for (int k = 0; k < n && good; ++k)
-            if (bytes[k]) { good = hsa_amd_memory_async_copy(dst[k], cpu, src[k], gpu, bytes[k], 0, nullptr, sig) == HSA_STATUS_SUCCESS; issued += good ? 1 : 0; }
-        if (issued) {
-            // (a failed issue leaves the count above zero: wait only for what was issued)
-            const hsa_signal_value_t target = live - issued + 1;
-            while (hsa_signal_wait_scacquire(sig, HSA_SIGNAL_CONDITION_LT, target, UINT64_MAX, HSA_WAIT_STATE_ACTIVE) >= target) {}
-            if (hsa_signal_load_relaxed(sig) < 0) good = false;
+        bool good = n <= kMax;
+        for (int k = 0; k < n && good; ++k) {
+            if (!bytes[k]) continue;
+            if (hsa_signal_create(1, 0, nullptr, &sig[issued]) != HSA_STATUS_SUCCESS) { good = false; break; }
+            if (hsa_amd_memory_async_copy(dst[k], cpu, src[k], gpu, bytes[k], 0, nullptr, sig[issued]) != HSA_STATUS_SUCCESS) {
+                (void)hsa_signal_destroy(sig[issued]);
+                good = false;
+                break;
+            }
+            ++issued;
         }
-        (void)hsa_signal_destroy(sig);
+        for (int k = 0; k < issued; ++k) {
+            while (hsa_signal_wait_scacquire(sig[k], HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_ACTIVE) >= 1) {}
+            if (hsa_signal_load_relaxed(sig[k]) < 0) good = false;
+            (void)hsa_signal_destroy(sig[k]);
+        }
         return good;
     }
 };

@@ -818,7 +818,7 @@ __device__ __forceinline__ void list_push(const BatchArgs& A, uint32_t t, uint32
 // LDS bytes gen_long needs for a sentence of n characters / nb bytes (an over-estimate of its Arena carve: gen_one files a
 // sentence that outgrows it at the smallest level that holds it).
 __host__ __device__ __forceinline__ uint64_t gen_long_bytes(uint32_t n, uint32_t nb, bool has_user) {
-    return 64 + 2 * ((uint64_t)(nb >> 6) + 4) + (uint64_t)(n + 2) * (has_user ? 18u : 16u) + 64;
+    return 64 + 2 * ((uint64_t)(nb >> 6) + 4) + (uint64_t)(n + 2) * (has_user ? 16u : 14u) + 64;  // ci 4, code 2 (+ user 2), grp 2, co 2, endc 4 per character
 }
 
 // Kernel 1 body: Sentence::compile + candidate enumeration of one sentence by one wavefront.
@@ -1173,7 +1173,7 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
 
 // The generator for sentences that outgrew the bulk generator's LDS: ONE WORKGROUP (several wavefronts) per sentence.  Long
 // sentences hold most of the characters of a mixed-length batch (BASELINE config 5: 5 % of the sentences, 55 % of the characters);
-// with one wavefront each their LDS footprint (~16 bytes per character) left 5-10 waves on a CU.  Same phases and the same
+// with one wavefront each their LDS footprint (14-16 bytes per character) left 5-10 waves on a CU.  Same phases and the same
 // outputs as gen_one (per-character records, candidates in the reference's insertion order with their end-list slots,
 // routing); the 64-position chunks of every phase are dealt round-robin to the workgroup's waves, and what gen_one carries
 // from chunk to chunk in registers becomes a small scan between two barriers:
