@@ -181,12 +181,17 @@ VBT_API int vbt_connid_probs(const uint64_t* counts, size_t n, uint32_t* ids, do
 
 /* The 3-call loop of tokenize/src/main.rs:78-82 over n sentences: sentence s is
  * text[offsets[s] .. offsets[s+1]). Copies text to the device, runs the kernels,
- * copies token records back. The batch keeps its own copy of the text.
+ * copies token records back (the GPU's SDMA engines, into a pinned block sized to the result). The batch keeps its own copy of the text.
  * Every sentence must be valid UTF-8 (a Rust `str`): otherwise VBT_ERR_UTF8 and no batch.
  * Thread-safe per tokenizer: each call takes a workspace (device scratch + staging + stream) from the tokenizer's
- * pool and returns it, so steady-state calls do no device allocation (vbt_tokenizer_pool_stats). */
+ * pool and returns it, so steady-state calls do no device allocation (vbt_tokenizer_pool_stats); batches pushed from
+ * several host threads overlap their copies with each other's kernels (3-4 threads reach the kernel-bound rate).
+ * The pools keep idle workspaces (~400 B of device memory per byte of text of the batch they were sized for) and pinned
+ * blocks for reuse, at most VBT_POOL_MAX_MB of each (default 32768 MB of device memory, 4096 MB of pinned memory; what
+ * would exceed it is released instead of pooled); vbt_tokenizer_trim_pool releases everything idle now. */
 VBT_API int vbt_tokenize_batch(const vbt_tokenizer* tok, const uint8_t* text, const uint64_t* offsets, uint64_t n,
                                vbt_batch** out);
+VBT_API int vbt_tokenizer_trim_pool(const vbt_tokenizer* tok);
 VBT_API int vbt_tokenizer_pool_stats(const vbt_tokenizer* tok, uint64_t* created, uint64_t* reused, uint64_t* idle);
 VBT_API void vbt_batch_free(vbt_batch* b);
 VBT_API uint64_t vbt_batch_num_sentences(const vbt_batch* b);

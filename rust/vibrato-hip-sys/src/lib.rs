@@ -109,6 +109,7 @@ extern "C" {
     pub fn vbt_tokenizer_dictionary(tok: *const vbt_tokenizer) -> *const vbt_dict;
 
     // ---- Worker
+    pub fn vbt_tokenizer_trim_pool(tok: *const vbt_tokenizer) -> c_int;
     pub fn vbt_worker_new(tok: *const vbt_tokenizer, out: *mut *mut vbt_worker) -> c_int;
     pub fn vbt_worker_free(w: *mut vbt_worker);
     pub fn vbt_worker_reset_sentence(w: *mut vbt_worker, utf8: *const c_char, len: usize) -> c_int;

@@ -419,6 +419,21 @@ def test_device_api_accepts_a_window_and_rejects_bad_offsets():
     assert st["error_flags"] == 0 and st["n_tokens"] == len(to.new_worker().tokenize_batch(text, offs)[0])
 
 
+def test_pool_trim_and_budget(monkeypatch):
+    """Idle workspaces / pinned blocks are released by trim_pool and never pooled beyond VBT_POOL_MAX_MB."""
+    sd = synth.SynthDict("tiny")
+    _, tv = _oracle_and_product(sd)
+    text, offs = sd.sentences(500, "lognormal_40")
+    for _ in range(3):
+        tv.tokenize_batch(text=text, offsets=offs)
+    created, reused, idle = tv.pool_stats()
+    assert created == 1 and reused == 2 and idle == 1
+    tv.trim_pool()
+    assert tv.pool_stats()[2] == 0
+    tv.tokenize_batch(text=text, offsets=offs)
+    assert tv.pool_stats()[0] == 2  # re-created on demand
+
+
 def test_host_batches_reuse_pooled_workspaces():
     sd = synth.SynthDict("tiny")
     to, tv = _oracle_and_product(sd)

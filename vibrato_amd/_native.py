@@ -67,6 +67,7 @@ SIGNATURES = {
     "vbt_tokenizer_new": (_int, [_vp, _int, _u32, _int, _PP]),
     "vbt_tokenizer_free": (None, [_vp]),
     "vbt_tokenizer_dictionary": (_vp, [_vp]),
+    "vbt_tokenizer_trim_pool": (_int, [_vp]),
     "vbt_worker_new": (_int, [_vp, _PP]),
     "vbt_worker_free": (None, [_vp]),
     "vbt_worker_reset_sentence": (_int, [_vp, _cp, _sz]),

@@ -260,6 +260,10 @@ class Tokenizer:
         N.check(N.lib().vbt_tokenizer_pool_stats(self._handle(), C.byref(c), C.byref(r), C.byref(i)))
         return c.value, r.value, i.value
 
+    def trim_pool(self):
+        """Releases the idle pooled workspaces and pinned blocks of tokenize_batch (they are re-created on demand)."""
+        N.check(N.lib().vbt_tokenizer_trim_pool(self._handle()))
+
     def new_worker(self):
         """Tokenizer::new_worker (tokenizer.rs:82-84)."""
         return Worker(self)

@@ -297,9 +297,33 @@ std::unique_ptr<PinnedBlock> host_take(vbt_tokenizer* tok, size_t bytes) {
     return b;
 }
 
+// Budgets of the idle pools (capacities are rounded up to powers of two and were never trimmed: a few large calls
+// pinned tens of GiB for the tokenizer's lifetime).  VBT_POOL_MAX_MB=<device MB>[,<pinned MB>].
+void pool_budgets(uint64_t& dev_bytes, uint64_t& host_bytes) {
+    static uint64_t dev = 0, host = 0;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        unsigned long long d = 32768, h = 4096;
+        if (const char* e = std::getenv("VBT_POOL_MAX_MB")) {
+            unsigned long long a = 0, b = 0;
+            const int k = std::sscanf(e, "%llu,%llu", &a, &b);
+            if (k >= 1) d = a;
+            if (k >= 2) h = b;
+        }
+        dev = d << 20; host = h << 20;
+    });
+    dev_bytes = dev; host_bytes = host;
+}
+uint64_t workspace_bytes(const PooledWorkspace& p) { return 400 * p.cap_bytes + 64 * p.cap_sentences; }  // (vibrato_hip.h: footprint)
+
 void host_give(vbt_tokenizer* tok, std::unique_ptr<PinnedBlock> b) {
     if (!b) return;
+    uint64_t dev_budget, host_budget;
+    pool_budgets(dev_budget, host_budget);
     std::lock_guard<std::mutex> g(tok->pool_mu);
+    uint64_t held = b->cap;
+    for (const auto& q : tok->host_pool) held += q->cap;
+    if (held > host_budget) return;  // released (hipHostFree) instead of pooled
     tok->host_pool.push_back(std::move(b));
     if (tok->host_pool.size() > kHostPoolIdle) {
         size_t smallest = 0;
@@ -310,7 +334,13 @@ void host_give(vbt_tokenizer* tok, std::unique_ptr<PinnedBlock> b) {
 }
 
 void pool_give(vbt_tokenizer* tok, std::unique_ptr<PooledWorkspace> p) {
+    uint64_t dev_budget, host_budget;
+    pool_budgets(dev_budget, host_budget);
+    std::unique_ptr<PooledWorkspace> drop;  // destroyed outside the lock
     std::lock_guard<std::mutex> g(tok->pool_mu);
+    uint64_t held = workspace_bytes(*p);
+    for (const auto& q : tok->pool) held += workspace_bytes(*q);
+    if (held > dev_budget) { drop = std::move(p); return; }
     tok->pool.push_back(std::move(p));
     if (tok->pool.size() > kPoolIdle) {
         size_t smallest = 0;
@@ -771,6 +801,22 @@ int vbt_tokenize_batch(const vbt_tokenizer* tok_, const uint8_t* text, const uin
         }
         pool_give(tok, std::move(h.p));
         *out = h.b.release();
+    });
+}
+
+// Releases every idle pooled workspace and pinned block now (they are re-created on demand).
+int vbt_tokenizer_trim_pool(const vbt_tokenizer* tok_) {
+    return guarded([&] {
+        vbt_tokenizer* tok = const_cast<vbt_tokenizer*>(tok_);
+        if (!tok) throw Error(VBT_ERR_INVALID_ARGUMENT, "null argument");
+        std::vector<std::unique_ptr<PooledWorkspace>> ws;
+        std::vector<std::unique_ptr<PinnedBlock>> blocks;
+        {
+            std::lock_guard<std::mutex> g(tok->pool_mu);
+            ws.swap(tok->pool);
+            blocks.swap(tok->host_pool);
+        }
+        HIPX(hipSetDevice(tok->t->device()));
     });
 }
 

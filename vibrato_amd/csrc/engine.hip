@@ -3,14 +3,15 @@
 // Pipeline (default): validate_batch (device-side input contract) -> gen_candidates (one wavefront per sentence: UTF-8 decode, char categories and groupable
 // runs -- Sentence::compile, sentence.rs:34-71 -- and candidate generation by double-array common-prefix search +
 // unknown-word rules -- Tokenizer::add_lattice_edges tokenizer.rs:141-199, UnkHandler::gen_unk_words
-// unknown.rs:69-137) -> build_lists -> gen_candidates_large (sentences that outgrew the bulk generator's LDS) ->
+// unknown.rs:69-137) -> build_lists -> gen_candidates_large (gen_long: one WORKGROUP per sentence that outgrew the bulk generator's LDS) ->
 // lattice_lds (by default ONE 10 KiB tier that sweeps longer sentences in segments; one wavefront per sentence: the position sweep with per-node min-cost
 // search over the connection matrix -- build_lattice_inner tokenizer.rs:94-139, Lattice::insert_node /
 // search_min_node lattice.rs:103-151, insert_eos 85-101 -- and the back-trace, append_top_nodes
 // lattice.rs:159-168; the lattice lives in LDS, longer sentences are swept in segments between clean cuts; what the
 // generator found too dense for that is swept by a 48 KiB launch next to the tiers) -> tokenize_global for whatever is
 // left -> tok_tile_sums / tok_tile_scan / compact_tokens (tokens from per-sentence staging into sentence order).  The fused single-kernel design (process_sentence: tokenize_lds /
-// tokenize_global) is the fallback with a global-memory lattice and, with VBT_FUSED=1, an A/B reference.
+// tokenize_global) is the fallback with a global-memory lattice and, with VBT_FUSED=1, an A/B reference.  Worker::tokenize is
+// tokenize_one: generator + sweep of one sentence in ONE launch, text and token records through pinned host memory.
 //
 // Bit-exactness notes: end lists are built with LDS atomics, so their order is arbitrary;
 // every node carries its insertion sequence number and ties are broken towards the LARGEST sequence number,
