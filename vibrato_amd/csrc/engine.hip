@@ -1677,6 +1677,10 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
         const uint4 rend = uniform4(pcg[seg_b]);  // record of the segment's end position (the terminator for the last segment)
         const uint32_t C = ((rend.x & 0xFFFFu) - seg_c) & 0xFFFFu;
         const uint32_t E = m_in + C;  // end-list slots: interface (BOS) + the segment's candidates; slot E is the EOS node's
+        if (E >= 8191u) {  // the candidate records hold a key's byte offset (slot * 8) in 16 bits: a shorter segment, or the next tier / the fused kernel
+            if (budget > lds_bytes / 3) { budget -= lds_bytes / 4; __syncthreads(); continue; }
+            fail = 26; break;
+        }
         const uint32_t sb = seg_s;    // sentence-global slot of local slot 0
         const uint4* __restrict__ nd = ndg + seg_c;
 
