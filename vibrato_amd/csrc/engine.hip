@@ -1930,8 +1930,9 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
                     const uint32_t khi = (uint32_t)(kb >> 32) + word[u] + wc[u];                 // wrapping i32 adds: connection + word cost (lattice.rs:125,139)
                     const uint32_t klo = __builtin_amdgcn_perm((uint32_t)kb, cy[u], 0x05040100u);  // predecessor's own field << 16 | the candidate's
                     const uint64_t live = __ballot((uint32_t)kb != 0xFFFFFFFFu) & mask;
-                    // (a lane without a live pair carries the dead key, a no-op for the minimum should it tie with m)
-                    const uint32_t hi = select_mask(live, 0xFFFFFFFFu, khi), lo = select_mask(live, 0xFFFFFFFFu, klo);
+                    // (a lane without a live pair carries the highest cost: it never wins against a live lane of its group, and the atomic
+                    // below is issued by live lanes only, so its low word is never looked at)
+                    const uint32_t hi = select_mask(live, 0xFFFFFFFFu, khi), lo = klo;
                     const uint32_t lg = slg[u];
                     // minimum cost of every candidate in registers; only the lanes that hold it go to LDS, where the atomic on the
                     // whole key settles ties (rare) towards the last inserted predecessor: no same-address pile-up
