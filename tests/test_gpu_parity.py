@@ -155,6 +155,32 @@ def test_full_size_batch_bit_exact(shape):
     assert np.array_equal(toks["end_byte"][last], lens[cnt > 0])
 
 
+def test_config4_sized_batch_on_one_gpu_equals_its_shards():
+    """BASELINE config 4's corpus (1 M sentences, 140 MB of text) as ONE batch on one GPU (a ~56 GB workspace): the records equal
+    those of the same corpus tokenized as 8 contiguous shards (what 8 ranks would each do), the first 20 000 sentences equal the
+    oracle's, and tokens tile every sentence (no spaces are skipped in this mode)."""
+    from vibrato_amd import sharding
+    sd = synth.SynthDict("ipadic")
+    to, tv = _oracle_and_product(sd)
+    text, offs = sd.sentences(1000000, "lognormal_40")
+    whole = tv.tokenize_batch(text=text, offsets=offs)
+    toks, off, cnt = whole.arrays()
+    assert len(cnt) == 1000000 and int(cnt.sum()) == len(toks) > 20_000_000
+    ordered, ends = sharding.tokens_in_sentence_order(off, cnt, toks)
+    bnd = sharding.shard_bounds(offs, 8)
+    for r in range(8):
+        ltext, loffs, (lo, hi) = sharding.local_shard(text, offs, r, 8)
+        part, _ = tv.tokenize_batch(text=np.ascontiguousarray(ltext), offsets=loffs).tokens_in_order()
+        assert part.tobytes() == ordered[int(ends[lo]):int(ends[hi])].tobytes(), r
+        del part
+    exp, exp_off = to.new_worker().tokenize_batch(text[:int(offs[20000])], offs[:20001])
+    assert ordered[:len(exp)].tobytes() == exp.tobytes()
+    first, last = ends[:-1][cnt > 0], ends[1:][cnt > 0] - 1
+    assert np.all(ordered["start_byte"][first] == 0)
+    assert np.array_equal(ordered["end_byte"][last], np.diff(offs).astype(np.uint32)[cnt > 0])
+    tv.trim_pool()
+
+
 def test_edge_cases(fixture_sources):
     s = fixture_sources
     d = V.SystemDictionaryBuilder.from_readers(s["lex.csv"], s["matrix.def"], s["char.def"], s["unk.def"])
