@@ -214,7 +214,7 @@ VBT_API void vbt_free(void* p);
  * max_sentences sentences / max_bytes bytes of text, and is reused across calls.
  * Footprint: about 400 bytes of device memory per byte of text (candidate records and staged trie hits at 8 slots of
  * 16 bytes per input byte each, token staging + compact tokens at 24 bytes each, per-character records, the fused
- * fallback's scratch) plus 50 bytes per sentence: ~6 GB for the 14 MB / 100k-sentence headline batch, and at most
+ * fallback's scratch) plus ~7 KB per sentence (head room of its node region): ~6.5 GB for the 14 MB / 100k-sentence headline batch, and at most
  * ~0.6 GB of text per workspace on a 288 GB part -- larger corpora are fed as a sequence of batches (the host entry
  * point vbt_tokenize_batch refuses a batch of 4 GiB or more outright; VBT_ERR_DEVICE when the allocation fails). */
 VBT_API int vbt_workspace_new(const vbt_tokenizer* tok, uint64_t max_sentences, uint64_t max_bytes, vbt_workspace** out);

@@ -314,7 +314,7 @@ void pool_budgets(uint64_t& dev_bytes, uint64_t& host_bytes) {
     });
     dev_bytes = dev; host_bytes = host;
 }
-uint64_t workspace_bytes(const PooledWorkspace& p) { return 400 * p.cap_bytes + 64 * p.cap_sentences; }  // (vibrato_hip.h: footprint)
+uint64_t workspace_bytes(const PooledWorkspace& p) { return 400 * p.cap_bytes + 7200 * p.cap_sentences; }  // (vibrato_hip.h: footprint)
 
 void host_give(vbt_tokenizer* tok, std::unique_ptr<PinnedBlock> b) {
     if (!b) return;

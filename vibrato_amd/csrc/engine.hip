@@ -150,9 +150,12 @@ __device__ __forceinline__ uint64_t uniform64(uint64_t v) {
 
 // Per-sentence regions of the workspace (per-character records, candidates, staged hits) are addressed by the
 // sentence's byte offset RELATIVE to the batch (offsets[0] may be anything: a window into a larger text buffer)
-// plus its index: sentence s owns the character slots [off(s) + s, off(s + 1) + s + 1).
+// plus kSentenceSlack slots per sentence before it: sentence s owns the character slots [off(s) + K s, off(s + 1) + K (s + 1)) -- its
+// bytes + 1 are what the per-character arrays need, the rest is head room for its node region (node_factor slots per character slot):
+// a short sentence of a dense lexicon has more than node_factor nodes per byte (0.3 % of the dense law's sentences took the
+// global-memory fallback for that, 0.6 of its 5.3 ms per step).
 __device__ __forceinline__ size_t sentence_slot(const BatchArgs& A, uint64_t b0, uint32_t sid) {
-    return (size_t)(b0 - uniform64(A.offsets[0])) + sid;
+    return (size_t)(b0 - uniform64(A.offsets[0])) + (size_t)kSentenceSlack * sid;
 }
 __device__ __forceinline__ bool batch_rejected(const BatchArgs& A) {
     return (__builtin_amdgcn_readfirstlane(A.ctrl[kError]) & (uint32_t)kErrFatal) != 0;
@@ -944,7 +947,7 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
     // end | start << 16, candidates of this start position before the hit} and expanded afterwards by
     // independent lanes.
     const uint64_t base = (uint64_t)A.node_factor * slot0;  // this sentence's node region (no allocation atomic)
-    const uint64_t region = (uint64_t)A.node_factor * (nb + 1);
+    const uint64_t region = (uint64_t)A.node_factor * (nb + kSentenceSlack);
     uint4* __restrict__ hits = A.g_hits + base;
     if (ln == 0) *hcount = 0;
     __syncthreads();
@@ -1290,7 +1293,7 @@ __device__ __forceinline__ void gen_long(const DevDict& D, const BatchArgs& A, u
 
     // one trie walk per start position (tokenizer.rs:155-198, unknown.rs:69-116): hits staged in global memory exactly as in gen_one
     const uint64_t base = (uint64_t)A.node_factor * slot0;
-    const uint64_t region = (uint64_t)A.node_factor * (nb + 1);
+    const uint64_t region = (uint64_t)A.node_factor * (nb + kSentenceSlack);
     uint4* __restrict__ hits = A.g_hits + base;
     for (uint32_t c0 = wv * 64; c0 < n; c0 += nw * 64) {
         const uint32_t i = c0 + ln;
@@ -2336,7 +2339,7 @@ __global__ void __launch_bounds__(kScanBlock) compact_tokens(BatchArgs A, const 
         uint32_t lo = 0, hi = kScanTile;  // last sentence of the tile whose offset is <= k (empty sentences share offsets: take the last)
         while (lo + 1 < hi) { const uint32_t mid = (lo + hi) >> 1; if (offs[mid] <= k) lo = mid; else hi = mid; }
         const uint32_t s = tile0 + lo;
-        const size_t from = (size_t)(A.offsets[s] - o0) + s + (k - offs[lo]);
+        const size_t from = (size_t)(A.offsets[s] - o0) + (size_t)kSentenceSlack * s + (k - offs[lo]);
         const size_t to = (size_t)base + k;
 #pragma unroll
         for (int w = 0; w < 3; ++w) dst[3 * to + w] = src[3 * from + w];
@@ -2370,7 +2373,7 @@ __global__ void __launch_bounds__(kScanBlock) compact_tokens_out(BatchArgs A, co
             uint32_t lo = 0, hi = kScanTile;  // last sentence of the tile whose offset is <= k
             while (lo + 1 < hi) { const uint32_t mid = (lo + hi) >> 1; if (offs[mid] <= k) lo = mid; else hi = mid; }
             const uint32_t sn = tile0 + lo;
-            const size_t from = (size_t)(A.offsets[sn] - o0) + sn + (k - offs[lo]);
+            const size_t from = (size_t)(A.offsets[sn] - o0) + (size_t)kSentenceSlack * sn + (k - offs[lo]);
             dst[w] = src[3 * from + part];
         }
         __syncthreads();  // offs[] is rewritten by the next tile
@@ -2580,7 +2583,7 @@ Workspace::Workspace(const Tokenizer& t, uint64_t max_s, uint64_t max_b) : tok(t
         return p;
     };
     d_tokens = static_cast<vbt_token_rec*>(alloc(nbts * sizeof(vbt_token_rec)));  // tokens <= chars <= bytes
-    d_tok_stage = static_cast<vbt_token_rec*>(alloc((nbts + ns + 1) * sizeof(vbt_token_rec)));  // per-sentence regions
+    d_tok_stage = static_cast<vbt_token_rec*>(alloc((nbts + kSentenceSlack * ns + 1) * sizeof(vbt_token_rec)));  // per-sentence regions
     d_tile_sums = static_cast<uint32_t*>(alloc(((ns + kScanTile - 1) / kScanTile + 1) * 4));
     d_tok_off = static_cast<uint32_t*>(alloc(ns * 4));
     d_tok_cnt = static_cast<uint32_t*>(alloc(ns * 4));
@@ -2606,7 +2609,7 @@ Workspace::Workspace(const Tokenizer& t, uint64_t max_s, uint64_t max_b) : tok(t
     profile = env_u32("VBT_PROFILE", 0) != 0;
     for (auto& e : ev) HIP_CHECK(hipEventCreate(reinterpret_cast<hipEvent_t*>(&e)));
     // two-kernel pipeline buffers
-    const size_t slots = nbts + ns + 1;
+    const size_t slots = nbts + kSentenceSlack * ns + 1;
     pipe.s_n = static_cast<uint32_t*>(alloc(ns * 4));
     pipe.s_C = static_cast<uint32_t*>(alloc(ns * 4));
     if (!fused) {

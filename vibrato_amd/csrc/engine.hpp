@@ -40,7 +40,7 @@ struct BatchArgs {
     uint32_t n;
     // outputs
     vbt_token_rec* tokens;     // compact result (sentence order)
-    vbt_token_rec* tok_stage;  // staging: sentence s writes its tokens at its own slot (offsets[s] - offsets[0] + s)
+    vbt_token_rec* tok_stage;  // staging: sentence s writes its tokens at its own slot (sentence_slot)
     uint32_t tok_cap;
     uint32_t* tok_off;
     uint32_t* tok_cnt;
@@ -56,11 +56,11 @@ struct BatchArgs {
     uint32_t* s_n;      // characters
     uint32_t* s_C;      // lattice candidates
     uint32_t* s_passes; // upper bound of the lattice passes
-    // per character slot (sentence s, char i -> slot offsets[s] + s + i; nb + 1 slots per sentence)
+    // per character slot (sentence s, char i -> slot offsets[s] - offsets[0] + kSentenceSlack * s + i; nb + kSentenceSlack slots per sentence)
     uint16_t* g_c2b;
     uint4* g_pc;        // {cand_off, groupable | is_space << 31, lens lo, lens hi}
     // per candidate (insertion order, contiguous per sentence; sentence s owns the node slots
-    // [node_factor * (offsets[s] + s), node_factor * (offsets[s+1] + s + 1)): no allocation atomics).
+    // [node_factor * slot(s), node_factor * slot(s + 1)): no allocation atomics).
     //   g_cand: 16 bytes, one scattered store by the generator: .x/.y what the sweep needs {right_id | end-list slot << 16,
     //   (u16) word_cost | left_id << 16}, .z/.w what only the tokens of the best path need {word_idx, end_char}
     uint4* g_cand;
@@ -94,6 +94,7 @@ struct BatchArgs {
 // ctrl[kNodeCursor] bump pointer of the candidate arrays
 enum CtrlSlot { kTotal = 0, kError = 1, kBump = 2, kNodeCursor = 4, kTierCtrl = 6, kCtrlWords = 32 };
 constexpr int kMaxTiers = 8;
+constexpr uint32_t kSentenceSlack = 24;  // character slots per sentence on top of its bytes (see sentence_slot in engine.hip)
 constexpr int kCtrlBlocks = 2;   // list-counter blocks: [0] the batch, [1] the input list of the optional long-first side stream
 constexpr int kGenLevels = 3;  // large-LDS instances of the generator behind the bulk one (32 KiB, 64 KiB, whole CU)
 constexpr int kListsBehindTiers = 1 + kGenLevels + 1;  // fallback, generator levels, pre-routed escapes (see engine.hip `dense_list`)
