@@ -240,12 +240,14 @@ VBT_API int vbt_workspace_results(const vbt_workspace* ws, const vbt_token_rec**
  * to the smallest LDS tier of the lattice kernel (n_tier0), to the larger LDS tiers (n_tier1) and to
  * the global-memory fallback kernel (n_tier2; a re-routed sentence is counted twice), tokens
  * written, device error flags (1 = token buffer full, 2 = scratch exhausted, 4 = sentence too
- * long, 8 = bad offsets, 16 = invalid UTF-8) and, with timing enabled, the hipEvent-measured duration (ms, on the launch stream) of the
- * candidate-generation kernels (ms_tier0) and of everything after them (ms_tier12). */
+ * long, 8 = bad offsets, 16 = invalid UTF-8) and, with timing enabled, the hipEvent-measured durations (ms, on the launch stream) of the
+ * bulk candidate generator (ms_tier0), of the lattice sweeps from their fork to their join (ms_tier12; the side streams that
+ * generate and sweep the long sentences of the batch started earlier and are joined here) and of what follows -- the global-memory
+ * fallback launch and the packing of the token records (ms_pack). */
 typedef struct vbt_call_stats {
     uint64_t n_sentences, n_tier0, n_tier1, n_tier2, n_tokens;
     uint32_t error_flags;
-    float ms_tier0, ms_tier12;
+    float ms_tier0, ms_tier12, ms_pack;
 } vbt_call_stats;
 VBT_API int vbt_workspace_set_timing(vbt_workspace* ws, int enabled);
 /* Worker::init_connid_counter / update_connid_counts (worker.rs:77-93, Lattice::add_connid_counts lattice.rs:170-183):

@@ -69,6 +69,7 @@ pub struct vbt_call_stats {
     pub error_flags: u32,
     pub ms_tier0: f32,
     pub ms_tier12: f32,
+    pub ms_pack: f32,
 }
 
 extern "C" {

@@ -112,5 +112,6 @@ def test_bench_py_self_launches_ranks_when_no_launcher_started_it():
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dict", "tiny", "--sentences", "100"], env=env, cwd=root,
                        capture_output=True, text=True, timeout=300)
     assert p.returncode != 0
-    assert p.stderr.count("bench.py needs an MI355X") == 2, p.stderr[-3000:]
+    # (the launcher tears the other rank down as soon as one has failed: one or both get as far as the message)
+    assert 1 <= p.stderr.count("bench.py needs an MI355X") <= 2, p.stderr[-3000:]
     assert "launch with torch.distributed.run" not in p.stderr

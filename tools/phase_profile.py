@@ -19,17 +19,26 @@ def main():
     ap.add_argument("--min-chars", type=int, default=0, help="keep only sentences with at least this many bytes/3")
     ap.add_argument("--max-chars", type=int, default=0)
     ap.add_argument("--law", default="lognormal_40")
+    ap.add_argument("--user", type=int, default=0, help="user lexicon entries (BASELINE config 5: 1000)")
+    ap.add_argument("--ignore-space", action="store_true")
+    ap.add_argument("--mgl", type=int, default=0)
+    ap.add_argument("--space-p", type=float, default=0.0)
+    ap.add_argument("--keep", type=int, default=0, help="after filtering keep only the first N sentences")
     args = ap.parse_args()
     import torch
     import vibrato_amd as V
     from tools import synth
     sd = synth.SynthDict(args.dict)
     dv = V.SystemDictionaryBuilder.from_readers_binmatrix(sd.lex, sd.matrix, sd.num_right, sd.num_left, sd.char_def, sd.unk)
-    tok = V.Tokenizer(dv, device=0)
-    text, offs = sd.sentences(args.sentences, args.law)
+    if args.user:
+        dv.reset_user_lexicon_from_reader(sd.user_csv(args.user))
+    tok = V.Tokenizer(dv, device=0).ignore_space(args.ignore_space).max_grouping_len(args.mgl)
+    text, offs = sd.sentences(args.sentences, args.law, space_p=args.space_p, seed=synth.SEED)
     if args.min_chars or args.max_chars:
         lens = np.diff(offs).astype(np.int64)
         keep = np.nonzero((lens >= 2.85 * args.min_chars) & ((lens <= 2.85 * args.max_chars) if args.max_chars else True))[0]
+        if args.keep:
+            keep = keep[:args.keep]
         parts = [text[int(offs[i]):int(offs[i + 1])] for i in keep]
         text = np.concatenate(parts) if parts else np.zeros(0, np.uint8)
         offs = np.zeros(len(keep) + 1, dtype=np.uint64)

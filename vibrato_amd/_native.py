@@ -37,7 +37,7 @@ class Token(C.Structure):
 
 class CallStats(C.Structure):
     _fields_ = [("n_sentences", C.c_uint64), ("n_tier0", C.c_uint64), ("n_tier1", C.c_uint64), ("n_tier2", C.c_uint64),
-                ("n_tokens", C.c_uint64), ("error_flags", C.c_uint32), ("ms_tier0", C.c_float), ("ms_tier12", C.c_float)]
+                ("n_tokens", C.c_uint64), ("error_flags", C.c_uint32), ("ms_tier0", C.c_float), ("ms_tier12", C.c_float), ("ms_pack", C.c_float)]
 
 
 # name -> (restype, argtypes); also the list of symbols include/vibrato_hip.h declares.

@@ -28,6 +28,15 @@
 
 #include "engine.hpp"
 
+#ifndef VBT_GEN_OCC
+#define VBT_GEN_OCC 8
+#endif
+#if VBT_GEN_OCC
+#define VBT_GEN_OCC_ATTR __attribute__((amdgpu_waves_per_eu(VBT_GEN_OCC, VBT_GEN_OCC)))
+#else
+#define VBT_GEN_OCC_ATTR
+#endif
+
 namespace vbt {
 namespace {
 
@@ -783,16 +792,27 @@ __global__ void __launch_bounds__(256) validate_batch(BatchArgs A, uint64_t tota
         else if (a < oN && (A.text[a] & 0xC0) == 0x80) bad |= kErrUtf8;  // a sentence starts inside a character
     }
     if (!(bad & kErrOffsets) && oN - o0 <= total_bytes) {
+        // Eight bytes per thread and round, read as the aligned 8-byte word they sit in plus the word behind it (4 bytes of
+        // look-ahead): two loads instead of twelve.  Bytes of those words outside the text count as 0 (an aligned word that holds
+        // a byte of the text lies in the text's page).
         const uint8_t* __restrict__ t = A.text + o0;
         const uint64_t nb = oN - o0;
-        for (uint64_t i0 = tid * 8; i0 < nb; i0 += nthreads * 8) {
-            uint32_t b[12];  // 8 lead positions + 4 bytes of look-ahead; past the end = 0 (not a continuation byte)
+        const uint64_t head = reinterpret_cast<uintptr_t>(t) & 7u;  // bytes of the first word in front of the text
+        const uint64_t* __restrict__ tw = reinterpret_cast<const uint64_t*>(t - head);
+        const uint64_t nwords = (head + nb + 7) >> 3;
+        for (uint64_t w = tid; w < nwords; w += nthreads) {
+            const uint64_t w0 = tw[w], w1 = w + 1 < nwords ? tw[w + 1] : 0ull;
+            const int64_t i0 = (int64_t)(w << 3) - (int64_t)head;  // text index of the word's first byte (negative inside the head)
+            uint32_t b[12];  // 8 lead positions + 4 bytes of look-ahead; outside the text = 0 (not a continuation byte)
 #pragma unroll
-            for (int k = 0; k < 12; ++k) b[k] = i0 + k < nb ? t[i0 + k] : 0u;
+            for (int k = 0; k < 12; ++k) {
+                const uint32_t v = (uint32_t)((k < 8 ? w0 >> (8 * k) : w1 >> (8 * (k - 8))) & 0xFFu);
+                b[k] = (i0 + k >= 0 && (uint64_t)(i0 + k) < nb) ? v : 0u;
+            }
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const uint32_t c = b[k];
-                if (i0 + k >= nb || (c & 0xC0) == 0x80) continue;  // continuation bytes are checked from their lead byte
+                if (i0 + k < 0 || (uint64_t)(i0 + k) >= nb || (c & 0xC0) == 0x80) continue;  // continuation bytes are checked from their lead byte
                 const uint32_t len = c < 0x80 ? 1u : c < 0xE0 ? 2u : c < 0xF0 ? 3u : 4u;
                 bool ok = c < 0x80 || (c >= 0xC2 && c < 0xF5);
 #pragma unroll
@@ -819,10 +839,56 @@ __device__ __forceinline__ void list_push(const BatchArgs& A, uint32_t t, uint32
     if (threadIdx.x == 0) A.lists[(size_t)t * A.list_stride + A.list_off + atomicAdd(&A.cctrl[2 * t], 1u)] = sid;
 }
 
+__device__ __forceinline__ void list_push_fb(const BatchArgs& A, uint32_t sid) {  // the batch's fallback list (see BatchArgs::fb_cctrl)
+    if (threadIdx.x == 0) A.lists[(size_t)A.n_tiers * A.list_stride + A.fb_list_off + atomicAdd(&A.fb_cctrl[2 * A.n_tiers], 1u)] = sid;
+}
+
 // LDS bytes gen_long needs for a sentence of n characters / nb bytes (an over-estimate of its Arena carve: gen_one files a
 // sentence that outgrows it at the smallest level that holds it).
 __host__ __device__ __forceinline__ uint64_t gen_long_bytes(uint32_t n, uint32_t nb, bool has_user) {
     return 64 + 2 * ((uint64_t)(nb >> 6) + 4) + (uint64_t)(n + 2) * (has_user ? 16u : 14u) + 64;  // ci 4, code 2 (+ user 2), grp 2, co 2, endc 4 per character
+}
+
+// characters of a sentence (lead bytes), counted by one wavefront
+__device__ __forceinline__ uint32_t count_chars(const uint8_t* __restrict__ txt, uint32_t nb) {
+    uint32_t n = 0;
+    for (uint32_t c0 = 0; c0 < nb; c0 += 64) {
+        const uint32_t bi = c0 + threadIdx.x;
+        const bool lead = bi < nb && (txt[bi] & 0xC0) != 0x80;
+        n += (uint32_t)__popcll(__ballot(lead));
+    }
+    return n;
+}
+
+// gen_one's per-character working arrays in its wavefront's LDS (~26 bytes per character).  `ok` = they fit: the test by which
+// gen_one (bulk generator) and route_long (side stream) split a batch between them -- both carve with this one function.
+struct GenOneLds {
+    uint64_t* lens;
+    uint32_t *ci, *cand_off;
+    uint16_t *code, *ucode, *grp;
+    uint32_t *endc, *hcount;
+    bool ok;
+};
+__device__ __forceinline__ GenOneLds carve_gen_one(char* base, uint32_t lds_bytes, uint32_t n, bool has_user) {
+    Arena ar{base, lds_bytes, 0, true};
+    GenOneLds L;
+    L.lens = ar.take<uint64_t>(n);
+    L.ci = ar.take<uint32_t>(n);
+    L.cand_off = ar.take<uint32_t>(n + 1);
+    L.code = ar.take<uint16_t>(n);
+    L.ucode = has_user ? ar.take<uint16_t>(n) : L.code;
+    L.grp = ar.take<uint16_t>(n);
+    L.endc = ar.take<uint32_t>(n + 1);
+    L.hcount = ar.take<uint32_t>(1);
+    L.ok = ar.ok;
+    return L;
+}
+// the smallest level of gen_long whose LDS holds the sentence
+__device__ __forceinline__ uint32_t gen_long_level(const BatchArgs& A, uint32_t n, uint32_t nb, bool has_user) {
+    const uint64_t need = gen_long_bytes(n, nb, has_user);
+    uint32_t lv = 0;
+    while (lv + 1 < (uint32_t)kGenLevels && need > A.gen_level_bytes[lv]) ++lv;
+    return lv;
 }
 
 // Kernel 1 body: Sentence::compile + candidate enumeration of one sentence by one wavefront.
@@ -845,46 +911,45 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
         if (A.direct_push) list_push(A, t, sid);  // (Worker's single launch: no build_lists behind it)
         else if (ln == 0) A.s_tier[sid] = (uint8_t)t;
     };
-    if (ln == 0) { A.s_n[sid] = 0; A.s_C[sid] = 0; A.s_tier[sid] = 0xFF; }
+    auto init = [&]() { if (ln == 0) { A.s_n[sid] = 0; A.s_C[sid] = 0; A.s_tier[sid] = 0xFF; } };
     if (nb64 == 0) {
+        init();
         if (ln == 0) A.tok_cnt[sid] = 0;
         return;
     }
-    if (nb64 >= 65535) { route(fallback); return; }  // positions are u16 in the LDS lattice
+    if (nb64 >= 65535) { init(); route(fallback); return; }  // positions are u16 in the LDS lattice
     const uint32_t nb = (uint32_t)nb64;
     const uint8_t* __restrict__ txt = A.text + b0;
     const size_t slot0 = sentence_slot(A, b0, sid);
 
-    uint32_t n = 0;
-    for (uint32_t c0 = 0; c0 < nb; c0 += 64) {
-        const uint32_t bi = c0 + ln;
-        const bool lead = bi < nb && (txt[bi] & 0xC0) != 0x80;
-        n += (uint32_t)__popcll(__ballot(lead));
-    }
+    const uint32_t n = count_chars(txt, nb);
     if (n == 0) {
+        init();
         if (ln == 0) A.tok_cnt[sid] = 0;
         return;
     }
-    Arena ar{g_smem, lds_bytes, 0, true};
-    uint64_t* lens = ar.take<uint64_t>(n);
-    uint32_t* ci = ar.take<uint32_t>(n);
-    uint32_t* cand_off = ar.take<uint32_t>(n + 1);
+    const GenOneLds L = carve_gen_one(g_smem, lds_bytes, n, D.has_user != 0);
+    if (!L.ok) {
+        // Outgrows this wavefront: gen_long, one workgroup per sentence.  In a batch (early_long) route_long found the sentence by the
+        // same test on a side stream, where its generator and its sweep are already under way: nothing of it is touched here.
+        if (A.early_long) return;
+        init();
+        route(A.n_tiers + 1 + gen_long_level(A, n, nb, D.has_user != 0));
+        return;
+    }
+    init();
+    uint64_t* const lens = L.lens;
+    uint32_t* const ci = L.ci;
+    uint32_t* const cand_off = L.cand_off;
     auto set_lens = [&](uint32_t i, uint64_t v) { lens[i] = v; };
     auto get_lens = [&](uint32_t i) -> uint64_t { return lens[i]; };
     auto set_co = [&](uint32_t i, uint32_t v) { cand_off[i] = v; };
     auto get_co = [&](uint32_t i) -> uint32_t { return cand_off[i]; };
-    uint16_t* code = ar.take<uint16_t>(n);
-    uint16_t* ucode = D.has_user ? ar.take<uint16_t>(n) : code;
-    uint16_t* grp = ar.take<uint16_t>(n);
-    uint32_t* endc = ar.take<uint32_t>(n + 1);  // candidates ending at each position (bounds the pass count)
-    uint32_t* hcount = ar.take<uint32_t>(1);  // hits staged so far
-    if (!ar.ok) {  // outgrows this wavefront: gen_long, at the smallest level whose LDS holds it (the levels run concurrently)
-        const uint64_t need = gen_long_bytes(n, nb, D.has_user != 0);
-        uint32_t lv = 0;
-        while (lv + 1 < (uint32_t)kGenLevels && need > A.gen_level_bytes[lv]) ++lv;
-        route(A.n_tiers + 1 + lv);
-        return;
-    }
+    uint16_t* const code = L.code;
+    uint16_t* const ucode = L.ucode;
+    uint16_t* const grp = L.grp;
+    uint32_t* const endc = L.endc;      // candidates ending at each position (bounds the pass count)
+    uint32_t* const hcount = L.hcount;  // hits staged so far
     for (uint32_t i = ln; i < n + 1; i += 64) endc[i] = i == 0 ? 1u : 0u;  // BOS ends at 0
 
     // decode (Sentence::compute_basic / compute_categories, sentence.rs:40-55); the 3 bytes after a
@@ -1019,8 +1084,8 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
     const uint32_t H = *hcount;  // <= C <= region
     for (uint32_t h0 = 0; h0 < H; h0 += 64) {
         const uint32_t h = h0 + ln;
+        const uint4 hr = h < H ? hits[h] : make_uint4(0, 0, 0, 0);
         if (h < H) {
-            const uint4 hr = hits[h];
             const uint32_t c = hr.y & 0xFFFFu, lex = hr.y >> 16, end = hr.z & 0xFFFFu, pos = hr.z >> 16;
             const Entry* __restrict__ ent = lex == 0 ? D.sys.entries : lex == 1 ? D.user.entries : D.unk_entries;
             const uint32_t dest = get_co(pos) + hr.w;
@@ -1193,7 +1258,9 @@ __device__ __forceinline__ void gen_long(const DevDict& D, const BatchArgs& A, u
     // fit after all" only happens beyond the last level: the fused kernel takes it)
     const uint32_t fallback = A.n_tiers, next_level = fallback;
     (void)level;
-    auto route = [&](uint32_t t) { list_push(A, t, sid); };  // (thread 0 appends: these launches run behind build_lists)
+    // (thread 0 appends: no build_lists behind these launches.  The fallback list is the batch's, everything else this launch's own.)
+    auto route = [&](uint32_t t) { if (t == fallback) list_push_fb(A, sid); else list_push(A, t, sid); };
+    if (tid == 0) { A.s_n[sid] = 0; A.s_C[sid] = 0; }
     if (nb64 == 0) {
         if (tid == 0) A.tok_cnt[sid] = 0;
         return;
@@ -1355,8 +1422,12 @@ __device__ __forceinline__ void gen_long(const DevDict& D, const BatchArgs& A, u
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
     // expand the hits: threads = hits (see gen_one)
+    // (the next round's hit records are requested before this round's entries: one round trip per round instead of two; in
+    // gen_one, with three rounds per sentence, the same was measured slightly slower)
+    uint4 hr_next = tid < H ? hits[tid] : make_uint4(0, 0, 0, 0);
     for (uint32_t h = tid; h < H; h += nthreads) {
-        const uint4 hr = hits[h];
+        const uint4 hr = hr_next;
+        if (h + nthreads < H) hr_next = hits[h + nthreads];
         const uint32_t c = hr.y & 0xFFFFu, lex = hr.y >> 16, end = hr.z & 0xFFFFu, pos = hr.z >> 16;
         const Entry* __restrict__ ent = lex == 0 ? D.sys.entries : lex == 1 ? D.user.entries : D.unk_entries;
         const uint32_t dest = (uint32_t)co[pos] + hr.w;
@@ -1456,6 +1527,7 @@ __device__ __forceinline__ void gen_long(const DevDict& D, const BatchArgs& A, u
                 const uint64_t third = r.space ? (uint64_t)grp[i] : r.lm;
                 const uint32_t yw = (r.nsl < 0x3FFFu ? r.nsl : 0x3FFFu) | cut | r.space;
                 pc[i] = make_uint4(r.co_i | (eo(i) << 16), yw, (uint32_t)third, (uint32_t)(third >> 32));
+                ci[i] = yw;  // (a copy for the routing replay below, over the position's CharInfo: only this lane read it, just now)
             }
             uint32_t nsl = r.nsl;
 #pragma unroll
@@ -1482,12 +1554,12 @@ __device__ __forceinline__ void gen_long(const DevDict& D, const BatchArgs& A, u
         if (fixed <= A.tier_bytes[t]) { tier = t; break; }
     if (A.seg_tier < A.n_tiers && tier > A.seg_tier) tier = A.seg_tier;
     if (tier == A.seg_tier && A.seg_tier + 1 < A.n_tiers && fixed > A.tier_bytes[tier]) {
-        // replay lattice_lds' choice of cuts on the finished records (wave 0; see gen_one): unsweepable -> the pre-routed escape list
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        if (wv != 0) return;
-        const uint4* __restrict__ pcr = A.g_pc + slot0;
+        // replay lattice_lds' choice of cuts on the finished records (wave 0; see gen_one): unsweepable -> the pre-routed escape list.
+        // What it reads per position sits in LDS -- the record's second word (over ci[]), the candidate offsets (co[]) and the
+        // end-list offsets (endc[]): from global memory every probe was a round trip of the one wave that is left.
+        if (wv != 0) return;  // (the barrier behind the records loop above made the other waves' LDS writes visible)
+        auto rec_y = [&](uint32_t p) -> uint32_t { return ci[p]; };
+        auto rec_co = [&](uint32_t p) -> uint32_t { return co[p]; };  // (co[n] = C)
         const uint32_t budget = A.tier_bytes[tier];
         uint32_t seg_a = 0, seg_c = 0, seg_p = 0, m_in = 1;
         bool sweepable = true;
@@ -1498,10 +1570,10 @@ __device__ __forceinline__ void gen_long(const DevDict& D, const BatchArgs& A, u
                 const uint32_t b = seg_a + w0 + ln + 1;
                 uint32_t nsl = 0, cx = 0, cut = 0;
                 if (b <= n) {
-                    nsl = pcr[b - 1].y & 0x3FFFu;
+                    nsl = rec_y(b - 1) & 0x3FFFu;
                     if (nsl == 0x3FFFu) nsl = 1u << 20;
-                    cx = pcr[b].x & 0xFFFFu;
-                    cut = b == n ? 1u : (pcr[b].y >> 30) & 1u;
+                    cx = rec_co(b);
+                    cut = b == n ? 1u : (rec_y(b) >> 30) & 1u;
                 }
                 uint32_t tot;
                 const uint32_t incl = wave_exscan(nsl, tot) + nsl + run;
@@ -1518,9 +1590,9 @@ __device__ __forceinline__ void gen_long(const DevDict& D, const BatchArgs& A, u
             }
             if (!best) { sweepable = false; break; }
             if (best >= n) break;
-            const uint32_t m_out = __builtin_amdgcn_readfirstlane(((pcr[best + 1].x >> 16) - (pcr[best].x >> 16)) & 0xFFFFu);  // nodes ending exactly at the cut
+            const uint32_t m_out = __builtin_amdgcn_readfirstlane((eo(best + 1) - eo(best)) & 0xFFFFu);  // nodes ending exactly at the cut
             if (m_out == 0 || m_out > 128) { sweepable = false; break; }
-            seg_a = best; seg_c = __builtin_amdgcn_readfirstlane(pcr[best].x & 0xFFFFu); seg_p += best_pass; m_in = m_out;
+            seg_a = best; seg_c = __builtin_amdgcn_readfirstlane(rec_co(best)); seg_p += best_pass; m_in = m_out;
         }
         if (!sweepable) tier = A.n_tiers + 1 + kGenLevels;  // the pre-routed escape list
     }
@@ -1560,12 +1632,39 @@ __global__ void __launch_bounds__(1024) build_lists(BatchArgs A, int only_list) 
 }
 
 // Kernel 1: one single-wave workgroup per sentence (small LDS, high occupancy) ...
-__global__ void __launch_bounds__(64) gen_candidates(DevDict D, BatchArgs A, uint32_t lds_bytes) {
+// (8 waves per SIMD: the kernel waits on memory three quarters of its time and its throughput follows its occupancy; left alone the
+// compiler keeps 105 SGPRs -- the two argument structs -- and 112 allocated SGPRs per wave fit only 7 times into a SIMD's 800)
+__global__ void __launch_bounds__(64) VBT_GEN_OCC_ATTR gen_candidates(DevDict D, BatchArgs A, uint32_t lds_bytes) {
     if (batch_rejected(A)) return;  // nothing gets routed: every later kernel finds empty work lists
     gen_one(D, A, A.sid0 + blockIdx.x, lds_bytes);
 }
+// Side stream, next to gen_candidates: finds the sentences that outgrow gen_one's LDS (by gen_one's own test) and files each at the
+// smallest level of gen_long that holds it.  One wavefront per sentence, four sentences per workgroup; a sentence of fewer bytes
+// than gen_one's LDS holds characters cannot outgrow it and costs one compare.
+__global__ void __launch_bounds__(256) route_long(DevDict D, BatchArgs A, uint32_t gen_lds, uint32_t min_bytes) {
+    if (batch_rejected(A)) return;
+    const uint32_t rel = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (rel >= A.n) return;
+    const uint32_t sid = A.sid0 + rel, ln = threadIdx.x & 63u;
+    const uint64_t b0 = A.offsets[sid], nb64 = A.offsets[sid + 1] - b0;
+    if (nb64 < min_bytes || nb64 >= 65535) return;  // (>= 65535 bytes: gen_one files it for the fused kernel)
+    const uint32_t nb = (uint32_t)nb64;
+    const uint8_t* __restrict__ txt = A.text + b0;
+    uint32_t n = 0;
+    for (uint32_t c0 = 0; c0 < nb; c0 += 64) {
+        const uint32_t bi = c0 + ln;
+        const bool lead = bi < nb && (txt[bi] & 0xC0) != 0x80;
+        n += (uint32_t)__popcll(__ballot(lead));
+    }
+    if (n == 0 || carve_gen_one(nullptr, gen_lds, n, D.has_user != 0).ok) return;
+    const uint32_t lv = gen_long_level(A, n, nb, D.has_user != 0), t = A.n_tiers + 1 + lv;
+    if (ln != 0) return;
+    // (the last level -- a whole CU's LDS -- is launched on the launch stream behind the bulk generator: its list is the batch's)
+    if (lv + 1 == (uint32_t)kGenLevels) A.lists[(size_t)t * A.list_stride + A.fb_list_off + atomicAdd(&A.fb_cctrl[2 * t], 1u)] = sid;
+    else A.lists[(size_t)t * A.list_stride + A.list_off + atomicAdd(&A.cctrl[2 * t], 1u)] = sid;
+}
 // ... and persistent workgroups (several wavefronts, a large LDS budget) for the sentences that did not fit: gen_long.
-__global__ void __launch_bounds__(1024) gen_candidates_large(DevDict D, BatchArgs A, uint32_t lds_bytes, uint32_t level) {
+__global__ void __launch_bounds__(1024) VBT_GEN_OCC_ATTR gen_candidates_large(DevDict D, BatchArgs A, uint32_t lds_bytes, uint32_t level) {
     uint32_t* const next_item = reinterpret_cast<uint32_t*>(g_smem + lds_bytes - 16);  // (the last 16 bytes stay out of gen_long's arena)
     const uint32_t t = A.n_tiers + level;
     const uint32_t count = A.cctrl[2 * t];
@@ -2165,7 +2264,7 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
             // (also from the pre-routed launch: the launch stream waits for it before it starts the escape tiers behind the segment tier)
             const bool escape = tier >= A.seg_tier && tier + 1 < A.n_tiers && fail != 27;
             if (ln == 0 && !escape) atomicAdd(&A.ctrl[fail < 32 ? fail : 28], 1u);
-            list_push(A, escape ? tier + 1 : A.n_tiers, sid);
+            if (escape) list_push(A, tier + 1, sid); else list_push_fb(A, sid);
         }
         __syncthreads();
     }
@@ -2315,31 +2414,40 @@ __global__ void __launch_bounds__(1024) tok_tile_scan(BatchArgs A, uint32_t* til
     }
     if (threadIdx.x == 0) A.ctrl[kTotal] = running;
 }
+// kPackSplit workgroups share a tile: each redoes the tile's (cheap) offset scan and copies every kPackSplit-th stripe of its
+// tokens -- the copy is a chain of dependent round trips per token (which sentence, where its slot starts, the record), so it
+// wants many waves in flight: one workgroup per tile left 6 waves on a CU and took 73 us for the 68 MB of the headline batch.
+constexpr uint32_t kPackSplit = 4;
 __global__ void __launch_bounds__(kScanBlock) compact_tokens(BatchArgs A, const uint32_t* tile_sums) {
     __shared__ uint32_t ws[kScanBlock / 64];
     __shared__ uint32_t offs[kScanTile + 1];  // exclusive token offsets of the tile's sentences, relative to the tile
+    __shared__ uint64_t slot[kScanTile];      // first staging slot of each sentence of the tile (sentence_slot)
     if (A.ctrl[kError] & (uint32_t)kErrFatal) return;
-    const uint32_t tile0 = blockIdx.x * kScanTile, s0 = tile0 + threadIdx.x * kScanItems;
+    const uint32_t tile = blockIdx.x / kPackSplit, part = blockIdx.x % kPackSplit;
+    const uint32_t tile0 = tile * kScanTile, s0 = tile0 + threadIdx.x * kScanItems;
+    const uint64_t o0 = A.offsets[0];
     uint32_t c[kScanItems], v = 0;
-    for (uint32_t i = 0; i < kScanItems; ++i) { c[i] = s0 + i < A.n ? A.tok_cnt[s0 + i] : 0u; v += c[i]; }
+    for (uint32_t i = 0; i < kScanItems; ++i) {
+        c[i] = s0 + i < A.n ? A.tok_cnt[s0 + i] : 0u;
+        v += c[i];
+        slot[threadIdx.x * kScanItems + i] = s0 + i < A.n ? (A.offsets[s0 + i] - o0) + (uint64_t)kSentenceSlack * (s0 + i) : 0ull;
+    }
     uint32_t tot;
     uint32_t ex = block_exscan(v, ws, tot);
-    const uint32_t base = tile_sums[blockIdx.x];
+    const uint32_t base = tile_sums[tile];
     for (uint32_t i = 0; i < kScanItems; ++i) {
         offs[threadIdx.x * kScanItems + i] = ex;
-        if (s0 + i < A.n) A.tok_off[s0 + i] = base + ex;
+        if (part == 0 && s0 + i < A.n) A.tok_off[s0 + i] = base + ex;
         ex += c[i];
     }
     if (threadIdx.x == 0) offs[kScanTile] = tot;
     __syncthreads();
-    const uint64_t o0 = A.offsets[0];
     const uint64_t* __restrict__ src = reinterpret_cast<const uint64_t*>(A.tok_stage);
     uint64_t* __restrict__ dst = reinterpret_cast<uint64_t*>(A.tokens);
-    for (uint32_t k = threadIdx.x; k < tot; k += kScanBlock) {
+    for (uint32_t k = part * kScanBlock + threadIdx.x; k < tot; k += kScanBlock * kPackSplit) {
         uint32_t lo = 0, hi = kScanTile;  // last sentence of the tile whose offset is <= k (empty sentences share offsets: take the last)
         while (lo + 1 < hi) { const uint32_t mid = (lo + hi) >> 1; if (offs[mid] <= k) lo = mid; else hi = mid; }
-        const uint32_t s = tile0 + lo;
-        const size_t from = (size_t)(A.offsets[s] - o0) + (size_t)kSentenceSlack * s + (k - offs[lo]);
+        const size_t from = (size_t)slot[lo] + (k - offs[lo]);
         const size_t to = (size_t)base + k;
 #pragma unroll
         for (int w = 0; w < 3; ++w) dst[3 * to + w] = src[3 * from + w];
@@ -2629,6 +2737,7 @@ Workspace::Workspace(const Tokenizer& t, uint64_t max_s, uint64_t max_b) : tok(t
             tier_events.push_back(e);
         }
         HIP_CHECK(hipEventCreateWithFlags(reinterpret_cast<hipEvent_t*>(&ev_fork2), hipEventDisableTiming));
+        for (auto& e : long_events) HIP_CHECK(hipEventCreateWithFlags(reinterpret_cast<hipEvent_t*>(&e), hipEventDisableTiming));
 
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gen_candidates_large), hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
         if (tiers.back() > 65536)  // a single workgroup may use the CU's whole 160 KiB
@@ -2653,6 +2762,7 @@ void Workspace::release() {
     tier_events.clear();
     if (ev_fork2) (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(ev_fork2));
     ev_fork2 = nullptr;
+    for (auto& e : long_events) if (e) { (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(e)); e = nullptr; }
     for (void* st : streams) (void)hipStreamDestroy(reinterpret_cast<hipStream_t>(st));
     streams.clear();
 }
@@ -2685,6 +2795,7 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
                 if (tiers[t] >= seg_bytes) { a.seg_tier = (uint32_t)t; break; }
     }
     a.sid0 = 0; a.cctrl = d_cctrl; a.list_off = 0;
+    a.fb_cctrl = d_cctrl; a.fb_list_off = 0; a.early_long = 0;
     a.lid_count = count_connids ? d_connid : nullptr;
     a.rid_count = count_connids ? d_connid + tok.dict().num_left : nullptr;
     a.s_counted = count_connids ? d_counted : nullptr;
@@ -2714,6 +2825,7 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
                                (const uint32_t*)over(t - 1), (const uint32_t*)count(t - 1), cursor(t), over(t), count(t));
         hipLaunchKernelGGL(D.matrix_wide ? tokenize_global<true> : tokenize_global<false>, dim3((uint32_t)std::min<uint64_t>(n, 1024)), dim3(64), 0, stream, D, a,
                            (const uint32_t*)over(T - 1), (const uint32_t*)count(T - 1), cursor(T));
+        rec(3);
     } else {
         // Stream plan.  The launch stream runs gen_candidates -> build_lists -> gen_candidates_large (gen_long: the sentences
         // that outgrew the bulk generator's LDS, one workgroup of several wavefronts each) and then forks one lattice_lds launch
@@ -2729,18 +2841,68 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
         const uint32_t cn = (uint32_t)n, lb = (cn + 1023) / 1024;
         a.sid0 = 0; a.n = cn; a.cctrl = d_cctrl; a.list_off = 0; a.direct_push = 0;
         for (int q = 0; q < kGenLevels; ++q) a.gen_level_bytes[q] = gen_level_lds[q] - 16;
+        const uint32_t persist = env_u32("VBT_LAT_PERSIST", 0);
+        auto launch_lattice = [&](const BatchArgs& a_, dim3 grid_, uint32_t lds_, hipStream_t st_, uint32_t tier_, uint32_t list_, uint32_t persistent_) {
+            auto k = D.space_cateset ? (D.matrix_wide ? lattice_lds<true, true> : lattice_lds<true, false>)
+                                     : (D.matrix_wide ? lattice_lds<false, true> : lattice_lds<false, false>);
+            hipLaunchKernelGGL(k, grid_, dim3(64), lds_, st_, D, a_, tier_, list_, persistent_);
+        };
+        auto launch_gen_levels = [&](const BatchArgs& a_, hipStream_t st_, uint32_t first, uint32_t last, bool longest_first) {
+            // Workgroups of 4 wavefronts (16 at the last level, which has a CU to itself), as many as a CU's LDS and its 32 wave slots admit.
+            for (uint32_t q = first; q <= last; ++q) {
+                const uint32_t lv = longest_first ? last + first - q : q;
+                const uint32_t lds = gen_level_lds[lv - 1];
+                const uint32_t nw = lds > 65536 ? 16u : std::max<uint32_t>(1, std::min<uint32_t>(16, lv == 1 ? env_u32("VBT_GEN_WAVES1", env_u32("VBT_GEN_WAVES", 4)) : env_u32("VBT_GEN_WAVES", 4)));
+                const uint32_t per_cu = std::max<uint32_t>(1, std::min<uint32_t>(32 / nw, 163840 / lds));
+                hipLaunchKernelGGL(gen_candidates_large, dim3(std::max<uint32_t>(1, std::min<uint32_t>(cn, per_cu * 256))), dim3(nw * 64), lds, st_, D, a_, lds, lv);
+            }
+        };
+        // Long sentences first (VBT_EARLY_LONG=1; off by default: measured slower, profiles/r03_long_first_experiment.md).  The
+        // sentences that outgrow the bulk generator's LDS are the longest of the batch, and a long sentence is one serial chain
+        // (~0.6-1.1 us per character in the sweep): the critical path of a mixed-length batch.  In this plan two side streams take them
+        // from the start, next to gen_candidates: route_long finds them (gen_one's own test; gen_one then leaves them alone), gen_long
+        // generates them level by level, longest first, and their sweeps start behind it -- the pre-routed escape sweep on the first
+        // side stream, the segment sweep (and what it escalates) on the second.  These launches keep their lists in the second
+        // counter block / list region: the launch stream's kernels read theirs meanwhile.  What it runs into: a workgroup that needs
+        // 16-48 KiB of LDS and four wave slots finds no room on a CU while a launch of 100 k one-wave workgroups is being dispatched
+        // (stream priorities do not change that), so the side streams' kernels mostly wait for the bulk launches to drain, and the
+        // bulk sweep loses LDS to the resident long sweeps when it can least afford it.
+        const bool main_seg = env_u32("VBT_MAIN_SEG", 1) != 0 && a.seg_tier < T;
+        const bool early = env_u32("VBT_EARLY_LONG", 0) != 0 && main_seg && a.seg_tier + 2 < T;
+        BatchArgs al = a;
+        if (early) {
+            a.early_long = 1;
+            al.early_long = 1;
+            al.cctrl = d_cctrl + kBlockCtrlWords; al.list_off = (uint32_t)half;
+            // (the side streams are the two tier streams this plan leaves idle: a process has four hardware pipes for its queues, and
+            // streams beyond that share them -- measured: with two more streams every small kernel and every event wait of the step
+            // took 40-100 us instead of 5-12)
+            hipStream_t l0 = reinterpret_cast<hipStream_t>(streams[a.seg_tier]), l1 = reinterpret_cast<hipStream_t>(streams[T - 1]);
+            auto E = [&](int i) { return reinterpret_cast<hipEvent_t>(long_events[i]); };
+            // route_long runs on the launch stream: next to gen_candidates it would queue behind 100 k workgroups for its wave slots
+            hipLaunchKernelGGL(route_long, dim3((cn + 3) / 4), dim3(256), 0, stream, D, al, gen_lds, (gen_lds - 16) / 28);
+            HIP_CHECK(hipEventRecord(E(0), stream));
+            HIP_CHECK(hipStreamWaitEvent(l0, E(0), 0));
+            launch_gen_levels(al, l0, 1, kGenLevels - 1, true);
+            HIP_CHECK(hipEventRecord(E(1), l0));
+            const size_t sg = a.seg_tier, x = sg + 1;
+            launch_lattice(al, dim3(waves_for(tiers[x], std::min<uint32_t>(cn, 4096))), tiers[x], l0, (uint32_t)x, (uint32_t)(T + 1 + kGenLevels), 1u);
+            HIP_CHECK(hipEventRecord(E(2), l0));
+            HIP_CHECK(hipStreamWaitEvent(l1, E(1), 0));
+            launch_lattice(al, dim3(waves_for(tiers[sg], cn)), tiers[sg], l1, (uint32_t)sg, (uint32_t)sg, 1u);
+            HIP_CHECK(hipStreamWaitEvent(l1, E(2), 0));  // the escape tiers take what failed in either sweep
+            for (size_t y = x; y < T; ++y)
+                launch_lattice(al, dim3(waves_for(tiers[y], std::min<uint32_t>(cn, 4096))), tiers[y], l1, (uint32_t)y, (uint32_t)y, 1u);
+            HIP_CHECK(hipEventRecord(E(3), l1));
+        }
         // (s_tier[] = 0xFF, "nothing routed yet", is written by validate_batch: one launch less per batch)
         hipLaunchKernelGGL(gen_candidates, dim3(cn), dim3(64), gen_lds, stream, D, a, gen_lds);
         hipLaunchKernelGGL(build_lists, dim3(lb), dim3(1024), 0, stream, a, -1);
-        // gen_one filed every sentence that outgrew it at the smallest level of gen_long that holds it.  The levels run one after
-        // the other on the launch stream: side by side on their own streams was measured and costs more in event round trips
-        // (+0.35 ms per step on the headline batch, whose upper levels are empty) than config 5 gains from the overlap.
-        // Workgroups of 4 wavefronts (16 at the last level, which has a CU to itself), as many as a CU's LDS and its 32 wave slots admit.
-        for (uint32_t lv = 1; lv <= kGenLevels; ++lv) {
-            const uint32_t lds = gen_level_lds[lv - 1], nw = lds > 65536 ? 16u : std::max<uint32_t>(1, std::min<uint32_t>(16, env_u32("VBT_GEN_WAVES", 4)));
-            const uint32_t per_cu = std::max<uint32_t>(1, std::min<uint32_t>(32 / nw, 163840 / lds));
-            hipLaunchKernelGGL(gen_candidates_large, dim3(std::max<uint32_t>(1, std::min<uint32_t>(cn, per_cu * 256))), dim3(nw * 64), lds, stream, D, a, lds, lv);
-        }
+        // Without the side streams gen_one files every sentence that outgrows it at the smallest level of gen_long that holds it, and
+        // the levels run one after the other on the launch stream.
+        // (with them only the last level stays here: its workgroups need a CU to themselves, and an empty launch of it would hold up the
+        // side stream until a CU has drained)
+        launch_gen_levels(a, stream, early ? kGenLevels : 1, kGenLevels, false);
         rec(1);
         // (forking the small tiers before the straggler generators was measured: 3.33 vs 3.2 ms, the stragglers then
         // compete with the sweep and the segment tier starts later)
@@ -2748,12 +2910,6 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
         // One lattice_lds launch per LDS tier up to the segment tier (default: a single 10 KiB tier).  The tiers above it are escape
         // tiers: nothing is routed to them up front, they take what the tier before them could not sweep, so they are
         // launched on the segment tier's stream, behind it.
-        const uint32_t persist = env_u32("VBT_LAT_PERSIST", 0);
-        auto launch_lattice = [&](dim3 grid_, uint32_t lds_, hipStream_t st_, uint32_t tier_, uint32_t list_, uint32_t persistent_) {
-            auto k = D.space_cateset ? (D.matrix_wide ? lattice_lds<true, true> : lattice_lds<true, false>)
-                                     : (D.matrix_wide ? lattice_lds<false, true> : lattice_lds<false, false>);
-            hipLaunchKernelGGL(k, grid_, dim3(64), lds_, st_, D, a, tier_, list_, persistent_);
-        };
         const size_t n_conc = a.seg_tier < T ? a.seg_tier + 1 : T;
         bool dense_launched = false;
         if (a.seg_tier + 1 < T) {
@@ -2762,13 +2918,12 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
             const size_t x = a.seg_tier + 1;
             hipStream_t side = reinterpret_cast<hipStream_t>(streams[x]);
             HIP_CHECK(hipStreamWaitEvent(side, reinterpret_cast<hipEvent_t>(ev_fork2), 0));
-            launch_lattice(dim3(waves_for(tiers[x], std::min<uint32_t>(cn, 4096))), tiers[x], side, (uint32_t)x, (uint32_t)(T + 1 + kGenLevels), 1u);
+            launch_lattice(a, dim3(waves_for(tiers[x], std::min<uint32_t>(cn, 4096))), tiers[x], side, (uint32_t)x, (uint32_t)(T + 1 + kGenLevels), 1u);
             HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(tier_events[x]), side));
             dense_launched = true;
         }
         // The segment tier (the critical path: the longest sentences, then the escape tier behind it) is launched on the launch
         // stream itself -- no event round trip before it starts nor before what follows it (VBT_MAIN_SEG=0: every tier on a side stream).
-        const bool main_seg = env_u32("VBT_MAIN_SEG", 1) != 0 && a.seg_tier < T;
         for (size_t i = 0; i < n_conc; ++i) {
             const size_t t = n_conc - 1 - i;
             const bool on_main = main_seg && t == a.seg_tier;
@@ -2777,31 +2932,34 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
             // one workgroup per list entry: the lists are built on the device, so the grid covers the whole batch and the
             // workgroups beyond a list's length exit at once (VBT_LAT_PERSIST=1: persistent waves with a work cursor)
             const uint32_t grid = !persist ? cn : (t < tier_waves.size() && tier_waves[t]) ? std::min<uint32_t>(tier_waves[t], waves_for(tiers[t], cn)) : waves_for(tiers[t], cn);
-            launch_lattice(dim3(grid), tiers[t], side, (uint32_t)t, (uint32_t)t, persist);
+            launch_lattice(a, dim3(grid), tiers[t], side, (uint32_t)t, (uint32_t)t, persist);
             // optional (VBT_HELP_BYTES): a smaller tier that has drained its own list sweeps the segment tier's list
             // too, in shorter segments.  Off by default: measured slower on the headline batch.
             if (a.seg_tier < T && t < a.seg_tier && tiers[t] >= env_u32("VBT_HELP_BYTES", 0xFFFFFFFFu))
-                launch_lattice(dim3(waves_for(tiers[t], cn)), tiers[t], side, (uint32_t)t, a.seg_tier, 1u);
+                launch_lattice(a, dim3(waves_for(tiers[t], cn)), tiers[t], side, (uint32_t)t, a.seg_tier, 1u);
             if (t == a.seg_tier) {
                 // the escape tiers take what failed here AND in the pre-routed launch: behind both
                 if (dense_launched) HIP_CHECK(hipStreamWaitEvent(side, reinterpret_cast<hipEvent_t>(tier_events[a.seg_tier + 1]), 0));
                 for (size_t x = t + 1; x < T; ++x)
-                    launch_lattice(dim3(waves_for(tiers[x], std::min<uint32_t>(cn, 4096))), tiers[x], side, (uint32_t)x, (uint32_t)x, 1u);
+                    launch_lattice(a, dim3(waves_for(tiers[x], std::min<uint32_t>(cn, 4096))), tiers[x], side, (uint32_t)x, (uint32_t)x, 1u);
             }
             if (!on_main) HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(tier_events[t]), side));
         }
         if (dense_launched) HIP_CHECK(hipStreamWaitEvent(stream, reinterpret_cast<hipEvent_t>(tier_events[a.seg_tier + 1]), 0));
         for (size_t t = 0; t < n_conc; ++t)
             if (!(main_seg && t == a.seg_tier)) HIP_CHECK(hipStreamWaitEvent(stream, reinterpret_cast<hipEvent_t>(tier_events[t]), 0));
-        // whatever the pipeline could not take: fused kernel, global-memory lattice
-        hipLaunchKernelGGL(D.matrix_wide ? tokenize_global<true> : tokenize_global<false>, dim3((uint32_t)std::min<uint64_t>(cn, 1024)), dim3(64), 0, stream, D, a,
+        if (early) HIP_CHECK(hipStreamWaitEvent(stream, reinterpret_cast<hipEvent_t>(long_events[3]), 0));  // (behind long_events[2] by construction)
+        rec(3);
+        // whatever the pipeline could not take: fused kernel, global-memory lattice (persistent waves with a work cursor; the list is
+        // empty or a handful of sentences, and the kernel uses scratch memory: launching 1024 of them cost 15 us, 128 cost 6)
+        hipLaunchKernelGGL(D.matrix_wide ? tokenize_global<true> : tokenize_global<false>, dim3((uint32_t)std::min<uint64_t>(cn, env_u32("VBT_FB_WGS", 128))), dim3(64), 0, stream, D, a,
                            (const uint32_t*)over(T), (const uint32_t*)(d_cctrl + 2 * T), d_cctrl + 2 * T + 1);
     }
     {   // pack the tokens in sentence order (tok_off, total)
         const uint32_t n_tiles = (uint32_t)((n + kScanTile - 1) / kScanTile);
         hipLaunchKernelGGL(tok_tile_sums, dim3(n_tiles), dim3(kScanBlock), 0, stream, a, d_tile_sums);
         hipLaunchKernelGGL(tok_tile_scan, dim3(1), dim3(1024), 0, stream, a, d_tile_sums, n_tiles);
-        if (!defer_pack) hipLaunchKernelGGL(compact_tokens, dim3(n_tiles), dim3(kScanBlock), 0, stream, a, (const uint32_t*)d_tile_sums);
+        if (!defer_pack) hipLaunchKernelGGL(compact_tokens, dim3(n_tiles * kPackSplit), dim3(kScanBlock), 0, stream, a, (const uint32_t*)d_tile_sums);
         last_args = a;
     }
     rec(2);
@@ -2823,6 +2981,7 @@ void Workspace::run_one(const uint8_t* h_text_dev, uint32_t nb, uint8_t* d_text,
     a.prof = nullptr;
     a.lists = d_over; a.list_stride = (uint32_t)(2 * std::max<uint64_t>(max_sentences, 1)); a.n_tiers = 1;
     a.tier_prio = 0; a.seg_tier = 0; a.sid0 = 0; a.cctrl = d_cctrl; a.list_off = 0; a.direct_push = 0;
+    a.fb_cctrl = d_cctrl; a.fb_list_off = 0; a.early_long = 0;
     a.lid_count = nullptr; a.rid_count = nullptr; a.s_counted = nullptr;
     constexpr uint32_t kOneLds = 65536;  // generator arrays (~26 B per character), then the lattice (whole up to ~400 characters, in segments beyond)
     a.tier_bytes[0] = kOneLds;
@@ -2874,7 +3033,8 @@ void Workspace::stats(vbt_call_stats* out) {
     }
     if (timing && last_n) {
         HIP_CHECK(hipEventElapsedTime(&out->ms_tier0, reinterpret_cast<hipEvent_t>(ev[0]), reinterpret_cast<hipEvent_t>(ev[1])));
-        HIP_CHECK(hipEventElapsedTime(&out->ms_tier12, reinterpret_cast<hipEvent_t>(ev[1]), reinterpret_cast<hipEvent_t>(ev[2])));
+        HIP_CHECK(hipEventElapsedTime(&out->ms_tier12, reinterpret_cast<hipEvent_t>(ev[1]), reinterpret_cast<hipEvent_t>(ev[3])));
+        HIP_CHECK(hipEventElapsedTime(&out->ms_pack, reinterpret_cast<hipEvent_t>(ev[3]), reinterpret_cast<hipEvent_t>(ev[2])));
     }
 }
 

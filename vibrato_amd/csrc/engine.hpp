@@ -81,6 +81,12 @@ struct BatchArgs {
     uint32_t sid0;
     uint32_t* cctrl;
     uint32_t list_off;  // offset of this launch's entries inside every list region
+    // where the fallback list (list n_tiers) of the BATCH lives: the long-sentence side streams keep every other list in a counter
+    // block / list region of their own (their lists fill while the launch stream's kernels are already reading theirs), but what
+    // they cannot take joins the one fallback launch at the end of the batch
+    uint32_t* fb_cctrl;
+    uint32_t fb_list_off;
+    uint32_t early_long;  // the sentences that outgrow gen_one are found and generated on the side streams: gen_one just leaves them alone
     // optional connection-id usage counters (Worker::update_connid_counts, worker.rs:77-93): nullptr = off
     unsigned long long* lid_count;
     unsigned long long* rid_count;
@@ -95,7 +101,7 @@ struct BatchArgs {
 enum CtrlSlot { kTotal = 0, kError = 1, kBump = 2, kNodeCursor = 4, kTierCtrl = 6, kCtrlWords = 32 };
 constexpr int kMaxTiers = 8;
 constexpr uint32_t kSentenceSlack = 24;  // character slots per sentence on top of its bytes (see sentence_slot in engine.hip)
-constexpr int kCtrlBlocks = 2;   // list-counter blocks: [0] the batch, [1] the input list of the optional long-first side stream
+constexpr int kCtrlBlocks = 2;   // list-counter blocks: [0] the launch stream's lists, [1] the lists of the long-sentence side streams
 constexpr int kGenLevels = 3;  // large-LDS instances of the generator behind the bulk one (32 KiB, 64 KiB, whole CU)
 constexpr int kListsBehindTiers = 1 + kGenLevels + 1;  // fallback, generator levels, pre-routed escapes (see engine.hip `dense_list`)
 constexpr int kBlockCtrlWords = 2 * (kMaxTiers + kListsBehindTiers);
@@ -151,6 +157,7 @@ class Workspace {
     std::vector<void*> streams;      // one side stream per LDS tier
     std::vector<void*> tier_events;
     void* ev_fork2 = nullptr;
+    void* long_events[4] = {nullptr, nullptr, nullptr, nullptr};  // long sentences first: fork, generator done, side stream 0 done, side stream 1 done
     bool fused = false;              // VBT_FUSED=1: the single fused kernel per sentence (A/B reference)
     unsigned long long* d_connid = nullptr;  // [num_left + num_right] usage counters, allocated on first use
     uint32_t* d_counted = nullptr;           // per-sentence watermark of the counted steps
