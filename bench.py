@@ -295,7 +295,8 @@ def main():
     h2h = None
     if not args.no_host_pipeline and world == 1:
         h2h = {"one_call": tok.host_pipeline_benchmark(text, offs, threads=1, rounds=1),
-               "pipelined": tok.host_pipeline_benchmark(text, offs, threads=4, rounds=4)}
+               "pipelined": tok.host_pipeline_benchmark(text, offs, threads=4, rounds=4),
+               "pipelined_8_threads": tok.host_pipeline_benchmark(text, offs, threads=8, rounds=4)}
 
     result = None
     if rank == 0:

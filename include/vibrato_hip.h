@@ -185,10 +185,11 @@ VBT_API int vbt_connid_probs(const uint64_t* counts, size_t n, uint32_t* ids, do
  * Every sentence must be valid UTF-8 (a Rust `str`): otherwise VBT_ERR_UTF8 and no batch.
  * Thread-safe per tokenizer: each call takes a workspace (device scratch + staging + stream) from the tokenizer's
  * pool and returns it, so steady-state calls do no device allocation (vbt_tokenizer_pool_stats); batches pushed from
- * several host threads overlap their copies with each other's kernels (3-4 threads reach the kernel-bound rate).
+ * several host threads overlap their copies with each other's kernels (6-8 threads reach the kernel-bound rate).
  * The pools keep idle workspaces (~400 B of device memory per byte of text of the batch they were sized for) and pinned
- * blocks for reuse, at most VBT_POOL_MAX_MB of each (default 32768 MB of device memory, 4096 MB of pinned memory; what
- * would exceed it is released instead of pooled); vbt_tokenizer_trim_pool releases everything idle now. */
+ * blocks for reuse, at most VBT_POOL_MAX_MB=<device MB>[,<pinned MB>] of each (default: a quarter of the GPU's memory -- 72 GiB on
+ * an MI355X -- and 8192 MB of pinned memory; what would exceed it is released instead of pooled, and a caller whose workspace
+ * never fits re-allocates it on every call); vbt_tokenizer_trim_pool releases everything idle now. */
 VBT_API int vbt_tokenize_batch(const vbt_tokenizer* tok, const uint8_t* text, const uint64_t* offsets, uint64_t n,
                                vbt_batch** out);
 VBT_API int vbt_tokenizer_trim_pool(const vbt_tokenizer* tok);

@@ -124,11 +124,14 @@ def test_all_tiers_agree(tiers, fused, monkeypatch):
 @pytest.mark.parametrize("env", [{"VBT_GEN_LDS": "2048"}, {"VBT_GEN_LDS": "1024", "VBT_GEN_WAVES": "2"}, {"VBT_GEN_LDS": "3072", "VBT_GEN_WAVES": "8"},
                                  {"VBT_GEN_LDS": "2048", "VBT_GEN_LEVELS": "4096,8192,163840", "VBT_GEN_WAVES": "1"},
                                  {"VBT_SEG_BYTES": "0"}, {"VBT_SEG_BYTES": "8192"}, {"VBT_TIERS": "4096,16384", "VBT_SEG_BYTES": "4096"},
-                                 {"VBT_TIERS": "3072", "VBT_SEG_BYTES": "2048"}])
+                                 {"VBT_TIERS": "3072", "VBT_SEG_BYTES": "2048"},
+                                 {"VBT_EARLY_LONG": "1"}, {"VBT_EARLY_LONG": "1", "VBT_GEN_LDS": "1024", "VBT_GEN_LEVELS": "4096,8192,163840"},
+                                 {"VBT_PACK_SCAN": "1"}, {"VBT_FB_WGS": "3", "VBT_TIERS": "1024"}])
 def test_generator_scheduling_variants_agree(env, monkeypatch):
     """A tiny bulk-generator LDS (most sentences then go through gen_long, the multi-wavefront generator, with 1 / 2 / 4 / 8
-    wavefronts per workgroup and through its small levels) and the segmented sweep of sentences that do not fit the segment tier
-    (split at clean cuts, interface carried over) must not change a single token."""
+    wavefronts per workgroup and through its small levels), the segmented sweep of sentences that do not fit the segment tier
+    (split at clean cuts, interface carried over), the long-sentences-first stream plan (side streams with lists of their own), the
+    tile-prefix kernel in front of the packing and a fallback launch of three waves must not change a single token."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     sd = synth.SynthDict("small")

@@ -251,7 +251,7 @@ uint64_t round_up_pow2(uint64_t v, uint64_t lo) {
 
 // Smallest idle workspace that holds the request, else a new one (capacities rounded up to powers of two so
 // that batches of similar size share it).  At most kPoolIdle workspaces stay idle; the smallest is dropped first.
-constexpr size_t kPoolIdle = 8;
+constexpr size_t kPoolIdle = 16;
 std::unique_ptr<PooledWorkspace> pool_take(vbt_tokenizer* tok, uint64_t n, uint64_t bytes) {
     {
         std::lock_guard<std::mutex> g(tok->pool_mu);
@@ -278,7 +278,7 @@ std::unique_ptr<PooledWorkspace> pool_take(vbt_tokenizer* tok, uint64_t n, uint6
     return p;
 }
 
-constexpr size_t kHostPoolIdle = 8;
+constexpr size_t kHostPoolIdle = 32;  // (two per batch in flight: 8 made six host threads free and re-pin their blocks all the time)
 std::unique_ptr<PinnedBlock> host_take(vbt_tokenizer* tok, size_t bytes) {
     {
         std::lock_guard<std::mutex> g(tok->pool_mu);
@@ -303,7 +303,14 @@ void pool_budgets(uint64_t& dev_bytes, uint64_t& host_bytes) {
     static uint64_t dev = 0, host = 0;
     static std::once_flag once;
     std::call_once(once, [] {
-        unsigned long long d = 32768, h = 4096;
+        // device default: a quarter of the GPU's memory (72 GiB on an MI355X: eight host threads streaming headline-sized batches
+        // hold 58 GiB of workspaces, and a workspace that does not fit the budget is freed and re-allocated on every call -- with
+        // the fixed 32 GiB of before, six threads ran at 0.6x and eight at 0.07x the throughput of four)
+        unsigned long long d = 32768, h = 8192;
+        {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (total_b >> 22) > d) d = total_b >> 22;
+        }
         if (const char* e = std::getenv("VBT_POOL_MAX_MB")) {
             unsigned long long a = 0, b = 0;
             const int k = std::sscanf(e, "%llu,%llu", &a, &b);

@@ -9,7 +9,7 @@
 // search_min_node lattice.rs:103-151, insert_eos 85-101 -- and the back-trace, append_top_nodes
 // lattice.rs:159-168; the lattice lives in LDS, longer sentences are swept in segments between clean cuts; what the
 // generator found too dense for that is swept by a 48 KiB launch next to the tiers) -> tokenize_global for whatever is
-// left -> tok_tile_sums / tok_tile_scan / compact_tokens (tokens from per-sentence staging into sentence order).  The fused single-kernel design (process_sentence: tokenize_lds /
+// left -> compact_tokens (tokens from per-sentence staging into sentence order; tok_tile_scan in front of it for huge batches).  The fused single-kernel design (process_sentence: tokenize_lds /
 // tokenize_global) is the fallback with a global-memory lattice and, with VBT_FUSED=1, an A/B reference.  Worker::tokenize is
 // tokenize_one: generator + sweep of one sentence in ONE launch, text and token records through pinned host memory.
 //
@@ -716,7 +716,7 @@ __device__ __forceinline__ uint64_t process_sentence(const DevDict& D, const Bat
     // compact_tokens packs them in sentence order afterwards -- no allocation atomic on a hot counter
     const size_t out_base = sentence_slot(A, b0, sid);
     __syncthreads();
-    if (ln == 0) A.tok_cnt[sid] = T;
+    if (ln == 0) { A.tok_cnt[sid] = T; if (T) atomicAdd(&A.tile_sums[sid / kScanTile], T); }
     for (uint32_t t = ln; t < T; t += 64) {
         const uint32_t c = path[T - 1 - t];  // Worker::token: index = n-1-i (worker.rs:65-68)
         // start_word = the position whose candidate range contains c: upper_bound(cand_off, c) - 1
@@ -788,6 +788,7 @@ __global__ void __launch_bounds__(256) validate_batch(BatchArgs A, uint64_t tota
     for (uint64_t s = tid; s < A.n; s += nthreads) {
         const uint64_t a = A.offsets[s], b = A.offsets[s + 1];
         if (A.s_tier) A.s_tier[A.sid0 + s] = 0xFF;  // nothing routed yet
+        if ((s & (kScanTile - 1)) == 0) A.tile_sums[s / kScanTile] = 0;  // token totals per packing tile: added up by the kernels that emit
         if (b < a || a < o0 || b > oN) bad |= kErrOffsets;
         else if (a < oN && (A.text[a] & 0xC0) == 0x80) bad |= kErrUtf8;  // a sentence starts inside a character
     }
@@ -1668,10 +1669,13 @@ __global__ void __launch_bounds__(1024) VBT_GEN_OCC_ATTR gen_candidates_large(De
     uint32_t* const next_item = reinterpret_cast<uint32_t*>(g_smem + lds_bytes - 16);  // (the last 16 bytes stay out of gen_long's arena)
     const uint32_t t = A.n_tiers + level;
     const uint32_t count = A.cctrl[2 * t];
-    for (;;) {
-        if (threadIdx.x == 0) *next_item = atomicAdd(&A.cctrl[2 * t + 1], 1u);
-        __syncthreads();
-        const uint32_t k = __builtin_amdgcn_readfirstlane(*next_item);
+    for (bool first = true;; first = false) {  // (first item = the workgroup's index, then the cursor: see tokenize_global)
+        uint32_t k = blockIdx.x;
+        if (!first) {
+            if (threadIdx.x == 0) *next_item = gridDim.x + atomicAdd(&A.cctrl[2 * t + 1], 1u);
+            __syncthreads();
+            k = __builtin_amdgcn_readfirstlane(*next_item);
+        }
         if (k >= count) break;
         gen_long(D, A, A.lists[(size_t)t * A.list_stride + A.list_off + k], lds_bytes - 16, level);
         __syncthreads();  // (also: next_item is read by every wave before thread 0 draws the next one)
@@ -2152,7 +2156,7 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
             }
             T = (uint32_t)__builtin_amdgcn_readfirstlane((int)T);
             __syncthreads();
-            if (ln == 0) A.tok_cnt[sid] = T;
+            if (ln == 0) { A.tok_cnt[sid] = T; if (T) atomicAdd(&A.tile_sums[sid / kScanTile], T); }
             for (uint32_t t = ln; t < T; t += 64) {
                 const uint32_t c = path[T - 1 - t];
                 const uint2 r = em[c];
@@ -2205,7 +2209,7 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
             __syncthreads();
             T = (uint32_t)__builtin_amdgcn_readfirstlane((int)T);
             __syncthreads();
-            if (ln == 0) A.tok_cnt[sid] = T;
+            if (ln == 0) { A.tok_cnt[sid] = T; if (T) atomicAdd(&A.tile_sums[sid / kScanTile], T); }
             for (uint32_t t = ln; t < T; t += 64) {
                 const uint32_t c = path[T - 1 - t];
                 const uint2 r = em[c];
@@ -2237,7 +2241,7 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
     const uint32_t ln = threadIdx.x;
     // long sentences are the critical path of a batch: let their waves win issue arbitration
     if (A.tier_prio && (A.seg_tier < A.n_tiers ? tier >= A.seg_tier : tier + A.tier_prio >= A.n_tiers)) __builtin_amdgcn_s_setprio(2);
-    const int src = (int)list_id;  // normally the tier's own list; helper launches sweep the segment tier's list with less LDS
+    const int src = (int)list_id;  // the tier's own list, or the pre-routed escape list
     const uint32_t* list = A.lists + (size_t)src * A.list_stride + A.list_off;
     const uint32_t count = A.cctrl[2 * src];
     uint32_t* cursor = &A.cctrl[2 * src + 1];
@@ -2246,9 +2250,9 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
     // whose lists are short -- persistent waves that draw entries from a cursor.
     bool first_item = true;
     for (;;) {
-        uint32_t item = blockIdx.x;
-        if (persistent) {
-            if (ln == 0) item = atomicAdd(cursor, 1u);
+        uint32_t item = blockIdx.x;  // (persistent waves too: their first item is their own index, see tokenize_global)
+        if (persistent && !first_item) {
+            if (ln == 0) item = gridDim.x + atomicAdd(cursor, 1u);
             item = __builtin_amdgcn_readfirstlane(item);  // lane 0 is always active here; keeps everything below scalar
         } else if (!first_item) break;
         first_item = false;
@@ -2343,10 +2347,14 @@ __global__ void __launch_bounds__(64) tokenize_global(DevDict D, BatchArgs A, co
     char* slab = nullptr;
     uint64_t slab_bytes = 0;
     unsigned long long* bump = reinterpret_cast<unsigned long long*>(&A.ctrl[kBump]);
-    for (;;) {
-        uint32_t k = 0;
-        if (threadIdx.x == 0) k = atomicAdd(cursor, 1u);
-        k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+    // (persistent waves: the first item of a workgroup is its own index, the following ones come from the cursor -- a launch
+    // whose every workgroup opens with an atomic on the one cursor word pays ~11 ns per workgroup before any work starts)
+    for (bool first = true;; first = false) {
+        uint32_t k = blockIdx.x;
+        if (!first) {
+            if (threadIdx.x == 0) k = gridDim.x + atomicAdd(cursor, 1u);
+            k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+        }
         if (k >= count) break;
         const uint32_t sid = in_list[k];
         for (int attempt = 0; attempt < 5; ++attempt) {
@@ -2376,9 +2384,12 @@ __global__ void __launch_bounds__(64) tokenize_global(DevDict D, BatchArgs A, co
 }
 
 // Token compaction.  The sweep kernels leave the tokens of sentence s in its own region of the staging buffer and its
-// count in tok_cnt[s]; these three small kernels turn that into the compact result: tok_off = exclusive prefix of the
-// counts (so token ranges are in sentence order), the records packed back to back, the total in ctrl[kTotal].
-constexpr uint32_t kScanBlock = 256, kScanItems = 1, kScanTile = kScanBlock * kScanItems;  // sentences per workgroup (small tiles: the copy needs the parallelism)
+// count in tok_cnt[s], and add the count to the total of the sentence's tile (tile_sums[s / kScanTile]); compact_tokens turns
+// that into the compact result: tok_off = exclusive prefix of the counts (so token ranges are in sentence order), the records
+// packed back to back, the total in ctrl[kTotal].  (tok_tile_scan: the prefix over the tiles as a kernel of its own, for batches
+// of more than 2048 tiles and for callers that pack later.)
+constexpr uint32_t kScanItems = 1;
+static_assert(kScanTile == kScanBlock * kScanItems, "one sentence per thread of a packing workgroup");
 __device__ __forceinline__ uint32_t block_exscan(uint32_t v, uint32_t* warp_sums, uint32_t& block_total) {
     uint32_t wtot;
     const uint32_t ex = wave_exscan_any(v, wtot);
@@ -2390,16 +2401,6 @@ __device__ __forceinline__ uint32_t block_exscan(uint32_t v, uint32_t* warp_sums
     __syncthreads();
     block_total = tot;
     return base + ex;
-}
-__global__ void __launch_bounds__(kScanBlock) tok_tile_sums(BatchArgs A, uint32_t* tile_sums) {
-    __shared__ uint32_t ws[kScanBlock / 64];
-    if (A.ctrl[kError] & (uint32_t)kErrFatal) { if (threadIdx.x == 0) tile_sums[blockIdx.x] = 0; return; }
-    const uint32_t s0 = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
-    uint32_t v = 0;
-    for (uint32_t i = 0; i < kScanItems; ++i) v += s0 + i < A.n ? A.tok_cnt[s0 + i] : 0u;
-    uint32_t tot;
-    block_exscan(v, ws, tot);
-    if (threadIdx.x == 0) tile_sums[blockIdx.x] = tot;
 }
 __global__ void __launch_bounds__(1024) tok_tile_scan(BatchArgs A, uint32_t* tile_sums, uint32_t n_tiles) {
     __shared__ uint32_t ws[16];
@@ -2418,8 +2419,12 @@ __global__ void __launch_bounds__(1024) tok_tile_scan(BatchArgs A, uint32_t* til
 // tokens -- the copy is a chain of dependent round trips per token (which sentence, where its slot starts, the record), so it
 // wants many waves in flight: one workgroup per tile left 6 waves on a CU and took 73 us for the 68 MB of the headline batch.
 constexpr uint32_t kPackSplit = 4;
-__global__ void __launch_bounds__(kScanBlock) compact_tokens(BatchArgs A, const uint32_t* tile_sums) {
+// `scanned` = 0: tile_sums[] still holds the totals per tile -- every workgroup adds up the tiles in front of its own (a few
+// hundred words out of L2: cheaper than a launch of the scan kernel in front of this one; the host picks the scan kernel for
+// batches of more than 2048 tiles) and the first one leaves the grand total in ctrl[kTotal].
+__global__ void __launch_bounds__(kScanBlock) compact_tokens(BatchArgs A, const uint32_t* tile_sums, uint32_t n_tiles, uint32_t scanned) {
     __shared__ uint32_t ws[kScanBlock / 64];
+    __shared__ uint32_t red[2][kScanBlock / 64];
     __shared__ uint32_t offs[kScanTile + 1];  // exclusive token offsets of the tile's sentences, relative to the tile
     __shared__ uint64_t slot[kScanTile];      // first staging slot of each sentence of the tile (sentence_slot)
     if (A.ctrl[kError] & (uint32_t)kErrFatal) return;
@@ -2434,7 +2439,20 @@ __global__ void __launch_bounds__(kScanBlock) compact_tokens(BatchArgs A, const 
     }
     uint32_t tot;
     uint32_t ex = block_exscan(v, ws, tot);
-    const uint32_t base = tile_sums[tile];
+    uint32_t base;
+    if (scanned) base = tile_sums[tile];
+    else {
+        uint32_t before = 0, all = 0;
+        for (uint32_t t = threadIdx.x; t < n_tiles; t += kScanBlock) { const uint32_t x = tile_sums[t]; all += x; before += t < tile ? x : 0u; }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { before += __shfl_xor(before, d); all += __shfl_xor(all, d); }
+        if ((threadIdx.x & 63u) == 0) { red[0][threadIdx.x >> 6] = before; red[1][threadIdx.x >> 6] = all; }
+        __syncthreads();
+        before = all = 0;
+        for (uint32_t w = 0; w < kScanBlock / 64; ++w) { before += red[0][w]; all += red[1][w]; }
+        base = before;
+        if (blockIdx.x == 0 && threadIdx.x == 0) A.ctrl[kTotal] = all;
+    }
     for (uint32_t i = 0; i < kScanItems; ++i) {
         offs[threadIdx.x * kScanItems + i] = ex;
         if (part == 0 && s0 + i < A.n) A.tok_off[s0 + i] = base + ex;
@@ -2782,7 +2800,7 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
     BatchArgs a = pipe;
     a.text = d_text; a.offsets = d_offsets; a.n = (uint32_t)n;
     a.tokens = d_tokens; a.tok_stage = d_tok_stage; a.tok_cap = (uint32_t)std::max<uint64_t>(max_bytes, 1);
-    a.tok_off = d_tok_off; a.tok_cnt = d_tok_cnt; a.ctrl = d_ctrl;
+    a.tok_off = d_tok_off; a.tok_cnt = d_tok_cnt; a.ctrl = d_ctrl; a.tile_sums = d_tile_sums;
     a.scratch = d_scratch; a.scratch_bytes = scratch_bytes;
     a.prof = profile ? d_prof : nullptr;
     a.lists = d_over; a.list_stride = (uint32_t)stride; a.n_tiers = (uint32_t)T;
@@ -2933,10 +2951,6 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
             // workgroups beyond a list's length exit at once (VBT_LAT_PERSIST=1: persistent waves with a work cursor)
             const uint32_t grid = !persist ? cn : (t < tier_waves.size() && tier_waves[t]) ? std::min<uint32_t>(tier_waves[t], waves_for(tiers[t], cn)) : waves_for(tiers[t], cn);
             launch_lattice(a, dim3(grid), tiers[t], side, (uint32_t)t, (uint32_t)t, persist);
-            // optional (VBT_HELP_BYTES): a smaller tier that has drained its own list sweeps the segment tier's list
-            // too, in shorter segments.  Off by default: measured slower on the headline batch.
-            if (a.seg_tier < T && t < a.seg_tier && tiers[t] >= env_u32("VBT_HELP_BYTES", 0xFFFFFFFFu))
-                launch_lattice(a, dim3(waves_for(tiers[t], cn)), tiers[t], side, (uint32_t)t, a.seg_tier, 1u);
             if (t == a.seg_tier) {
                 // the escape tiers take what failed here AND in the pre-routed launch: behind both
                 if (dense_launched) HIP_CHECK(hipStreamWaitEvent(side, reinterpret_cast<hipEvent_t>(tier_events[a.seg_tier + 1]), 0));
@@ -2957,9 +2971,11 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
     }
     {   // pack the tokens in sentence order (tok_off, total)
         const uint32_t n_tiles = (uint32_t)((n + kScanTile - 1) / kScanTile);
-        hipLaunchKernelGGL(tok_tile_sums, dim3(n_tiles), dim3(kScanBlock), 0, stream, a, d_tile_sums);
-        hipLaunchKernelGGL(tok_tile_scan, dim3(1), dim3(1024), 0, stream, a, d_tile_sums, n_tiles);
-        if (!defer_pack) hipLaunchKernelGGL(compact_tokens, dim3(n_tiles * kPackSplit), dim3(kScanBlock), 0, stream, a, (const uint32_t*)d_tile_sums);
+        // (the totals per tile were added up by the kernels that emitted the tokens; their prefix is taken inside compact_tokens
+        // unless the batch is huge or the caller packs later and wants the grand total first)
+        const bool scan_kernel = defer_pack || n_tiles > 2048 || env_u32("VBT_PACK_SCAN", 0);
+        if (scan_kernel) hipLaunchKernelGGL(tok_tile_scan, dim3(1), dim3(1024), 0, stream, a, d_tile_sums, n_tiles);
+        if (!defer_pack) hipLaunchKernelGGL(compact_tokens, dim3(n_tiles * kPackSplit), dim3(kScanBlock), 0, stream, a, (const uint32_t*)d_tile_sums, n_tiles, scan_kernel ? 1u : 0u);
         last_args = a;
     }
     rec(2);
@@ -2976,7 +2992,7 @@ void Workspace::run_one(const uint8_t* h_text_dev, uint32_t nb, uint8_t* d_text,
     BatchArgs a = pipe;
     a.text = d_text; a.offsets = d_offsets; a.n = 1;
     a.tokens = d_tokens; a.tok_stage = tokens_out; a.tok_cap = (uint32_t)std::max<uint64_t>(max_bytes, 1);
-    a.tok_off = d_tok_off; a.tok_cnt = count_out; a.ctrl = d_ctrl;
+    a.tok_off = d_tok_off; a.tok_cnt = count_out; a.ctrl = d_ctrl; a.tile_sums = d_tile_sums;  // (tile sums: written, never read on this path)
     a.scratch = d_scratch; a.scratch_bytes = scratch_bytes;
     a.prof = nullptr;
     a.lists = d_over; a.list_stride = (uint32_t)(2 * std::max<uint64_t>(max_sentences, 1)); a.n_tiers = 1;

@@ -44,6 +44,7 @@ struct BatchArgs {
     uint32_t tok_cap;
     uint32_t* tok_off;
     uint32_t* tok_cnt;
+    uint32_t* tile_sums;  // tokens per tile of kScanTile sentences, added up by the kernels that write tok_cnt (zeroed by validate_batch)
     // control block (device, kCtrlWords u32): see CtrlSlot
     uint32_t* ctrl;
     // global scratch arena for the last tier
@@ -100,6 +101,7 @@ struct BatchArgs {
 // ctrl[kNodeCursor] bump pointer of the candidate arrays
 enum CtrlSlot { kTotal = 0, kError = 1, kBump = 2, kNodeCursor = 4, kTierCtrl = 6, kCtrlWords = 32 };
 constexpr int kMaxTiers = 8;
+constexpr uint32_t kScanBlock = 256, kScanTile = 256;  // token packing: sentences per tile (small tiles: the copy needs the parallelism)
 constexpr uint32_t kSentenceSlack = 24;  // character slots per sentence on top of its bytes (see sentence_slot in engine.hip)
 constexpr int kCtrlBlocks = 2;   // list-counter blocks: [0] the launch stream's lists, [1] the lists of the long-sentence side streams
 constexpr int kGenLevels = 3;  // large-LDS instances of the generator behind the bulk one (32 KiB, 64 KiB, whole CU)
