@@ -21,7 +21,7 @@ timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/cfg5_st
 # host-to-host pipeline: hip + memory-copy + kernel trace (no counters)
 timeout 300 rocprofv3 --hip-trace --memory-copy-trace --kernel-trace --output-format csv -d $OUT/h2h_trace -o h2h -- python tools/h2h_bench.py 1 1 4 4 > $OUT/h2h_trace.log 2>&1
 rm -f $OUT/h2h_trace/*hip_api_trace.csv   # (7 MB of API calls: not needed for the timeline)
-TAG=sdma python tools/h2h_bench.py 1 1 3 4 4 4 4 4 2>&1 | grep -v amdgpu > $OUT/h2h_modes.txt
+TAG=sdma python tools/h2h_bench.py 1 1 4 4 8 4 8 4 2>&1 | grep -v amdgpu > $OUT/h2h_modes.txt
 TAG=kernel_stores VBT_H2H_OUT=0 python tools/h2h_bench.py 1 1 3 4 4 4 2>&1 | grep -v amdgpu >> $OUT/h2h_modes.txt
 cat $OUT/h2h_modes.txt
 # bench.py --gpus 2 started WITHOUT a launcher (it starts its own ranks); one GPU on this box: both ranks on device 0, gloo instead of RCCL
