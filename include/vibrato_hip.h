@@ -242,9 +242,9 @@ VBT_API int vbt_workspace_results(const vbt_workspace* ws, const vbt_token_rec**
  * the global-memory fallback kernel (n_tier2; a re-routed sentence is counted twice), tokens
  * written, device error flags (1 = token buffer full, 2 = scratch exhausted, 4 = sentence too
  * long, 8 = bad offsets, 16 = invalid UTF-8) and, with timing enabled, the hipEvent-measured durations (ms, on the launch stream) of the
- * bulk candidate generator (ms_tier0), of the lattice sweeps from their fork to their join (ms_tier12; the side streams that
- * generate and sweep the long sentences of the batch started earlier and are joined here) and of what follows -- the global-memory
- * fallback launch and the packing of the token records (ms_pack). */
+ * input check and the candidate generators (ms_tier0: validate_batch, gen_candidates, build_lists, the gen_long levels), of the
+ * lattice sweeps from their fork to their join (ms_tier12) and of what follows -- the global-memory fallback launch and the packing
+ * of the token records (ms_pack). */
 typedef struct vbt_call_stats {
     uint64_t n_sentences, n_tier0, n_tier1, n_tier2, n_tokens;
     uint32_t error_flags;
