@@ -66,28 +66,34 @@ __device__ __forceinline__ T load_policy(const T* p) {
 
 // ---------------------------------------------------------------- wave helpers
 
+// Inclusive prefix sum over the 64 lanes of a wavefront in registers: four row shifts inside the 16-lane rows, then the last lane of
+// a row broadcast into the next one (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3) -- the gfx9 DPP scan; lanes
+// without a source add 0.  (Was six __shfl_up = six trips through the LDS crossbar.)  Every lane of the wave must be active.
+__device__ __forceinline__ uint32_t wave_inscan_dpp(uint32_t x) {
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false);  // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false);  // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false);  // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, false);  // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);  // row_bcast:15
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);  // row_bcast:31
+    return x;
+}
 __device__ __forceinline__ uint32_t wave_exscan(uint32_t v, uint32_t& total) {
-    uint32_t x = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t y = __shfl_up(x, d);
-        if ((int)threadIdx.x >= d) x += y;
-    }
+    const uint32_t x = wave_inscan_dpp(v);
     total = (uint32_t)__builtin_amdgcn_readlane((int)x, 63);  // an SGPR: what depends on it stays wave-uniform for the compiler
     return x - v;
 }
-
-__device__ __forceinline__ uint32_t wave_exscan_any(uint32_t v, uint32_t& total) {  // (workgroups of several waves)
-    uint32_t x = v;
-    const int lane = (int)(threadIdx.x & 63u);
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t y = __shfl_up(x, d);
-        if (lane >= d) x += y;
-    }
-    total = (uint32_t)__builtin_amdgcn_readlane((int)x, 63);  // an SGPR: what depends on it stays wave-uniform for the compiler
-    return x - v;
+__device__ __forceinline__ uint32_t wave_exscan_any(uint32_t v, uint32_t& total) { return wave_exscan(v, total); }  // (workgroups of several waves)
+// the same ladder with max (unsigned: identity 0): inclusive prefix maximum over the lanes
+__device__ __forceinline__ uint32_t wave_inscan_max_dpp(uint32_t x) {
+#define VBT_MAX_DPP(ctrl, rows) { const uint32_t o_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, ctrl, rows, 0xF, false); x = o_ > x ? o_ : x; }
+    VBT_MAX_DPP(0x111, 0xF) VBT_MAX_DPP(0x112, 0xF) VBT_MAX_DPP(0x114, 0xF) VBT_MAX_DPP(0x118, 0xF) VBT_MAX_DPP(0x142, 0xA) VBT_MAX_DPP(0x143, 0xC)
+#undef VBT_MAX_DPP
+    return x;
 }
+// sum / maximum over the wave, wave-uniform (lane 63 of the inclusive scans)
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)wave_inscan_dpp(v), 63); }
+__device__ __forceinline__ uint32_t wave_umax(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)wave_inscan_max_dpp(v), 63); }
 
 // Packed lattice key: high word = min_cost biased to unsigned order (cost ^ 0x80000000), low word =
 // 0xFFFFFFFE - insertion sequence number.  Unsigned-minimum over keys = minimum cost with ties broken
@@ -1146,9 +1152,8 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
                 nsl = step_passes(nc, cnt);
             }
             uint32_t m = e;  // inclusive prefix maximum over the lanes
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(m, d); if ((int)ln >= d) m = o > m ? o : m; }
-            uint32_t before = __shfl_up(m, 1);
+            m = wave_inscan_max_dpp(m);
+            uint32_t before = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x138, 0xF, 0xF, false);  // wave_shr:1 (lane 0: 0)
             before = ln == 0 ? far : (before > far ? before : far);
             if (i < n) {
                 const uint32_t cut = (i == 0 || before <= i) ? 0x40000000u : 0u;
@@ -1161,8 +1166,8 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
             const uint32_t top = (uint32_t)__builtin_amdgcn_readlane((int)m, 63);
             far = top > far ? top : far;
             uint32_t mc = cnt;
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) { nsl += __shfl_xor(nsl, d); const uint32_t o = __shfl_xor(mc, d); mc = o > mc ? o : mc; }
+            nsl = wave_sum(nsl);
+            mc = wave_umax(mc);
             passes += nsl;
             maxcnt = mc > maxcnt ? mc : maxcnt;
         }
@@ -1480,8 +1485,7 @@ __device__ __forceinline__ void gen_long(const DevDict& D, const BatchArgs& A, u
         return r;
     };
     auto wave_max = [&](uint32_t v) {
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = __shfl_xor(v, d); v = o > v ? o : v; }
+        v = wave_umax(v);
         return v;
     };
     // (the furthest ends are kept per position over the dead trie codes: the second pass must not read another position's length
@@ -1501,9 +1505,8 @@ __device__ __forceinline__ void gen_long(const DevDict& D, const BatchArgs& A, u
         for (uint32_t c0 = 0; c0 < npc; c0 += 64) {
             const uint32_t i = c0 + ln;
             uint32_t m = i < npc ? chunk[i] : 0u;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(m, d); if ((int)ln >= d) m = o > m ? o : m; }
-            uint32_t before = __shfl_up(m, 1);
+            m = wave_inscan_max_dpp(m);
+            uint32_t before = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x138, 0xF, 0xF, false);  // wave_shr:1 (lane 0: 0)
             before = ln == 0 ? far : (before > far ? before : far);
             const uint32_t top = (uint32_t)__builtin_amdgcn_readlane((int)m, 63);
             if (i < npc) chunk[i] = (uint16_t)before;
@@ -1519,9 +1522,8 @@ __device__ __forceinline__ void gen_long(const DevDict& D, const BatchArgs& A, u
             r.e = i < n ? (uint32_t)far_end[i] : 0u;
             const uint32_t far = chunk[ch];
             uint32_t m = r.e;  // inclusive prefix maximum over the lanes
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(m, d); if ((int)ln >= d) m = o > m ? o : m; }
-            uint32_t before = __shfl_up(m, 1);
+            m = wave_inscan_max_dpp(m);
+            uint32_t before = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x138, 0xF, 0xF, false);  // wave_shr:1 (lane 0: 0)
             before = ln == 0 ? far : (before > far ? before : far);
             if (i < n) {
                 const uint32_t cut = (i == 0 || before <= i) ? 0x40000000u : 0u;
@@ -1531,8 +1533,7 @@ __device__ __forceinline__ void gen_long(const DevDict& D, const BatchArgs& A, u
                 ci[i] = yw;  // (a copy for the routing replay below, over the position's CharInfo: only this lane read it, just now)
             }
             uint32_t nsl = r.nsl;
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) nsl += __shfl_xor(nsl, d);
+            nsl = wave_sum(nsl);
             const uint32_t mc = wave_max(r.cnt);
             if (ln == 0) { atomicAdd(&red[kPasses], nsl); atomicMax(&red[kMaxCnt], mc); }
         }
@@ -2415,10 +2416,13 @@ __global__ void __launch_bounds__(1024) tok_tile_scan(BatchArgs A, uint32_t* til
     }
     if (threadIdx.x == 0) A.ctrl[kTotal] = running;
 }
-// kPackSplit workgroups share a tile: each redoes the tile's (cheap) offset scan and copies every kPackSplit-th stripe of its
+// kPackSplit (8) workgroups share a tile: each redoes the tile's (cheap) offset scan and copies every kPackSplit-th stripe of its
 // tokens -- the copy is a chain of dependent round trips per token (which sentence, where its slot starts, the record), so it
 // wants many waves in flight: one workgroup per tile left 6 waves on a CU and took 73 us for the 68 MB of the headline batch.
-constexpr uint32_t kPackSplit = 4;
+#ifndef VBT_PACK_SPLIT
+#define VBT_PACK_SPLIT 8
+#endif
+constexpr uint32_t kPackSplit = VBT_PACK_SPLIT;
 // `scanned` = 0: tile_sums[] still holds the totals per tile -- every workgroup adds up the tiles in front of its own (a few
 // hundred words out of L2: cheaper than a launch of the scan kernel in front of this one; the host picks the scan kernel for
 // batches of more than 2048 tiles) and the first one leaves the grand total in ctrl[kTotal].
@@ -2444,8 +2448,8 @@ __global__ void __launch_bounds__(kScanBlock) compact_tokens(BatchArgs A, const 
     else {
         uint32_t before = 0, all = 0;
         for (uint32_t t = threadIdx.x; t < n_tiles; t += kScanBlock) { const uint32_t x = tile_sums[t]; all += x; before += t < tile ? x : 0u; }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) { before += __shfl_xor(before, d); all += __shfl_xor(all, d); }
+        before = wave_sum(before);
+        all = wave_sum(all);
         if ((threadIdx.x & 63u) == 0) { red[0][threadIdx.x >> 6] = before; red[1][threadIdx.x >> 6] = all; }
         __syncthreads();
         before = all = 0;
