@@ -82,3 +82,54 @@ def test_oracle_equals_python_restatement(seed):
                     ora.lib().ora_worker_token(wo._h, i, rec.ctypes.data)
                     got.append({k: int(rec[0][k]) for k in ora.TOKEN_DTYPE.names})
                 assert got == py.tokenize(s), (seed, ignore_space, mgl, s)
+
+
+def _matrix_from_def(text):
+    lines = [ln for ln in text.split("\n") if ln.strip()]
+    num_right, num_left = (int(x) for x in lines[0].split())
+    m = [0] * (num_right * num_left)
+    for ln in lines[1:]:
+        r, l, c = (int(x) for x in ln.split())
+        m[l * num_right + r] = c
+    return num_right, num_left, m
+
+
+def test_python_restatement_on_the_reference_golden_vectors(tokenize_golden, fixture_sources):
+    """The second restatement is itself held to the reference's own end-to-end vectors (the 21 cases of vibrato/src/tests/tokenizer.rs,
+    tokenizer.rs:208-361, token.rs, lib.rs that test_oracle_golden.py pins the oracle with): what the two agree on elsewhere is anchored."""
+    def text(x):
+        return x.decode("utf-8") if isinstance(x, (bytes, bytearray)) else x
+    n_checked = 0
+    for case in tokenize_golden:
+        src = {k: text(v) for k, v in fixture_sources.items()} if case["dict"] == "fixture" else \
+            {"lex.csv": case["dict"]["lex"], "matrix.def": case["dict"]["matrix"], "char.def": case["dict"]["char"], "unk.def": case["dict"]["unk"]}
+        num_right, num_left, m = _matrix_from_def(text(src["matrix.def"]))
+        lex_rows = pyref.parse_rows(text(src["lex.csv"]))
+        py = pyref.PyTokenizer(text(src["lex.csv"]), num_right, num_left, m, text(src["char.def"]), text(src["unk.def"]),
+                               user_csv=text(fixture_sources["user.csv"]) if case["user"] else None,
+                               ignore_space=case["ignore_space"], max_grouping_len=case["max_grouping_len"])
+        user_rows = pyref.parse_rows(text(fixture_sources["user.csv"])) if case["user"] else []
+        unk_feature = {}  # unknown word id -> feature: unk.def rows in category order (unknown.rs:238-261)
+        by_cate = {}
+        for name, _, _, _, feat in pyref.parse_rows(text(src["unk.def"])):
+            by_cate.setdefault(py.cp.cate_map[name], []).append(feat)
+        k = 0
+        for cid in range(len(py.cp.cate_map)):
+            for feat in by_cate.get(cid, []):
+                unk_feature[k] = feat
+                k += 1
+        for sent in case["sentences"]:
+            toks = py.tokenize(sent["text"])
+            assert len(toks) == sent["num_tokens"], (case["name"], sent["text"])
+            raw = sent["text"].encode("utf-8")
+            for exp in sent["tokens"]:
+                t = toks[exp["index"]]
+                lex, wid = t["word_idx"] >> 30, t["word_idx"] & 0x3FFFFFFF
+                got = {"surface": raw[t["start_byte"]:t["end_byte"]].decode("utf-8"), "range_char": [t["start_char"], t["end_char"]],
+                       "range_byte": [t["start_byte"], t["end_byte"]], "total_cost": t["total_cost"],
+                       "feature": lex_rows[wid][4] if lex == pyref.LEX_SYSTEM else user_rows[wid][4] if lex == pyref.LEX_USER else unk_feature[wid]}
+                for key in ["surface", "range_char", "range_byte", "feature", "total_cost"]:
+                    if key in exp:
+                        assert got[key] == exp[key], (case["name"], sent["text"], exp["index"], key)
+        n_checked += 1
+    assert n_checked == 21
