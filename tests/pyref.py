@@ -90,6 +90,9 @@ class PyTokenizer:
         self.unk_offsets.append(len(self.unk_entries))
         self.space_cateset = (1 << self.cp.cate_map["SPACE"]) if ignore_space else None  # tokenizer.rs:40-53
         self.max_grouping_len = max_grouping_len if max_grouping_len else None  # 0 = unlimited (tokenizer.rs:67-74)
+        # event counters of SURVEY.md 8(d) (the algorithmic bytes of the roofline are made of these), summed over tokenize() calls
+        self.counters = dict.fromkeys(["n_sentences", "n_bytes", "n_chars", "n_trie_steps", "n_trie_hits", "n_lex_matches", "n_unk_nodes",
+                                       "n_nodes", "n_pairs_ref", "n_pairs_dedup", "n_tokens"], 0)
 
     @staticmethod
     def _lexicon(rows):
@@ -97,13 +100,24 @@ class PyTokenizer:
         for wid, (surface, left, right, cost, _) in enumerate(rows):  # word id = index over kept rows
             by_surface.setdefault(surface, []).append(wid)
             params.append((left, right, cost))
-        return {"by_surface": by_surface, "params": params, "max_len": max((len(s) for s in by_surface), default=0)}
+        return {"by_surface": by_surface, "params": params}
 
-    @staticmethod
-    def _prefixes(lex, chars, start):
-        """lexicon.rs:33-46: matches in increasing end_char; one surface's entries in ascending word id."""
-        for length in range(1, min(lex["max_len"], len(chars) - start) + 1):
-            for wid in lex["by_surface"].get("".join(chars[start:start + length]), ()):
+    def _prefixes(self, lex, chars, start):
+        """lexicon.rs:33-46: matches in increasing end_char; one surface's entries in ascending word id.  Counts what a trie walk from
+        `start` does: one step per character tried -- the last one failing unless the sentence ends first -- and one hit per surface found."""
+        if "prefixes" not in lex:
+            lex["prefixes"] = {s[:k] for s in lex["by_surface"] for k in range(1, len(s) + 1)}
+        c = self.counters
+        for length in range(1, len(chars) - start + 1):
+            c["n_trie_steps"] += 1
+            key = "".join(chars[start:start + length])
+            if key not in lex["prefixes"]:
+                break
+            ids = lex["by_surface"].get(key, ())
+            if ids:
+                c["n_trie_hits"] += 1
+                c["n_lex_matches"] += len(ids)
+            for wid in ids:
                 yield length, wid, lex["params"][wid]
 
     def cost(self, right_id, left_id):
@@ -112,8 +126,12 @@ class PyTokenizer:
     def tokenize(self, text):
         chars = list(text)
         n = len(chars)
-        if n == 0:  # worker.rs:50-52
+        cnt = self.counters
+        if n == 0:  # worker.rs:50-52: nothing is computed (and nothing counted) for an empty sentence
             return []
+        cnt["n_sentences"] += 1
+        cnt["n_bytes"] += len(text.encode("utf-8"))
+        cnt["n_chars"] += n
         c2b, b = [], 0
         for ch in chars:
             c2b.append(b)
@@ -128,8 +146,15 @@ class PyTokenizer:
         ends = [[] for _ in range(n + 1)]
         ends[0].append({"right": 0, "min_cost": 0, "start_node": None})  # BOS (lattice.rs:72-83)
 
+        seen_left = set()  # left ids of the current step: search_min_node's result depends only on (start_node, left_id)
+
         def insert_node(start_node, start_word, end_word, lex, wid, param):  # lattice.rs:103-151
             left, right, wcost = param
+            cnt["n_nodes"] += 1
+            cnt["n_pairs_ref"] += len(ends[start_node])
+            if left not in seen_left:
+                seen_left.add(left)
+                cnt["n_pairs_dedup"] += len(ends[start_node])
             min_idx, min_cost = 0xFFFF, I32_MAX
             for i, prev in enumerate(ends[start_node]):
                 c = _wrap_i32(prev["min_cost"] + self.cost(prev["right"], left))
@@ -145,6 +170,7 @@ class PyTokenizer:
 
             def scan(end):
                 for wid in range(self.unk_offsets[ci["base"]], self.unk_offsets[ci["base"] + 1]):
+                    cnt["n_unk_nodes"] += 1
                     emit(start, end, wid, self.unk_entries[wid])
 
             grouped = False
@@ -175,6 +201,7 @@ class PyTokenizer:
             if start_word == n:
                 break
             has_matched = False  # tokenizer.rs:141-199
+            seen_left.clear()
             if self.user is not None:
                 for length, wid, param in self._prefixes(self.user, chars, start_word):
                     insert_node(start_node, start_word, start_word + length, LEX_USER, wid, param)
@@ -192,6 +219,8 @@ class PyTokenizer:
             c = _wrap_i32(prev["min_cost"] + self.cost(prev["right"], 0))
             if c <= min_cost:
                 min_idx, min_cost = i, c
+        cnt["n_pairs_ref"] += len(ends[start_node])
+        cnt["n_pairs_dedup"] += len(ends[start_node])
         tokens = []
         end, idx = start_node, min_idx
         while end != 0:
@@ -200,4 +229,5 @@ class PyTokenizer:
                            "word_idx": (node["lex"] << 30) | node["wid"], "total_cost": node["min_cost"]})
             end, idx = node["start_node"], node["min_idx"]
         tokens.reverse()
+        cnt["n_tokens"] += len(tokens)
         return tokens

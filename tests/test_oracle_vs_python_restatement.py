@@ -73,15 +73,18 @@ def test_oracle_equals_python_restatement(seed):
             wo = ora.Tokenizer(do, ignore_space, mgl).new_worker()
             py = pyref.PyTokenizer(d["lex"], d["n_ids"], d["n_ids"], d["matrix"], d["char_def"], d["unk"], user_csv=d["user"],
                                    ignore_space=ignore_space, max_grouping_len=mgl)
+            wo.reset_counters()
             for s in sentences:
                 wo.reset_sentence(s)
-                wo.tokenize()
+                wo.tokenize(counted=True)
                 got = []
                 for i in range(wo.num_tokens()):
                     rec = np.zeros(1, dtype=ora.TOKEN_DTYPE)
                     ora.lib().ora_worker_token(wo._h, i, rec.ctypes.data)
                     got.append({k: int(rec[0][k]) for k in ora.TOKEN_DTYPE.names})
                 assert got == py.tokenize(s), (seed, ignore_space, mgl, s)
+            # the event counters the roofline's algorithmic bytes are made of, counted by two routes
+            assert wo.counters() == py.counters, (seed, ignore_space, mgl)
 
 
 def _matrix_from_def(text):
