@@ -140,6 +140,34 @@ def test_generator_scheduling_variants_agree(env, monkeypatch):
     _assert_batch_equal(to, tv, text, offs)
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_tie_heavy_random_dictionaries_match_oracle(seed):
+    """Equal-cost paths as the norm: 2-5 connection ids, word and connection costs from six values, duplicate surfaces, user entries
+    shadowing system entries, every invoke / group / length combination in char.def, spaces and characters outside every range (the
+    dictionaries of tests/test_oracle_vs_python_restatement.py, where the oracle is checked against an independent restatement).  The
+    synthetic BASELINE dictionaries almost never tie; here the `<=` of lattice.rs:141-146 -- the last inserted predecessor wins -- decides
+    most nodes, in whole sentences and across the cuts of segmented ones."""
+    import random
+    from tests.test_oracle_vs_python_restatement import make_dictionary, HIRA, KATA, ALPHA, NUM, OTHER
+    rng = random.Random(977 + seed)
+    d = make_dictionary(rng)
+    alphabet = HIRA * 3 + KATA * 2 + ALPHA * 2 + NUM + "   " + OTHER
+    sents = ["".join(rng.choice(alphabet) for _ in range(rng.choice([0, 1, 2, 5, 9, 14, 23, 40, 80, 200, 500, 1200]))) for _ in range(600)]
+    raw = [x.encode("utf-8") for x in sents]
+    text = np.frombuffer(b"".join(raw), dtype=np.uint8)
+    offs = np.zeros(len(raw) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([len(x) for x in raw])
+    for ignore_space, mgl in ((False, 0), (True, 1), (True, 3)):
+        do = ora.Dictionary.from_sources(d["lex"], d["matrix_def"], d["char_def"], d["unk"])
+        dv = V.SystemDictionaryBuilder.from_readers(d["lex"], d["matrix_def"], d["char_def"], d["unk"])
+        if d["user"] is not None:
+            do.reset_user_lexicon(d["user"])
+            dv.reset_user_lexicon_from_reader(d["user"])
+        to = ora.Tokenizer(do, ignore_space, mgl)
+        tv = V.Tokenizer(dv).ignore_space(ignore_space).max_grouping_len(mgl)
+        _assert_batch_equal(to, tv, text, offs)
+
+
 @pytest.mark.parametrize("shape", ["ipadic", "unidic"])
 def test_full_size_batch_bit_exact(shape):
     """BASELINE configs 2 and 3 at full size: 100k sentences over the ipadic- / unidic-shaped
