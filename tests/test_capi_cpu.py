@@ -30,6 +30,20 @@ def test_library_exports_every_declared_symbol():
         assert getattr(L, name) is not None
 
 
+def test_rust_sys_crate_declares_every_entry_point_and_the_stats_struct():
+    """rust/vibrato-hip-sys is what a vibrato maintainer binds; it cannot be compiled here, so at least its extern
+    block has to list exactly the header's entry points and its mirror of vbt_call_stats the header's fields, in order."""
+    header = open(os.path.join(ROOT, "include", "vibrato_hip.h")).read()
+    sys_rs = open(os.path.join(ROOT, "rust", "vibrato-hip-sys", "src", "lib.rs")).read()
+    declared = set(re.findall(r"VBT_API[^;(]*?\b(vbt_\w+)\s*\(", header))
+    assert declared == set(re.findall(r"pub fn (vbt_\w+)\s*\(", sys_rs))
+    body = re.search(r"typedef struct vbt_call_stats \{(.*?)\} vbt_call_stats;", header, re.S).group(1)
+    c_fields = [f.strip() for decl in body.split(";") if decl.strip() for f in decl.strip().split(None, 1)[1].split(",")]
+    rs_body = re.search(r"pub struct vbt_call_stats \{(.*?)\}", sys_rs, re.S).group(1)
+    assert c_fields == re.findall(r"pub (\w+):", rs_body)
+    assert c_fields == [f for f, _ in N.CallStats._fields_]
+
+
 def test_lexicon_golden(unit_golden, fixture_sources):
     for c in unit_golden["lexicon_common_prefix"]:
         if c.get("dict") == "fixture":
