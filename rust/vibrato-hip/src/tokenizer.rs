@@ -122,6 +122,16 @@ impl Tokenizer {
         check(unsafe { sys::vbt_tokenize_batch(self.raw()?, text.as_ptr(), offsets.as_ptr(), (offsets.len() - 1) as u64, &mut raw) })?;
         Ok(Batch::from_raw(raw, self))
     }
+
+    /// Releases the idle device workspaces and pinned blocks `tokenize_batch` keeps for reuse (about 400 bytes of device memory per
+    /// byte of text of every batch that was in flight at once; at most a quarter of the GPU's memory, `VBT_POOL_MAX_MB`). They are
+    /// created again on demand. Thread-safe; a no-op before the first batch.
+    pub fn trim_pool(&self) -> Result<()> {
+        match self.device.get() {
+            Some(d) => check(unsafe { sys::vbt_tokenizer_trim_pool(d.0) }),
+            None => Ok(()),
+        }
+    }
 }
 
 impl Drop for Tokenizer {
