@@ -2717,7 +2717,7 @@ Workspace::Workspace(const Tokenizer& t, uint64_t max_s, uint64_t max_b) : tok(t
     d_tile_sums = static_cast<uint32_t*>(alloc(((ns + kScanTile - 1) / kScanTile + 1) * 4));
     d_tok_off = static_cast<uint32_t*>(alloc(ns * 4));
     d_tok_cnt = static_cast<uint32_t*>(alloc(ns * 4));
-    d_over = static_cast<uint32_t*>(alloc(2 * ns * 4 * (tiers.size() + kListsBehindTiers)));  // two regions per list: long-first pass + bulk
+    d_over = static_cast<uint32_t*>(alloc(2 * ns * 4 * (tiers.size() + kListsBehindTiers)));  // two regions per list: the launch stream's and (VBT_EARLY_LONG=1) the long sentences' side streams'
     d_ctrl = static_cast<uint32_t*>(alloc((kCtrlWords + (size_t)kCtrlBlocks * kBlockCtrlWords) * 4));  // one block: cleared by one memset per batch
     d_cctrl = d_ctrl + kCtrlWords;
     if (const char* e = std::getenv("VBT_TIER_WAVES")) {  // experiment: fixed lattice grid per tier
@@ -3036,7 +3036,7 @@ void Workspace::stats(vbt_call_stats* out) {
         out->n_tier2 = cc[2 * (T - 1)];
         out->n_tier1 = last_n - out->n_tier0 - out->n_tier2;
     } else {
-        for (uint32_t c = 0; c < (uint32_t)kCtrlBlocks; ++c) {  // the batch, then the long-first input list (tier counts there are 0)
+        for (uint32_t c = 0; c < (uint32_t)kCtrlBlocks; ++c) {  // the launch stream's lists, then those of the long sentences' side streams (empty unless VBT_EARLY_LONG=1)
             const uint32_t* k = cc.data() + (size_t)c * kBlockCtrlWords;
             out->n_tier0 += k[0];
             out->n_tier2 += k[2 * T];
