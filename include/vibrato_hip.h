@@ -138,6 +138,17 @@ VBT_API uint32_t vbt_dict_common_prefix(const vbt_dict* dict, uint32_t lex_type,
  * HIP device `device` (-1 = current device). max_grouping_len 0 = unlimited. */
 VBT_API int vbt_tokenizer_new(vbt_dict* dict, int ignore_space, uint32_t max_grouping_len, int device,
                               vbt_tokenizer** out);
+/* The same over several GPUs of the node (new; SURVEY.md 8(b) `device_mask`, as an explicit list): one replica of the device
+ * image per listed HIP device.  The reference leaves parallelism to the caller -- one Worker per thread over a shared &Tokenizer
+ * (worker.rs:9-19, tokenizer.rs:82-84); here one tokenizer spans the devices and vbt_tokenize_batch splits every batch into
+ * `n_devices` contiguous shards balanced by bytes, runs them side by side (a pooled workspace + stream per device) and has every
+ * device's DMA engines write its shard of the results into the ONE pinned result block at the shard's offset: a gather to the
+ * caller, no collective.  Results are identical to a single-device tokenizer's.  A device may be listed more than once (two
+ * shards in flight on one GPU; how the path is tested on a one-GPU box).  Worker and the vbt_workspace_* device API use the
+ * first listed device. */
+VBT_API int vbt_tokenizer_new_multi(vbt_dict* dict, int ignore_space, uint32_t max_grouping_len, const int* devices,
+                                    uint32_t n_devices, vbt_tokenizer** out);
+VBT_API uint32_t vbt_tokenizer_num_devices(const vbt_tokenizer* tok);
 VBT_API void vbt_tokenizer_free(vbt_tokenizer* tok);
 VBT_API const vbt_dict* vbt_tokenizer_dictionary(const vbt_tokenizer* tok); /* Tokenizer::dictionary, tokenizer.rs:77 */
 

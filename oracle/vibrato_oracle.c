@@ -1368,6 +1368,16 @@ ORA_API void ora_worker_add_connid_counts(const ora_worker *w, uint64_t *lid, ui
     for (uint32_t b = 0; b < le->n; b++) { lid[0] += 1; rid[le->v[b].right_id] += 1; }
 }
 
+/* Shape of the lattice of the last tokenized sentence (statistics for DESIGN.md's sizing of the sweep kernel; not part of the
+ * reference): per end position the number of inserted nodes (np_out[i] = ends[i].n, i in 0..len_char) and per start_node the
+ * number of nodes inserted from it (nc_out[i]).  Returns len_char. */
+ORA_API uint32_t ora_worker_lattice_shape(const ora_worker *w, uint32_t *np_out, uint32_t *nc_out) {
+    for (uint32_t i = 0; i <= w->len_char; i++) { np_out[i] = w->ends[i].n; nc_out[i] = 0; }
+    for (uint32_t e = 1; e <= w->len_char; e++)
+        for (uint32_t a = 0; a < w->ends[e].n; a++) nc_out[w->ends[e].v[a].start_node]++;
+    return w->len_char;
+}
+
 ORA_API void ora_worker_tokenize(ora_worker *w) { tokenize_impl(w, 0); }
 ORA_API void ora_worker_tokenize_counted(ora_worker *w) { tokenize_impl(w, 1); }
 ORA_API uint32_t ora_worker_num_tokens(const ora_worker *w) { return w->n_top; }

@@ -24,13 +24,14 @@ pub struct Tokenizer {
     ignore_space: bool,
     max_grouping_len: usize,
     device_index: i32,
+    device_list: Vec<i32>,
     device: OnceLock<Device>,
 }
 
 impl Tokenizer {
     /// Creates a new instance (`tokenizer.rs:26-33`); the dictionary is moved in.
     pub const fn new(dict: Dictionary) -> Self {
-        Self { dict, ignore_space: false, max_grouping_len: 0, device_index: -1, device: OnceLock::new() }
+        Self { dict, ignore_space: false, max_grouping_len: 0, device_index: -1, device_list: Vec::new(), device: OnceLock::new() }
     }
 
     /// Enables MeCab compatible mode: ignores spaces (`tokenizer.rs:42-58`).
@@ -58,6 +59,20 @@ impl Tokenizer {
         self
     }
 
+    /// Several GPUs of the node (new): one replica of the dictionary image per listed HIP device; `tokenize_batch` splits every
+    /// batch into contiguous shards balanced by bytes, runs them side by side and gathers the results into one host block. The
+    /// reference leaves parallelism to the caller (one `Worker` per thread, `worker.rs:9-19`); this is the same for one batch call.
+    /// Workers use the first listed device.
+    pub fn devices(mut self, indices: &[i32]) -> Self {
+        self.device_list = indices.to_vec();
+        self
+    }
+
+    /// Number of devices the batches of this tokenizer are split over.
+    pub fn num_devices(&self) -> usize {
+        self.device_list.len().max(1)
+    }
+
     /// Gets the reference to the dictionary (`tokenizer.rs:77-79`).
     pub const fn dictionary(&self) -> &Dictionary {
         &self.dict
@@ -82,7 +97,14 @@ impl Tokenizer {
         let mgl = u32::try_from(self.max_grouping_len).unwrap_or(0); // lengths beyond u32 never limit anything
         let mut raw = ptr::null_mut();
         // Safety: on success the library takes the dictionary handle over (Tokenizer::new moves it); on failure we keep it.
-        check(unsafe { sys::vbt_tokenizer_new(self.dict.raw(), self.ignore_space as i32, mgl, self.device_index, &mut raw) })?;
+        if self.device_list.is_empty() {
+            check(unsafe { sys::vbt_tokenizer_new(self.dict.raw(), self.ignore_space as i32, mgl, self.device_index, &mut raw) })?;
+        } else {
+            let n = u32::try_from(self.device_list.len()).map_err(|_| VibratoError::invalid_argument("devices", "too many devices"))?;
+            check(unsafe {
+                sys::vbt_tokenizer_new_multi(self.dict.raw(), self.ignore_space as i32, mgl, self.device_list.as_ptr(), n, &mut raw)
+            })?;
+        }
         self.dict.rebind_borrowed(unsafe { sys::vbt_tokenizer_dictionary(raw) });
         let _ = self.device.set(Device(raw));
         Ok(raw)

@@ -1,0 +1,146 @@
+#!/usr/bin/env python3
+"""Static check of the sweep kernel's gather ring in the compiled ISA (CPU only; also run by the CPU test suite).
+
+lattice_sentence issues its connection-cost gathers as inline assembly (engine.hip: `issue_gathers`) and waits for them with a
+hand-placed `s_waitcnt vmcnt(N)`, so the compiler does not know that the destination registers are written asynchronously.
+That is only sound if, between a gather and the instruction that consumes its result, nothing touches the destination
+register: no copy (register allocation splitting a live range), no spill, no reuse.  This script proves exactly that on
+the assembly hipcc emits:
+
+  for every `buffer_load_{sshort,dword}` G inside an inline-asm block of a kernel and every path through the control-flow
+  graph behind it, the first instruction that mentions G's destination register lies behind an inline `s_waitcnt vmcnt(N)`
+  at which G has provably landed (at least N inline gathers were issued behind G: loads return in order), or is the next
+  gather into the same ring slot.
+
+usage: python tools/check_ring_isa.py [engine.s]      (without an argument: compiles engine.hip to assembly first)
+"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KERNELS = ("lattice_lds", "tokenize_one")
+
+
+def mentions(text, reg):
+    """does the instruction text mention VGPR number `reg` (alone or inside a range v[a:b])?"""
+    for m in re.finditer(r"\bv(\d+)\b", text):
+        if int(m.group(1)) == reg:
+            return True
+    for m in re.finditer(r"\bv\[(\d+):(\d+)\]", text):
+        if int(m.group(1)) <= reg <= int(m.group(2)):
+            return True
+    return False
+
+
+def kernel_bodies(asm):
+    lines = asm.split("\n")
+    i = 0
+    while i < len(lines):
+        m = re.match(r"^(_Z\w+):", lines[i])
+        if m and any(k in m.group(1) for k in KERNELS):
+            j = i
+            while j < len(lines) and ".end_amdhsa_kernel" not in lines[j] and not lines[j].startswith(".Lfunc_end"):
+                j += 1
+            yield m.group(1), lines[i + 1:j]
+            i = j
+        i += 1
+
+
+def check_kernel(name, body):
+    # instruction list (text, inside an inline-asm block?) and label positions
+    insts, labels, in_asm = [], {}, False
+    for l in body:
+        t = l.strip()
+        m = re.match(r"^(\.LBB\w+):", l)
+        if m:
+            labels[m.group(1)] = len(insts)
+            continue
+        if t.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if t.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        if not t or t.startswith(";") or t.startswith("."):
+            continue
+        insts.append((t.split(";")[0].strip(), in_asm))
+
+    def successors(i):
+        t = insts[i][0]
+        op = t.split()[0]
+        if op == "s_endpgm":
+            return []
+        if op == "s_branch":
+            return [labels[t.split()[1]]]
+        if op.startswith("s_cbranch"):
+            return [labels[t.split()[1]], i + 1]
+        return [i + 1] if i + 1 < len(insts) else []
+
+    errors, n_loads = [], 0
+    load_re = re.compile(r"^buffer_load_(sshort|dword)\s+v(\d+),")
+    for idx, (t, a) in enumerate(insts):
+        m = load_re.match(t)
+        if not (a and m):
+            continue
+        n_loads += 1
+        reg = int(m.group(2))
+        # Along every path from behind the gather G: `after` counts the inline gathers issued behind G.  An inline
+        # `s_waitcnt vmcnt(N)` retires all but the N most recent loads (loads return in order), so G has landed there iff
+        # after >= N.  The first instruction that mentions G's register must come behind such a wait -- or be another inline
+        # gather into the same register (an unconsumed slot of a pass without that unit: in-order write after write).
+        stack = [(j, 0, False) for j in successors(idx)]
+        seen = set()
+        verdict = None
+        while stack and not verdict:
+            j, after, landed = stack.pop()
+            if (j, after, landed) in seen:
+                continue
+            seen.add((j, after, landed))
+            tj, aj = insts[j]
+            mw = re.match(r"^s_waitcnt\s+vmcnt\((\d+)\)", tj)
+            if aj and mw and after >= int(mw.group(1)):
+                landed = True
+            if mentions(tj, reg):
+                if aj and load_re.match(tj) and int(load_re.match(tj).group(2)) == reg:
+                    continue  # overwritten by the next gather into this ring slot
+                if not landed:
+                    verdict = f"v{reg}: touched by `{tj}` (#{j}) while the gather at #{idx} may still be in flight ({after} loads behind it)"
+                continue
+            if aj and load_re.match(tj):
+                after = min(after + 1, 64)
+            stack.extend((k, after, landed) for k in successors(j))
+        if verdict:
+            errors.append(verdict)
+    return n_loads, errors
+
+
+def main():
+    if len(sys.argv) > 1:
+        asm = open(sys.argv[1]).read()
+    else:
+        with tempfile.TemporaryDirectory() as d:
+            out = os.path.join(d, "engine.s")
+            src = os.path.join(ROOT, "vibrato_amd", "csrc", "engine.hip")
+            subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", "-S",
+                                   "--cuda-device-only", "-o", out, "-x", "hip", src], stderr=subprocess.DEVNULL)
+            asm = open(out).read()
+    bad = 0
+    total = 0
+    for name, body in kernel_bodies(asm):
+        n, errs = check_kernel(name, body)
+        total += n
+        print(f"{name[:90]}: {n} ring gathers, {len(errs)} violations")
+        for e in errs[:20]:
+            print("   ", e)
+        bad += len(errs)
+    if total == 0:
+        print("no inline-asm gathers found: the check does not apply to this build")
+        return 2
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

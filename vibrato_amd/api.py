@@ -198,18 +198,22 @@ class Token:
 class Tokenizer:
     """vibrato::Tokenizer (tokenizer.rs:13-84). Creating one uploads the dictionary image to the GPU."""
 
-    def __init__(self, dictionary, device=-1):
+    def __init__(self, dictionary, device=-1, devices=None):
+        """device: HIP device of the dictionary image (-1 = current).  devices: a list of HIP devices instead -- one replica of the
+        image on each, tokenize_batch splits every batch over them and gathers the results into one host block (new; a device
+        may be listed twice)."""
         self._dict_in = dictionary
         self._ignore_space = False
         self._max_grouping_len = 0
         self._device = device
+        self._devices = list(devices) if devices is not None else None
         self._h = None
         self._dict = None
         self._build_lock = threading.Lock()
 
     @classmethod
-    def new(cls, dictionary, device=-1):
-        return cls(dictionary, device)
+    def new(cls, dictionary, device=-1, devices=None):
+        return cls(dictionary, device, devices)
 
     def ignore_space(self, yes):
         """Tokenizer::ignore_space (tokenizer.rs:42-55)."""
@@ -234,8 +238,13 @@ class Tokenizer:
             with self._build_lock:  # the device image is built once, whichever thread gets here first
                 if not self._h:
                     h = C.c_void_p()
-                    N.check(N.lib().vbt_tokenizer_new(self._dict_in._handle(), int(self._ignore_space), self._max_grouping_len,
-                                                      self._device, C.byref(h)))
+                    if self._devices is not None:
+                        devs = (C.c_int * len(self._devices))(*self._devices)
+                        N.check(N.lib().vbt_tokenizer_new_multi(self._dict_in._handle(), int(self._ignore_space), self._max_grouping_len,
+                                                                devs, len(self._devices), C.byref(h)))
+                    else:
+                        N.check(N.lib().vbt_tokenizer_new(self._dict_in._handle(), int(self._ignore_space), self._max_grouping_len,
+                                                          self._device, C.byref(h)))
                     self._dict_in._h = None  # moved (Tokenizer::new consumes the dictionary)
                     self._dict = C.c_void_p(N.lib().vbt_tokenizer_dictionary(h))
                     self._h = h
@@ -248,6 +257,10 @@ class Tokenizer:
                 self._h = None
         except Exception:  # interpreter teardown: module globals may be gone
             pass
+
+    def num_devices(self):
+        """Devices the tokenizer's batches are split over (1 unless created with `devices=[...]`)."""
+        return int(N.lib().vbt_tokenizer_num_devices(self._handle()))
 
     def dictionary(self):
         """Tokenizer::dictionary (tokenizer.rs:77-79)."""

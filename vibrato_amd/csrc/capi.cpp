@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -77,44 +78,59 @@ struct Sdma {
         if (hsa_init() != HSA_STATUS_SUCCESS) return;  // (reference counted: the HIP runtime holds it already)
         Find f{(uint32_t)((prop.pciBusID << 8) | (prop.pciDeviceID << 3)), (uint32_t)prop.pciDomainID};
         if (hsa_iterate_agents(visit, &f) != HSA_STATUS_SUCCESS || !f.has_gpu || !f.has_cpu) return;
-        gpu = f.gpu; cpu = f.cpu; ok = true;
+        gpu = f.gpu; cpu = f.cpu;
+        // the CPU agent of the GPU's own NUMA node, where the runtime knows it (a two-socket host: the first CPU agent may be the far one)
+        hsa_agent_t near{};
+        if (hsa_agent_get_info(gpu, static_cast<hsa_agent_info_t>(HSA_AMD_AGENT_INFO_NEAREST_CPU), &near) == HSA_STATUS_SUCCESS && near.handle) cpu = near;
+        ok = true;
     }
-    // dst[k] (pinned host) <- src[k] (device), bytes[k]; returns when all have landed.  One completion signal per copy, initial
-    // value 1: what rocprofv3's memory-copy tracing expects of a caller (it aborts on a shared, counted signal).
-    bool d2h(const void* const* src, void* const* dst, const size_t* bytes, int n) const {
-        constexpr int kMax = 4;
-        hsa_signal_t sig[kMax];
-        int issued = 0;
-        bool good = n <= kMax;
-        for (int k = 0; k < n && good; ++k) {
+    // dst[k] (pinned host) <- src[k] (device), bytes[k].  issue() starts the copies and appends one completion signal per copy
+    // (initial value 1: what rocprofv3's memory-copy tracing expects of a caller, it aborts on a shared, counted signal); wait()
+    // returns when all have landed.  Split in two so that the copies of several devices run side by side.
+    bool issue(const void* const* src, void* const* dst, const size_t* bytes, int n, std::vector<hsa_signal_t>& sigs) const {
+        for (int k = 0; k < n; ++k) {
             if (!bytes[k]) continue;
-            if (hsa_signal_create(1, 0, nullptr, &sig[issued]) != HSA_STATUS_SUCCESS) { good = false; break; }
-            if (hsa_amd_memory_async_copy(dst[k], cpu, src[k], gpu, bytes[k], 0, nullptr, sig[issued]) != HSA_STATUS_SUCCESS) {
-                (void)hsa_signal_destroy(sig[issued]);
-                good = false;
-                break;
+            hsa_signal_t sig;
+            if (hsa_signal_create(1, 0, nullptr, &sig) != HSA_STATUS_SUCCESS) return false;
+            if (hsa_amd_memory_async_copy(dst[k], cpu, src[k], gpu, bytes[k], 0, nullptr, sig) != HSA_STATUS_SUCCESS) {
+                (void)hsa_signal_destroy(sig);
+                return false;
             }
-            ++issued;
+            sigs.push_back(sig);
         }
-        for (int k = 0; k < issued; ++k) {
-            while (hsa_signal_wait_scacquire(sig[k], HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_ACTIVE) >= 1) {}
-            if (hsa_signal_load_relaxed(sig[k]) < 0) good = false;
-            (void)hsa_signal_destroy(sig[k]);
+        return true;
+    }
+    static bool wait(std::vector<hsa_signal_t>& sigs) {
+        bool good = true;
+        for (hsa_signal_t sig : sigs) {
+            while (hsa_signal_wait_scacquire(sig, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_ACTIVE) >= 1) {}
+            if (hsa_signal_load_relaxed(sig) < 0) good = false;
+            (void)hsa_signal_destroy(sig);
         }
+        sigs.clear();
         return good;
     }
 };
 
-struct vbt_tokenizer {
+// One device of a tokenizer: the dictionary's device image, the idle workspaces of that device and its DMA engines.
+struct Replica {
     std::unique_ptr<Tokenizer> t;
+    std::vector<std::unique_ptr<PooledWorkspace>> pool;  // idle workspaces (guarded by the tokenizer's pool_mu)
+    std::unique_ptr<Sdma> sdma;                          // device -> pinned-host copies on the DMA engines (created at the first host batch)
+    uint64_t dev_budget = 0;                             // bytes of idle workspaces this device keeps (VBT_POOL_MAX_MB, default a quarter of its memory)
+};
+
+struct vbt_tokenizer {
+    // reps[0] owns the dictionary; a multi-device tokenizer (vbt_tokenizer_new_multi) holds one replica of the device image per
+    // listed device and vbt_tokenize_batch splits every batch over them.  `t` = reps[0]->t: what Worker and the device API use.
+    std::vector<std::unique_ptr<Replica>> reps;
+    Tokenizer* t = nullptr;
     vbt_dict dict_view;  // borrowed view handed out by vbt_tokenizer_dictionary
     std::mutex pool_mu;
-    std::vector<std::unique_ptr<PooledWorkspace>> pool;  // idle workspaces
     std::vector<std::unique_ptr<PinnedBlock>> host_pool;  // idle pinned blocks
     uint64_t pool_created = 0, pool_reused = 0;
-    std::unique_ptr<Sdma> sdma;  // device -> pinned-host copies on the DMA engines (created at the first host batch)
-    int out_mode = -1;                  // VBT_H2H_OUT: 0 = the packing kernel stores into the pinned block, 1 = SDMA copies (default)
-    ~vbt_tokenizer() { pool.clear(); }  // before the Tokenizer (workspaces reference it)
+    std::atomic<int> out_mode{-1};      // VBT_H2H_OUT: 0 = the packing kernel stores into the pinned block, 1 = SDMA copies (default); published with release once the replicas' Sdma exist
+    ~vbt_tokenizer() { for (auto& r : reps) r->pool.clear(); }  // before the Tokenizers (workspaces reference them)
 };
 struct vbt_workspace { std::unique_ptr<Workspace> w; };
 
@@ -249,29 +265,30 @@ uint64_t round_up_pow2(uint64_t v, uint64_t lo) {
     return r;
 }
 
-// Smallest idle workspace that holds the request, else a new one (capacities rounded up to powers of two so
-// that batches of similar size share it).  At most kPoolIdle workspaces stay idle; the smallest is dropped first.
+// Smallest idle workspace of the replica that holds the request, else a new one (capacities rounded up to powers of two so
+// that batches of similar size share it).  At most kPoolIdle workspaces stay idle per device; the smallest is dropped first.
 constexpr size_t kPoolIdle = 16;
-std::unique_ptr<PooledWorkspace> pool_take(vbt_tokenizer* tok, uint64_t n, uint64_t bytes) {
+std::unique_ptr<PooledWorkspace> pool_take(vbt_tokenizer* tok, Replica& rep, uint64_t n, uint64_t bytes) {
     {
         std::lock_guard<std::mutex> g(tok->pool_mu);
-        size_t best = tok->pool.size();
-        for (size_t i = 0; i < tok->pool.size(); ++i) {
-            const auto& p = tok->pool[i];
-            if (p->cap_sentences >= n && p->cap_bytes >= bytes && (best == tok->pool.size() || p->cap_bytes < tok->pool[best]->cap_bytes)) best = i;
+        size_t best = rep.pool.size();
+        for (size_t i = 0; i < rep.pool.size(); ++i) {
+            const auto& p = rep.pool[i];
+            if (p->cap_sentences >= n && p->cap_bytes >= bytes && (best == rep.pool.size() || p->cap_bytes < rep.pool[best]->cap_bytes)) best = i;
         }
-        if (best != tok->pool.size()) {
-            auto p = std::move(tok->pool[best]);
-            tok->pool.erase(tok->pool.begin() + (long)best);
+        if (best != rep.pool.size()) {
+            auto p = std::move(rep.pool[best]);
+            rep.pool.erase(rep.pool.begin() + (long)best);
             ++tok->pool_reused;
             return p;
         }
         ++tok->pool_created;
     }
+    HIPX(hipSetDevice(rep.t->device()));
     auto p = std::make_unique<PooledWorkspace>();
     p->cap_sentences = round_up_pow2(n, 64);
     p->cap_bytes = round_up_pow2(bytes, 4096);
-    p->ws = std::make_unique<Workspace>(*tok->t, p->cap_sentences, p->cap_bytes);
+    p->ws = std::make_unique<Workspace>(*rep.t, p->cap_sentences, p->cap_bytes);
     HIPX(hipMalloc(&p->d_text, p->cap_bytes));
     HIPX(hipMalloc(reinterpret_cast<void**>(&p->d_off), (p->cap_sentences + 1) * 8));
     HIPX(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
@@ -293,68 +310,76 @@ std::unique_ptr<PinnedBlock> host_take(vbt_tokenizer* tok, size_t bytes) {
     }
     auto b = std::make_unique<PinnedBlock>();
     b->cap = round_up_pow2(bytes, 1 << 16);
-    HIPX(hipHostMalloc(&b->p, b->cap, hipHostMallocDefault));
+    HIPX(hipHostMalloc(&b->p, b->cap, hipHostMallocPortable | hipHostMallocMapped));  // (reachable from every device of a multi-device tokenizer)
     return b;
 }
 
 // Budgets of the idle pools (capacities are rounded up to powers of two and were never trimmed: a few large calls
-// pinned tens of GiB for the tokenizer's lifetime).  VBT_POOL_MAX_MB=<device MB>[,<pinned MB>].
-void pool_budgets(uint64_t& dev_bytes, uint64_t& host_bytes) {
-    static uint64_t dev = 0, host = 0;
-    static std::once_flag once;
-    std::call_once(once, [] {
-        // device default: a quarter of the GPU's memory (72 GiB on an MI355X: eight host threads streaming headline-sized batches
-        // hold 58 GiB of workspaces, and a workspace that does not fit the budget is freed and re-allocated on every call -- with
-        // the fixed 32 GiB of before, six threads ran at 0.6x and eight at 0.07x the throughput of four)
-        unsigned long long d = 32768, h = 8192;
-        {
-            size_t free_b = 0, total_b = 0;
-            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (total_b >> 22) > d) d = total_b >> 22;
-        }
-        if (const char* e = std::getenv("VBT_POOL_MAX_MB")) {
-            unsigned long long a = 0, b = 0;
-            const int k = std::sscanf(e, "%llu,%llu", &a, &b);
-            if (k >= 1) d = a;
-            if (k >= 2) h = b;
-        }
-        dev = d << 20; host = h << 20;
-    });
-    dev_bytes = dev; host_bytes = host;
+// pinned tens of GiB for the tokenizer's lifetime).  VBT_POOL_MAX_MB=<device MB>[,<pinned MB>]; the device budget is per device.
+// device default: a quarter of that GPU's memory (72 GiB on an MI355X: eight host threads streaming headline-sized batches
+// hold 58 GiB of workspaces, and a workspace that does not fit the budget is freed and re-allocated on every call -- with
+// the fixed 32 GiB of before, six threads ran at 0.6x and eight at 0.07x the throughput of four)
+uint64_t device_pool_budget() {  // of the CURRENT device (called once per replica, right after its image was uploaded)
+    unsigned long long d = 32768;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (total_b >> 22) > d) d = total_b >> 22;
+    if (const char* e = std::getenv("VBT_POOL_MAX_MB")) {
+        unsigned long long a = 0, b = 0;
+        if (std::sscanf(e, "%llu,%llu", &a, &b) >= 1) d = a;
+    }
+    return (uint64_t)d << 20;
+}
+uint64_t host_pool_budget() {
+    unsigned long long h = 8192;
+    if (const char* e = std::getenv("VBT_POOL_MAX_MB")) {
+        unsigned long long a = 0, b = 0;
+        if (std::sscanf(e, "%llu,%llu", &a, &b) >= 2) h = b;
+    }
+    return (uint64_t)h << 20;
 }
 uint64_t workspace_bytes(const PooledWorkspace& p) { return 400 * p.cap_bytes + 7200 * p.cap_sentences; }  // (vibrato_hip.h: footprint)
 
 void host_give(vbt_tokenizer* tok, std::unique_ptr<PinnedBlock> b) {
     if (!b) return;
-    uint64_t dev_budget, host_budget;
-    pool_budgets(dev_budget, host_budget);
-    std::lock_guard<std::mutex> g(tok->pool_mu);
-    uint64_t held = b->cap;
-    for (const auto& q : tok->host_pool) held += q->cap;
-    if (held > host_budget) return;  // released (hipHostFree) instead of pooled
-    tok->host_pool.push_back(std::move(b));
-    if (tok->host_pool.size() > kHostPoolIdle) {
-        size_t smallest = 0;
-        for (size_t i = 1; i < tok->host_pool.size(); ++i)
-            if (tok->host_pool[i]->cap < tok->host_pool[smallest]->cap) smallest = i;
-        tok->host_pool.erase(tok->host_pool.begin() + (long)smallest);
+    static const uint64_t host_budget = host_pool_budget();
+    std::unique_ptr<PinnedBlock> drop;  // hipHostFree synchronises the device: outside the lock
+    {
+        std::lock_guard<std::mutex> g(tok->pool_mu);
+        uint64_t held = b->cap;
+        for (const auto& q : tok->host_pool) held += q->cap;
+        if (held > host_budget) drop = std::move(b);
+        else {
+            tok->host_pool.push_back(std::move(b));
+            if (tok->host_pool.size() > kHostPoolIdle) {
+                size_t smallest = 0;
+                for (size_t i = 1; i < tok->host_pool.size(); ++i)
+                    if (tok->host_pool[i]->cap < tok->host_pool[smallest]->cap) smallest = i;
+                drop = std::move(tok->host_pool[smallest]);
+                tok->host_pool.erase(tok->host_pool.begin() + (long)smallest);
+            }
+        }
     }
 }
 
-void pool_give(vbt_tokenizer* tok, std::unique_ptr<PooledWorkspace> p) {
-    uint64_t dev_budget, host_budget;
-    pool_budgets(dev_budget, host_budget);
+void pool_give(vbt_tokenizer* tok, Replica& rep, std::unique_ptr<PooledWorkspace> p) {
     std::unique_ptr<PooledWorkspace> drop;  // destroyed outside the lock
-    std::lock_guard<std::mutex> g(tok->pool_mu);
-    uint64_t held = workspace_bytes(*p);
-    for (const auto& q : tok->pool) held += workspace_bytes(*q);
-    if (held > dev_budget) { drop = std::move(p); return; }
-    tok->pool.push_back(std::move(p));
-    if (tok->pool.size() > kPoolIdle) {
-        size_t smallest = 0;
-        for (size_t i = 1; i < tok->pool.size(); ++i)
-            if (tok->pool[i]->cap_bytes < tok->pool[smallest]->cap_bytes) smallest = i;
-        tok->pool.erase(tok->pool.begin() + (long)smallest);
+    {
+        std::lock_guard<std::mutex> g(tok->pool_mu);
+        uint64_t held = workspace_bytes(*p);
+        for (const auto& q : rep.pool) held += workspace_bytes(*q);
+        if (held > rep.dev_budget) drop = std::move(p);
+        else {
+            rep.pool.push_back(std::move(p));
+            if (rep.pool.size() > kPoolIdle) {
+                size_t smallest = 0;
+                for (size_t i = 1; i < rep.pool.size(); ++i)
+                    if (rep.pool[i]->cap_bytes < rep.pool[smallest]->cap_bytes) smallest = i;
+                drop = std::move(rep.pool[smallest]);
+                rep.pool.erase(rep.pool.begin() + (long)smallest);
+            }
+        }
     }
+    if (drop) { (void)hipSetDevice(rep.t->device()); drop.reset(); }
 }
 
 const Dictionary& dict_of(const vbt_dict* dict) {
@@ -503,23 +528,40 @@ uint32_t vbt_dict_common_prefix(const vbt_dict* dict, uint32_t lex_type, const u
     return (uint32_t)m.size();
 }
 
-int vbt_tokenizer_new(vbt_dict* dict, int ignore_space, uint32_t max_grouping_len, int device, vbt_tokenizer** out) {
+int vbt_tokenizer_new_multi(vbt_dict* dict, int ignore_space, uint32_t max_grouping_len, const int* devices, uint32_t n_devices, vbt_tokenizer** out) {
     return guarded([&] {
         if (!dict || !dict->d || !dict->owned || !out) throw Error(VBT_ERR_INVALID_ARGUMENT, "dict: null or already consumed");
+        if (!devices || n_devices == 0 || n_devices > 64) throw Error(VBT_ERR_INVALID_ARGUMENT, "devices: expected 1..64 HIP device indices");
         // Tokenizer::new moves the dictionary in (tokenizer.rs:26). On failure the caller keeps the handle.
-        auto t = std::make_unique<Tokenizer>(dict->d, ignore_space != 0, max_grouping_len, device);
-        t->adopt(std::unique_ptr<Dictionary>(dict->d));
+        auto h = std::make_unique<vbt_tokenizer>();
+        for (uint32_t k = 0; k < n_devices; ++k) {
+            auto rep = std::make_unique<Replica>();
+            rep->t = std::make_unique<Tokenizer>(dict->d, ignore_space != 0, max_grouping_len, devices[k]);  // (leaves that device current)
+            rep->dev_budget = device_pool_budget();
+            h->reps.push_back(std::move(rep));
+        }
+        h->reps[0]->t->adopt(std::unique_ptr<Dictionary>(dict->d));  // the other replicas borrow it: reps[0] is destroyed last
         dict->d = nullptr;
-        auto* h = new vbt_tokenizer();
-        h->t = std::move(t);
+        h->t = h->reps[0]->t.get();
         h->dict_view.d = const_cast<Dictionary*>(&h->t->dict());
         h->dict_view.owned = false;
-        *out = h;
+        *out = h.release();
         delete dict;
     });
 }
 
-void vbt_tokenizer_free(vbt_tokenizer* tok) { delete tok; }
+int vbt_tokenizer_new(vbt_dict* dict, int ignore_space, uint32_t max_grouping_len, int device, vbt_tokenizer** out) {
+    return vbt_tokenizer_new_multi(dict, ignore_space, max_grouping_len, &device, 1, out);
+}
+
+uint32_t vbt_tokenizer_num_devices(const vbt_tokenizer* tok) { return tok ? (uint32_t)tok->reps.size() : 0; }
+
+void vbt_tokenizer_free(vbt_tokenizer* tok) {
+    if (!tok) return;
+    for (auto& r : tok->reps) r->pool.clear();
+    while (tok->reps.size() > 1) tok->reps.pop_back();  // the replicas that borrow the dictionary go first
+    delete tok;
+}
 
 const vbt_dict* vbt_tokenizer_dictionary(const vbt_tokenizer* tok) { return &tok->dict_view; }  // borrowed: do not free
 
@@ -724,6 +766,20 @@ int vbt_worker_token(const vbt_worker* w, uint32_t i, vbt_token* out) {
     });
 }
 
+// Splits n sentences into `parts` contiguous ranges balanced by bytes (vibrato_amd/sharding.py: shard_bounds, the rule the
+// multi-process path uses): range k ends at the first sentence that starts at or behind k / parts of the text.
+static void shard_bounds(const uint64_t* offs, uint64_t n, uint32_t parts, std::vector<uint64_t>& bounds) {
+    bounds.assign(parts + 1, n);
+    bounds[0] = 0;
+    const uint64_t total = offs[n] - offs[0];
+    for (uint32_t r = 1; r < parts; ++r) {
+        const uint64_t target = offs[0] + (uint64_t)(((unsigned __int128)total * r) / parts);
+        bounds[r] = (uint64_t)(std::lower_bound(offs, offs + n + 1, target) - offs);
+        if (bounds[r] > n) bounds[r] = n;
+        if (bounds[r] < bounds[r - 1]) bounds[r] = bounds[r - 1];
+    }
+}
+
 int vbt_tokenize_batch(const vbt_tokenizer* tok_, const uint8_t* text, const uint64_t* offsets, uint64_t n, vbt_batch** out) {
     return guarded([&] {
         vbt_tokenizer* tok = const_cast<vbt_tokenizer*>(tok_);  // the pools are internally synchronised: the handle stays logically const
@@ -733,53 +789,87 @@ int vbt_tokenize_batch(const vbt_tokenizer* tok_, const uint8_t* text, const uin
             if (offsets[i] < offsets[i - 1]) throw Error(VBT_ERR_INVALID_ARGUMENT, "offsets must be non-decreasing");
         const uint64_t bytes = offsets[n] - lo;
         if (bytes >= 0xFFFFFFFFull || n >= 0xFFFFFFFFull) throw Error(VBT_ERR_INVALID_ARGUMENT, "batch too large (split it)");
-        HIPX(hipSetDevice(tok->t->device()));
-        // the batch's own copy of the input, in pinned memory: [n + 1 rebased offsets][text]
-        struct Holder {  // blocks and workspace go back to their pools on every path
+        const uint32_t R = (uint32_t)tok->reps.size();
+        // One shard per device (a single-device tokenizer: one shard = the batch).  Every shard gets a pooled workspace + stream
+        // of its device; the kernels of all devices run side by side, and every device's DMA engines write its shard of the
+        // results into ONE pinned block at the shard's offset: a gather to the caller with no collective and no copy kernel.
+        struct Shard { std::unique_ptr<PooledWorkspace> p; uint64_t s0 = 0, s1 = 0, b0 = 0, b1 = 0, tok_base = 0; uint32_t* tail = nullptr; };
+        struct Holder {  // blocks and workspaces go back to their pools on every path
             vbt_tokenizer* tok;
             std::unique_ptr<vbt_batch> b;
-            std::unique_ptr<PooledWorkspace> p;
+            std::vector<Shard> sh;
             ~Holder() {
-                if (p) { (void)hipStreamSynchronize(p->stream); pool_give(tok, std::move(p)); }
+                for (size_t k = 0; k < sh.size(); ++k)
+                    if (sh[k].p) { (void)hipSetDevice(tok->reps[k]->t->device()); (void)hipStreamSynchronize(sh[k].p->stream); pool_give(tok, *tok->reps[k], std::move(sh[k].p)); }
                 if (b) { host_give(tok, std::move(b->in_blk)); host_give(tok, std::move(b->out_blk)); }
             }
-        } h{tok, std::make_unique<vbt_batch>(), nullptr};
+        } h{tok, std::make_unique<vbt_batch>(), {}};
         vbt_batch& b = *h.b;
         b.tok = tok;
         b.n = n;
-        b.in_blk = host_take(tok, (n + 1) * 8 + bytes + 24);
+        // the batch's own copy of the input, in pinned memory: [n + 1 rebased offsets][text][8 bytes per shard: totals][per shard: its offsets rebased to the shard]
+        const size_t text_end = (n + 1) * 8 + ((bytes + 7) & ~(uint64_t)7);
+        b.in_blk = host_take(tok, text_end + 8 * R + (R > 1 ? (n + R) * 8 : 0) + 24);
         uint64_t* offs = static_cast<uint64_t*>(b.in_blk->p);
         for (uint64_t i = 0; i <= n; ++i) offs[i] = offsets[i] - lo;
         uint8_t* txt = reinterpret_cast<uint8_t*>(offs + n + 1);
         if (bytes) std::memcpy(txt, text + lo, bytes);
         b.offsets = offs;
         b.text = txt;
-        h.p = pool_take(tok, n, bytes);
-        PooledWorkspace& p = *h.p;
-        if (bytes) HIPX(hipMemcpyAsync(p.d_text, txt, bytes, hipMemcpyHostToDevice, p.stream));
-        HIPX(hipMemcpyAsync(p.d_off, offs, (n + 1) * 8, hipMemcpyHostToDevice, p.stream));
+        uint32_t* tails = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(b.in_blk->p) + text_end);  // per shard {n_tokens, error flags}
+        uint64_t* shard_offs = reinterpret_cast<uint64_t*>(tails + 2 * R);
+        std::vector<uint64_t> bounds;
+        shard_bounds(offs, n, R, bounds);
         // How the results reach the host (VBT_H2H_OUT): 1 (default) = packed on the device, then copied by the GPU's SDMA engines
         // (Sdma above); 0 = the packing kernel stores them straight into this batch's pinned block.  Either way the total and the
         // error flags come back first, in 8 bytes, so that the pinned block is sized exactly.
-        if (tok->out_mode < 0) {
+        if (tok->out_mode.load(std::memory_order_acquire) < 0) {
             std::lock_guard<std::mutex> g(tok->pool_mu);
-            if (tok->out_mode < 0) {
+            if (tok->out_mode.load(std::memory_order_relaxed) < 0) {
                 const char* e = std::getenv("VBT_H2H_OUT");
                 int mode = e && *e ? std::atoi(e) : 1;
-                if (mode == 1) {
-                    tok->sdma = std::make_unique<Sdma>(tok->t->device());
-                    if (!tok->sdma->ok) mode = 0;
-                }
-                tok->out_mode = mode;
+                if (mode == 1)
+                    for (auto& r : tok->reps) {
+                        r->sdma = std::make_unique<Sdma>(r->t->device());
+                        if (!r->sdma->ok) mode = 0;
+                    }
+                tok->out_mode.store(mode, std::memory_order_release);  // (behind the Sdma objects: a thread that sees the mode sees them)
             }
         }
-        const bool use_sdma = tok->out_mode == 1;
-        p.ws->run(static_cast<const uint8_t*>(p.d_text), p.d_off, n, bytes, p.stream, /*defer_pack=*/!use_sdma);
-        uint32_t* tail = reinterpret_cast<uint32_t*>(txt + ((bytes + 7) & ~(uint64_t)7));  // {n_tokens, error flags}
-        tail[0] = tail[1] = 0;
-        HIPX(hipMemcpyAsync(tail, p.ws->d_ctrl, 8, hipMemcpyDeviceToHost, p.stream));
-        HIPX(hipStreamSynchronize(p.stream));
-        const uint32_t error_flags = tail[1];
+        const bool use_sdma = tok->out_mode.load(std::memory_order_acquire) == 1;
+        h.sh.resize(R);
+        for (uint32_t k = 0; k < R; ++k) {
+            Shard& s = h.sh[k];
+            s.s0 = bounds[k]; s.s1 = bounds[k + 1]; s.b0 = offs[s.s0]; s.b1 = offs[s.s1];
+            s.tail = tails + 2 * k;
+            s.tail[0] = s.tail[1] = 0;
+            const uint64_t ns = s.s1 - s.s0, nb = s.b1 - s.b0;
+            if (ns == 0) continue;
+            const uint64_t* so = offs;  // a single shard reads the batch's offsets as they are
+            if (R > 1) {
+                uint64_t* q = shard_offs + s.s0 + k;
+                for (uint64_t i = 0; i <= ns; ++i) q[i] = offs[s.s0 + i] - s.b0;
+                so = q;
+            }
+            HIPX(hipSetDevice(tok->reps[k]->t->device()));
+            s.p = pool_take(tok, *tok->reps[k], ns, nb);
+            PooledWorkspace& p = *s.p;
+            if (nb) HIPX(hipMemcpyAsync(p.d_text, txt + s.b0, nb, hipMemcpyHostToDevice, p.stream));
+            HIPX(hipMemcpyAsync(p.d_off, so, (ns + 1) * 8, hipMemcpyHostToDevice, p.stream));
+            p.ws->run(static_cast<const uint8_t*>(p.d_text), p.d_off, ns, nb, p.stream, /*defer_pack=*/!use_sdma);
+            HIPX(hipMemcpyAsync(s.tail, p.ws->d_ctrl, 8, hipMemcpyDeviceToHost, p.stream));
+        }
+        uint32_t error_flags = 0;
+        uint64_t total = 0;
+        for (uint32_t k = 0; k < R; ++k) {
+            Shard& s = h.sh[k];
+            if (!s.p) continue;
+            HIPX(hipSetDevice(tok->reps[k]->t->device()));
+            HIPX(hipStreamSynchronize(s.p->stream));
+            error_flags |= s.tail[1];
+            s.tok_base = total;
+            total += s.tail[0];
+        }
         if (error_flags & kErrUtf8) {
             // every sentence must be a Rust `str` (the reference's callers pass &str; its CLI fails on invalid input lines).  The
             // device's first kernel validates the text; only this error path walks it again on the host to name the sentence.
@@ -787,26 +877,44 @@ int vbt_tokenize_batch(const vbt_tokenizer* tok_, const uint8_t* text, const uin
                 if (!valid_utf8(txt + offs[i], offs[i + 1] - offs[i])) throw Error(VBT_ERR_UTF8, "sentence " + std::to_string(i) + " is not valid UTF-8");
         }
         check_device_errors(error_flags);
-        b.n_tokens = tail[0];
+        if (total >= 0xFFFFFFFFull) throw Error(VBT_ERR_INVALID_ARGUMENT, "batch too large (split it)");
+        b.n_tokens = total;
         b.out_blk = host_take(tok, n * 8 + (size_t)b.n_tokens * sizeof(vbt_token_rec) + 16);
         uint32_t* o = static_cast<uint32_t*>(b.out_blk->p);
+        vbt_token_rec* otok = reinterpret_cast<vbt_token_rec*>(o + 2 * n);
         b.tok_off = o;
         b.tok_cnt = o + n;
-        b.tokens = reinterpret_cast<const vbt_token_rec*>(o + 2 * n);
-        if (n && use_sdma) {
-            const void* src[3] = {p.ws->d_tok_off, p.ws->d_tok_cnt, p.ws->d_tokens};
-            void* dst[3] = {o, o + n, o + 2 * n};
-            const size_t len[3] = {(size_t)n * 4, (size_t)n * 4, (size_t)b.n_tokens * sizeof(vbt_token_rec)};
-            if (!tok->sdma->d2h(src, dst, len, 3)) throw Error(VBT_ERR_DEVICE, "device -> host copy of the results failed (hsa_amd_memory_async_copy)");
-        } else if (n) {
-            void* dev = nullptr;
-            HIPX(hipHostGetDevicePointer(&dev, o, 0));
-            uint32_t* od = static_cast<uint32_t*>(dev);
-            static const bool no_pack = std::getenv("VBT_H2H_NO_PACK") != nullptr;  // timing experiment only: results stay on the device
-            if (!no_pack) p.ws->pack_to(reinterpret_cast<vbt_token_rec*>(od + 2 * n), od, od + n, p.stream);
-            HIPX(hipStreamSynchronize(p.stream));
+        b.tokens = otok;
+        std::vector<hsa_signal_t> sigs;
+        bool copies_ok = true;
+        for (uint32_t k = 0; k < R; ++k) {
+            Shard& s = h.sh[k];
+            if (!s.p) continue;
+            const uint64_t ns = s.s1 - s.s0;
+            PooledWorkspace& p = *s.p;
+            if (use_sdma) {
+                const void* src[3] = {p.ws->d_tok_off, p.ws->d_tok_cnt, p.ws->d_tokens};
+                void* dst[3] = {o + s.s0, o + n + s.s0, otok + s.tok_base};
+                const size_t len[3] = {(size_t)ns * 4, (size_t)ns * 4, (size_t)s.tail[0] * sizeof(vbt_token_rec)};
+                copies_ok = tok->reps[k]->sdma->issue(src, dst, len, 3, sigs) && copies_ok;
+            } else {
+                HIPX(hipSetDevice(tok->reps[k]->t->device()));
+                void* dev = nullptr;
+                HIPX(hipHostGetDevicePointer(&dev, o, 0));
+                uint32_t* od = static_cast<uint32_t*>(dev);
+                p.ws->pack_to(reinterpret_cast<vbt_token_rec*>(od + 2 * n) + s.tok_base, od + s.s0, od + n + s.s0, p.stream);
+            }
         }
-        pool_give(tok, std::move(h.p));
+        copies_ok = Sdma::wait(sigs) && copies_ok;
+        if (!copies_ok) throw Error(VBT_ERR_DEVICE, "device -> host copy of the results failed (hsa_amd_memory_async_copy)");
+        for (uint32_t k = 0; k < R; ++k) {
+            Shard& s = h.sh[k];
+            if (!s.p) continue;
+            if (!use_sdma) { HIPX(hipSetDevice(tok->reps[k]->t->device())); HIPX(hipStreamSynchronize(s.p->stream)); }
+            if (s.tok_base)  // a shard's token offsets start at 0: rebase them to the batch
+                for (uint64_t i = s.s0; i < s.s1; ++i) o[i] += (uint32_t)s.tok_base;
+            pool_give(tok, *tok->reps[k], std::move(s.p));
+        }
         *out = h.b.release();
     });
 }
@@ -816,14 +924,14 @@ int vbt_tokenizer_trim_pool(const vbt_tokenizer* tok_) {
     return guarded([&] {
         vbt_tokenizer* tok = const_cast<vbt_tokenizer*>(tok_);
         if (!tok) throw Error(VBT_ERR_INVALID_ARGUMENT, "null argument");
-        std::vector<std::unique_ptr<PooledWorkspace>> ws;
+        std::vector<std::vector<std::unique_ptr<PooledWorkspace>>> ws(tok->reps.size());
         std::vector<std::unique_ptr<PinnedBlock>> blocks;
         {
             std::lock_guard<std::mutex> g(tok->pool_mu);
-            ws.swap(tok->pool);
+            for (size_t k = 0; k < tok->reps.size(); ++k) ws[k].swap(tok->reps[k]->pool);
             blocks.swap(tok->host_pool);
         }
-        HIPX(hipSetDevice(tok->t->device()));
+        for (size_t k = 0; k < ws.size(); ++k) { HIPX(hipSetDevice(tok->reps[k]->t->device())); ws[k].clear(); }
     });
 }
 
@@ -835,7 +943,7 @@ int vbt_tokenizer_pool_stats(const vbt_tokenizer* tok_, uint64_t* created, uint6
         std::lock_guard<std::mutex> g(tok->pool_mu);
         if (created) *created = tok->pool_created;
         if (reused) *reused = tok->pool_reused;
-        if (idle) *idle = tok->pool.size();
+        if (idle) { *idle = 0; for (const auto& r : tok->reps) *idle += r->pool.size(); }
     });
 }
 

@@ -125,27 +125,6 @@ __device__ __forceinline__ uint32_t group_min_u32(uint32_t x) {
     if constexpr (kLevels >= 6) { const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false); x = r[0] < r[1] ? r[0] : r[1]; }
     return x;
 }
-__device__ __forceinline__ uint32_t group_min_u32(uint32_t x, uint32_t lg) {  // lg is wave-uniform, <= 6
-    // nested, ascending: one scalar compare + branch per level actually taken (a switch becomes a compare tree with flow blocks)
-    if (lg >= 1) {
-        x = dpp_min_u32<0xB1>(x);
-        if (lg >= 2) {
-            x = dpp_min_u32<0x4E>(x);
-            if (lg >= 3) {
-                x = dpp_min_u32<0x141>(x);
-                if (lg >= 4) {
-                    x = dpp_min_u32<0x140>(x);
-                    if (lg >= 5) {
-                        { const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false); x = r[0] < r[1] ? r[0] : r[1]; }
-                        if (lg >= 6) { const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false); x = r[0] < r[1] ? r[0] : r[1]; }
-                    }
-                }
-            }
-        }
-    }
-    return x;
-}
-
 // 128-bit window helpers (shift distances 0..64), by value so everything stays in registers
 struct U128 { uint64_t lo, hi; };
 __device__ __forceinline__ U128 shr128(U128 w, uint32_t d) {
@@ -750,28 +729,44 @@ __device__ __forceinline__ uint64_t process_sentence(const DevDict& D, const Bat
     return 0;
 }
 
-// prefetch distance of the matrix gathers of lattice_lds in passes (= unroll factor of its sweep loop).  2..8 measure the
-// same within 3 % on a full batch (other waves hide the latency); 8 keeps a lone sentence's sweep off the HBM latency.
+// Geometry of the sweep kernel (lattice_lds).  A sweep step -- all candidates of one start word x all nodes ending at its start node --
+// is cut into PASSES of up to kRoundCands candidates x up to kRoundPreds predecessors.  In a pass lane = (candidate cl = lane >> 2,
+// phase k = lane & 3): the lane walks the predecessors j = 4 i + k, i = 0 .. 3 ("units": one instruction stream per unit covers
+// 4 predecessors x 16 candidates), keeps the minimum of its own phase in registers, and the four phases of a candidate are
+// combined with two quad-permute levels at the end of the step.  VBT_DEPTH = passes whose connection costs are in flight.
 #ifndef VBT_DEPTH
 #define VBT_DEPTH 6
 #endif
 #ifndef VBT_LAT_WAVES
 #define VBT_LAT_WAVES 4
 #endif
-// One pass of the fused gather+recurrence loop of lattice_lds: 64 lanes = 64 padded (candidate c, predecessor j) pairs
-// of one sweep step, pair q = q0 + lane, c = q >> lg, j = q & (2^lg - 1), 2^lg >= the number of predecessors.  The
-// record is built once per pass by the lane that owns the step: absolute LDS byte addresses (of the first predecessor's right
-// id and key, of the first candidate), q0, lg and the step's np / nc -- a lane holds a real pair iff j < np && c < nc (two
-// compares at consumption; a precomputed 64-bit lane mask cost the record builder ~30 VALU instructions per pass).
-struct alignas(16) LPass { uint32_t baseR, baseK, baseC, q0, np, nc, lg, pad; };
-
-// LDS bytes of the lattice arrays of lattice_lds for a (segment of a) sentence with C candidates, `passes` passes and
-// m_in nodes ending at its first position.  Must over-estimate the Arena carve there; gen_candidates routes sentences
-// to LDS tiers with it.
-__host__ __device__ __forceinline__ uint64_t lattice_fixed_bytes(uint32_t C, uint32_t passes, uint32_t m_in) {
-    const uint64_t E = (uint64_t)C + m_in;
-    return 8 * (E + 1) + 8 * (C + 1ull) + 2 * (E + 1) + sizeof(LPass) * (passes + 2ull) + 48;
+#ifndef VBT_ROUND_PREDS
+#define VBT_ROUND_PREDS 16
+#endif
+#ifndef VBT_DUMMY_EXEC0
+#define VBT_DUMMY_EXEC0 1
+#endif
+constexpr uint32_t kRoundPreds = VBT_ROUND_PREDS, kRoundCands = 16;  // (build knob: 8 or 16 predecessors = 2 or 4 units, i.e. gathers, per pass)
+static_assert(kRoundPreds == 8 || kRoundPreds == 16, "a pass walks 2 or 4 units of 4 predecessors");
+constexpr uint32_t kUnits = kRoundPreds / 4;
+// 16-byte pass record in LDS, built once per pass by the lane that owns the step:
+//   w0 = LDS address of the slot record of the pass's first predecessor, w1 = LDS address of its first candidate's record,
+//   w2 = predecessors (<= 16) | candidates (<= 16) << 8 | first round of its candidates << 16 | last round << 17 | first pass of the step << 18,
+//   w3 = predecessors | candidates << 16 of the whole step (connection-id counting)
+struct alignas(16) LPass { uint32_t w0, w1, w2, w3; };
+__host__ __device__ __forceinline__ uint32_t step_passes(uint32_t nc, uint32_t np) {
+    return ((np + kRoundPreds - 1) / kRoundPreds) * ((nc + kRoundCands - 1) / kRoundCands);
 }
+// LDS bytes of the lattice arrays of lattice_lds for a (segment of a) sentence with C candidates, `passes` passes and a window of
+// E end-list slots.  Must over-estimate the Arena carve there; gen_candidates routes sentences to LDS tiers with it.
+__host__ __device__ __forceinline__ uint64_t lattice_fixed_bytes(uint32_t C, uint32_t passes, uint32_t E) {
+    return 8ull * (E + 2ull) + 8ull * (C + 2ull) + sizeof(LPass) * (passes + 2ull) + 48;
+}
+// Cost word of a slot whose node was never inserted (its start position is never visited).  Biased cost 0xC0000000 = +2^30: with
+// 16-bit connection and word costs a sentence of < 8000 characters keeps every live cost inside +-2^29, so such a predecessor
+// loses every minimum without being tested for; lattice_sentence tests the slot's own field instead where that bound does not
+// hold (i32 matrix cells, longer sentences).
+constexpr uint32_t kDeadHi = 0xC0000000u;
 
 // =====================================================================================
 // Two-kernel pipeline (default).  Candidate generation is memory-latency bound (dependent
@@ -846,9 +841,7 @@ __device__ __forceinline__ void list_push(const BatchArgs& A, uint32_t t, uint32
     if (threadIdx.x == 0) A.lists[(size_t)t * A.list_stride + A.list_off + atomicAdd(&A.cctrl[2 * t], 1u)] = sid;
 }
 
-__device__ __forceinline__ void list_push_fb(const BatchArgs& A, uint32_t sid) {  // the batch's fallback list (see BatchArgs::fb_cctrl)
-    if (threadIdx.x == 0) A.lists[(size_t)A.n_tiers * A.list_stride + A.fb_list_off + atomicAdd(&A.fb_cctrl[2 * A.n_tiers], 1u)] = sid;
-}
+__device__ __forceinline__ void list_push_fb(const BatchArgs& A, uint32_t sid) { list_push(A, A.n_tiers, sid); }  // the fallback list (fused kernel)
 
 // LDS bytes gen_long needs for a sentence of n characters / nb bytes (an over-estimate of its Arena carve: gen_one files a
 // sentence that outgrows it at the smallest level that holds it).
@@ -868,7 +861,7 @@ __device__ __forceinline__ uint32_t count_chars(const uint8_t* __restrict__ txt,
 }
 
 // gen_one's per-character working arrays in its wavefront's LDS (~26 bytes per character).  `ok` = they fit: the test by which
-// gen_one (bulk generator) and route_long (side stream) split a batch between them -- both carve with this one function.
+// gen_one files what does not fit for gen_long.
 struct GenOneLds {
     uint64_t* lens;
     uint32_t *ci, *cand_off;
@@ -937,9 +930,7 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
     }
     const GenOneLds L = carve_gen_one(g_smem, lds_bytes, n, D.has_user != 0);
     if (!L.ok) {
-        // Outgrows this wavefront: gen_long, one workgroup per sentence.  In a batch (early_long) route_long found the sentence by the
-        // same test on a side stream, where its generator and its sweep are already under way: nothing of it is touched here.
-        if (A.early_long) return;
+        // Outgrows this wavefront: gen_long, one workgroup per sentence.
         init();
         route(A.n_tiers + 1 + gen_long_level(A, n, nb, D.has_user != 0));
         return;
@@ -1083,12 +1074,13 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     PROF_MARK(1);
 
-    // expand the hits: lanes = hits, every entry load independent of every other; a candidate becomes ONE 16-byte record -- the
-    // sweep half {right_id | end-list slot << 16, (u16) word_cost | left_id << 16} and the token half {word_idx, end_char} -- at its
+    // expand the hits: lanes = hits, every entry load independent of every other; a candidate becomes ONE 16-byte record --
+    // {first cell of its left id's matrix row, (u16) word_cost | end-list slot << 16, word_idx, end_char | right_id << 16} -- at its
     // place in the reference's insertion order (cand_off[start] + candidates of that start before the hit).  One scattered store
     // per candidate: the generator is bound by the number of its scattered store requests (two 8-byte stores into separate arrays
     // cost 5 % more; the sweep's load phase does not notice the wider record)
     const uint32_t H = *hcount;  // <= C <= region
+    const uint32_t row_cells = D.num_right;  // a left id's row of the connection matrix starts at cell left_id * num_right
     for (uint32_t h0 = 0; h0 < H; h0 += 64) {
         const uint32_t h = h0 + ln;
         const uint4 hr = h < H ? hits[h] : make_uint4(0, 0, 0, 0);
@@ -1105,8 +1097,8 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
                 for (uint32_t q = 0; q < 4; ++q) {
                     if (t0 + q < c) {
                         const uint32_t k = dest + t0 + q;
-                        A.g_cand[base + k] = make_uint4((e[q].left_right >> 16) | ((slot0 + t0 + q) << 16), (e[q].cost & 0xFFFFu) | (e[q].left_right << 16),
-                                                        (lex << 30) | e[q].word_id, end);
+                        A.g_cand[base + k] = make_uint4((e[q].left_right & 0xFFFFu) * row_cells, (e[q].cost & 0xFFFFu) | ((slot0 + t0 + q) << 16),
+                                                        (lex << 30) | e[q].word_id, end | (e[q].left_right & 0xFFFF0000u));
                     }
                 }
             }
@@ -1115,19 +1107,15 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
     __syncthreads();
     // exclusive end-list offset of position p (0 .. n + 1): the cursors now hold the inclusive prefix
     auto eo = [&](uint32_t p) { return p == 0 ? 0u : p == 1 ? 1u : endc[p - 1]; };
-    // passes of the lattice kernel that the step at one position takes: ceil(candidates x 2^lg / 64), 2^lg >= predecessors
-    auto step_passes = [](uint32_t nc, uint32_t np) {
-        const uint32_t lg = np <= 1 ? 0u : 32u - (uint32_t)__builtin_clz(np - 1);
-        return (uint32_t)((((uint64_t)nc << lg) + 63) >> 6);
-    };
     uint32_t passes = 0, maxcnt = 1;
     {   // per-character records for the lattice kernel:
-        // {cand_off | end-list offset << 16, pass bound of the position's step | clean cut << 30 | space << 31,
+        // {cand_off | end-list offset << 16, pass bound of the position's step | window end << 14 | space << 31,
         //  length mask (64 bits; for a space position of ignore_space mode its groupable run instead: the sweep never
         //  starts a word there, tokenizer.rs:113-125)}
-        // Clean cut before position i: no candidate of an earlier position ends beyond i (with ignore_space, a
-        // visited space run hands its visit to the position behind the run, so such a run counts as spanning up to the
-        // furthest end of that position's candidates).  lattice_lds may split the sweep of a long sentence there.
+        // Window end of position i: the end-list offset behind the furthest end of any candidate of the positions <= i (with
+        // ignore_space, a visited space run hands its visit to the position behind the run, so such a run counts as spanning up
+        // to the furthest end of that position's candidates) -- the slots a sweep segment that ends behind i has to hold
+        // (lattice_lds may cut the sweep of a long sentence anywhere).
         uint4* pc = A.g_pc + slot0;
         uint32_t far = 0;  // furthest end of any candidate of the positions before this chunk
         for (uint32_t c0 = 0; c0 < n; c0 += 64) {
@@ -1153,15 +1141,11 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
             }
             uint32_t m = e;  // inclusive prefix maximum over the lanes
             m = wave_inscan_max_dpp(m);
-            uint32_t before = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x138, 0xF, 0xF, false);  // wave_shr:1 (lane 0: 0)
-            before = ln == 0 ? far : (before > far ? before : far);
             if (i < n) {
-                const uint32_t cut = (i == 0 || before <= i) ? 0x40000000u : 0u;
+                const uint32_t upto = m > far ? m : far;  // furthest end of any candidate of the positions <= i (<= n)
                 const uint64_t third = space ? (uint64_t)grp[i] : lm;
-                const uint32_t yw = (nsl < 0x3FFFu ? nsl : 0x3FFFu) | cut | space;
+                const uint32_t yw = (nsl < 0x3FFFu ? nsl : 0x3FFFu) | (eo(upto + 1) << 14) | space;
                 pc[i] = make_uint4(co_i | (eo(i) << 16), yw, (uint32_t)third, (uint32_t)(third >> 32));
-                // (a copy for the routing replay below, over the dead half of lens[] -- positions <= i are consumed)
-                reinterpret_cast<uint32_t*>(lens)[i] = yw;
             }
             const uint32_t top = (uint32_t)__builtin_amdgcn_readlane((int)m, 63);
             far = top > far ? top : far;
@@ -1183,59 +1167,13 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
         A.s_n[sid] = n; A.s_C[sid] = C; A.s_passes[sid] = passes;
     }
     // smallest tier whose LDS holds the lattice arrays (connection costs are never staged)
-    const uint64_t fixed = lattice_fixed_bytes(C, passes, 1u);
+    const uint64_t fixed = lattice_fixed_bytes(C, passes, eo(n + 1));
     uint32_t tier = fallback;
     for (uint32_t t = 0; t < A.n_tiers; ++t)
         if (fixed <= A.tier_bytes[t]) { tier = t; break; }
-    // longer sentences are swept in segments inside the segment tier instead of one huge LDS block
+    // longer sentences are swept in segments inside the segment tier instead of one huge LDS block (lattice_lds cuts anywhere;
+    // what it cannot sweep there -- a window of end lists wider than the tier -- it hands to the escape tiers itself)
     if (A.seg_tier < A.n_tiers && tier > A.seg_tier) tier = A.seg_tier;
-    if (tier == A.seg_tier && A.seg_tier + 1 < A.n_tiers && fixed > A.tier_bytes[tier]) {
-        // The sentence has to be swept in segments.  Replay lattice_lds' choice of cuts on the finished records: where some stretch
-        // is too dense for any admissible cut (it would fail there and be re-swept by the escape tier, which only starts when the
-        // whole segment tier has drained), file the sentence for the escape launch that runs NEXT TO the other tiers.  A wrong
-        // guess either way only costs time: lattice_lds still escalates what it cannot sweep.
-        __syncthreads();
-        // what the replay reads per position: the record's second word (pass bound, clean cut), the candidate offset and the
-        // end-list offset -- from LDS (a global round trip per probe was 5 % of the kernel)
-        auto rec_y = [&](uint32_t p) -> uint32_t { return reinterpret_cast<const uint32_t*>(lens)[p]; };
-        auto rec_co = [&](uint32_t p) -> uint32_t { return p < n ? cand_off[p] : C; };
-        auto rec_eo = [&](uint32_t p) -> uint32_t { return eo(p); };
-        const uint32_t budget = A.tier_bytes[tier];
-        uint32_t seg_a = 0, seg_c = 0, seg_p = 0, m_in = 1;
-        bool sweepable = true;
-        for (uint32_t guard = 0; guard <= n; ++guard) {
-            if (lattice_fixed_bytes(C - seg_c, passes - seg_p, m_in) <= budget) break;
-            uint32_t best = 0, best_pass = 0, run = 0;
-            for (uint32_t w0 = 0; w0 < 256 && seg_a + w0 < n; w0 += 64) {
-                const uint32_t b = seg_a + w0 + ln + 1;
-                uint32_t nsl = 0, cx = 0, cut = 0;
-                if (b <= n) {
-                    nsl = rec_y(b - 1) & 0x3FFFu;
-                    if (nsl == 0x3FFFu) nsl = 1u << 20;
-                    cx = rec_co(b);
-                    cut = b == n ? 1u : (rec_y(b) >> 30) & 1u;
-                }
-                uint32_t tot;
-                const uint32_t incl = wave_exscan(nsl, tot) + nsl + run;
-                const uint32_t est = b == n ? passes - seg_p : incl;
-                const bool fits = b <= n && lattice_fixed_bytes((cx - seg_c) & 0xFFFFu, est, m_in) <= budget;
-                const uint64_t m = __ballot(fits && cut);
-                if (m) {
-                    const uint32_t top = 63u - (uint32_t)__builtin_clzll(m);
-                    best = seg_a + w0 + top + 1;
-                    best_pass = (uint32_t)__builtin_amdgcn_readlane((int)est, (int)top);
-                }
-                run += tot;
-                if (__ballot(fits) == 0) break;
-            }
-            if (!best) { sweepable = false; break; }
-            if (best >= n) break;
-            const uint32_t m_out = __builtin_amdgcn_readfirstlane((rec_eo(best + 1) - rec_eo(best)) & 0xFFFFu);  // nodes ending exactly at the cut: the next segment's interface
-            if (m_out == 0 || m_out > 128) { sweepable = false; break; }
-            seg_a = best; seg_c = __builtin_amdgcn_readfirstlane(rec_co(best)); seg_p += best_pass; m_in = m_out;
-        }
-        if (!sweepable) tier = A.n_tiers + 1 + kGenLevels;  // the pre-routed escape list
-    }
     route(tier);
     PROF_MARK(2);
     if (A.prof && ln == 0) {
@@ -1431,6 +1369,7 @@ __device__ __forceinline__ void gen_long(const DevDict& D, const BatchArgs& A, u
     // (the next round's hit records are requested before this round's entries: one round trip per round instead of two; in
     // gen_one, with three rounds per sentence, the same was measured slightly slower)
     uint4 hr_next = tid < H ? hits[tid] : make_uint4(0, 0, 0, 0);
+    const uint32_t row_cells = D.num_right;  // (see gen_one)
     for (uint32_t h = tid; h < H; h += nthreads) {
         const uint4 hr = hr_next;
         if (h + nthreads < H) hr_next = hits[h + nthreads];
@@ -1446,18 +1385,14 @@ __device__ __forceinline__ void gen_long(const DevDict& D, const BatchArgs& A, u
             for (uint32_t q = 0; q < 4; ++q) {
                 if (t0 + q < c) {
                     const uint32_t k = dest + t0 + q;
-                    A.g_cand[base + k] = make_uint4((e[q].left_right >> 16) | ((es0 + t0 + q) << 16), (e[q].cost & 0xFFFFu) | (e[q].left_right << 16),
-                                                    (lex << 30) | e[q].word_id, end);
+                    A.g_cand[base + k] = make_uint4((e[q].left_right & 0xFFFFu) * row_cells, (e[q].cost & 0xFFFFu) | ((es0 + t0 + q) << 16),
+                                                    (lex << 30) | e[q].word_id, end | (e[q].left_right & 0xFFFF0000u));
                 }
             }
         }
     }
     __syncthreads();
     auto eo = [&](uint32_t p) { return p == 0 ? 0u : p == 1 ? 1u : endc[p - 1]; };  // exclusive end-list offset: the cursors hold the inclusive prefix now
-    auto step_passes = [](uint32_t nc, uint32_t np) {
-        const uint32_t lg = np <= 1 ? 0u : 32u - (uint32_t)__builtin_clz(np - 1);
-        return (uint32_t)((((uint64_t)nc << lg) + 63) >> 6);
-    };
     auto get_lens = [&](uint32_t i) -> uint64_t { const uint4 r = pcw[i]; return ((uint64_t)r.w << 32) | r.z; };
     // per-character records (layout and meaning: gen_one).  Per position: e = the furthest end of its candidates (for a space
     // position of ignore_space mode: of the position behind the run); first the maximum per chunk, then its exclusive prefix
@@ -1523,14 +1458,11 @@ __device__ __forceinline__ void gen_long(const DevDict& D, const BatchArgs& A, u
             const uint32_t far = chunk[ch];
             uint32_t m = r.e;  // inclusive prefix maximum over the lanes
             m = wave_inscan_max_dpp(m);
-            uint32_t before = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x138, 0xF, 0xF, false);  // wave_shr:1 (lane 0: 0)
-            before = ln == 0 ? far : (before > far ? before : far);
             if (i < n) {
-                const uint32_t cut = (i == 0 || before <= i) ? 0x40000000u : 0u;
+                const uint32_t upto = m > far ? m : far;  // furthest end of any candidate of the positions <= i
                 const uint64_t third = r.space ? (uint64_t)grp[i] : r.lm;
-                const uint32_t yw = (r.nsl < 0x3FFFu ? r.nsl : 0x3FFFu) | cut | r.space;
+                const uint32_t yw = (r.nsl < 0x3FFFu ? r.nsl : 0x3FFFu) | (eo(upto + 1) << 14) | r.space;
                 pc[i] = make_uint4(r.co_i | (eo(i) << 16), yw, (uint32_t)third, (uint32_t)(third >> 32));
-                ci[i] = yw;  // (a copy for the routing replay below, over the position's CharInfo: only this lane read it, just now)
             }
             uint32_t nsl = r.nsl;
             nsl = wave_sum(nsl);
@@ -1550,54 +1482,11 @@ __device__ __forceinline__ void gen_long(const DevDict& D, const BatchArgs& A, u
         A.s_n[sid] = n; A.s_C[sid] = C; A.s_passes[sid] = passes;
     }
     // smallest tier whose LDS holds the lattice arrays, else the segment tier (see gen_one)
-    const uint64_t fixed = lattice_fixed_bytes(C, passes, 1u);
+    const uint64_t fixed = lattice_fixed_bytes(C, passes, eo(n + 1));
     uint32_t tier = fallback;
     for (uint32_t t = 0; t < A.n_tiers; ++t)
         if (fixed <= A.tier_bytes[t]) { tier = t; break; }
     if (A.seg_tier < A.n_tiers && tier > A.seg_tier) tier = A.seg_tier;
-    if (tier == A.seg_tier && A.seg_tier + 1 < A.n_tiers && fixed > A.tier_bytes[tier]) {
-        // replay lattice_lds' choice of cuts on the finished records (wave 0; see gen_one): unsweepable -> the pre-routed escape list.
-        // What it reads per position sits in LDS -- the record's second word (over ci[]), the candidate offsets (co[]) and the
-        // end-list offsets (endc[]): from global memory every probe was a round trip of the one wave that is left.
-        if (wv != 0) return;  // (the barrier behind the records loop above made the other waves' LDS writes visible)
-        auto rec_y = [&](uint32_t p) -> uint32_t { return ci[p]; };
-        auto rec_co = [&](uint32_t p) -> uint32_t { return co[p]; };  // (co[n] = C)
-        const uint32_t budget = A.tier_bytes[tier];
-        uint32_t seg_a = 0, seg_c = 0, seg_p = 0, m_in = 1;
-        bool sweepable = true;
-        for (uint32_t guard = 0; guard <= n; ++guard) {
-            if (lattice_fixed_bytes(C - seg_c, passes - seg_p, m_in) <= budget) break;
-            uint32_t best = 0, best_pass = 0, run = 0;
-            for (uint32_t w0 = 0; w0 < 256 && seg_a + w0 < n; w0 += 64) {
-                const uint32_t b = seg_a + w0 + ln + 1;
-                uint32_t nsl = 0, cx = 0, cut = 0;
-                if (b <= n) {
-                    nsl = rec_y(b - 1) & 0x3FFFu;
-                    if (nsl == 0x3FFFu) nsl = 1u << 20;
-                    cx = rec_co(b);
-                    cut = b == n ? 1u : (rec_y(b) >> 30) & 1u;
-                }
-                uint32_t tot;
-                const uint32_t incl = wave_exscan(nsl, tot) + nsl + run;
-                const uint32_t est = b == n ? passes - seg_p : incl;
-                const bool fits = b <= n && lattice_fixed_bytes((cx - seg_c) & 0xFFFFu, est, m_in) <= budget;
-                const uint64_t m = __ballot(fits && cut);
-                if (m) {
-                    const uint32_t top = 63u - (uint32_t)__builtin_clzll(m);
-                    best = seg_a + w0 + top + 1;
-                    best_pass = (uint32_t)__builtin_amdgcn_readlane((int)est, (int)top);
-                }
-                run += tot;
-                if (__ballot(fits) == 0) break;
-            }
-            if (!best) { sweepable = false; break; }
-            if (best >= n) break;
-            const uint32_t m_out = __builtin_amdgcn_readfirstlane((eo(best + 1) - eo(best)) & 0xFFFFu);  // nodes ending exactly at the cut
-            if (m_out == 0 || m_out > 128) { sweepable = false; break; }
-            seg_a = best; seg_c = __builtin_amdgcn_readfirstlane(rec_co(best)); seg_p += best_pass; m_in = m_out;
-        }
-        if (!sweepable) tier = A.n_tiers + 1 + kGenLevels;  // the pre-routed escape list
-    }
     route(tier);
 }
 
@@ -1640,31 +1529,6 @@ __global__ void __launch_bounds__(64) VBT_GEN_OCC_ATTR gen_candidates(DevDict D,
     if (batch_rejected(A)) return;  // nothing gets routed: every later kernel finds empty work lists
     gen_one(D, A, A.sid0 + blockIdx.x, lds_bytes);
 }
-// Side stream, next to gen_candidates: finds the sentences that outgrow gen_one's LDS (by gen_one's own test) and files each at the
-// smallest level of gen_long that holds it.  One wavefront per sentence, four sentences per workgroup; a sentence of fewer bytes
-// than gen_one's LDS holds characters cannot outgrow it and costs one compare.
-__global__ void __launch_bounds__(256) route_long(DevDict D, BatchArgs A, uint32_t gen_lds, uint32_t min_bytes) {
-    if (batch_rejected(A)) return;
-    const uint32_t rel = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (rel >= A.n) return;
-    const uint32_t sid = A.sid0 + rel, ln = threadIdx.x & 63u;
-    const uint64_t b0 = A.offsets[sid], nb64 = A.offsets[sid + 1] - b0;
-    if (nb64 < min_bytes || nb64 >= 65535) return;  // (>= 65535 bytes: gen_one files it for the fused kernel)
-    const uint32_t nb = (uint32_t)nb64;
-    const uint8_t* __restrict__ txt = A.text + b0;
-    uint32_t n = 0;
-    for (uint32_t c0 = 0; c0 < nb; c0 += 64) {
-        const uint32_t bi = c0 + ln;
-        const bool lead = bi < nb && (txt[bi] & 0xC0) != 0x80;
-        n += (uint32_t)__popcll(__ballot(lead));
-    }
-    if (n == 0 || carve_gen_one(nullptr, gen_lds, n, D.has_user != 0).ok) return;
-    const uint32_t lv = gen_long_level(A, n, nb, D.has_user != 0), t = A.n_tiers + 1 + lv;
-    if (ln != 0) return;
-    // (the last level -- a whole CU's LDS -- is launched on the launch stream behind the bulk generator: its list is the batch's)
-    if (lv + 1 == (uint32_t)kGenLevels) A.lists[(size_t)t * A.list_stride + A.fb_list_off + atomicAdd(&A.fb_cctrl[2 * t], 1u)] = sid;
-    else A.lists[(size_t)t * A.list_stride + A.list_off + atomicAdd(&A.cctrl[2 * t], 1u)] = sid;
-}
 // ... and persistent workgroups (several wavefronts, a large LDS budget) for the sentences that did not fit: gen_long.
 __global__ void __launch_bounds__(1024) VBT_GEN_OCC_ATTR gen_candidates_large(DevDict D, BatchArgs A, uint32_t lds_bytes, uint32_t level) {
     uint32_t* const next_item = reinterpret_cast<uint32_t*>(g_smem + lds_bytes - 16);  // (the last 16 bytes stay out of gen_long's arena)
@@ -1687,28 +1551,38 @@ __global__ void __launch_bounds__(1024) VBT_GEN_OCC_ATTR gen_candidates_large(De
 // tiers run persistent waves).  Sentences whose lattice does not fit after all go to the fallback list (fused kernel
 // with global scratch).
 //
-// What lives in LDS per (segment of a) sentence: per end-list slot the packed key (8 B) and the right id (2 B); per
-// candidate {slot | word cost, own sequence field | left id} (8 B); the pass records (32 B each).  Nothing per
-// character: the per-character records of gen_candidates are consumed straight from global memory by the reachability
-// sweep, 64 positions at a time, and the end lists were laid out by gen_candidates (every candidate arrives with its slot).
+// What lives in LDS per (segment of a) sentence: per end-list slot an 8-byte record {lo = (0xFFFE - sequence) << 16 | right id,
+// hi = min_cost biased to unsigned order} -- the low word is static and written by the load phase, the cost by the step that
+// inserts the node; per candidate 8 bytes {first cell of its matrix row, byte offset of its slot record | word cost << 16}
+// (the low half of the first word becomes the node's back pointer once its step is done); the pass records (16 B each).
+// Nothing per character: the per-character records of gen_candidates are consumed straight from global memory by the
+// reachability sweep, 64 positions at a time, and the end lists were laid out by gen_candidates (every candidate arrives
+// with its slot).
 //
-// Key of a node: high word = min_cost biased to unsigned order; low word = (0xFFFE - sequence of the best predecessor) << 16
-// | (0xFFFE - own sequence).  The recurrence runs over PASSES: 64 lanes = 64 (candidate c, predecessor j) pairs of one
-// sweep step.  A lane adds the connection cost of its pair (loaded kDepth passes ahead into a register ring) and c's word
-// cost to j's key; the minimum cost of every candidate is found in registers (DPP ladder over its lanes) and only the lanes
-// that hold it fold their key into the candidate's key with an LDS atomic minimum -- (cost, predecessor field, own field):
-// minimum cost, ties to the last inserted predecessor = the `<=` of lattice.rs:141-146.  Steps of more than 64 pairs simply
-// take several passes; the candidate keys start dead and accumulate.  LDS operations of one wave execute in order, so no
-// barrier separates a pass from the next.
+// The recurrence (lattice.rs:103-151) runs over PASSES of <= 16 candidates x <= 16 predecessors of one sweep step (LPass).
+// Lane = (candidate cl = lane >> 2, phase k = lane & 3) walks the predecessors 4 i + k: it reads the predecessor's record
+// (four addresses per instruction, each broadcast to 16 lanes), adds the connection cost of its pair -- gathered VBT_DEPTH passes
+// ahead into a register ring -- and keeps the 64-bit minimum (cost, 0xFFFE - sequence of the predecessor): minimum cost, ties to
+// the last inserted predecessor = the `<=` of lattice.rs:141-146.  At the end of the step two quad-permute levels combine the
+// four phases, phase 0 adds the word cost and stores the node's cost into its slot record and the winner's field as its back
+// pointer.  LDS operations of one wave execute in order, so no barrier separates a pass from the next.
+//
+// A sentence whose lattice does not fit the tier's LDS is swept in segments cut at ANY position b (a multiple of 8 positions
+// behind the segment's start, not behind a space): slots are numbered by end position over the whole sentence, so the nodes
+// of the finished segment that end behind the cut are final and sit in the slot range [eo(b), window end); that range is
+// moved to the front of the slot window and the next segment carries on -- its load phase touches only the slots of its own
+// candidates, the reachability state (three scalars) stays in registers.
 template <bool kSpaceMode, bool kWide>
 __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const BatchArgs& A, uint32_t tier, uint32_t sid) {
     typedef __attribute__((address_space(3))) const uint64_t lds_cu64;
-    typedef __attribute__((address_space(3))) uint64_t lds_u64;
-    typedef __attribute__((address_space(3))) const uint16_t lds_cu16;
+    typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    typedef __attribute__((address_space(3))) uint16_t lds_u16;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     const uint32_t ln = threadIdx.x;
     const uint32_t lds_bytes = A.tier_bytes[tier];
-    const uint32_t NR = D.num_right;
-    constexpr uint32_t kDepth = VBT_DEPTH;  // prefetch distance of the matrix gathers, in passes
+    constexpr uint32_t kD = VBT_DEPTH;  // passes whose gathers are in flight
+    constexpr uint32_t kSh = kWide ? 2u : 1u;  // log2 of the matrix cell size
     // absolute LDS address of the dynamic shared memory (records hold absolute addresses: no base add per access)
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)g_smem;
     auto uniform4 = [](uint4 q) {
@@ -1725,57 +1599,58 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
         const size_t slot0 = sentence_slot(A, uniform64(A.offsets[sid]), sid);
         const size_t node0 = (size_t)A.node_factor * slot0;
         const uint4* __restrict__ pcg = A.g_pc + slot0;   // per-character records (+ the terminator at nT)
-        const uint4* __restrict__ ndg = A.g_cand + node0;  // candidate records in insertion order: .x/.y the sweep half, .z/.w the token half
-        struct TokenHalf { const uint4* p; __device__ __forceinline__ uint2 operator[](uint32_t c) const { const uint4 r = p[c]; return make_uint2(r.z, r.w); } } em{ndg};
+        const uint4* __restrict__ ndg = A.g_cand + node0;  // candidate records in insertion order: {first cell of the matrix row, word cost | slot << 16, word_idx, end_char | right id << 16}
         const uint32_t ET = __builtin_amdgcn_readfirstlane(pcg[nT].z);  // end-list slots of the sentence (BOS included)
         const uint32_t kBosSeq = CT + 1;
-        // A sentence whose lattice does not fit this tier's LDS is swept in segments that end at clean cuts
-        // (positions no candidate spans, flagged by gen_candidates): only the nodes ending exactly at the cut
-        // -- the interface, carried in registers -- connect a segment to the next.  Sequence numbers, slots and back
-        // pointers stay sentence-global; each segment leaves (cost, back pointer) per node in global memory.
-        uint32_t seg_a = 0, seg_c = 0, seg_p = 0, seg_s = 0, fail = 0;
-        constexpr uint32_t kCarry = 2;  // interface nodes per lane: up to 128 nodes may end at a cut
-        uint64_t carry_key[kCarry];
-        uint32_t carry_right[kCarry], m_in = 1;
-#pragma unroll
-        for (uint32_t q = 0; q < kCarry; ++q) { carry_key[q] = kDeadKey; carry_right[q] = 0; }
-        if (ln == 0) carry_key[0] = ((uint64_t)0x80000000u << 32) | (0xFFFEu - kBosSeq);  // BOS: cost 0, no predecessor (right id 0)
+        // where a dead predecessor's sentinel cost could meet a live cost, every predecessor's own field is tested instead (kDeadHi)
+        const bool exact = kWide || nT >= 8000u;
+        uint32_t seg_a = 0, seg_c = 0, seg_p = 0, sb = 0, m_in = 1, fail = 0;
         bool multi = false, done = false;
         uint32_t counted = A.lid_count ? __builtin_amdgcn_readfirstlane(A.s_counted[sid]) : 0u;
         uint32_t prof_S = 0, prof_SL = 0;
         uint32_t budget = lds_bytes;  // what a segment may be estimated at; shrinks when an estimate turns out too low
-        uint32_t cap_b = nT;          // latest admissible segment end (pulled in when too many nodes end at a cut)
+        // reachability state of the position sweep (tokenizer.rs:106-138), carried from segment to segment
+        uint64_t sw_w = 0;
+        uint32_t sw_cur = 1, sw_pend = 0;
+        // the slot records sit at the start of the arena in every segment: the hand-over moves them in place
+        uint2* const e_rec = reinterpret_cast<uint2*>(g_smem);
+        const uint32_t offK = lds0;
+        if (ln == 0) e_rec[0] = make_uint2(((0xFFFEu - kBosSeq) & 0xFFFFu) << 16, 0x80000000u);  // BOS: cost 0, right id 0 (lattice.rs:72-83)
         while (!done) {
-        uint32_t seg_b = nT, seg_pass = passesT - seg_p;
-        if (lattice_fixed_bytes(CT - seg_c, passesT - seg_p, m_in) > budget || cap_b < nT) {
-            // furthest clean cut within 256 positions whose segment fits
-            uint32_t best = 0, best_pass = 0, run = 0;
+        uint32_t seg_b = nT, seg_pass = passesT - seg_p, wend = ET;
+        if (lattice_fixed_bytes(CT - seg_c, passesT - seg_p, ET - sb) > budget) {
+            // furthest admissible cut within 256 positions whose segment fits: any position a multiple of 8 behind the segment's
+            // start (the bit-serial sweep below runs in groups of 8 positions) that does not follow a space (a visited space run and
+            // the word it hands its visit to stay in one segment, tokenizer.rs:113-125)
+            uint32_t best = 0, best_pass = 0, best_wend = 0, run = 0;
             for (uint32_t w0 = 0; w0 < 256 && seg_a + w0 < nT; w0 += 64) {
                 const uint32_t b = seg_a + w0 + ln + 1;  // candidate segment end
-                uint32_t nsl = 0, cx = 0, cut = 0;
+                uint32_t nsl = 0, cx = 0, we = 0, sp = 0;
                 if (b <= nT) {
                     const uint4 rp = pcg[b - 1], rb = pcg[b];
                     nsl = rp.y & 0x3FFFu;
                     if (nsl == 0x3FFFu) nsl = 1u << 20;  // saturated: unknown, treat as too many
-                    cx = rb.x;
-                    cut = b == nT ? 1u : (rb.y >> 30) & 1u;
+                    cx = rb.x & 0xFFFFu;
+                    we = (rp.y >> 14) & 0xFFFFu;  // end of the slot window of a segment that ends here
+                    sp = rp.y >> 31;
                 }
                 uint32_t tot;
                 const uint32_t incl = wave_exscan(nsl, tot) + nsl + run;
                 const uint32_t est = b == nT ? passesT - seg_p : incl;  // (the sentence's bound includes the EOS step)
-                const uint64_t bytes = lattice_fixed_bytes(((cx & 0xFFFFu) - seg_c) & 0xFFFFu, est, m_in);
-                const bool fits = b <= cap_b && bytes <= budget;
-                const uint64_t m = __ballot(fits && cut);
+                const uint32_t wsl = b == nT ? ET : we;
+                const bool fits = b <= nT && lattice_fixed_bytes((cx - seg_c) & 0xFFFFu, est, wsl - sb) <= budget;
+                const uint64_t m = __ballot(fits && (b == nT || (!sp && ((ln + 1) & 7u) == 0)));
                 if (m) {
                     const uint32_t top = 63u - (uint32_t)__builtin_clzll(m);
                     best = seg_a + w0 + top + 1;
                     best_pass = (uint32_t)__builtin_amdgcn_readlane((int)est, (int)top);  // (top is wave-uniform)
+                    best_wend = (uint32_t)__builtin_amdgcn_readlane((int)wsl, (int)top);
                 }
                 run += tot;
                 if (__ballot(fits) == 0) break;
             }
             if (!best) { fail = 30; break; }
-            seg_b = best; seg_pass = best_pass;  // passes of [seg_a, seg_b)
+            seg_b = best; seg_pass = best_pass; wend = best_wend;
             multi = true;
         }
         const bool last_seg = seg_b == nT;
@@ -1783,18 +1658,16 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
         const uint4* __restrict__ pc = pcg + seg_a;
         const uint4 rend = uniform4(pcg[seg_b]);  // record of the segment's end position (the terminator for the last segment)
         const uint32_t C = ((rend.x & 0xFFFFu) - seg_c) & 0xFFFFu;
-        const uint32_t E = m_in + C;  // end-list slots: interface (BOS) + the segment's candidates; slot E is the EOS node's
-        if (E >= 8191u) {  // the candidate records hold a key's byte offset (slot * 8) in 16 bits: a shorter segment, or the next tier / the fused kernel
+        const uint32_t E = wend - sb;  // slots of the window [eo(seg_a), wend); slot E is the EOS node's (last segment)
+        if (E >= 8190u || m_in > E) {  // the candidate records hold a slot's byte offset (slot * 8) in 16 bits: a shorter segment, or the next tier / the fused kernel
             if (budget > lds_bytes / 3) { budget -= lds_bytes / 4; __syncthreads(); continue; }
             fail = 26; break;
         }
-        const uint32_t sb = seg_s;    // sentence-global slot of local slot 0
         const uint4* __restrict__ nd = ndg + seg_c;
 
         Arena ar{g_smem, lds_bytes, 0, true};
-        uint64_t* e_key = ar.take<uint64_t>(E + 1);  // end-major packed keys
-        uint2* cnd = ar.take<uint2>(C + 1);          // per candidate: {byte offset of its key (end-list slot * 8) | (u16) word_cost << 16, (0xFFFE - sequence) | left_id << 16}
-        uint16_t* e_right = ar.take<uint16_t>(E + 1);
+        (void)ar.take<uint2>(E + 2);              // e_rec: the slot records
+        uint2* cnd = ar.take<uint2>(C + 2);       // per candidate: {first cell of its matrix row (low half: its back pointer, once inserted), byte offset of its slot record | word_cost << 16}
         ar.used = (ar.used + 15) & ~15ull;
         LPass* rec = reinterpret_cast<LPass*>(g_smem + ar.used);  // pass records take the rest; afterwards the token path
         const uint32_t sl_cap = ar.ok && lds_bytes > ar.used ? (uint32_t)((lds_bytes - ar.used) / sizeof(LPass)) : 0u;
@@ -1802,38 +1675,36 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
             if (budget > lds_bytes / 3) { budget -= lds_bytes / 4; __syncthreads(); continue; }
             fail = 26; break;
         }
-        const uint32_t offK = lds0 + (uint32_t)(reinterpret_cast<char*>(e_key) - g_smem), offC = lds0 + (uint32_t)(reinterpret_cast<char*>(cnd) - g_smem);
-        const uint32_t offR = lds0 + (uint32_t)(reinterpret_cast<char*>(e_right) - g_smem);
+        const uint32_t offC = lds0 + (uint32_t)(reinterpret_cast<char*>(cnd) - g_smem);
 
         // the per-character records of the first 64 positions are requested now, ahead of the candidate loads: by the time the
         // reachability sweep wants them they have arrived (the sweep of a chunk then prefetches the next chunk's)
         uint4 rc_next = pc[ln < n ? ln : n], rn_next = pc[ln < n ? ln + 1 : n];
-        // ---- load: candidates from global (every record carries its slot); interface; EOS ----
-        for (uint32_t c0 = 0; c0 < C; c0 += 64 * 4) {  // 4 independent 16-byte loads per lane in flight (the sweep half is kept)
-            uint2 r[4];
+        // ---- load: candidates from global (every record carries its slot); EOS ----
+        const uint32_t fld0 = 0xFFFEu - seg_c;  // own field of candidate c of this segment: fld0 - c
+        for (uint32_t c0 = 0; c0 < C; c0 += 64 * 4) {  // 4 independent 16-byte loads per lane in flight
+            uint4 r[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const uint32_t c = c0 + u * 64 + ln;
-                { const uint4 q4 = nd[c < C ? c : 0u]; r[u] = make_uint2(q4.x, q4.y); }
+                r[u] = nd[c < C ? c : 0u];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const uint32_t c = c0 + u * 64 + ln;
                 if (c < C) {
-                    const uint32_t es = (r[u].x >> 16) - sb;
-                    e_right[es] = (uint16_t)r[u].x;
-                    e_key[es] = kDeadKey;  // never inserted until a sweep step reaches its start position
-                    cnd[c] = make_uint2((es << 3) | (r[u].y << 16), ((0xFFFEu - (seg_c + c)) & 0xFFFFu) | (r[u].y & 0xFFFF0000u));
+                    const uint32_t es = (r[u].y >> 16) - sb;
+                    // never inserted until a sweep step reaches its start position (exact mode: the field says so, the step writes it)
+                    const uint32_t fld = exact ? 0xFFFFu : ((fld0 - c) & 0xFFFFu);
+                    e_rec[es] = make_uint2((fld << 16) | (r[u].w >> 16), kDeadHi);
+                    cnd[c] = make_uint2(r[u].x, (es << 3) | (r[u].y << 16));
                 }
             }
         }
-#pragma unroll
-        for (uint32_t q = 0; q < kCarry; ++q)
-            if (q * 64 + ln < m_in) { e_right[q * 64 + ln] = (uint16_t)carry_right[q]; e_key[q * 64 + ln] = carry_key[q]; }
-        if (ln == 0) {
-            // EOS pseudo candidate (insert_eos, lattice.rs:85-101): left_id 0, word cost 0
-            cnd[C] = make_uint2(E << 3, (0xFFFEu - (seg_c + C)) & 0xFFFFu);
-            e_key[E] = kDeadKey;
+        if (last_seg && ln == 0) {
+            // EOS pseudo candidate (insert_eos, lattice.rs:85-101): left_id 0 (matrix row 0), word cost 0
+            cnd[C] = make_uint2(0u, E << 3);
+            e_rec[E] = make_uint2(((fld0 - C) & 0xFFFFu) << 16, kDeadHi);
         }
         PROF_MARK(3);
 
@@ -1844,20 +1715,23 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
         // position p + r and drops the reachability of everything in between (the reference continues from
         // start_word + 1).  The length masks of 64 positions come straight from the per-character records in global
         // memory into one VGPR pair and are read with v_readlane.  The visited positions of a chunk become sweep steps,
-        // every step is cut into passes of 64 padded (candidate, predecessor) pairs, and the pass records are laid out
-        // contiguously (exclusive scan of the pass counts).
+        // every step is cut into passes of <= 16 candidates x <= 16 predecessors, and the pass records are laid out
+        // contiguously (exclusive scan of the pass counts).  The state (w, cur, pend) is carried across segments: a non-final
+        // segment is a multiple of 8 positions long, so the unrolled loop stops exactly at its end.
         uint32_t SL = 0, S = 0, sn_eos = n;
         bool windowed = true, overflow = false;
-        // the q-th of the nsl passes of a step (executed by the lane that owns the step)
-        auto make_pass = [&](uint32_t p_beg, uint32_t np, uint32_t c_beg, uint32_t nc, uint32_t lg, uint32_t q) {
-            return LPass{offR + (p_beg << 1), offK + (p_beg << 3), offC + (c_beg << 3), q << 6, np, nc, lg, 0u};
+        uint64_t nx_w = 0;           // the state behind the segment's last position (committed at the hand-over: a segment may be retried shorter)
+        uint32_t nx_cur = 0, nx_pend = 0;
+        // pass (candidate chunk k, round r) of a step (executed by the lane that owns the step)
+        auto make_pass = [&](uint32_t p_beg, uint32_t np, uint32_t c_beg, uint32_t nc, uint32_t k, uint32_t r, uint32_t rounds, uint32_t first) {
+            const uint32_t np_r = np - kRoundPreds * r < kRoundPreds ? np - kRoundPreds * r : kRoundPreds;
+            const uint32_t nc_r = nc - kRoundCands * k < kRoundCands ? nc - kRoundCands * k : kRoundCands;
+            return LPass{offK + ((p_beg + kRoundPreds * r) << 3), offC + ((c_beg + kRoundCands * k) << 3),
+                         np_r | (nc_r << 8) | (r == 0 ? 0x10000u : 0u) | (r + 1 == rounds ? 0x20000u : 0u) | (first ? 0x40000u : 0u), np | (nc << 16)};
         };
         {
-            uint32_t cur0 = 0;
-#pragma unroll
-            for (uint32_t q = 0; q < kCarry; ++q) cur0 |= __ballot(q * 64 + ln < m_in && (uint32_t)carry_key[q] != 0xFFFFFFFFu) != 0 ? 1u : 0u;
-            uint64_t w = 0;
-            uint32_t cur = cur0, pend = 0, stop = 0;
+            uint64_t w = sw_w;
+            uint32_t cur = sw_cur, pend = sw_pend, stop = 0;
             for (uint32_t chunk = 0; chunk < n && !stop; chunk += 64) {
                 const uint32_t i = chunk + ln;
                 const bool in = i < n;
@@ -1907,16 +1781,20 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
                 }
                 const uint32_t p_beg = (rc.x >> 16) - sb, np = ((rn.x >> 16) - (rc.x >> 16)) & 0xFFFFu;
                 const uint32_t c_beg = ((xa & 0xFFFFu) - seg_c) & 0xFFFFu, nc = ((xb & 0xFFFFu) - (xa & 0xFFFFu)) & 0xFFFFu;
-                const uint32_t lg = np <= 1 ? 0u : 32u - (uint32_t)__builtin_clz(np - 1);
-                const uint32_t nsl = step ? (uint32_t)((((uint64_t)nc << lg) + 63) >> 6) : 0u;
+                const uint32_t rounds = (np + kRoundPreds - 1) / kRoundPreds;
+                const uint32_t nsl = step ? rounds * ((nc + kRoundCands - 1) / kRoundCands) : 0u;
                 uint32_t tot;
                 const uint32_t ex = wave_exscan(nsl, tot);
                 if (SL + tot + 2 > sl_cap) overflow = true;
                 if (!overflow)
-                    for (uint32_t q = 0; q < nsl; ++q) rec[SL + ex + q] = make_pass(p_beg, np, c_beg, nc, lg, q);
+                    for (uint32_t q = 0, k = 0, r = 0; q < nsl; ++q) {
+                        rec[SL + ex + q] = make_pass(p_beg, np, c_beg, nc, k, r, rounds, q == 0);
+                        if (++r == rounds) { r = 0; ++k; }
+                    }
                 SL += tot;
                 S += (uint32_t)__popcll(any);
             }
+            nx_w = w; nx_cur = cur; nx_pend = pend;
         }
         if (!windowed) { fail = 27; break; }  // > 63 skipped spaces in a row: generic pre-pass of the fused kernel
         uint32_t eos_rec = 0;  // first pass record of the EOS step
@@ -1925,192 +1803,255 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
             const uint32_t y0 = __builtin_amdgcn_readfirstlane(pc[sn_eos].x) >> 16;
             const uint32_t y1 = sn_eos < n ? __builtin_amdgcn_readfirstlane(pc[sn_eos + 1].x) >> 16 : ET;
             const uint32_t p_beg = y0 - sb, np = y1 - y0;
-            const uint32_t lg = np <= 1 ? 0u : 32u - (uint32_t)__builtin_clz(np - 1);
-            const uint32_t nsl = ((1u << lg) + 63) >> 6;
+            const uint32_t nsl = (np + kRoundPreds - 1) / kRoundPreds;
             if (SL + nsl + 2 > sl_cap) overflow = true;
             if (!overflow)
-                for (uint32_t q = ln; q < nsl; q += 64) rec[SL + q] = make_pass(p_beg, np, C, 1u, lg, q);
+                for (uint32_t q = ln; q < nsl; q += 64) rec[SL + q] = make_pass(p_beg, np, C, 1u, 0u, q, nsl, q == 0);
             eos_rec = SL;
             SL += nsl;
             ++S;
-        } else if (sn_eos != n) { fail = 31; break; }  // cannot happen: a trailing space run spans every later cut
+        } else if (sn_eos != n) { fail = 31; break; }  // cannot happen: no cut follows a space
         prof_SL += SL; prof_S += S;
         if (overflow || SL >= (1u << 18)) {  // more passes than estimated (gen_candidates bounds them per position)
             if (budget > lds_bytes / 3) { budget -= lds_bytes / 4; __syncthreads(); continue; }
             fail = 29; break;
         }
-        // one empty pass behind the last one (no lane holds a pair): the software pipeline reads ahead up to it
-        if (ln == 0) rec[SL] = LPass{offR, offK, offC, 0u, 0u, 0u, 0u, 0u};  // np = nc = 0: no lane holds a pair
+        // one empty pass behind the last one (no predecessors, no candidates): the software pipeline reads ahead up to it
+        if (ln == 0) rec[SL] = LPass{offK, offC, 0u, 0u};
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         PROF_MARK(4);
 
         // ---- fused gather + cost recurrence (matrix_connector.rs:79-85, lattice.rs:103-151) ----
-        {
-            // The connection matrix through a buffer resource: buffer_load_sshort returns the sign-extended cell in a full
-            // VGPR (no word extraction), addresses are 32-bit offsets (no 64-bit add per lane), and the hardware range check
-            // makes the garbage offsets of lanes without a pair harmless (out of range reads return 0).
-            const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<int16_t*>(D.matrix), 0, (int)D.matrix_bytes, 0x00020000);
-            // lane-wise select by a wave-uniform 64-bit lane mask held in SGPRs: bit ? b : a
-            auto select_mask = [](uint64_t mask, uint32_t a, uint32_t b) {
-                uint32_t out;
-                asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(out) : "v"(a), "v"(b), "s"(mask));
-                return out;
+        auto recurrence = [&](auto exact_c) {
+            constexpr bool kExact = decltype(exact_c)::value;
+            // The connection matrix through a structured buffer resource (stride = one cell, index = left id * num_right + right id:
+            // one SDWA add per gather, no 64-bit address per lane; num_records is set to the byte size, at least the cell count
+            // under either reading of that field: lanes without a pair are masked off, nothing relies on the range check).  The gathers are
+            // inline assembly: four loads per pass whatever its shape (a unit without predecessors loads for one lane), lanes without a
+            // pair masked off through EXEC -- so the number of loads in flight is static and the one s_waitcnt per pass is exact.
+            const uint64_t mb = (uint64_t)reinterpret_cast<uintptr_t>(D.matrix);
+            u32x4 rsrc;
+            rsrc.x = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)mb);
+            rsrc.y = ((uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(mb >> 32)) & 0xFFFFu) | ((1u << kSh) << 16);
+            rsrc.z = (uint32_t)__builtin_amdgcn_readfirstlane(D.matrix_bytes);
+            rsrc.w = 0x00020000u;
+            const uint32_t kk = ln & 3u, k8 = kk << 3, cl8 = (ln >> 2) << 3;
+            const uint32_t fin_rank = kk ? 0xFFFFu : (ln >> 2);  // the lanes that write a candidate's node: phase 0
+            const uint32_t offRec = lds0 + (uint32_t)(reinterpret_cast<char*>(rec) - g_smem);
+            // lanes whose phase is below t (1..4): the predecessors 4 i + k of unit i that exist
+            auto kmask = [](uint32_t t) -> uint64_t {
+                const uint32_t m = t >= 4u ? 0xFFFFFFFFu : ((1u << t) - 1u) * 0x11111111u;
+                return ((uint64_t)m << 32) | m;
             };
-            // Software pipeline, three stages ahead of a pass's execution at iteration p:
-            //   A1 (iteration p - kDepth - 2): read its record from LDS (broadcast);
-            //   A2 (iteration p - kDepth - 1): record -> this lane's pair -> LDS addresses; read the pair's candidate and right id;
-            //   B  (iteration p - kDepth)    : gather the pair's connection cost from the matrix.
-            // Every stage consumes what the previous iteration requested, so an iteration issues all its independent LDS
-            // reads up front (next record, next pair, this pass's predecessor keys) and waits for them once.  Pass p lives in
-            // ring slot p % kRing from A2 on; the loop is unrolled kRing times, so slot indices are static.
-            constexpr uint32_t kRing = kDepth + 2;
-            uint32_t word[kRing], keyaddr[kRing], taddr[kRing], wc[kRing], cy[kRing];  // VGPRs: connection cost in flight (sign-extended), LDS addresses of
-                                                                                       // the predecessor's and the candidate's key, word cost, {own field, left id}
-            uint32_t smlo[kRing], smhi[kRing], slg[kRing];                               // SGPRs (wave-uniform): lane mask, lg
-            auto stage_a1 = [&](uint32_t p, uint4& r0, uint4& r1) {
-                const uint4* r = reinterpret_cast<const uint4*>(&rec[p < SL ? p : SL]);  // passes > SL do not exist: they re-read the empty one
-                r0 = r[0]; r1 = r[1];
+            auto sel = [](uint64_t mask, uint32_t a, uint32_t b) { return __builtin_amdgcn_inverse_ballot_w64(mask) ? b : a; };  // bit ? b : a (v_cndmask on an SGPR mask)
+            uint32_t word[kD][kUnits];      // VGPR ring: connection costs in flight (sign-extended), slot = pass % kD
+            uint32_t paddr[kD], caddr[kD];  // VGPR ring: LDS address of this lane's first predecessor record / of its candidate record
+            uint32_t s_w2[kD];              // SGPR ring: shape word of the pass
+            uint32_t best_hi = 0xFFFFFFFFu, best_lo = 0xFFFFFFFFu;
+            auto read_rec = [&](uint32_t p) -> uint4 {
+                const uint32_t a = offRec + ((p < SL ? p : SL) << 4);  // passes > SL do not exist: they re-read the empty one
+                typedef __attribute__((address_space(3))) const u32x4 lds_cu128;
+                const u32x4 v = *reinterpret_cast<lds_cu128*>(a);
+                return make_uint4(v.x, v.y, v.z, v.w);
             };
-            auto stage_a2 = [&](const uint4& r0, const uint4& r1, uint32_t u, uint2& cd, uint32_t& right) {
-                const uint32_t lg = __builtin_amdgcn_readfirstlane(r1.z);  // (< 32)
-                const uint32_t q = ln + r0.w, cc = q >> lg, j = q & ((1u << lg) - 1u);
-                const uint64_t cdv = *reinterpret_cast<lds_cu64*>(r0.z + (cc << 3));
-                cd = make_uint2((uint32_t)cdv, (uint32_t)(cdv >> 32));
-                right = *reinterpret_cast<lds_cu16*>(r0.x + (j << 1));
-                asm volatile("" : "+v"(right));  // (a 32-bit value from here on: carried as i16 through the pipeline's phi it is masked again at its use)
-                keyaddr[u] = r0.y + (j << 3);
-                const uint64_t mask = __builtin_amdgcn_ballot_w64(j < r1.x) & __builtin_amdgcn_ballot_w64(cc < r1.y);  // the lanes that hold a real pair (np, nc of the step)
-                smlo[u] = (uint32_t)mask; smhi[u] = (uint32_t)(mask >> 32);
-                slg[u] = lg;
-            };
-            auto stage_b = [&](uint32_t u, const uint2& cd, uint32_t right) {
-                // lanes without a pair hold garbage ids: they all load cell 0 (one cache line; scattered garbage offsets cost the
-                // texture addresser 8 % of the kernel, measured)
-                const uint64_t mask = ((uint64_t)smhi[u] << 32) | smlo[u];
-                const uint32_t cell = __umul24(cd.y >> 16, NR) + right;
-#ifdef VBT_NO_GATHER  // ceiling experiment (profiles/): the sweep WITHOUT its matrix gather -- wrong results by design, never shipped
-                word[u] = cell & 0xFFu; (void)mrs; (void)mask;
-                if constexpr (false)
-#endif
-                if constexpr (kWide) word[u] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(mrs, (int)select_mask(mask, 0u, cell << 2), 0, 0);  // i32 cells
-                else word[u] = (uint32_t)(int32_t)(int16_t)__builtin_amdgcn_raw_buffer_load_b16(mrs, (int)select_mask(mask, 0u, cell << 1), 0, 0);
-                taddr[u] = offK + (cd.x & 0xFFFFu);          // the candidate's key (its record holds the byte offset)
-                wc[u] = (uint32_t)((int32_t)cd.x >> 16);     // word cost, sign-extended
-                cy[u] = cd.y;                                // low half: the candidate's own sequence field
-            };
-            uint4 pr0, pr1;      // record of the pass whose A2 is next
-            uint2 p_cd;          // candidate and right id of the pass whose B is next
-            uint32_t p_right;
-            stage_a1(0, pr0, pr1);
+            // issue side of a pass, part 1: its shape, this lane's addresses, and the LDS reads the gathers need
+            struct Iss { uint32_t w2, pa, ca, leftidx, lo[kUnits]; };
+            auto issue_reads = [&](const uint4& pr) {
+                Iss s;
+                s.w2 = (uint32_t)__builtin_amdgcn_readfirstlane(pr.z);
+                s.pa = pr.x + k8;
+                s.ca = pr.y + cl8;
+                s.leftidx = *reinterpret_cast<lds_cu32*>(s.ca);
 #pragma unroll
-            for (uint32_t p = 0; p <= kDepth; ++p) {
-                uint4 n0, n1;
-                uint2 ncd;
-                uint32_t nr;
-                stage_a1(p + 1, n0, n1);
-                stage_a2(pr0, pr1, p, ncd, nr);
-                if (p > 0) stage_b(p - 1, p_cd, p_right);
-                pr0 = n0; pr1 = n1; p_cd = ncd; p_right = nr;
-                // the gathers must be ISSUED in pass order: the wait-count analysis merges this state into the loop header, and a
-                // reordered prologue (the scheduler is free to) makes every iteration's first pass wait for all gathers in flight
+                for (uint32_t i = 0; i < kUnits; ++i) s.lo[i] = *reinterpret_cast<lds_cu32*>(s.pa + 32u * i);  // low half: right id of predecessor 4 i + k (garbage behind the list: masked below)
+                return s;
+            };
+            // part 2: the four gathers into ring slot u
+            auto issue_gathers = [&](uint32_t u, const Iss& s) {
+                const uint32_t np_r = s.w2 & 0xFFu, nc_r = (s.w2 >> 8) & 0xFFu;
+                const uint64_t cm = nc_r >= 16u ? ~0ull : (1ull << (4u * nc_r)) - 1ull;  // lanes of candidates that exist
+                uint64_t m[kUnits];
+                uint32_t vo[kUnits];
+#pragma unroll
+                for (uint32_t i = 0; i < kUnits; ++i) {
+                    m[i] = np_r > 4u * i ? cm & kmask(np_r - 4u * i) : 0ull;
+                    vo[i] = (s.lo[i] & 0xFFFFu) + s.leftidx;
+                }
+#if !VBT_DUMMY_EXEC0
+                // (A/B: a unit without predecessors loads for ONE lane instead of none -- the first lane of unit 0, lane 0 in the empty
+                // pass behind the last one -- at whatever cell its garbage right id names)
+                const uint64_t one = m[0] ? m[0] & (0ull - m[0]) : 1ull;
+#pragma unroll
+                for (uint32_t i = 1; i < kUnits; ++i) if (!m[i]) m[i] = one;
+                if (!m[0]) m[0] = one;
+#endif
+                // A unit without predecessors still issues its load, with EXEC = 0: such a load moves nothing and writes no register,
+                // but it takes its place in vmcnt (tools/calib/exec0_vmcnt.hip: 128 000 of 128 000 trials on gfx950), so the
+                // count in flight stays static.  The empty passes behind the last one are never waited for: the counter is drained
+                // behind the loop, before the ring's registers go back to the compiler -- a load that lands late must not find its
+                // register reused (tools/check_ring_isa.py proves that on the compiled ISA).
+#define VBT_G1(OP, I) "s_mov_b64 exec, %[m" #I "]\n\t" OP " %[d" #I "], %[a" #I "], %[rs], 0 idxen\n\t"
+                if constexpr (kUnits == 4) {
+#define VBT_GATHER(OP)                                                                                                        \
+                    asm volatile(VBT_G1(OP, 0) VBT_G1(OP, 1) VBT_G1(OP, 2) VBT_G1(OP, 3) "s_mov_b64 exec, -1"                   \
+                                 : [d0] "=&v"(word[u][0]), [d1] "=&v"(word[u][1]), [d2] "=&v"(word[u][2]), [d3] "=&v"(word[u][kUnits - 1]) \
+                                 : [a0] "v"(vo[0]), [a1] "v"(vo[1]), [a2] "v"(vo[2]), [a3] "v"(vo[kUnits - 1]), [rs] "s"(rsrc),  \
+                                   [m0] "s"(m[0]), [m1] "s"(m[1]), [m2] "s"(m[2]), [m3] "s"(m[kUnits - 1]))
+                    if constexpr (kWide) VBT_GATHER("buffer_load_dword");
+                    else VBT_GATHER("buffer_load_sshort");
+#undef VBT_GATHER
+                } else {
+#define VBT_GATHER(OP)                                                                                                        \
+                    asm volatile(VBT_G1(OP, 0) VBT_G1(OP, 1) "s_mov_b64 exec, -1"                                               \
+                                 : [d0] "=&v"(word[u][0]), [d1] "=&v"(word[u][1])                                               \
+                                 : [a0] "v"(vo[0]), [a1] "v"(vo[1]), [rs] "s"(rsrc), [m0] "s"(m[0]), [m1] "s"(m[1]))
+                    if constexpr (kWide) VBT_GATHER("buffer_load_dword");
+                    else VBT_GATHER("buffer_load_sshort");
+#undef VBT_GATHER
+                }
+#undef VBT_G1
+                s_w2[u] = s.w2; paddr[u] = s.pa; caddr[u] = s.ca;
+            };
+            uint4 pr = read_rec(0);  // record of the pass whose gathers are issued next
+#pragma unroll
+            for (uint32_t p = 0; p < kD; ++p) {
+                const uint4 nx = read_rec(p + 1);
+                const Iss s = issue_reads(pr);
+                issue_gathers(p, s);
+                pr = nx;
                 __builtin_amdgcn_sched_barrier(0);
             }
-            for (uint32_t s0 = 0; s0 < SL; s0 += kRing) {
+            for (uint32_t s0 = 0; s0 < SL; s0 += kD) {
 #pragma unroll
-                for (uint32_t u = 0; u < kRing; ++u) {
+                for (uint32_t u = 0; u < kD; ++u) {
                     const uint32_t si = s0 + u;
-                    const uint64_t mask = ((uint64_t)smhi[u] << 32) | smlo[u];
-                    // ---- all independent LDS reads of the iteration ----
-                    uint4 n0, n1;
-                    uint2 ncd;
-                    uint32_t nr;
-                    // (first in the LDS queue: it is the only read this pass's own chain waits for -- lgkmcnt(4) -- the others are
-                    // consumed an iteration later)
-                    const uint64_t kb = *reinterpret_cast<lds_cu64*>(keyaddr[u]);  // key of this lane's predecessor
-                    stage_a1(si + kDepth + 2, n0, n1);
-                    stage_a2(pr0, pr1, (u + kRing - 1) % kRing, ncd, nr);            // pass si + kDepth + 1
-                    __builtin_amdgcn_sched_barrier(0);  // (keep these reads together, ahead of their first consumer: one wait for all)
-                    stage_b((u + kDepth) % kRing, p_cd, p_right);                  // pass si + kDepth
-                    pr0 = n0; pr1 = n1; p_cd = ncd; p_right = nr;
+                    const uint32_t w2 = s_w2[u];
+                    const uint32_t np_r = w2 & 0xFFu, nc_r = (w2 >> 8) & 0xFFu;
+                    const uint32_t pa = paddr[u], ca = caddr[u];
+                    // ---- all LDS reads of the iteration: this pass's predecessor records first (the only ones its own chain
+                    // waits for), its candidate record, then what the issue side of pass si + kD needs and the record behind it ----
+                    uint64_t kb[4];
+                    kb[0] = *reinterpret_cast<lds_cu64*>(pa);
+                    if (np_r > 4u) {
+                        kb[1] = *reinterpret_cast<lds_cu64*>(pa + 32u);
+                        if constexpr (kUnits == 4)
+                            if (np_r > 8u) {
+                                kb[2] = *reinterpret_cast<lds_cu64*>(pa + 64u);
+                                kb[3] = *reinterpret_cast<lds_cu64*>(pa + 96u);
+                            }
+                    }
+                    const uint32_t cy = *reinterpret_cast<lds_cu32*>(ca + 4u);  // byte offset of the candidate's slot record | word cost << 16
+                    const Iss is = issue_reads(pr);
+                    const uint4 nrec = read_rec(si + kD + 1);
+                    // ---- the gathers of pass si have landed once at most those of the kD - 1 passes behind it are in flight ----
+                    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(word[u][0]), "+v"(word[u][1]), "+v"(word[u][kUnits - 2]), "+v"(word[u][kUnits - 1]) : "n"(kUnits * (kD - 1)));
                     // ---- pass si ----
-                    const uint32_t khi = (uint32_t)(kb >> 32) + word[u] + wc[u];                 // wrapping i32 adds: connection + word cost (lattice.rs:125,139)
-                    const uint32_t klo = __builtin_amdgcn_perm((uint32_t)kb, cy[u], 0x05040100u);  // predecessor's own field << 16 | the candidate's
-                    const uint64_t live = __ballot((uint32_t)kb != 0xFFFFFFFFu) & mask;
-                    // (a lane without a live pair carries the highest cost: it never wins against a live lane of its group, and the atomic
-                    // below is issued by live lanes only, so its low word is never looked at)
-                    const uint32_t hi = select_mask(live, 0xFFFFFFFFu, khi), lo = klo;
-                    const uint32_t lg = slg[u];
-                    // minimum cost of every candidate in registers; only the lanes that hold it go to LDS, where the atomic on the
-                    // whole key settles ties (rare) towards the last inserted predecessor: no same-address pile-up
-                    const uint32_t m = group_min_u32(hi, lg < 6 ? lg : 6u);  // (more than 64 predecessors: one candidate per pass)
-                    // (only lanes with a live pair: a lane without one holds whatever its garbage candidate address read, and a
-                    // misaligned 64-bit LDS atomic is a memory violation)
-                    if (__builtin_amdgcn_inverse_ballot_w64(__builtin_amdgcn_ballot_w64(hi == m) & live))
-                        __hip_atomic_fetch_min(reinterpret_cast<lds_u64*>(taddr[u]), ((uint64_t)hi << 32) | lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (np_r) {
+                        // (the minimum of a lane's phase starts at the maximum: reset when its step is done, below)
+                        auto unit = [&](uint32_t i) {
+                            const uint32_t nk_hi = (uint32_t)(kb[i] >> 32) + word[u][i < kUnits ? i : 0];  // wrapping i32 add of the connection cost (lattice.rs:139)
+                            const uint32_t nk_lo = (uint32_t)kb[i];                        // the predecessor's own field | right id
+                            uint64_t vm = kmask(np_r - 4u * i);
+                            if constexpr (kExact) vm &= __builtin_amdgcn_ballot_w64(nk_lo < 0xFFFF0000u);  // never inserted: field 0xFFFF
+                            const uint64_t nk = ((uint64_t)nk_hi << 32) | nk_lo, bk = ((uint64_t)best_hi << 32) | best_lo;
+                            const uint64_t lt = __builtin_amdgcn_ballot_w64(nk < bk) & vm;
+                            best_hi = sel(lt, best_hi, nk_hi);
+                            best_lo = sel(lt, best_lo, nk_lo);
+                        };
+                        unit(0);
+                        if (np_r > 4u) {
+                            unit(1);
+                            if constexpr (kUnits == 4)
+                                if (np_r > 8u) {
+                                    unit(2);
+                                    if (np_r > 12u) unit(3);
+                                }
+                        }
+                        if (w2 & 0x20000u) {
+                            // the four phases of a candidate: minimum cost, then among the lanes that hold it the smallest field
+                            // (= the last inserted predecessor), by two quad-permute levels each
+                            const uint32_t m_hi = group_min_u32<2>(best_hi);
+                            const uint32_t m_lo = group_min_u32<2>(best_hi == m_hi ? best_lo : 0xFFFFFFFFu);
+                            best_hi = 0xFFFFFFFFu; best_lo = 0xFFFFFFFFu;
+                            if (fin_rank < nc_r) {
+                                const uint32_t sa = offK + (cy & 0xFFFFu);
+                                *reinterpret_cast<lds_u32*>(sa + 4u) = m_hi + (uint32_t)((int32_t)cy >> 16);  // + word cost (lattice.rs:125)
+                                if constexpr (kExact) *reinterpret_cast<lds_u16*>(sa + 2u) = (uint16_t)(fld0 - ((ca - offC) >> 3));  // inserted: its own field
+                                *reinterpret_cast<lds_u16*>(ca) = (uint16_t)(m_lo >> 16);  // back pointer: the winner's field
+                            }
+                        }
+                    }
                     // LDS operations of one wave execute in order: a compiler-level fence is all the next pass needs
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
+                    // ---- gathers of pass si + kD into the ring slot this pass has just left ----
+                    issue_gathers(u, is);
+                    pr = nrec;
                 }
             }
-        }
+            // the last gathers in flight are those of the empty passes (EXEC = 0: they retire at once): done before the ring's registers
+            // go back to the compiler
+#pragma unroll
+            for (uint32_t u = 0; u < kD; ++u)
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(word[u][0]), "+v"(word[u][1]), "+v"(word[u][kUnits - 2]), "+v"(word[u][kUnits - 1]));
+        };
+        if (exact) recurrence(std::true_type{}); else recurrence(std::false_type{});
         PROF_MARK(6);
 
-        // back pointer of a node = sequence of its best predecessor
-        auto key_pred = [](uint64_t k) { return 0xFFFEu - (((uint32_t)k) >> 16); };
+        // a node of this segment: its cost word and its back pointer (sequence of its best predecessor)
+        auto node_cost = [&](uint32_t c) { return e_rec[(cnd[c].y & 0xFFFFu) >> 3].y ^ 0x80000000u; };
+        auto node_pred = [&](uint32_t c) { return 0xFFFEu - (cnd[c].x & 0xFFFFu); };
         if (multi) {
             // leave (total cost, back pointer) of every node of the segment in the sentence's (dead) hit-staging region
             uint2* __restrict__ nb = reinterpret_cast<uint2*>(A.g_hits + node0 + seg_c);
-            for (uint32_t c = ln; c < C; c += 64) {
-                const uint64_t k = e_key[(cnd[c].x & 0xFFFFu) >> 3];
-                nb[2 * c] = make_uint2(key_cost(k), key_pred(k));
-            }
-        }
-        uint32_t i0 = 0, m_out = 0;
-        if (!last_seg) {
-            // the interface: nodes ending exactly at the cut
-            i0 = (rend.x >> 16) - sb;
-            m_out = E - i0;
-            if (m_out > 64 * kCarry || m_out == 0) {  // more nodes end here than the carry holds: cut earlier
-                if (seg_b > seg_a + 1 && m_out) { cap_b = seg_b - 1; __syncthreads(); continue; }
-                fail = 32; break;
-            }
+            for (uint32_t c = ln; c < C; c += 64) nb[2 * c] = make_uint2(node_cost(c), node_pred(c));
         }
         if (A.lid_count) {
             // Lattice::add_connid_counts (lattice.rs:170-183): for every inserted node r and every node l in
             // ends[r.start_node]: lid_count[r.left_id] += 1, rid_count[l.right_id] += 1; then the same for EOS
             // (left_id 0) against ends[len_char].  Only inserted ("live") nodes exist in the reference's lists.
-            // A segment is counted once it is final (its interface fits the carry); s_counted[sid] remembers how far
-            // the sentence has been counted, so a retry in an escape tier or in the fused kernel never counts a step twice.
+            // s_counted[sid] remembers how far the sentence has been counted, so a retry in an escape tier or in the
+            // fused kernel never counts a step twice.
             const uint32_t c_skip = counted >= nT ? CT : __builtin_amdgcn_readfirstlane(pcg[counted].x) & 0xFFFFu;  // candidates are in start order
             for (uint32_t k = 0; k < SL; ++k) {
-                const uint4 r0 = uniform4(*reinterpret_cast<const uint4*>(&rec[k])), r1 = uniform4(*(reinterpret_cast<const uint4*>(&rec[k]) + 1));
-                if (r0.w) continue;  // one record per step: its first pass
-                const uint32_t c_beg = (r0.z - offC) >> 3, nc = r1.y, np = r1.x;
-                const bool eos_step = last_seg && k == eos_rec;
+                const uint4 r = uniform4(*reinterpret_cast<const uint4*>(&rec[k]));
+                if (!(r.z & 0x40000u)) continue;  // one record per step: its first pass
+                const uint32_t c_beg = (r.y - offC) >> 3, nc = r.w >> 16, np = r.w & 0xFFFFu;
+                const bool eos_step = last_seg && k >= eos_rec;
                 if (eos_step ? counted > nT : seg_c + c_beg < c_skip) continue;
-                uint32_t p_beg = (r0.y - offK) >> 3, p_end = p_beg + np;
+                uint32_t p_beg = (r.x - offK) >> 3, p_end = p_beg + np;
                 if (eos_step) { p_beg = (rend.x >> 16) - sb; p_end = E; }  // EOS pairs with ends[len_char]
                 uint32_t live = 0;
                 for (uint32_t j0 = p_beg; j0 < p_end; j0 += 64) {
                     const uint32_t j = j0 + ln;
-                    const bool alive = j < p_end && (uint32_t)e_key[j] != 0xFFFFFFFFu;
+                    const uint2 er = j < p_end ? e_rec[j] : make_uint2(0xFFFF0000u, kDeadHi);
+                    const bool alive = j < p_end && (exact ? (er.x >> 16) != 0xFFFFu : er.y != kDeadHi);
                     live += (uint32_t)__popcll(__ballot(alive));
-                    if (alive) atomicAdd(&A.rid_count[e_right[j]], (unsigned long long)nc);
+                    if (alive) atomicAdd(&A.rid_count[er.x & 0xFFFFu], (unsigned long long)nc);
                 }
-                for (uint32_t c = c_beg + ln; c < c_beg + nc; c += 64) atomicAdd(&A.lid_count[cnd[c].y >> 16], (unsigned long long)live);
+                if (eos_step) { if (ln == 0) atomicAdd(&A.lid_count[0], (unsigned long long)live); }
+                else for (uint32_t c = c_beg + ln; c < c_beg + nc; c += 64) atomicAdd(&A.lid_count[nd[c].x / D.num_right], (unsigned long long)live);
             }
             const uint32_t upto = last_seg ? nT + 1 : seg_b;
             if (upto > counted) { counted = upto; if (ln == 0) A.s_counted[sid] = counted; }
         }
         if (!last_seg) {
-#pragma unroll
-            for (uint32_t q = 0; q < kCarry; ++q) {
-                carry_key[q] = q * 64 + ln < m_out ? e_key[i0 + q * 64 + ln] : kDeadKey;
-                carry_right[q] = q * 64 + ln < m_out ? (uint32_t)e_right[i0 + q * 64 + ln] : 0u;
+            // hand-over: the slots behind the cut -- final nodes that start in front of it (and the still untouched slots of later
+            // candidates among them) -- move to the front of the window, 64 records at a time, ascending (the destination of a
+            // chunk never reaches the source of a later one)
+            const uint32_t i0 = (rend.x >> 16) - sb, m_out = E - i0;
+            for (uint32_t k0 = 0; k0 < m_out; k0 += 64) {
+                const uint32_t k = k0 + ln;
+                const uint2 r = e_rec[i0 + (k < m_out ? k : 0u)];
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (k < m_out) e_rec[k] = r;
             }
             m_in = m_out;
-            seg_a = seg_b; seg_c += C; seg_p += seg_pass; seg_s = rend.x >> 16; cap_b = nT;
+            sw_w = nx_w; sw_cur = nx_cur; sw_pend = nx_pend;
+            sb = rend.x >> 16; seg_a = seg_b; seg_c += C; seg_p += seg_pass;
+            budget = lds_bytes;
             __syncthreads();
             continue;
         }
@@ -2131,48 +2072,30 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
             return prev_end;
         };
         if (!multi) {
-            uint16_t* path = reinterpret_cast<uint16_t*>(rec);  // the pass records are dead now; tokens <= steps
-            // The walk along the back pointers is serial (lane 0, one LDS round trip per dependent read).  Where the dead record
-            // area also holds one back pointer per candidate, all lanes resolve key -> predecessor first (candidate -> its slot ->
-            // the slot's key: two reads, 64 candidates at a time), and the walk reads one u16 per token instead of two u64.
-            uint16_t* bp = path + ((n + 2u) & ~1u);
-            const bool flat = (size_t)(reinterpret_cast<char*>(bp + C + 1) - g_smem) <= lds_bytes;
-            if (flat) {
-                for (uint32_t c0 = 0; c0 < C; c0 += 64 * 4) {
-                    uint32_t sl[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) { const uint32_t c = c0 + u * 64 + ln; sl[u] = (cnd[c < C ? c : 0u].x & 0xFFFFu) >> 3; }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) { const uint32_t c = c0 + u * 64 + ln; if (c < C) bp[c] = (uint16_t)key_pred(e_key[sl[u]]); }
-                }
-                __syncthreads();
-            }
+            uint16_t* path = reinterpret_cast<uint16_t*>(rec);  // the pass records are dead now; tokens <= steps that have a pass
+            // the walk along the back pointers is serial: lane 0, one LDS round trip per token
             if (ln == 0) {
-                uint32_t seq = key_pred(e_key[E]);
-                if (flat) {
-                    while (seq != kBosSeq && T < n) { path[T++] = (uint16_t)seq; seq = bp[seq]; }
-                } else {
-                    while (seq != kBosSeq && T < n) { path[T++] = (uint16_t)seq; seq = key_pred(e_key[(cnd[seq].x & 0xFFFFu) >> 3]); }
-                }
+                uint32_t seq = node_pred(C);
+                while (seq != kBosSeq && T < n) { path[T++] = (uint16_t)seq; seq = node_pred(seq); }
             }
             T = (uint32_t)__builtin_amdgcn_readfirstlane((int)T);
             __syncthreads();
             if (ln == 0) { A.tok_cnt[sid] = T; if (T) atomicAdd(&A.tile_sums[sid / kScanTile], T); }
             for (uint32_t t = ln; t < T; t += 64) {
                 const uint32_t c = path[T - 1 - t];
-                const uint2 r = em[c];
-                const uint32_t prev_end = t ? em[path[T - t]].y : 0u;
-                const uint32_t stp = start_of(prev_end), en = r.y;
+                const uint4 r = ndg[c];
+                const uint32_t prev_end = t ? ndg[path[T - t]].w & 0xFFFFu : 0u;
+                const uint32_t stp = start_of(prev_end), en = r.w & 0xFFFFu;
                 vbt_token_rec o;
                 o.start_char = stp; o.end_char = en;
                 o.start_byte = c2b[stp]; o.end_byte = c2b[en];
-                o.word_idx = r.x;
-                o.total_cost = (int32_t)key_cost(e_key[(cnd[c].x & 0xFFFFu) >> 3]);
+                o.word_idx = r.z;
+                o.total_cost = (int32_t)node_cost(c);
                 A.tok_stage[slot0 + t] = o;  // the sentence's own staging region: no allocation atomic (compact_tokens packs them)
             }
         } else {
             // segmented sentence: pull all back pointers into LDS (the arena is free now), walk, emit from global
-            const uint32_t back_eos = key_pred(e_key[E]);
+            const uint32_t back_eos = node_pred(C);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's own dumps: stores complete
             __syncthreads();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -2213,13 +2136,13 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
             if (ln == 0) { A.tok_cnt[sid] = T; if (T) atomicAdd(&A.tile_sums[sid / kScanTile], T); }
             for (uint32_t t = ln; t < T; t += 64) {
                 const uint32_t c = path[T - 1 - t];
-                const uint2 r = em[c];
-                const uint32_t prev_end = t ? em[path[T - t]].y : 0u;
-                const uint32_t stp = start_of(prev_end), en = r.y;
+                const uint4 r = ndg[c];
+                const uint32_t prev_end = t ? ndg[path[T - t]].w & 0xFFFFu : 0u;
+                const uint32_t stp = start_of(prev_end), en = r.w & 0xFFFFu;
                 vbt_token_rec o;
                 o.start_char = stp; o.end_char = en;
                 o.start_byte = c2b[stp]; o.end_byte = c2b[en];
-                o.word_idx = r.x;
+                o.word_idx = r.z;
                 o.total_cost = (int32_t)nbg[2 * c].x;
                 A.tok_stage[slot0 + t] = o;
             }
@@ -2238,11 +2161,11 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
 }
 
 template <bool kSpaceMode, bool kWide>
-__global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, BatchArgs A, uint32_t tier, uint32_t list_id, uint32_t persistent) {
+__global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, BatchArgs A, uint32_t tier, uint32_t persistent) {
     const uint32_t ln = threadIdx.x;
     // long sentences are the critical path of a batch: let their waves win issue arbitration
     if (A.tier_prio && (A.seg_tier < A.n_tiers ? tier >= A.seg_tier : tier + A.tier_prio >= A.n_tiers)) __builtin_amdgcn_s_setprio(2);
-    const int src = (int)list_id;  // the tier's own list, or the pre-routed escape list
+    const int src = (int)tier;  // the tier's own list
     const uint32_t* list = A.lists + (size_t)src * A.list_stride + A.list_off;
     const uint32_t count = A.cctrl[2 * src];
     uint32_t* cursor = &A.cctrl[2 * src + 1];
@@ -2266,7 +2189,6 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
             // Could not be swept here (no admissible cut, estimates too low, ...): the next escape tier -- more LDS,
             // launched behind this one -- retries; after the last one the fused kernel with the global-memory
             // lattice redoes the sentence.
-            // (also from the pre-routed launch: the launch stream waits for it before it starts the escape tiers behind the segment tier)
             const bool escape = tier >= A.seg_tier && tier + 1 < A.n_tiers && fail != 27;
             if (ln == 0 && !escape) atomicAdd(&A.ctrl[fail < 32 ? fail : 28], 1u);
             if (escape) list_push(A, tier + 1, sid); else list_push_fb(A, sid);
@@ -2718,7 +2640,7 @@ Workspace::Workspace(const Tokenizer& t, uint64_t max_s, uint64_t max_b) : tok(t
     d_tok_off = static_cast<uint32_t*>(alloc(ns * 4));
     d_tok_cnt = static_cast<uint32_t*>(alloc(ns * 4));
     d_over = static_cast<uint32_t*>(alloc(2 * ns * 4 * (tiers.size() + kListsBehindTiers)));  // two regions per list: the launch stream's and (VBT_EARLY_LONG=1) the long sentences' side streams'
-    d_ctrl = static_cast<uint32_t*>(alloc((kCtrlWords + (size_t)kCtrlBlocks * kBlockCtrlWords) * 4));  // one block: cleared by one memset per batch
+    d_ctrl = static_cast<uint32_t*>(alloc((kCtrlWords + (size_t)kBlockCtrlWords) * 4));  // one block: cleared by one memset per batch
     d_cctrl = d_ctrl + kCtrlWords;
     if (const char* e = std::getenv("VBT_TIER_WAVES")) {  // experiment: fixed lattice grid per tier
         std::string spec = e;
@@ -2759,7 +2681,6 @@ Workspace::Workspace(const Tokenizer& t, uint64_t max_s, uint64_t max_b) : tok(t
             tier_events.push_back(e);
         }
         HIP_CHECK(hipEventCreateWithFlags(reinterpret_cast<hipEvent_t*>(&ev_fork2), hipEventDisableTiming));
-        for (auto& e : long_events) HIP_CHECK(hipEventCreateWithFlags(reinterpret_cast<hipEvent_t*>(&e), hipEventDisableTiming));
 
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gen_candidates_large), hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
         if (tiers.back() > 65536)  // a single workgroup may use the CU's whole 160 KiB
@@ -2784,7 +2705,6 @@ void Workspace::release() {
     tier_events.clear();
     if (ev_fork2) (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(ev_fork2));
     ev_fork2 = nullptr;
-    for (auto& e : long_events) if (e) { (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(e)); e = nullptr; }
     for (void* st : streams) (void)hipStreamDestroy(reinterpret_cast<hipStream_t>(st));
     streams.clear();
 }
@@ -2797,10 +2717,10 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
     HIP_CHECK(hipSetDevice(tok.device()));
     last_n = n;
     last_stream = stream_;
-    HIP_CHECK(hipMemsetAsync(d_ctrl, 0, (kCtrlWords + (size_t)kCtrlBlocks * kBlockCtrlWords) * 4, stream));  // ctrl + cctrl
+    HIP_CHECK(hipMemsetAsync(d_ctrl, 0, (kCtrlWords + (size_t)kBlockCtrlWords) * 4, stream));  // ctrl + cctrl
     if (n == 0) return;
     const size_t T = tiers.size();
-    const size_t half = std::max<uint64_t>(max_sentences, 1), stride = 2 * half;
+    const size_t stride = 2 * std::max<uint64_t>(max_sentences, 1);
     BatchArgs a = pipe;
     a.text = d_text; a.offsets = d_offsets; a.n = (uint32_t)n;
     a.tokens = d_tokens; a.tok_stage = d_tok_stage; a.tok_cap = (uint32_t)std::max<uint64_t>(max_bytes, 1);
@@ -2817,7 +2737,6 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
                 if (tiers[t] >= seg_bytes) { a.seg_tier = (uint32_t)t; break; }
     }
     a.sid0 = 0; a.cctrl = d_cctrl; a.list_off = 0;
-    a.fb_cctrl = d_cctrl; a.fb_list_off = 0; a.early_long = 0;
     a.lid_count = count_connids ? d_connid : nullptr;
     a.rid_count = count_connids ? d_connid + tok.dict().num_left : nullptr;
     a.s_counted = count_connids ? d_counted : nullptr;
@@ -2864,88 +2783,33 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
         a.sid0 = 0; a.n = cn; a.cctrl = d_cctrl; a.list_off = 0; a.direct_push = 0;
         for (int q = 0; q < kGenLevels; ++q) a.gen_level_bytes[q] = gen_level_lds[q] - 16;
         const uint32_t persist = env_u32("VBT_LAT_PERSIST", 0);
-        auto launch_lattice = [&](const BatchArgs& a_, dim3 grid_, uint32_t lds_, hipStream_t st_, uint32_t tier_, uint32_t list_, uint32_t persistent_) {
+        auto launch_lattice = [&](const BatchArgs& a_, dim3 grid_, uint32_t lds_, hipStream_t st_, uint32_t tier_, uint32_t persistent_) {
             auto k = D.space_cateset ? (D.matrix_wide ? lattice_lds<true, true> : lattice_lds<true, false>)
                                      : (D.matrix_wide ? lattice_lds<false, true> : lattice_lds<false, false>);
-            hipLaunchKernelGGL(k, grid_, dim3(64), lds_, st_, D, a_, tier_, list_, persistent_);
+            hipLaunchKernelGGL(k, grid_, dim3(64), lds_, st_, D, a_, tier_, persistent_);
         };
-        auto launch_gen_levels = [&](const BatchArgs& a_, hipStream_t st_, uint32_t first, uint32_t last, bool longest_first) {
-            // Workgroups of 4 wavefronts (16 at the last level, which has a CU to itself), as many as a CU's LDS and its 32 wave slots admit.
-            for (uint32_t q = first; q <= last; ++q) {
-                const uint32_t lv = longest_first ? last + first - q : q;
-                const uint32_t lds = gen_level_lds[lv - 1];
-                const uint32_t nw = lds > 65536 ? 16u : std::max<uint32_t>(1, std::min<uint32_t>(16, lv == 1 ? env_u32("VBT_GEN_WAVES1", env_u32("VBT_GEN_WAVES", 4)) : env_u32("VBT_GEN_WAVES", 4)));
-                const uint32_t per_cu = std::max<uint32_t>(1, std::min<uint32_t>(32 / nw, 163840 / lds));
-                hipLaunchKernelGGL(gen_candidates_large, dim3(std::max<uint32_t>(1, std::min<uint32_t>(cn, per_cu * 256))), dim3(nw * 64), lds, st_, D, a_, lds, lv);
-            }
-        };
-        // Long sentences first (VBT_EARLY_LONG=1; off by default: measured slower, profiles/r03_long_first_experiment.md).  The
-        // sentences that outgrow the bulk generator's LDS are the longest of the batch, and a long sentence is one serial chain
-        // (~0.6-1.1 us per character in the sweep): the critical path of a mixed-length batch.  In this plan two side streams take them
-        // from the start, next to gen_candidates: route_long finds them (gen_one's own test; gen_one then leaves them alone), gen_long
-        // generates them level by level, longest first, and their sweeps start behind it -- the pre-routed escape sweep on the first
-        // side stream, the segment sweep (and what it escalates) on the second.  These launches keep their lists in the second
-        // counter block / list region: the launch stream's kernels read theirs meanwhile.  What it runs into: a workgroup that needs
-        // 16-48 KiB of LDS and four wave slots finds no room on a CU while a launch of 100 k one-wave workgroups is being dispatched
-        // (stream priorities do not change that), so the side streams' kernels mostly wait for the bulk launches to drain, and the
-        // bulk sweep loses LDS to the resident long sweeps when it can least afford it.
-        const bool main_seg = env_u32("VBT_MAIN_SEG", 1) != 0 && a.seg_tier < T;
-        const bool early = env_u32("VBT_EARLY_LONG", 0) != 0 && main_seg && a.seg_tier + 2 < T;
-        BatchArgs al = a;
-        if (early) {
-            a.early_long = 1;
-            al.early_long = 1;
-            al.cctrl = d_cctrl + kBlockCtrlWords; al.list_off = (uint32_t)half;
-            // (the side streams are the two tier streams this plan leaves idle: a process has four hardware pipes for its queues, and
-            // streams beyond that share them -- measured: with two more streams every small kernel and every event wait of the step
-            // took 40-100 us instead of 5-12)
-            hipStream_t l0 = reinterpret_cast<hipStream_t>(streams[a.seg_tier]), l1 = reinterpret_cast<hipStream_t>(streams[T - 1]);
-            auto E = [&](int i) { return reinterpret_cast<hipEvent_t>(long_events[i]); };
-            // route_long runs on the launch stream: next to gen_candidates it would queue behind 100 k workgroups for its wave slots
-            hipLaunchKernelGGL(route_long, dim3((cn + 3) / 4), dim3(256), 0, stream, D, al, gen_lds, (gen_lds - 16) / 28);
-            HIP_CHECK(hipEventRecord(E(0), stream));
-            HIP_CHECK(hipStreamWaitEvent(l0, E(0), 0));
-            launch_gen_levels(al, l0, 1, kGenLevels - 1, true);
-            HIP_CHECK(hipEventRecord(E(1), l0));
-            const size_t sg = a.seg_tier, x = sg + 1;
-            launch_lattice(al, dim3(waves_for(tiers[x], std::min<uint32_t>(cn, 4096))), tiers[x], l0, (uint32_t)x, (uint32_t)(T + 1 + kGenLevels), 1u);
-            HIP_CHECK(hipEventRecord(E(2), l0));
-            HIP_CHECK(hipStreamWaitEvent(l1, E(1), 0));
-            launch_lattice(al, dim3(waves_for(tiers[sg], cn)), tiers[sg], l1, (uint32_t)sg, (uint32_t)sg, 1u);
-            HIP_CHECK(hipStreamWaitEvent(l1, E(2), 0));  // the escape tiers take what failed in either sweep
-            for (size_t y = x; y < T; ++y)
-                launch_lattice(al, dim3(waves_for(tiers[y], std::min<uint32_t>(cn, 4096))), tiers[y], l1, (uint32_t)y, (uint32_t)y, 1u);
-            HIP_CHECK(hipEventRecord(E(3), l1));
-        }
         // (s_tier[] = 0xFF, "nothing routed yet", is written by validate_batch: one launch less per batch)
         hipLaunchKernelGGL(gen_candidates, dim3(cn), dim3(64), gen_lds, stream, D, a, gen_lds);
         hipLaunchKernelGGL(build_lists, dim3(lb), dim3(1024), 0, stream, a, -1);
-        // Without the side streams gen_one files every sentence that outgrows it at the smallest level of gen_long that holds it, and
-        // the levels run one after the other on the launch stream.
-        // (with them only the last level stays here: its workgroups need a CU to themselves, and an empty launch of it would hold up the
-        // side stream until a CU has drained)
-        launch_gen_levels(a, stream, early ? kGenLevels : 1, kGenLevels, false);
-        rec(1);
-        // (forking the small tiers before the straggler generators was measured: 3.33 vs 3.2 ms, the stragglers then
-        // compete with the sweep and the segment tier starts later)
-        HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_fork2), stream));
-        // One lattice_lds launch per LDS tier up to the segment tier (default: a single 10 KiB tier).  The tiers above it are escape
-        // tiers: nothing is routed to them up front, they take what the tier before them could not sweep, so they are
-        // launched on the segment tier's stream, behind it.
-        const size_t n_conc = a.seg_tier < T ? a.seg_tier + 1 : T;
-        bool dense_launched = false;
-        if (a.seg_tier + 1 < T) {
-            // what gen_candidates found too dense to sweep in segments of the segment tier: the first escape tier's LDS, its own
-            // stream, next to the others (a 48 KiB workgroup finds room on a busy CU; a whole-CU one would wait for a CU to drain)
-            const size_t x = a.seg_tier + 1;
-            hipStream_t side = reinterpret_cast<hipStream_t>(streams[x]);
-            HIP_CHECK(hipStreamWaitEvent(side, reinterpret_cast<hipEvent_t>(ev_fork2), 0));
-            launch_lattice(a, dim3(waves_for(tiers[x], std::min<uint32_t>(cn, 4096))), tiers[x], side, (uint32_t)x, (uint32_t)(T + 1 + kGenLevels), 1u);
-            HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(tier_events[x]), side));
-            dense_launched = true;
+        // gen_one files every sentence that outgrows it at the smallest level of gen_long that holds it; the levels run one after
+        // the other on the launch stream: workgroups of 4 wavefronts (16 at the last level, which has a CU to itself), as many as
+        // a CU's LDS and its 32 wave slots admit.  (Next to the bulk generator, on side streams, their 16-160 KiB workgroups do not
+        // get onto a CU before the bulk launch has been dispatched: profiles/r03_long_first_experiment.md.)
+        for (uint32_t lv = 1; lv <= (uint32_t)kGenLevels; ++lv) {
+            const uint32_t lds = gen_level_lds[lv - 1];
+            const uint32_t nw = lds > 65536 ? 16u : std::max<uint32_t>(1, std::min<uint32_t>(16, lv == 1 ? env_u32("VBT_GEN_WAVES1", env_u32("VBT_GEN_WAVES", 4)) : env_u32("VBT_GEN_WAVES", 4)));
+            const uint32_t per_cu = std::max<uint32_t>(1, std::min<uint32_t>(32 / nw, 163840 / lds));
+            hipLaunchKernelGGL(gen_candidates_large, dim3(std::max<uint32_t>(1, std::min<uint32_t>(cn, per_cu * 256))), dim3(nw * 64), lds, stream, D, a, lds, lv);
         }
-        // The segment tier (the critical path: the longest sentences, then the escape tier behind it) is launched on the launch
+        rec(1);
+        HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_fork2), stream));
+        // One lattice_lds launch per LDS tier up to the segment tier (default: a single tier).  The tiers above it are escape
+        // tiers: nothing is routed to them up front, they take what the tier before them could not sweep (a window of end lists
+        // wider than its LDS), so they are launched on the segment tier's stream, behind it.
+        const size_t n_conc = a.seg_tier < T ? a.seg_tier + 1 : T;
+        // The segment tier (the critical path: the longest sentences, then the escape tiers behind it) is launched on the launch
         // stream itself -- no event round trip before it starts nor before what follows it (VBT_MAIN_SEG=0: every tier on a side stream).
+        const bool main_seg = env_u32("VBT_MAIN_SEG", 1) != 0 && a.seg_tier < T;
         for (size_t i = 0; i < n_conc; ++i) {
             const size_t t = n_conc - 1 - i;
             const bool on_main = main_seg && t == a.seg_tier;
@@ -2954,19 +2818,14 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
             // one workgroup per list entry: the lists are built on the device, so the grid covers the whole batch and the
             // workgroups beyond a list's length exit at once (VBT_LAT_PERSIST=1: persistent waves with a work cursor)
             const uint32_t grid = !persist ? cn : (t < tier_waves.size() && tier_waves[t]) ? std::min<uint32_t>(tier_waves[t], waves_for(tiers[t], cn)) : waves_for(tiers[t], cn);
-            launch_lattice(a, dim3(grid), tiers[t], side, (uint32_t)t, (uint32_t)t, persist);
-            if (t == a.seg_tier) {
-                // the escape tiers take what failed here AND in the pre-routed launch: behind both
-                if (dense_launched) HIP_CHECK(hipStreamWaitEvent(side, reinterpret_cast<hipEvent_t>(tier_events[a.seg_tier + 1]), 0));
+            launch_lattice(a, dim3(grid), tiers[t], side, (uint32_t)t, persist);
+            if (t == a.seg_tier)
                 for (size_t x = t + 1; x < T; ++x)
-                    launch_lattice(a, dim3(waves_for(tiers[x], std::min<uint32_t>(cn, 4096))), tiers[x], side, (uint32_t)x, (uint32_t)x, 1u);
-            }
+                    launch_lattice(a, dim3(waves_for(tiers[x], std::min<uint32_t>(cn, 4096))), tiers[x], side, (uint32_t)x, 1u);
             if (!on_main) HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(tier_events[t]), side));
         }
-        if (dense_launched) HIP_CHECK(hipStreamWaitEvent(stream, reinterpret_cast<hipEvent_t>(tier_events[a.seg_tier + 1]), 0));
         for (size_t t = 0; t < n_conc; ++t)
             if (!(main_seg && t == a.seg_tier)) HIP_CHECK(hipStreamWaitEvent(stream, reinterpret_cast<hipEvent_t>(tier_events[t]), 0));
-        if (early) HIP_CHECK(hipStreamWaitEvent(stream, reinterpret_cast<hipEvent_t>(long_events[3]), 0));  // (behind long_events[2] by construction)
         rec(3);
         // whatever the pipeline could not take: fused kernel, global-memory lattice (persistent waves with a work cursor; the list is
         // empty or a handful of sentences, and the kernel uses scratch memory: launching 1024 of them cost 15 us, 128 cost 6)
@@ -3001,7 +2860,6 @@ void Workspace::run_one(const uint8_t* h_text_dev, uint32_t nb, uint8_t* d_text,
     a.prof = nullptr;
     a.lists = d_over; a.list_stride = (uint32_t)(2 * std::max<uint64_t>(max_sentences, 1)); a.n_tiers = 1;
     a.tier_prio = 0; a.seg_tier = 0; a.sid0 = 0; a.cctrl = d_cctrl; a.list_off = 0; a.direct_push = 0;
-    a.fb_cctrl = d_cctrl; a.fb_list_off = 0; a.early_long = 0;
     a.lid_count = nullptr; a.rid_count = nullptr; a.s_counted = nullptr;
     constexpr uint32_t kOneLds = 65536;  // generator arrays (~26 B per character), then the lattice (whole up to ~400 characters, in segments beyond)
     a.tier_bytes[0] = kOneLds;
@@ -3025,7 +2883,7 @@ void Workspace::stats(vbt_call_stats* out) {
     HIP_CHECK(hipSetDevice(tok.device()));
     HIP_CHECK(hipStreamSynchronize(reinterpret_cast<hipStream_t>(last_stream)));
     uint32_t ctrl[kCtrlWords];
-    std::vector<uint32_t> cc((size_t)kCtrlBlocks * kBlockCtrlWords);
+    std::vector<uint32_t> cc((size_t)kBlockCtrlWords);
     HIP_CHECK(hipMemcpy(ctrl, d_ctrl, sizeof(ctrl), hipMemcpyDeviceToHost));
     HIP_CHECK(hipMemcpy(cc.data(), d_cctrl, cc.size() * 4, hipMemcpyDeviceToHost));
     std::memset(out, 0, sizeof(*out));
@@ -3036,13 +2894,9 @@ void Workspace::stats(vbt_call_stats* out) {
         out->n_tier2 = cc[2 * (T - 1)];
         out->n_tier1 = last_n - out->n_tier0 - out->n_tier2;
     } else {
-        for (uint32_t c = 0; c < (uint32_t)kCtrlBlocks; ++c) {  // the launch stream's lists, then those of the long sentences' side streams (empty unless VBT_EARLY_LONG=1)
-            const uint32_t* k = cc.data() + (size_t)c * kBlockCtrlWords;
-            out->n_tier0 += k[0];
-            out->n_tier2 += k[2 * T];
-            for (size_t t = 1; t < T; ++t) out->n_tier1 += k[2 * t];
-            out->n_tier1 += k[2 * (T + 1 + kGenLevels)];  // pre-routed to the concurrent escape launch
-        }
+        out->n_tier0 = cc[0];
+        out->n_tier2 = cc[2 * T];
+        for (size_t t = 1; t < T; ++t) out->n_tier1 += cc[2 * t];
     }
     out->n_tokens = ctrl[kTotal];
     out->error_flags = ctrl[kError];

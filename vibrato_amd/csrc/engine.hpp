@@ -59,18 +59,17 @@ struct BatchArgs {
     uint32_t* s_passes; // upper bound of the lattice passes
     // per character slot (sentence s, char i -> slot offsets[s] - offsets[0] + kSentenceSlack * s + i; nb + kSentenceSlack slots per sentence)
     uint16_t* g_c2b;
-    uint4* g_pc;        // {cand_off, groupable | is_space << 31, lens lo, lens hi}
+    uint4* g_pc;        // {cand_off | end-list offset << 16, pass bound | window end << 14 | is_space << 31, lens lo, lens hi}
     // per candidate (insertion order, contiguous per sentence; sentence s owns the node slots
     // [node_factor * slot(s), node_factor * slot(s + 1)): no allocation atomics).
-    //   g_cand: 16 bytes, one scattered store by the generator: .x/.y what the sweep needs {right_id | end-list slot << 16,
-    //   (u16) word_cost | left_id << 16}, .z/.w what only the tokens of the best path need {word_idx, end_char}
+    //   g_cand: 16 bytes, one scattered store by the generator: {first cell of the left id's matrix row, (u16) word_cost |
+    //   end-list slot << 16, word_idx, end_char | right_id << 16}
     uint4* g_cand;
     uint4* g_hits;      // staging of the trie hits of gen_candidates, same per-sentence regions as g_cand
     uint32_t node_factor;
     uint8_t* s_tier;    // LDS tier chosen by gen_candidates (0xFF = none / empty sentence)
     // work lists: list t (t < n_tiers) feeds LDS tier t, list n_tiers the global-memory fallback (fused kernel),
-    // lists n_tiers + 1 .. n_tiers + kGenLevels the large-LDS instances of gen_candidates; list n_tiers + 1 + kGenLevels the sentences
-    // gen_candidates found unsweepable in segments (swept by an escape-tier launch that runs concurrently with the other tiers)
+    // lists n_tiers + 1 .. n_tiers + kGenLevels the large-LDS instances of gen_candidates
     uint32_t* lists;
     uint32_t list_stride;
     uint32_t n_tiers;
@@ -82,12 +81,6 @@ struct BatchArgs {
     uint32_t sid0;
     uint32_t* cctrl;
     uint32_t list_off;  // offset of this launch's entries inside every list region
-    // where the fallback list (list n_tiers) of the BATCH lives: the long-sentence side streams keep every other list in a counter
-    // block / list region of their own (their lists fill while the launch stream's kernels are already reading theirs), but what
-    // they cannot take joins the one fallback launch at the end of the batch
-    uint32_t* fb_cctrl;
-    uint32_t fb_list_off;
-    uint32_t early_long;  // the sentences that outgrow gen_one are found and generated on the side streams: gen_one just leaves them alone
     // optional connection-id usage counters (Worker::update_connid_counts, worker.rs:77-93): nullptr = off
     unsigned long long* lid_count;
     unsigned long long* rid_count;
@@ -103,9 +96,8 @@ enum CtrlSlot { kTotal = 0, kError = 1, kBump = 2, kNodeCursor = 4, kTierCtrl = 
 constexpr int kMaxTiers = 8;
 constexpr uint32_t kScanBlock = 256, kScanTile = 256;  // token packing: sentences per tile (small tiles: the copy needs the parallelism)
 constexpr uint32_t kSentenceSlack = 24;  // character slots per sentence on top of its bytes (see sentence_slot in engine.hip)
-constexpr int kCtrlBlocks = 2;   // list-counter blocks: [0] the launch stream's lists, [1] the lists of the long-sentence side streams
 constexpr int kGenLevels = 3;  // large-LDS instances of the generator behind the bulk one (32 KiB, 64 KiB, whole CU)
-constexpr int kListsBehindTiers = 1 + kGenLevels + 1;  // fallback, generator levels, pre-routed escapes (see engine.hip `dense_list`)
+constexpr int kListsBehindTiers = 1 + kGenLevels;  // fallback, generator levels
 constexpr int kBlockCtrlWords = 2 * (kMaxTiers + kListsBehindTiers);
 constexpr int kProfSlots = 256;  // the counters are spread over this many copies (hot-word atomics serialise)
 constexpr int kProfWords = 12;   // kProfPhases cycle totals, sentences, lattice steps, lattice passes, candidates
@@ -159,7 +151,6 @@ class Workspace {
     std::vector<void*> streams;      // one side stream per LDS tier
     std::vector<void*> tier_events;
     void* ev_fork2 = nullptr;
-    void* long_events[4] = {nullptr, nullptr, nullptr, nullptr};  // long sentences first: fork, generator done, side stream 0 done, side stream 1 done
     bool fused = false;              // VBT_FUSED=1: the single fused kernel per sentence (A/B reference)
     unsigned long long* d_connid = nullptr;  // [num_left + num_right] usage counters, allocated on first use
     uint32_t* d_counted = nullptr;           // per-sentence watermark of the counted steps
