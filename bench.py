@@ -20,7 +20,8 @@ The line (contract in the task statement): value = sentences of the whole job pe
 algorithmic bytes from the oracle's event counters / hipEvent kernel time, measured on rank 0's shard), `cpu_baseline` (the C
 restatement of vibrato's CPU path in oracle/, timed on this host: the whole batch at N = 1, a 20k-sentence sample of rank 0's
 shard at N > 1) and, at N = 1, three legs that are never `value`: `suite` (BASELINE config 5 and the dense lexicon law through
-the same timed loop), `worker_loop` (the reference's per-sentence 3-call loop through Worker) and `host_to_host`.
+the same timed loop), `worker_loop` (the reference's per-sentence 3-call loop through Worker), `host_to_host` and `format`
+(text in -> MeCab-format text out, next to the oracle's tokenize + print loop).
 """
 import argparse
 import json
@@ -132,6 +133,8 @@ def main():
                                                            "`reorder` + `map` tools; statistics from a training batch on the GPU)")
     ap.add_argument("--no-host-pipeline", action="store_true", help="skip the host-to-host leg (vbt_tokenize_batch from host buffers to host "
                                                                     "results: one call, and host threads streaming batches); never `value`")
+    ap.add_argument("--gather", default="root", choices=["root", "all"], help="the final exchange at --gpus N > 1: every rank's packed results to rank 0 "
+                                                                           "(a gather: grouped send/recv) or to every rank (all_gather_into_tensor)")
     ap.add_argument("--no-suite", action="store_true", help="skip the extra single-GPU legs (BASELINE config 5, dense lexicon law); never `value`")
     ap.add_argument("--no-worker-loop", action="store_true", help="skip the per-sentence Worker leg (the reference's 3-call loop); never `value`")
     args = ap.parse_args()
@@ -236,8 +239,9 @@ def main():
         max_t = sharding.agree_max(ntok_local, device="cuda")
         slot = sharding.packed_bytes(max_s, max_t)
         views = sharding.workspace_views(ws, n, ntok_local)
+        to_all = args.gather == "all"
         gather = {"send": [torch.empty(slot, dtype=torch.uint8, device="cuda") for _ in range(2)],
-                  "out": [torch.empty(world * slot, dtype=torch.uint8, device="cuda") for _ in range(2)],
+                  "out": [torch.empty(world * slot, dtype=torch.uint8, device="cuda") if (to_all or rank == 0) else None for _ in range(2)],
                   "work": [None, None], "comm": torch.cuda.Stream(), "slot": slot, "max_s": max_s, "k": 0}
 
     def step():
@@ -253,7 +257,10 @@ def main():
         ready.record()
         with torch.cuda.stream(gather["comm"]):
             gather["comm"].wait_event(ready)
-            _, gather["work"][b] = sharding.gather_packed(gather["send"][b], gather["out"][b], async_op=True)
+            if to_all:
+                _, gather["work"][b] = sharding.gather_packed(gather["send"][b], gather["out"][b], async_op=True)
+            else:
+                _, gather["work"][b] = sharding.gather_to_root(gather["send"][b], gather["out"][b], root=0, async_op=True)
 
     def drain():
         if gather is not None:
@@ -280,13 +287,14 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        # what the last gather delivered (every rank holds all shards): totals per rank from the slot headers
-        last = gather["out"][(gather["k"] - 1) & 1].view(world, -1)
-        heads = last[:, :16].cpu().numpy()
-        sent_by_rank = [int(heads[r, :8].view(np.int64)[0]) for r in range(world)]
-        tok_by_rank = [int(heads[r, 8:12].view(np.uint32)[0]) for r in range(world)]
-        gathered_ok = sum(sent_by_rank) == n_total and tok_by_rank[rank] == total_tokens
-        total_tokens = sum(tok_by_rank)
+        # what the last gather delivered (rank 0 holds all shards): totals per rank from the slot headers
+        if rank == 0:
+            last = gather["out"][(gather["k"] - 1) & 1].view(world, -1)
+            heads = last[:, :16].cpu().numpy()
+            sent_by_rank = [int(heads[r, :8].view(np.int64)[0]) for r in range(world)]
+            tok_by_rank = [int(heads[r, 8:12].view(np.uint32)[0]) for r in range(world)]
+            gathered_ok = sum(sent_by_rank) == n_total and tok_by_rank[rank] == total_tokens
+            total_tokens = sum(tok_by_rank)
 
     kernel_ms = st["ms_tier0"] + st["ms_tier12"] + st["ms_pack"]
 
@@ -372,6 +380,9 @@ def main():
                     "frac": round(achieved / HBM_PEAK_BPS, 6),
                     "traffic": trk.get("lattice_lds"), "traffic_source": tr["source"] if tr else None,
                     "algorithmic_bytes_per_launch": int(b_lat), "kernel_ms": round(ms_lat, 4),
+                    "pairs_per_launch": {"dedup_cells_in_the_numerator": int(cnt["n_pairs_dedup"] * scale), "reference_pairs_gathered_by_the_kernel": int(cnt["n_pairs_ref"] * scale),
+                                         "note": "the kernel gathers one cell per (candidate, predecessor) pair of the reference's search_min_node; the "
+                                                 "numerator counts one per distinct (start node, left id, predecessor)"},
                     "issue": issue("lattice_lds", ms_lat),
                     "gen_candidates": {"achieved": round(b_gen / (ms_gen * 1e-3) / 1e9, 3) if ms_gen > 0 else None,
                                        "frac": round(b_gen / (ms_gen * 1e-3) / HBM_PEAK_BPS, 6) if ms_gen > 0 else None,
@@ -440,6 +451,36 @@ def main():
                                 "cpu_us_per_sentence_same_host": cpu["us_per_sentence"] if cpu else None})
             del wk
 
+        # ---- the output stage: text in -> MeCab-format text out (tokenize/src/main.rs:78-95), never `value` ----
+        fmt = None
+        if not args.no_host_pipeline and world == 1:
+            bt = tok.tokenize_batch(text=text, offsets=offs)  # warm: pooled workspace and pinned blocks exist
+            bt.format_bytes("mecab")
+            del bt
+            t_e = time.perf_counter()
+            bt = tok.tokenize_batch(text=text, offsets=offs)
+            t_tok = time.perf_counter() - t_e
+            out_b, t_fmt = bt.format_bytes("mecab")
+            t_e2e = time.perf_counter() - t_e
+            n_f = min(n, 20000)
+            f_offs = offs[:n_f + 1]
+            f_text = text[:int(f_offs[-1])]
+            need, obuf = w.tokenize_format_batch(f_text, f_offs, "mecab")  # sizes the buffer (and warms the oracle)
+            t_c = time.perf_counter()
+            got_n, obuf = w.tokenize_format_batch(f_text, f_offs, "mecab", out=obuf)
+            t_cpu = time.perf_counter() - t_c
+            same = bool(out_b[:got_n] == obuf[:got_n].tobytes())  # the oracle's bytes for the first n_f sentences are a prefix of the product's
+            parity = parity and same
+            fmt = {"mode": "mecab", "output_bytes": len(out_b), "format_ms": round(t_fmt * 1e3, 3), "format_MB_per_s": round(len(out_b) / t_fmt / 1e6, 1),
+                   "tokenize_batch_ms": round(t_tok * 1e3, 3), "text_in_to_text_out_ms": round(t_e2e * 1e3, 3),
+                   "text_in_to_text_out_sentences_per_s": round(n / t_e2e, 1),
+                   "what": "vbt_tokenize_batch (host text in, token records in pinned host memory) then vbt_batch_format(MECAB): two parallel passes "
+                           "over chunks of sentences (sizes, prefix, render in place), one call, python wall clock incl. the copy of the text out of the library",
+                   "cpu_port_1thread": {"sample_sentences": n_f, "sentences_per_s": round(n_f / t_cpu, 1), "output_MB_per_s": round(got_n / t_cpu / 1e6, 2),
+                                        "what": "oracle: tokenize + print per line, the loop of tokenize/src/main.rs:78-95, one thread"},
+                   "bytes_identical_to_oracle_sample": same}
+            del bt, out_b, obuf
+
         # ---- the other single-GPU BASELINE workloads through the same timed loop (never `value`) ----
         suite = None
         if not args.no_suite and world == 1 and args.dict == "unidic" and not args.ignore_space and not args.user_lexicon and not args.reorder:
@@ -480,7 +521,7 @@ def main():
 
         value = n_total * args.steps / elapsed
         par = (f"dp{world}: {n_total}-sentence corpus in {world} contiguous shards balanced by bytes, one process per GPU, no data-path "
-               f"collective; final device-resident all_gather of the packed results ({backend}), overlapped with the next step"
+               f"collective; final device-resident gather of the packed results ({'to every rank: all_gather_into_tensor' if args.gather == 'all' else 'to rank 0: grouped send/recv'}, {backend}), overlapped with the next step"
                if world > 1 else "dp1")
         result = {
             "metric": "sentences/sec", "value": round(value, 1), "unit": "sentences/s", "n_gpus": world,
@@ -493,12 +534,12 @@ def main():
                        "ignore_space": args.ignore_space, "max_grouping_len": args.max_grouping_len, "user_lexicon_words": args.user_lexicon,
                        "connection_ids_reordered": reorder_info, "parallelism": par},
             "parity_vs_oracle_sample": parity, "tokens_per_step": total_tokens,
-            "gather": ({"bytes_per_rank_slot": gather["slot"], "collective": "all_gather_into_tensor", "device_resident": True,
+            "gather": ({"bytes_per_rank_slot": gather["slot"], "collective": "all_gather_into_tensor" if args.gather == "all" else "gather to rank 0 (grouped send/recv)", "device_resident": True,
                         "delivered_all_shards": bool(gathered_ok)} if world > 1 else None),
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all,
             "speedup_vs_cpu_1thread": round(value / cpu["value"], 1) if cpu else None,
             "suite": suite, "worker_loop": worker_loop,
-            "host_to_host": h2h,
+            "host_to_host": h2h, "format": fmt,
             "setup_s": round(t_setup, 1),
         }
         print(json.dumps(result, ensure_ascii=False), flush=True)

@@ -91,7 +91,8 @@ VBT_API int vbt_dict_from_sources_binmatrix(const char* lex, size_t lex_len, con
  * connector/raw_connector.rs; dual != 0: DualConnector connector/dual_connector.rs, a small matrix over classes of connection
  * ids + an 8-wide raw part, built as the reference builds it except that ties of its greedy template choice -- which the
  * reference resolves by hash-set iteration order -- go to the highest template index).  The device image materialises either as
- * a dense matrix when the tokenizer is created (VBT_ERR_UNSUPPORTED there if a cost does not fit i16). */
+ * a dense matrix when the tokenizer is created: i16 cells when every cost fits, else i32 cells (the reference's Raw / Dual cost is
+ * an i32 sum, raw_connector.rs:153-161, dual_connector.rs:267-279); VBT_ERR_UNSUPPORTED there only for a matrix of 4 GiB or more. */
 VBT_API int vbt_dict_from_sources_bigram(const char* lex, size_t lex_len, const char* bigram_right, size_t right_len,
                                          const char* bigram_left, size_t left_len, const char* bigram_cost, size_t cost_len,
                                          const char* char_def, size_t char_len, const char* unk_def, size_t unk_len, int dual,
@@ -216,7 +217,8 @@ VBT_API const vbt_token_rec* vbt_batch_records(const vbt_batch* b, uint64_t sent
 VBT_API int vbt_batch_arrays(const vbt_batch* b, const vbt_token_rec** tokens, const uint32_t** tok_off,
                              const uint32_t** tok_cnt);
 /* Byte-identical output of the `tokenize` CLI for the whole batch (tokenize/src/main.rs:83-127).
- * *out is malloc'ed; release with vbt_free. */
+ * *out is malloc'ed; release with vbt_free.  Rendered by up to VBT_FORMAT_THREADS host threads (default: the host's cores, at
+ * most 32) in two passes over chunks of sentences: exact sizes, then every chunk in place. */
 VBT_API int vbt_batch_format(const vbt_batch* b, int mode, char** out, size_t* len);
 VBT_API void vbt_free(void* p);
 

@@ -134,6 +134,8 @@ def lib():
         L.ora_worker_reset_counters.argtypes = [vp]
         L.ora_tokenize_batch.restype = u64
         L.ora_tokenize_batch.argtypes = [vp, vp, vp, u64, vp, u64, vp, C.c_int]
+        L.ora_tokenize_format_batch.restype = u64
+        L.ora_tokenize_format_batch.argtypes = [vp, vp, vp, u64, C.c_int, vp, u64]
         _lib = L
     return _lib
 
@@ -338,6 +340,22 @@ class Worker:
 
     def reset_counters(self):
         lib().ora_worker_reset_counters(self._h)
+
+    def tokenize_format_batch(self, text_u8, offsets_u64, mode="mecab", out=None):
+        """Text in, `tokenize` output out (tokenize/src/main.rs:78-127), one thread, into a caller-owned np.uint8 buffer
+        (sized by a first call when None).  Returns (bytes, buffer)."""
+        text = np.ascontiguousarray(text_u8, dtype=np.uint8)
+        offs = np.ascontiguousarray(offsets_u64, dtype=np.uint64)
+        m = {"mecab": 0, "wakati": 1, "detail": 2}[mode]
+        if out is None:
+            need = lib().ora_tokenize_format_batch(self._h, text.ctypes.data, offs.ctypes.data, len(offs) - 1, m, None, 0)
+            if need == 2**64 - 1:
+                raise OracleError("invalid utf-8")
+            out = np.empty(int(need), dtype=np.uint8)
+        got = lib().ora_tokenize_format_batch(self._h, text.ctypes.data, offs.ctypes.data, len(offs) - 1, m, out.ctypes.data, len(out))
+        if got == 2**64 - 1:
+            raise OracleError("invalid utf-8")
+        return int(got), out
 
     def tokenize_batch(self, text_u8, offsets_u64, counted=False, want_tokens=True):
         """text_u8: np.uint8 array; offsets_u64: n+1 offsets. Returns (tokens, tok_off)."""

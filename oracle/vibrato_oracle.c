@@ -564,12 +564,12 @@ static int lexicon_verify(const lexicon *lx, uint32_t num_left, uint32_t num_rig
 /* -------------------------------------------- matrix.def (matrix_connector.rs) */
 
 static size_t next_line(const char *buf, size_t len, size_t pos, size_t *ls, size_t *le) {
-    /* BufRead::lines(): split on '\n', strip one trailing '\r' */
+    /* BufRead::lines(): split on '\n'; '\r' is stripped only as part of "\r\n" (not from an unterminated last line) */
     *ls = pos;
     size_t i = pos;
     while (i < len && buf[i] != '\n') i++;
     size_t e = i;
-    if (e > pos && buf[e - 1] == '\r') e--;
+    if (i < len && e > pos && buf[e - 1] == '\r') e--;
     *le = e;
     return i < len ? i + 1 : len;
 }
@@ -1421,6 +1421,47 @@ ORA_API uint64_t ora_tokenize_batch(ora_worker *w, const uint8_t *text, const ui
     }
     if (tok_off) tok_off[n] = total;
     return total;
+}
+
+/* What `tokenize` does per input line (tokenize/src/main.rs:78-127): tokenize, then print every token in the chosen output mode
+ * (0 mecab, 1 wakati, 2 detail).  The cpu_baseline companion of the product's vbt_batch_format: text in, formatted text out, one
+ * thread.  Appends to out[0..cap); returns the bytes the whole output takes (more than cap: nothing beyond cap was written), or
+ * (uint64_t)-1 on invalid UTF-8. */
+ORA_API uint64_t ora_tokenize_format_batch(ora_worker *w, const uint8_t *text, const uint64_t *offsets, uint64_t n, int mode,
+                                           char *out, uint64_t cap) {
+    static const char *const lex_names[3] = {"System", "User", "Unknown"};
+    const ora_dict *d = w->tok->dict;
+    uint64_t at = 0;
+    char num[160];
+#define ORA_PUT(ptr, len_) do { uint64_t l_ = (len_); if (at + l_ <= cap) memcpy(out + at, (ptr), l_); at += l_; } while (0)
+    for (uint64_t s = 0; s < n; s++) {
+        const uint8_t *sent = text + offsets[s];
+        if (!ora_worker_reset_sentence(w, sent, (size_t)(offsets[s + 1] - offsets[s]))) return (uint64_t)-1;
+        tokenize_impl(w, 0);
+        for (uint32_t i = 0; i < w->n_top; i++) {
+            ora_token t;
+            ora_worker_token(w, i, &t);
+            const node *nd = &w->top_node[w->n_top - i - 1];
+            if (mode == 1 && i) ORA_PUT(" ", 1);
+            ORA_PUT(sent + t.start_byte, t.end_byte - t.start_byte);
+            if (mode == 1) continue;
+            uint32_t flen;
+            const char *f = ora_dict_word_feature(d, nd->lex_type, nd->word_id, &flen);
+            ORA_PUT("\t", 1);
+            ORA_PUT(f, flen);
+            if (mode == 2) {
+                int32_t prm[3];
+                ora_dict_word_param(d, nd->lex_type, nd->word_id, prm);
+                int k = snprintf(num, sizeof(num), "\tlex_type=%s\tleft_id=%u\tright_id=%u\tword_cost=%d\ttotal_cost=%d", lex_names[nd->lex_type],
+                                 (unsigned)nd->left_id, (unsigned)nd->right_id, (int)prm[2], (int)nd->min_cost);
+                ORA_PUT(num, (uint64_t)k);
+            }
+            ORA_PUT("\n", 1);
+        }
+        if (mode == 1) ORA_PUT("\n", 1); else ORA_PUT("EOS\n", 4);
+    }
+#undef ORA_PUT
+    return at;
 }
 
 /* common-prefix enumeration for the lexicon tests (tests/lexicon.rs:8-57,

@@ -123,6 +123,18 @@ def test_csv_dialect():
         assert [m[:2] for m in d.common_prefix('q"r')] == [[1, 3]]
 
 
+def test_lone_carriage_return_at_the_end_of_a_definition_file_is_not_stripped():
+    """BufRead::lines() strips '\\r' only as part of "\\r\\n": an unterminated last line that ends in '\\r' keeps it, and the
+    reference's integer parse then fails (matrix_connector.rs:27-77) -- product and oracle alike; "\\r\\n" everywhere parses."""
+    lex, ch, unk = "a,0,0,0,x", "DEFAULT 0 1 0", "DEFAULT,0,0,0,*"
+    for mk, err in ((lambda m: V.SystemDictionaryBuilder.from_readers(lex, m, ch, unk), V.VibratoError),
+                    (lambda m: ora.Dictionary.from_sources(lex, m, ch, unk), Exception)):
+        mk("1 1\r\n0 0 5\r\n")
+        mk("1 1\n0 0 5")
+        with pytest.raises(err):
+            mk("1 1\n0 0 5\r")
+
+
 def test_host_trie_matches_oracle_on_synthetic_lexicon():
     sd = synth.SynthDict("small")
     dv = V.SystemDictionaryBuilder.from_readers_binmatrix(sd.lex, sd.matrix, sd.num_right, sd.num_left, sd.char_def, sd.unk)

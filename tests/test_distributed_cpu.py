@@ -1,5 +1,5 @@
 """N>1 path without a GPU: two gloo ranks shard a batch, tokenize their ranges independently, pack
-their results and exchange them with the one collective the path has (sharding.gather_packed); the
+their results and exchange them with the one collective the path has (sharding.gather_to_root, or gather_packed to every rank); the
 union must equal the single-process result.  The compute stand-in on CPU is the oracle (the HIP path
 needs a GPU -- tests/test_distributed_gpu.py runs the same exchange over the HIP workspace); the
 sharding, packing and collective code under test is exactly what bench.py --gpus N uses."""
@@ -36,6 +36,11 @@ def _worker(rank, world, port, q):
     sharding.pack_results(send, n_local, len(toks), as_u8(np.array([len(toks)], dtype=np.uint32)),
                           as_u8(toff[:-1].astype(np.uint32)), as_u8(np.diff(toff).astype(np.uint32)), as_u8(toks), max_s)
     out, _ = sharding.gather_packed(send)
+    # the same slots as a true gather (bench.py's default): the root holds every shard, the other ranks receive nothing
+    out_root, _ = sharding.gather_to_root(send, root=0)
+    assert (out_root is None) == (rank != 0)
+    if rank == 0:
+        assert bytes(out_root.numpy().tobytes()) == bytes(out.numpy().tobytes())
     dist.barrier()
     dist.destroy_process_group()
     if rank == 0:

@@ -181,10 +181,41 @@ def _rccl_worker(port, q):
             ready.record()
             with torch.cuda.stream(comm):
                 comm.wait_event(ready)
-                _, work[b] = sharding.gather_packed(send[b], out[b], async_op=True)
+                # (both forms of the final exchange on the real backend: to every rank, and the gather to rank 0 that bench.py defaults to)
+                if k < 2:
+                    _, work[b] = sharding.gather_packed(send[b], out[b], async_op=True)
+                else:
+                    _, work[b] = sharding.gather_to_root(send[b], out[b], root=0, async_op=True)
         for wk in work:
             wk.wait()
         torch.cuda.synchronize()
+        # Does a collective in flight slow the kernels down?  (RCCL's collectives are CU kernels; shader-driven copies were
+        # measured to stall the other kernels in flight)  The same 20 steps with and without the gather of
+        # the previous step running on the communication stream; the ratio goes to profiles/ via gpurun_out/.
+        import time as _time
+        def timed(with_gather):
+            torch.cuda.synchronize()
+            t0 = _time.perf_counter()
+            pending = None
+            for k in range(20):
+                ws.run(d_text.data_ptr(), d_offs.data_ptr(), n_local, nbytes, stream)
+                if with_gather:
+                    if pending is not None:
+                        pending.wait()
+                    sharding.pack_results(send[0], n_local, ntok, v["total"], v["tok_off"], v["tok_cnt"], v["tokens"], max_s)
+                    ready = torch.cuda.Event()
+                    ready.record()
+                    with torch.cuda.stream(comm):
+                        comm.wait_event(ready)
+                        _, pending = sharding.gather_to_root(send[0], out[0], root=0, async_op=True)
+            if pending is not None:
+                pending.wait()
+            torch.cuda.synchronize()
+            return (_time.perf_counter() - t0) / 20
+        timed(False); timed(True)
+        t_plain, t_gather = timed(False), timed(True)
+        overlap = {"ms_per_step_kernels_only": round(t_plain * 1e3, 4), "ms_per_step_with_gather_in_flight": round(t_gather * 1e3, 4),
+                   "ratio": round(t_gather / t_plain, 4), "slot_bytes": slot, "sentences": n_local, "world_size": 1, "backend": dist.get_backend()}
         tmax = torch.tensor([1.5], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         assert float(tmax.item()) == 1.5
@@ -196,7 +227,7 @@ def _rccl_worker(port, q):
             res.append((n_s, n_t, ordered.tobytes()))
         backend = dist.get_backend()
         dist.destroy_process_group()
-        q.put(("ok", (backend, res)))
+        q.put(("ok", (backend, res, overlap)))
     except Exception as e:
         import traceback
         q.put(("error", f"{e}\n{traceback.format_exc()}"))
@@ -219,8 +250,14 @@ def test_rccl_backend_world_size_one_gather_on_the_communication_stream():
     p.join(timeout=120)
     assert status == "ok", payload
     assert p.exitcode == 0
-    backend, res = payload
+    backend, res, overlap = payload
     assert backend == "nccl"
+    print("rccl world-size-1 step with / without the gather in flight:", overlap)
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out_dir):
+        import json
+        with open(os.path.join(out_dir, "rccl_ws1_overlap.json"), "w") as f:
+            json.dump(overlap, f)
     sd = synth.SynthDict("small")
     d = ora.Dictionary.from_sources_binmatrix(sd.lex, sd.matrix, sd.num_right, sd.num_left, sd.char_def, sd.unk)
     text, offs = sd.sentences(N_SENT, "mixed", space_p=0.05)

@@ -611,3 +611,65 @@ def test_worker_loop_benchmark_counts_tokens():
         finally:
             del os.environ["VBT_WORKER_SPIN"]
         assert r["tokens"] == 2 * len(exp_tok) and r["us_per_call"] > 0
+
+
+@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0]])
+def test_multi_device_tokenizer_equals_single_device_and_oracle(devices):
+    """vbt_tokenizer_new_multi (one replica of the image per listed device; a one-GPU box lists device 0 more than once): every
+    batch is split into contiguous shards balanced by bytes, the shards run side by side and every shard's results land in the
+    ONE pinned block at its offset.  Records, offsets and counts must equal the single-device tokenizer's and the oracle's --
+    also with fewer sentences than devices, empty sentences at the shard boundaries and an empty batch."""
+    sd = synth.SynthDict("small")
+    do = ora.Dictionary.from_sources_binmatrix(sd.lex, sd.matrix, sd.num_right, sd.num_left, sd.char_def, sd.unk)
+    to = ora.Tokenizer(do, True, 24)
+    mk = lambda **kw: V.Tokenizer(V.SystemDictionaryBuilder.from_readers_binmatrix(sd.lex, sd.matrix, sd.num_right, sd.num_left, sd.char_def, sd.unk),
+                                  **kw).ignore_space(True).max_grouping_len(24)
+    one, multi = mk(), mk(devices=devices)
+    assert multi.num_devices() == len(devices) and one.num_devices() == 1
+    text, offs = sd.sentences(5000, "mixed", space_p=0.05)
+    _assert_batch_equal(to, multi, text, offs)
+    a, b = one.tokenize_batch(text=text, offsets=offs).arrays(), multi.tokenize_batch(text=text, offsets=offs).arrays()
+    for x, y in zip(a, b):
+        assert x.tobytes() == y.tobytes()
+    # fewer sentences than devices, and empty sentences around the shard boundaries
+    t2 = "猫が好き".encode()
+    for sents in ([t2], [b"", t2, b"", b""], [b"", b""], []):
+        raw = np.frombuffer(b"".join(sents), dtype=np.uint8)
+        o = np.zeros(len(sents) + 1, dtype=np.uint64)
+        o[1:] = np.cumsum([len(x) for x in sents])
+        _assert_batch_equal(to, multi, raw, o)
+    # the Worker of a multi-device tokenizer runs on its first device
+    w = multi.new_worker()
+    w.reset_sentence(t2.decode())
+    w.tokenize()
+    assert w.num_tokens() > 0
+
+
+def test_results_through_the_packing_kernel_when_sdma_is_off(tmp_path):
+    """VBT_H2H_OUT=0 (also what the library falls back to when no HSA agent matches the device): tok_tile_scan, then
+    compact_tokens_out stores tok_off / tok_cnt / the records straight into the mapped pinned block.  out_mode is latched per
+    tokenizer, so the path runs in a process of its own; a batch of more than one packing tile, with empty sentences, on one and
+    on two replicas."""
+    import subprocess
+    import sys
+    code = '''
+import numpy as np, sys
+sys.path.insert(0, %r)
+import vibrato_amd as V
+from oracle import oracle as ora
+from tools import synth
+sd = synth.SynthDict("small")
+do = ora.Dictionary.from_sources_binmatrix(sd.lex, sd.matrix, sd.num_right, sd.num_left, sd.char_def, sd.unk)
+to = ora.Tokenizer(do, False, 0)
+text, offs = sd.sentences(3000, "lognormal_40")
+offs = np.concatenate([offs[:1500], offs[1500:1501], offs[1500:1501], offs[1500:]]).astype(np.uint64)  # two empty sentences in the middle
+exp, eoff = to.new_worker().tokenize_batch(text, offs)
+for devs in (None, [0, 0]):
+    dv = V.SystemDictionaryBuilder.from_readers_binmatrix(sd.lex, sd.matrix, sd.num_right, sd.num_left, sd.char_def, sd.unk)
+    tv = V.Tokenizer(dv, devices=devs)
+    got, goff = tv.tokenize_batch(text=text, offsets=offs).tokens_in_order()
+    assert np.array_equal(goff, eoff) and got.tobytes() == exp.tobytes(), devs
+print("OK")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, VBT_H2H_OUT="0"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-2000:]

@@ -485,6 +485,23 @@ class Batch:
             N.lib().vbt_free(p)
 
 
+def _batch_format_bytes(self, mode="mecab"):
+    """The same as bytes, plus the seconds the C call took (no UTF-8 decode, one copy out of the library's buffer)."""
+    import time
+    m = {"mecab": 0, "wakati": 1, "detail": 2}[mode]
+    p, n = C.c_void_p(), C.c_size_t()
+    t0 = time.perf_counter()
+    N.check(N.lib().vbt_batch_format(self._h, m, C.byref(p), C.byref(n)))
+    dt = time.perf_counter() - t0
+    try:
+        return C.string_at(p, n.value), dt
+    finally:
+        N.lib().vbt_free(p)
+
+
+Batch.format_bytes = _batch_format_bytes
+
+
 def compute_connid_probs(lid_count, rid_count):
     """ConnIdCounter::compute_probs (mapper.rs:108-146): per side, (id, count / sum) without id 0, sorted by
     probability descending then id ascending -- the content of the reference's *.lmap / *.rmap files."""

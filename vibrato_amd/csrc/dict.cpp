@@ -341,13 +341,14 @@ bool verify_ids(const std::vector<WordParam>& params, uint32_t num_left, uint32_
 
 // ---- line helpers -------------------------------------------------------------------
 
-// BufRead::lines(): split on '\n', strip one trailing '\r'.
+// BufRead::lines(): split on '\n'; a '\r' is stripped only as part of "\r\n" (an unterminated last line keeps it, and the
+// reference's integer parse then fails on it).
 bool next_line(std::string_view buf, size_t& pos, std::string_view& line) {
     if (pos >= buf.size()) return false;
     size_t e = buf.find('\n', pos);
     size_t end = e == std::string_view::npos ? buf.size() : e;
     line = buf.substr(pos, end - pos);
-    if (!line.empty() && line.back() == '\r') line.remove_suffix(1);
+    if (e != std::string_view::npos && !line.empty() && line.back() == '\r') line.remove_suffix(1);
     pos = e == std::string_view::npos ? buf.size() : e + 1;
     return true;
 }

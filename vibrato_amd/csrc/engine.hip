@@ -749,18 +749,24 @@ __device__ __forceinline__ uint64_t process_sentence(const DevDict& D, const Bat
 constexpr uint32_t kRoundPreds = VBT_ROUND_PREDS, kRoundCands = 16;  // (build knob: 8 or 16 predecessors = 2 or 4 units, i.e. gathers, per pass)
 static_assert(kRoundPreds == 8 || kRoundPreds == 16, "a pass walks 2 or 4 units of 4 predecessors");
 constexpr uint32_t kUnits = kRoundPreds / 4;
-// 16-byte pass record in LDS, built once per pass by the lane that owns the step:
+// 32-byte pass record, built once per pass by the lane that owns the step, in the sentence's own region of GLOBAL memory (the dead
+// upper half of its hit-staging region) and read back by the sweep loop with scalar loads: everything that steers a pass arrives in
+// SGPRs, lane masks included, without a VALU or SALU instruction spent on it.
 //   w0 = LDS address of the slot record of the pass's first predecessor, w1 = LDS address of its first candidate's record,
-//   w2 = predecessors (<= 16) | candidates (<= 16) << 8 | first round of its candidates << 16 | last round << 17 | first pass of the step << 18,
-//   w3 = predecessors | candidates << 16 of the whole step (connection-id counting)
-struct alignas(16) LPass { uint32_t w0, w1, w2, w3; };
+//   w2 = predecessors (<= 16) | candidates (<= 16) << 8 | units (1..4; 0: an empty pass) << 16 | last round of its candidates << 20
+//        | first pass of the step << 21,
+//   w3 = predecessors | candidates << 16 of the whole step (connection-id counting),
+//   cm = lanes (4 per candidate) of the candidates that exist, lm = the lanes of the LAST unit that hold a pair (cm & the phases
+//        4 i + k < predecessors); every unit before the last is full.
+struct alignas(32) LPass { uint32_t w0, w1, w2, w3; uint64_t cm, lm; };
 __host__ __device__ __forceinline__ uint32_t step_passes(uint32_t nc, uint32_t np) {
     return ((np + kRoundPreds - 1) / kRoundPreds) * ((nc + kRoundCands - 1) / kRoundCands);
 }
-// LDS bytes of the lattice arrays of lattice_lds for a (segment of a) sentence with C candidates, `passes` passes and a window of
-// E end-list slots.  Must over-estimate the Arena carve there; gen_candidates routes sentences to LDS tiers with it.
-__host__ __device__ __forceinline__ uint64_t lattice_fixed_bytes(uint32_t C, uint32_t passes, uint32_t E) {
-    return 8ull * (E + 2ull) + 8ull * (C + 2ull) + sizeof(LPass) * (passes + 2ull) + 48;
+// LDS bytes of the lattice arrays of lattice_lds for a (segment of a) sentence of n positions with C candidates and a window of
+// E end-list slots: 8 bytes per slot, 8 per candidate, 2 per position (the token path).  Must over-estimate the Arena carve
+// there; gen_candidates routes sentences to LDS tiers with it.
+__host__ __device__ __forceinline__ uint64_t lattice_fixed_bytes(uint32_t C, uint32_t n, uint32_t E) {
+    return 8ull * (E + 2ull) + 8ull * (C + 2ull) + 2ull * (n + 4ull) + 48;
 }
 // Cost word of a slot whose node was never inserted (its start position is never visited).  Biased cost 0xC0000000 = +2^30: with
 // 16-bit connection and word costs a sentence of < 8000 characters keeps every live cost inside +-2^29, so such a predecessor
@@ -1167,7 +1173,7 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
         A.s_n[sid] = n; A.s_C[sid] = C; A.s_passes[sid] = passes;
     }
     // smallest tier whose LDS holds the lattice arrays (connection costs are never staged)
-    const uint64_t fixed = lattice_fixed_bytes(C, passes, eo(n + 1));
+    const uint64_t fixed = lattice_fixed_bytes(C, n, eo(n + 1));
     uint32_t tier = fallback;
     for (uint32_t t = 0; t < A.n_tiers; ++t)
         if (fixed <= A.tier_bytes[t]) { tier = t; break; }
@@ -1482,7 +1488,7 @@ __device__ __forceinline__ void gen_long(const DevDict& D, const BatchArgs& A, u
         A.s_n[sid] = n; A.s_C[sid] = C; A.s_passes[sid] = passes;
     }
     // smallest tier whose LDS holds the lattice arrays, else the segment tier (see gen_one)
-    const uint64_t fixed = lattice_fixed_bytes(C, passes, eo(n + 1));
+    const uint64_t fixed = lattice_fixed_bytes(C, n, eo(n + 1));
     uint32_t tier = fallback;
     for (uint32_t t = 0; t < A.n_tiers; ++t)
         if (fixed <= A.tier_bytes[t]) { tier = t; break; }
@@ -1602,6 +1608,12 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
         const uint4* __restrict__ ndg = A.g_cand + node0;  // candidate records in insertion order: {first cell of the matrix row, word cost | slot << 16, word_idx, end_char | right id << 16}
         const uint32_t ET = __builtin_amdgcn_readfirstlane(pcg[nT].z);  // end-list slots of the sentence (BOS included)
         const uint32_t kBosSeq = CT + 1;
+        // The sentence's hit-staging region (dead after gen_candidates; 16 bytes per node slot): its lower half holds (total cost,
+        // back pointer) of every node of a sentence that is swept in segments, its upper half the pass records of the current segment.
+        const uint32_t nbT = (uint32_t)(uniform64(A.offsets[sid + 1]) - uniform64(A.offsets[sid]));
+        const uint32_t half_bytes = 8u * A.node_factor * (nbT + kSentenceSlack);
+        LPass* const rec = reinterpret_cast<LPass*>(reinterpret_cast<char*>(A.g_hits + node0) + half_bytes);
+        const uint32_t rec_cap = half_bytes / (uint32_t)sizeof(LPass);
         // where a dead predecessor's sentinel cost could meet a live cost, every predecessor's own field is tested instead (kDeadHi)
         const bool exact = kWide || nT >= 8000u;
         uint32_t seg_a = 0, seg_c = 0, seg_p = 0, sb = 0, m_in = 1, fail = 0;
@@ -1618,7 +1630,8 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
         if (ln == 0) e_rec[0] = make_uint2(((0xFFFEu - kBosSeq) & 0xFFFFu) << 16, 0x80000000u);  // BOS: cost 0, right id 0 (lattice.rs:72-83)
         while (!done) {
         uint32_t seg_b = nT, seg_pass = passesT - seg_p, wend = ET;
-        if (lattice_fixed_bytes(CT - seg_c, passesT - seg_p, ET - sb) > budget) {
+        // (pass records of a segment live in global memory: rec_cap of them, the empty ones behind the last included)
+        if (lattice_fixed_bytes(CT - seg_c, nT - seg_a, ET - sb) > budget || passesT - seg_p + 2 * kD + 4 > rec_cap) {
             // furthest admissible cut within 256 positions whose segment fits: any position a multiple of 8 behind the segment's
             // start (the bit-serial sweep below runs in groups of 8 positions) that does not follow a space (a visited space run and
             // the word it hands its visit to stay in one segment, tokenizer.rs:113-125)
@@ -1638,7 +1651,7 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
                 const uint32_t incl = wave_exscan(nsl, tot) + nsl + run;
                 const uint32_t est = b == nT ? passesT - seg_p : incl;  // (the sentence's bound includes the EOS step)
                 const uint32_t wsl = b == nT ? ET : we;
-                const bool fits = b <= nT && lattice_fixed_bytes((cx - seg_c) & 0xFFFFu, est, wsl - sb) <= budget;
+                const bool fits = b <= nT && lattice_fixed_bytes((cx - seg_c) & 0xFFFFu, b - seg_a, wsl - sb) <= budget && est + 2 * kD + 4 <= rec_cap;
                 const uint64_t m = __ballot(fits && (b == nT || (!sp && ((ln + 1) & 7u) == 0)));
                 if (m) {
                     const uint32_t top = 63u - (uint32_t)__builtin_clzll(m);
@@ -1668,9 +1681,8 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
         Arena ar{g_smem, lds_bytes, 0, true};
         (void)ar.take<uint2>(E + 2);              // e_rec: the slot records
         uint2* cnd = ar.take<uint2>(C + 2);       // per candidate: {first cell of its matrix row (low half: its back pointer, once inserted), byte offset of its slot record | word_cost << 16}
-        ar.used = (ar.used + 15) & ~15ull;
-        LPass* rec = reinterpret_cast<LPass*>(g_smem + ar.used);  // pass records take the rest; afterwards the token path
-        const uint32_t sl_cap = ar.ok && lds_bytes > ar.used ? (uint32_t)((lds_bytes - ar.used) / sizeof(LPass)) : 0u;
+        uint16_t* path = ar.take<uint16_t>(n + 4);  // the token path of the back-trace (tokens <= positions)
+        const uint32_t sl_cap = rec_cap > 2 * kD + 4 ? rec_cap - (2 * kD + 2) : 0u;
         if (!ar.ok || sl_cap < 3) {  // the estimate was too low: try a shorter segment before giving up
             if (budget > lds_bytes / 3) { budget -= lds_bytes / 4; __syncthreads(); continue; }
             fail = 26; break;
@@ -1726,8 +1738,12 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
         auto make_pass = [&](uint32_t p_beg, uint32_t np, uint32_t c_beg, uint32_t nc, uint32_t k, uint32_t r, uint32_t rounds, uint32_t first) {
             const uint32_t np_r = np - kRoundPreds * r < kRoundPreds ? np - kRoundPreds * r : kRoundPreds;
             const uint32_t nc_r = nc - kRoundCands * k < kRoundCands ? nc - kRoundCands * k : kRoundCands;
+            const uint32_t nu = (np_r + 3u) >> 2, t = np_r - 4u * (nu - 1u);  // units, predecessors of the last one (1..4)
+            const uint64_t cm = nc_r >= 16u ? ~0ull : (1ull << (4u * nc_r)) - 1ull;
+            const uint32_t pat = t >= 4u ? 0xFFFFFFFFu : ((1u << t) - 1u) * 0x11111111u;  // phases below t, in every quad
             return LPass{offK + ((p_beg + kRoundPreds * r) << 3), offC + ((c_beg + kRoundCands * k) << 3),
-                         np_r | (nc_r << 8) | (r == 0 ? 0x10000u : 0u) | (r + 1 == rounds ? 0x20000u : 0u) | (first ? 0x40000u : 0u), np | (nc << 16)};
+                         np_r | (nc_r << 8) | (nu << 16) | (r + 1 == rounds ? 0x100000u : 0u) | (first ? 0x200000u : 0u), np | (nc << 16),
+                         cm, cm & (((uint64_t)pat << 32) | pat)};
         };
         {
             uint64_t w = sw_w;
@@ -1816,10 +1832,14 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
             if (budget > lds_bytes / 3) { budget -= lds_bytes / 4; __syncthreads(); continue; }
             fail = 29; break;
         }
-        // one empty pass behind the last one (no predecessors, no candidates): the software pipeline reads ahead up to it
-        if (ln == 0) rec[SL] = LPass{offK, offC, 0u, 0u};
+        // empty passes behind the last one (no units, no lanes): the sweep loop runs in trips of kD passes and reads kD + 1 records
+        // ahead, i.e. up to record SL + 2 kD (whatever else lies there would be issued as gathers with garbage lane masks and indices)
+        if (ln < 2 * kD + 2) rec[SL + ln] = LPass{offK, offC, 0u, 0u, 0ull, 0ull};
+        // the records are read back through the scalar cache: this wave's stores complete (workgroup scope: s_waitcnt vmcnt(0); the
+        // vector L1 is write-through), then the scalar cache forgets whatever it holds of this region (an earlier segment's records)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
         PROF_MARK(4);
 
         // ---- fused gather + cost recurrence (matrix_connector.rs:79-85, lattice.rs:103-151) ----
@@ -1828,8 +1848,8 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
             // The connection matrix through a structured buffer resource (stride = one cell, index = left id * num_right + right id:
             // one SDWA add per gather, no 64-bit address per lane; num_records is set to the byte size, at least the cell count
             // under either reading of that field: lanes without a pair are masked off, nothing relies on the range check).  The gathers are
-            // inline assembly: four loads per pass whatever its shape (a unit without predecessors loads for one lane), lanes without a
-            // pair masked off through EXEC -- so the number of loads in flight is static and the one s_waitcnt per pass is exact.
+            // inline assembly: kUnits loads per pass whatever its shape, lanes without a pair masked off through EXEC -- so the number of
+            // loads in flight is static and the one s_waitcnt per pass is exact.
             const uint64_t mb = (uint64_t)reinterpret_cast<uintptr_t>(D.matrix);
             u32x4 rsrc;
             rsrc.x = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)mb);
@@ -1837,144 +1857,136 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
             rsrc.z = (uint32_t)__builtin_amdgcn_readfirstlane(D.matrix_bytes);
             rsrc.w = 0x00020000u;
             const uint32_t kk = ln & 3u, k8 = kk << 3, cl8 = (ln >> 2) << 3;
-            const uint32_t fin_rank = kk ? 0xFFFFu : (ln >> 2);  // the lanes that write a candidate's node: phase 0
-            const uint32_t offRec = lds0 + (uint32_t)(reinterpret_cast<char*>(rec) - g_smem);
-            // lanes whose phase is below t (1..4): the predecessors 4 i + k of unit i that exist
-            auto kmask = [](uint32_t t) -> uint64_t {
-                const uint32_t m = t >= 4u ? 0xFFFFFFFFu : ((1u << t) - 1u) * 0x11111111u;
-                return ((uint64_t)m << 32) | m;
-            };
+            constexpr uint64_t kPhase0 = 0x1111111111111111ull;  // the lanes that write a candidate's node: phase 0
             auto sel = [](uint64_t mask, uint32_t a, uint32_t b) { return __builtin_amdgcn_inverse_ballot_w64(mask) ? b : a; };  // bit ? b : a (v_cndmask on an SGPR mask)
             uint32_t word[kD][kUnits];      // VGPR ring: connection costs in flight (sign-extended), slot = pass % kD
             uint32_t paddr[kD], caddr[kD];  // VGPR ring: LDS address of this lane's first predecessor record / of its candidate record
-            uint32_t s_w2[kD];              // SGPR ring: shape word of the pass
+            uint32_t s_w2[kD];              // SGPR rings: shape word of the pass, the lanes of its last unit
+            uint64_t s_lm[kD];
             uint32_t best_hi = 0xFFFFFFFFu, best_lo = 0xFFFFFFFFu;
-            auto read_rec = [&](uint32_t p) -> uint4 {
-                const uint32_t a = offRec + ((p < SL ? p : SL) << 4);  // passes > SL do not exist: they re-read the empty one
-                typedef __attribute__((address_space(3))) const u32x4 lds_cu128;
-                const u32x4 v = *reinterpret_cast<lds_cu128*>(a);
-                return make_uint4(v.x, v.y, v.z, v.w);
-            };
-            // issue side of a pass, part 1: its shape, this lane's addresses, and the LDS reads the gathers need
-            struct Iss { uint32_t w2, pa, ca, leftidx, lo[kUnits]; };
-            auto issue_reads = [&](const uint4& pr) {
+            // The pass records come through the scalar cache (s_load_dwordx8: constant address space).  The compiler treats such memory
+            // as immutable, so the pointer is laundered behind the stores + s_dcache_inv above: no load of it can be moved in front of them.
+            typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+            typedef __attribute__((address_space(4))) const u32x8 crec_t;
+            uint64_t rbase = (uint64_t)reinterpret_cast<uintptr_t>(rec);
+            rbase = uniform64(rbase);
+            asm volatile("" : "+s"(rbase));
+            const crec_t* const rq = reinterpret_cast<const crec_t*>(rbase);
+            // issue side of a pass, part 1: this lane's addresses and the LDS reads the gathers need
+            struct Iss { uint32_t pa, ca, leftidx, lo[kUnits]; };
+            auto issue_reads = [&](const u32x8& pr) {
                 Iss s;
-                s.w2 = (uint32_t)__builtin_amdgcn_readfirstlane(pr.z);
-                s.pa = pr.x + k8;
-                s.ca = pr.y + cl8;
+                s.pa = pr[0] + k8;
+                s.ca = pr[1] + cl8;
                 s.leftidx = *reinterpret_cast<lds_cu32*>(s.ca);
 #pragma unroll
                 for (uint32_t i = 0; i < kUnits; ++i) s.lo[i] = *reinterpret_cast<lds_cu32*>(s.pa + 32u * i);  // low half: right id of predecessor 4 i + k (garbage behind the list: masked below)
                 return s;
             };
-            // part 2: the four gathers into ring slot u
-            auto issue_gathers = [&](uint32_t u, const Iss& s) {
-                const uint32_t np_r = s.w2 & 0xFFu, nc_r = (s.w2 >> 8) & 0xFFu;
-                const uint64_t cm = nc_r >= 16u ? ~0ull : (1ull << (4u * nc_r)) - 1ull;  // lanes of candidates that exist
-                uint64_t m[kUnits];
+            // part 2: the gathers into ring slot u.  Unit i runs under EXEC = cm while a later unit exists, = lm as the last one, = 0
+            // behind it: a load under EXEC = 0 moves nothing and writes no register, but it takes its place in vmcnt
+            // (tools/calib/exec0_vmcnt.hip: 128 000 of 128 000 trials on gfx950), so the count in flight stays static.  The empty passes
+            // behind the last one are never waited for: the counter is drained behind the loop, before the ring's registers go back to
+            // the compiler -- a load that lands late must not find its register reused (tools/check_ring_isa.py proves that on the
+            // compiled ISA).
+            auto issue_gathers = [&](uint32_t u, const Iss& s, const u32x8& pr) {
+                const uint32_t nu = (pr[2] >> 16) & 7u;
+                const uint64_t cm = ((uint64_t)pr[5] << 32) | pr[4], lm = ((uint64_t)pr[7] << 32) | pr[6];
                 uint32_t vo[kUnits];
 #pragma unroll
-                for (uint32_t i = 0; i < kUnits; ++i) {
-                    m[i] = np_r > 4u * i ? cm & kmask(np_r - 4u * i) : 0ull;
-                    vo[i] = (s.lo[i] & 0xFFFFu) + s.leftidx;
-                }
-#if !VBT_DUMMY_EXEC0
-                // (A/B: a unit without predecessors loads for ONE lane instead of none -- the first lane of unit 0, lane 0 in the empty
-                // pass behind the last one -- at whatever cell its garbage right id names)
-                const uint64_t one = m[0] ? m[0] & (0ull - m[0]) : 1ull;
-#pragma unroll
-                for (uint32_t i = 1; i < kUnits; ++i) if (!m[i]) m[i] = one;
-                if (!m[0]) m[0] = one;
-#endif
-                // A unit without predecessors still issues its load, with EXEC = 0: such a load moves nothing and writes no register,
-                // but it takes its place in vmcnt (tools/calib/exec0_vmcnt.hip: 128 000 of 128 000 trials on gfx950), so the
-                // count in flight stays static.  The empty passes behind the last one are never waited for: the counter is drained
-                // behind the loop, before the ring's registers go back to the compiler -- a load that lands late must not find its
-                // register reused (tools/check_ring_isa.py proves that on the compiled ISA).
-#define VBT_G1(OP, I) "s_mov_b64 exec, %[m" #I "]\n\t" OP " %[d" #I "], %[a" #I "], %[rs], 0 idxen\n\t"
+                for (uint32_t i = 0; i < kUnits; ++i) vo[i] = (s.lo[i] & 0xFFFFu) + s.leftidx;
+#define VBT_LD(OP, I) OP " %[d" #I "], %[a" #I "], %[rs], 0 idxen\n\t"
                 if constexpr (kUnits == 4) {
 #define VBT_GATHER(OP)                                                                                                        \
-                    asm volatile(VBT_G1(OP, 0) VBT_G1(OP, 1) VBT_G1(OP, 2) VBT_G1(OP, 3) "s_mov_b64 exec, -1"                   \
-                                 : [d0] "=&v"(word[u][0]), [d1] "=&v"(word[u][1]), [d2] "=&v"(word[u][2]), [d3] "=&v"(word[u][kUnits - 1]) \
-                                 : [a0] "v"(vo[0]), [a1] "v"(vo[1]), [a2] "v"(vo[2]), [a3] "v"(vo[kUnits - 1]), [rs] "s"(rsrc),  \
-                                   [m0] "s"(m[0]), [m1] "s"(m[1]), [m2] "s"(m[2]), [m3] "s"(m[kUnits - 1]))
+                    asm volatile("s_cmp_gt_u32 %[nu], 1\n\ts_cselect_b64 exec, %[cm], %[lm]\n\t" VBT_LD(OP, 0)                  \
+                                 "s_cselect_b64 exec, %[lm], 0\n\ts_cmp_gt_u32 %[nu], 2\n\ts_cselect_b64 exec, %[cm], exec\n\t" VBT_LD(OP, 1) \
+                                 "s_cselect_b64 exec, %[lm], 0\n\ts_cmp_gt_u32 %[nu], 3\n\ts_cselect_b64 exec, %[cm], exec\n\t" VBT_LD(OP, 2) \
+                                 "s_cselect_b64 exec, %[lm], 0\n\t" VBT_LD(OP, 3) "s_mov_b64 exec, -1"                          \
+                                 : [d0] "=&v"(word[u][0]), [d1] "=&v"(word[u][1]), [d2] "=&v"(word[u][kUnits - 2]), [d3] "=&v"(word[u][kUnits - 1]) \
+                                 : [a0] "v"(vo[0]), [a1] "v"(vo[1]), [a2] "v"(vo[kUnits - 2]), [a3] "v"(vo[kUnits - 1]), [rs] "s"(rsrc),   \
+                                   [nu] "s"(nu), [cm] "s"(cm), [lm] "s"(lm) : "scc")
                     if constexpr (kWide) VBT_GATHER("buffer_load_dword");
                     else VBT_GATHER("buffer_load_sshort");
 #undef VBT_GATHER
                 } else {
 #define VBT_GATHER(OP)                                                                                                        \
-                    asm volatile(VBT_G1(OP, 0) VBT_G1(OP, 1) "s_mov_b64 exec, -1"                                               \
+                    asm volatile("s_cmp_gt_u32 %[nu], 1\n\ts_cselect_b64 exec, %[cm], %[lm]\n\t" VBT_LD(OP, 0)                  \
+                                 "s_cselect_b64 exec, %[lm], 0\n\t" VBT_LD(OP, 1) "s_mov_b64 exec, -1"                          \
                                  : [d0] "=&v"(word[u][0]), [d1] "=&v"(word[u][1])                                               \
-                                 : [a0] "v"(vo[0]), [a1] "v"(vo[1]), [rs] "s"(rsrc), [m0] "s"(m[0]), [m1] "s"(m[1]))
+                                 : [a0] "v"(vo[0]), [a1] "v"(vo[1]), [rs] "s"(rsrc), [nu] "s"(nu), [cm] "s"(cm), [lm] "s"(lm) : "scc")
                     if constexpr (kWide) VBT_GATHER("buffer_load_dword");
                     else VBT_GATHER("buffer_load_sshort");
 #undef VBT_GATHER
                 }
-#undef VBT_G1
-                s_w2[u] = s.w2; paddr[u] = s.pa; caddr[u] = s.ca;
+#undef VBT_LD
+                s_w2[u] = pr[2]; s_lm[u] = lm; paddr[u] = s.pa; caddr[u] = s.ca;
             };
-            uint4 pr = read_rec(0);  // record of the pass whose gathers are issued next
+            u32x8 pr = rq[0];  // record of the pass whose gathers are issued next
 #pragma unroll
             for (uint32_t p = 0; p < kD; ++p) {
-                const uint4 nx = read_rec(p + 1);
+                const u32x8 nx = rq[p + 1];
                 const Iss s = issue_reads(pr);
-                issue_gathers(p, s);
+                issue_gathers(p, s, pr);
                 pr = nx;
                 __builtin_amdgcn_sched_barrier(0);
             }
             for (uint32_t s0 = 0; s0 < SL; s0 += kD) {
+                const crec_t* const rt = rq + s0;  // (the records of this trip sit at constant offsets from here)
 #pragma unroll
                 for (uint32_t u = 0; u < kD; ++u) {
-                    const uint32_t si = s0 + u;
                     const uint32_t w2 = s_w2[u];
-                    const uint32_t np_r = w2 & 0xFFu, nc_r = (w2 >> 8) & 0xFFu;
+                    const uint64_t lm = s_lm[u];
+                    const uint32_t nu = (w2 >> 16) & 7u;
                     const uint32_t pa = paddr[u], ca = caddr[u];
                     // ---- all LDS reads of the iteration: this pass's predecessor records first (the only ones its own chain
-                    // waits for), its candidate record, then what the issue side of pass si + kD needs and the record behind it ----
+                    // waits for), its candidate record, then what the issue side of pass si + kD needs; and the record behind that ----
                     uint64_t kb[4];
                     kb[0] = *reinterpret_cast<lds_cu64*>(pa);
-                    if (np_r > 4u) {
+                    if (nu > 1u) {
                         kb[1] = *reinterpret_cast<lds_cu64*>(pa + 32u);
                         if constexpr (kUnits == 4)
-                            if (np_r > 8u) {
+                            if (nu > 2u) {
                                 kb[2] = *reinterpret_cast<lds_cu64*>(pa + 64u);
                                 kb[3] = *reinterpret_cast<lds_cu64*>(pa + 96u);
                             }
                     }
                     const uint32_t cy = *reinterpret_cast<lds_cu32*>(ca + 4u);  // byte offset of the candidate's slot record | word cost << 16
                     const Iss is = issue_reads(pr);
-                    const uint4 nrec = read_rec(si + kD + 1);
+                    const u32x8 nrec = rt[u + kD + 1];
                     // ---- the gathers of pass si have landed once at most those of the kD - 1 passes behind it are in flight ----
-                    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(word[u][0]), "+v"(word[u][1]), "+v"(word[u][kUnits - 2]), "+v"(word[u][kUnits - 1]) : "n"(kUnits * (kD - 1)));
+                    if constexpr (kUnits == 4)
+                        asm volatile("s_waitcnt vmcnt(%4)" : "+v"(word[u][0]), "+v"(word[u][1]), "+v"(word[u][kUnits - 2]), "+v"(word[u][kUnits - 1]) : "n"(kUnits * (kD - 1)));
+                    else
+                        asm volatile("s_waitcnt vmcnt(%2)" : "+v"(word[u][0]), "+v"(word[u][1]) : "n"(kUnits * (kD - 1)));
                     // ---- pass si ----
-                    if (np_r) {
-                        // (the minimum of a lane's phase starts at the maximum: reset when its step is done, below)
+                    if (nu) {
+                        // (the minimum of a lane's phase starts at the maximum: reset when its step is done, below; every unit before
+                        // the last is full, the last one holds a pair in the lanes lm -- lanes of candidates that do not exist are never read)
                         auto unit = [&](uint32_t i) {
                             const uint32_t nk_hi = (uint32_t)(kb[i] >> 32) + word[u][i < kUnits ? i : 0];  // wrapping i32 add of the connection cost (lattice.rs:139)
-                            const uint32_t nk_lo = (uint32_t)kb[i];                        // the predecessor's own field | right id
-                            uint64_t vm = kmask(np_r - 4u * i);
-                            if constexpr (kExact) vm &= __builtin_amdgcn_ballot_w64(nk_lo < 0xFFFF0000u);  // never inserted: field 0xFFFF
+                            const uint32_t nk_lo = (uint32_t)kb[i];                                         // the predecessor's own field | right id
                             const uint64_t nk = ((uint64_t)nk_hi << 32) | nk_lo, bk = ((uint64_t)best_hi << 32) | best_lo;
-                            const uint64_t lt = __builtin_amdgcn_ballot_w64(nk < bk) & vm;
+                            uint64_t lt = __builtin_amdgcn_ballot_w64(nk < bk) & (nu == i + 1u ? lm : ~0ull);
+                            if constexpr (kExact) lt &= __builtin_amdgcn_ballot_w64(nk_lo < 0xFFFF0000u);  // never inserted: field 0xFFFF
                             best_hi = sel(lt, best_hi, nk_hi);
                             best_lo = sel(lt, best_lo, nk_lo);
                         };
                         unit(0);
-                        if (np_r > 4u) {
+                        if (nu > 1u) {
                             unit(1);
                             if constexpr (kUnits == 4)
-                                if (np_r > 8u) {
+                                if (nu > 2u) {
                                     unit(2);
-                                    if (np_r > 12u) unit(3);
+                                    if (nu > 3u) unit(3);
                                 }
                         }
-                        if (w2 & 0x20000u) {
+                        if (w2 & 0x100000u) {
                             // the four phases of a candidate: minimum cost, then among the lanes that hold it the smallest field
                             // (= the last inserted predecessor), by two quad-permute levels each
                             const uint32_t m_hi = group_min_u32<2>(best_hi);
                             const uint32_t m_lo = group_min_u32<2>(best_hi == m_hi ? best_lo : 0xFFFFFFFFu);
                             best_hi = 0xFFFFFFFFu; best_lo = 0xFFFFFFFFu;
-                            if (fin_rank < nc_r) {
+                            if (__builtin_amdgcn_inverse_ballot_w64(lm & kPhase0)) {  // phase 0 of every candidate that exists
                                 const uint32_t sa = offK + (cy & 0xFFFFu);
                                 *reinterpret_cast<lds_u32*>(sa + 4u) = m_hi + (uint32_t)((int32_t)cy >> 16);  // + word cost (lattice.rs:125)
                                 if constexpr (kExact) *reinterpret_cast<lds_u16*>(sa + 2u) = (uint16_t)(fld0 - ((ca - offC) >> 3));  // inserted: its own field
@@ -1986,15 +1998,17 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     // ---- gathers of pass si + kD into the ring slot this pass has just left ----
-                    issue_gathers(u, is);
+                    issue_gathers(u, is, pr);
                     pr = nrec;
                 }
             }
             // the last gathers in flight are those of the empty passes (EXEC = 0: they retire at once): done before the ring's registers
             // go back to the compiler
 #pragma unroll
-            for (uint32_t u = 0; u < kD; ++u)
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(word[u][0]), "+v"(word[u][1]), "+v"(word[u][kUnits - 2]), "+v"(word[u][kUnits - 1]));
+            for (uint32_t u = 0; u < kD; ++u) {
+                if constexpr (kUnits == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(word[u][0]), "+v"(word[u][1]), "+v"(word[u][kUnits - 2]), "+v"(word[u][kUnits - 1]));
+                else asm volatile("s_waitcnt vmcnt(0)" : "+v"(word[u][0]), "+v"(word[u][1]));
+            }
         };
         if (exact) recurrence(std::true_type{}); else recurrence(std::false_type{});
         PROF_MARK(6);
@@ -2004,8 +2018,8 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
         auto node_pred = [&](uint32_t c) { return 0xFFFEu - (cnd[c].x & 0xFFFFu); };
         if (multi) {
             // leave (total cost, back pointer) of every node of the segment in the sentence's (dead) hit-staging region
-            uint2* __restrict__ nb = reinterpret_cast<uint2*>(A.g_hits + node0 + seg_c);
-            for (uint32_t c = ln; c < C; c += 64) nb[2 * c] = make_uint2(node_cost(c), node_pred(c));
+            uint2* __restrict__ nb = reinterpret_cast<uint2*>(A.g_hits + node0) + seg_c;
+            for (uint32_t c = ln; c < C; c += 64) nb[c] = make_uint2(node_cost(c), node_pred(c));
         }
         if (A.lid_count) {
             // Lattice::add_connid_counts (lattice.rs:170-183): for every inserted node r and every node l in
@@ -2016,7 +2030,7 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
             const uint32_t c_skip = counted >= nT ? CT : __builtin_amdgcn_readfirstlane(pcg[counted].x) & 0xFFFFu;  // candidates are in start order
             for (uint32_t k = 0; k < SL; ++k) {
                 const uint4 r = uniform4(*reinterpret_cast<const uint4*>(&rec[k]));
-                if (!(r.z & 0x40000u)) continue;  // one record per step: its first pass
+                if (!(r.z & 0x200000u)) continue;  // one record per step: its first pass
                 const uint32_t c_beg = (r.y - offC) >> 3, nc = r.w >> 16, np = r.w & 0xFFFFu;
                 const bool eos_step = last_seg && k >= eos_rec;
                 if (eos_step ? counted > nT : seg_c + c_beg < c_skip) continue;
@@ -2072,7 +2086,6 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
             return prev_end;
         };
         if (!multi) {
-            uint16_t* path = reinterpret_cast<uint16_t*>(rec);  // the pass records are dead now; tokens <= steps that have a pass
             // the walk along the back pointers is serial: lane 0, one LDS round trip per token
             if (ln == 0) {
                 uint32_t seq = node_pred(C);
@@ -2114,7 +2127,7 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
                     for (uint32_t c0 = lo; c0 < hi; c0 += 64 * 8) {
                         uint32_t v[8];
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) { const uint32_t c = c0 + u * 64 + ln; v[u] = c < hi ? nbg[2 * c].y : 0u; }
+                        for (int u = 0; u < 8; ++u) { const uint32_t c = c0 + u * 64 + ln; v[u] = c < hi ? nbg[c].y : 0u; }
 #pragma unroll
                         for (int u = 0; u < 8; ++u) { const uint32_t c = c0 + u * 64 + ln; if (c < hi) back[c - lo] = (uint16_t)v[u]; }
                     }
@@ -2143,7 +2156,7 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
                 o.start_char = stp; o.end_char = en;
                 o.start_byte = c2b[stp]; o.end_byte = c2b[en];
                 o.word_idx = r.z;
-                o.total_cost = (int32_t)nbg[2 * c].x;
+                o.total_cost = (int32_t)nbg[c].x;
                 A.tok_stage[slot0 + t] = o;
             }
         }

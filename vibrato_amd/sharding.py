@@ -1,9 +1,10 @@
 """Sentence sharding for multi-GPU runs: one process per GPU, each tokenizes an independent
 contiguous range of sentences (a Worker holds only per-sentence state, worker.rs:13-19, and the
 dictionary is immutable), so there is no data-path collective.  The only exchange is the final
-gather of the per-rank results, which stays device-resident: one padded `all_gather_into_tensor`
-(RCCL over xGMI when the backend is "nccl"; RCCL has no gatherv) of a buffer that carries the
-rank's totals, per-sentence token ranges and 24-byte token records."""
+gather of the per-rank results, which stays device-resident: every rank's padded slot -- its totals,
+per-sentence token ranges and 24-byte token records -- goes to the root (`gather_to_root`: grouped
+send/recv under RCCL over xGMI when the backend is "nccl"; RCCL has no gatherv) or, on request, to
+every rank (`gather_packed`: one `all_gather_into_tensor`)."""
 import numpy as np
 
 TOKEN_BYTES = 24
@@ -89,6 +90,24 @@ def gather_packed(send, world_out=None, group=None, async_op=False):
         parts = list(world_out.view(world, -1).unbind(0))
         work = dist.all_gather(parts, send, group=group, async_op=async_op)
     return world_out.view(world, -1), work
+
+
+def gather_to_root(send, root_out=None, root=0, group=None, async_op=False):
+    """The path's final exchange as a true GATHER (north star: "RCCL over xGMI only for the final gather"): every rank sends its
+    packed slot to `root` only -- grouped send/recv under RCCL, 1/world of the all-gather's inbound traffic per non-root rank, and
+    nothing at all lands on them.  `root_out` ([world * slot_bytes] uint8, device-resident) is needed on the root only.
+    Returns (out tensor [world, slot_bytes] on the root, None elsewhere; work or None)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    is_root = dist.get_rank(group) == root
+    parts = None
+    if is_root:
+        if root_out is None:
+            root_out = torch.empty(world * send.numel(), dtype=torch.uint8, device=send.device)
+        parts = list(root_out.view(world, -1).unbind(0))
+    work = dist.gather(send, parts, dst=root, group=group, async_op=async_op)
+    return (root_out.view(world, -1) if is_root else None), work
 
 
 def unpack_results(slot, max_sentences):
