@@ -735,7 +735,7 @@ __device__ __forceinline__ uint64_t process_sentence(const DevDict& D, const Bat
 // 4 predecessors x 16 candidates), keeps the minimum of its own phase in registers, and the four phases of a candidate are
 // combined with two quad-permute levels at the end of the step.  VBT_DEPTH = passes whose connection costs are in flight.
 #ifndef VBT_DEPTH
-#define VBT_DEPTH 6
+#define VBT_DEPTH 3
 #endif
 #ifndef VBT_LAT_WAVES
 #define VBT_LAT_WAVES 4
@@ -749,16 +749,23 @@ __device__ __forceinline__ uint64_t process_sentence(const DevDict& D, const Bat
 constexpr uint32_t kRoundPreds = VBT_ROUND_PREDS, kRoundCands = 16;  // (build knob: 8 or 16 predecessors = 2 or 4 units, i.e. gathers, per pass)
 static_assert(kRoundPreds == 8 || kRoundPreds == 16, "a pass walks 2 or 4 units of 4 predecessors");
 constexpr uint32_t kUnits = kRoundPreds / 4;
-// 32-byte pass record, built once per pass by the lane that owns the step, in the sentence's own region of GLOBAL memory (the dead
-// upper half of its hit-staging region) and read back by the sweep loop with scalar loads: everything that steers a pass arrives in
-// SGPRs, lane masks included, without a VALU or SALU instruction spent on it.
-//   w0 = LDS address of the slot record of the pass's first predecessor, w1 = LDS address of its first candidate's record,
-//   w2 = predecessors (<= 16) | candidates (<= 16) << 8 | units (1..4; 0: an empty pass) << 16 | last round of its candidates << 20
-//        | first pass of the step << 21,
-//   w3 = predecessors | candidates << 16 of the whole step (connection-id counting),
-//   cm = lanes (4 per candidate) of the candidates that exist, lm = the lanes of the LAST unit that hold a pair (cm & the phases
-//        4 i + k < predecessors); every unit before the last is full.
-struct alignas(32) LPass { uint32_t w0, w1, w2, w3; uint64_t cm, lm; };
+// 64-byte pass records, in the sentence's own region of GLOBAL memory (the dead upper half of its hit-staging region), read back by
+// the sweep loop with ONE scalar load per pass: everything that steers an iteration arrives in SGPRs, lane masks included, without
+// a VALU or SALU instruction spent on it.  The loop's software pipeline is baked into the data: iteration i issues the gathers of
+// pass i + VBT_DEPTH and consumes pass i, so record r holds the ISSUE half of pass r and the CONSUME half of pass r - VBT_DEPTH -- no
+// register rings for what an iteration needs of an older record.  Built once per pass by the lane that owns the step (two records
+// touched per pass).
+//   issue half:   w0 / w1 = LDS address of the slot record of the pass's first predecessor / of its first candidate's record;
+//                 m[i] = EXEC of unit i's gather: the lanes (4 per candidate) of the candidates that exist while a later unit follows,
+//                 the lanes that hold a pair as the last unit, 0 behind it
+//   consume half: w0c = the predecessor address of pass r - VBT_DEPTH;  w1c = its candidate address | its units (1..4; 0: an empty
+//                 pass) << 20 | first round of its candidates << 23 | last round << 24;  lm = the lanes of its LAST unit that hold a
+//                 pair (every unit before the last is full);  vm = the lanes that hold a pair in ANY unit of the step (phase <
+//                 predecessors, candidate exists): what the combine at the end of the step looks at
+// (what only the connection-id counting needs of a pass -- predecessors | first pass of the step << 15 | candidates << 16 of the
+// whole step -- sits in a u32 array behind the records)
+struct alignas(64) LPass { uint32_t w0, w1, w0c, w1c; uint64_t m[4]; uint64_t lm, vm; };
+static_assert(sizeof(LPass) == 64, "one s_load_dwordx16 per pass");
 __host__ __device__ __forceinline__ uint32_t step_passes(uint32_t nc, uint32_t np) {
     return ((np + kRoundPreds - 1) / kRoundPreds) * ((nc + kRoundCands - 1) / kRoundCands);
 }
@@ -1582,8 +1589,6 @@ template <bool kSpaceMode, bool kWide>
 __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const BatchArgs& A, uint32_t tier, uint32_t sid) {
     typedef __attribute__((address_space(3))) const uint64_t lds_cu64;
     typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
-    typedef __attribute__((address_space(3))) uint32_t lds_u32;
-    typedef __attribute__((address_space(3))) uint16_t lds_u16;
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     const uint32_t ln = threadIdx.x;
     const uint32_t lds_bytes = A.tier_bytes[tier];
@@ -1612,8 +1617,11 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
         // back pointer) of every node of a sentence that is swept in segments, its upper half the pass records of the current segment.
         const uint32_t nbT = (uint32_t)(uniform64(A.offsets[sid + 1]) - uniform64(A.offsets[sid]));
         const uint32_t half_bytes = 8u * A.node_factor * (nbT + kSentenceSlack);
-        LPass* const rec = reinterpret_cast<LPass*>(reinterpret_cast<char*>(A.g_hits + node0) + half_bytes);
-        const uint32_t rec_cap = half_bytes / (uint32_t)sizeof(LPass);
+        // (a sentence that is swept whole dumps nothing: its records take the whole region)
+        const bool whole = lattice_fixed_bytes(CT, nT, ET) <= lds_bytes && passesT + 3 * kD + 4 <= 2 * half_bytes / (uint32_t)(sizeof(LPass) + 4);
+        LPass* const rec = reinterpret_cast<LPass*>(reinterpret_cast<char*>(A.g_hits + node0) + (whole ? 0u : half_bytes));
+        const uint32_t rec_cap = (whole ? 2 * half_bytes : half_bytes) / (uint32_t)(sizeof(LPass) + 4);
+        uint32_t* const rec_w3 = reinterpret_cast<uint32_t*>(rec + rec_cap);  // per pass: step totals for the connection-id counting
         // where a dead predecessor's sentinel cost could meet a live cost, every predecessor's own field is tested instead (kDeadHi)
         const bool exact = kWide || nT >= 8000u;
         uint32_t seg_a = 0, seg_c = 0, seg_p = 0, sb = 0, m_in = 1, fail = 0;
@@ -1631,7 +1639,7 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
         while (!done) {
         uint32_t seg_b = nT, seg_pass = passesT - seg_p, wend = ET;
         // (pass records of a segment live in global memory: rec_cap of them, the empty ones behind the last included)
-        if (lattice_fixed_bytes(CT - seg_c, nT - seg_a, ET - sb) > budget || passesT - seg_p + 2 * kD + 4 > rec_cap) {
+        if (lattice_fixed_bytes(CT - seg_c, nT - seg_a, ET - sb) > budget || passesT - seg_p + 3 * kD + 4 > rec_cap) {
             // furthest admissible cut within 256 positions whose segment fits: any position a multiple of 8 behind the segment's
             // start (the bit-serial sweep below runs in groups of 8 positions) that does not follow a space (a visited space run and
             // the word it hands its visit to stay in one segment, tokenizer.rs:113-125)
@@ -1651,7 +1659,7 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
                 const uint32_t incl = wave_exscan(nsl, tot) + nsl + run;
                 const uint32_t est = b == nT ? passesT - seg_p : incl;  // (the sentence's bound includes the EOS step)
                 const uint32_t wsl = b == nT ? ET : we;
-                const bool fits = b <= nT && lattice_fixed_bytes((cx - seg_c) & 0xFFFFu, b - seg_a, wsl - sb) <= budget && est + 2 * kD + 4 <= rec_cap;
+                const bool fits = b <= nT && lattice_fixed_bytes((cx - seg_c) & 0xFFFFu, b - seg_a, wsl - sb) <= budget && est + 3 * kD + 4 <= rec_cap;
                 const uint64_t m = __ballot(fits && (b == nT || (!sp && ((ln + 1) & 7u) == 0)));
                 if (m) {
                     const uint32_t top = 63u - (uint32_t)__builtin_clzll(m);
@@ -1673,7 +1681,7 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
         const uint32_t C = ((rend.x & 0xFFFFu) - seg_c) & 0xFFFFu;
         const uint32_t E = wend - sb;  // slots of the window [eo(seg_a), wend); slot E is the EOS node's (last segment)
         if (E >= 8190u || m_in > E) {  // the candidate records hold a slot's byte offset (slot * 8) in 16 bits: a shorter segment, or the next tier / the fused kernel
-            if (budget > lds_bytes / 3) { budget -= lds_bytes / 4; __syncthreads(); continue; }
+            if (budget > lds_bytes / 3 && !whole) { budget -= lds_bytes / 4; __syncthreads(); continue; }  // (a sentence taken for whole keeps its records where a segmented one dumps its nodes: the next tier sweeps it)
             fail = 26; break;
         }
         const uint4* __restrict__ nd = ndg + seg_c;
@@ -1682,9 +1690,9 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
         (void)ar.take<uint2>(E + 2);              // e_rec: the slot records
         uint2* cnd = ar.take<uint2>(C + 2);       // per candidate: {first cell of its matrix row (low half: its back pointer, once inserted), byte offset of its slot record | word_cost << 16}
         uint16_t* path = ar.take<uint16_t>(n + 4);  // the token path of the back-trace (tokens <= positions)
-        const uint32_t sl_cap = rec_cap > 2 * kD + 4 ? rec_cap - (2 * kD + 2) : 0u;
+        const uint32_t sl_cap = rec_cap > 3 * kD + 4 ? rec_cap - (3 * kD + 2) : 0u;
         if (!ar.ok || sl_cap < 3) {  // the estimate was too low: try a shorter segment before giving up
-            if (budget > lds_bytes / 3) { budget -= lds_bytes / 4; __syncthreads(); continue; }
+            if (budget > lds_bytes / 3 && !whole) { budget -= lds_bytes / 4; __syncthreads(); continue; }  // (a sentence taken for whole keeps its records where a segmented one dumps its nodes: the next tier sweeps it)
             fail = 26; break;
         }
         const uint32_t offC = lds0 + (uint32_t)(reinterpret_cast<char*>(cnd) - g_smem);
@@ -1734,16 +1742,27 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
         bool windowed = true, overflow = false;
         uint64_t nx_w = 0;           // the state behind the segment's last position (committed at the hand-over: a segment may be retried shorter)
         uint32_t nx_cur = 0, nx_pend = 0;
-        // pass (candidate chunk k, round r) of a step (executed by the lane that owns the step)
-        auto make_pass = [&](uint32_t p_beg, uint32_t np, uint32_t c_beg, uint32_t nc, uint32_t k, uint32_t r, uint32_t rounds, uint32_t first) {
+        // pass P (candidate chunk k, round r of a step), written by the lane that owns the step: its issue half into record P, its
+        // consume half into record P + kD
+        auto put_pass = [&](uint32_t P, uint32_t p_beg, uint32_t np, uint32_t c_beg, uint32_t nc, uint32_t k, uint32_t r, uint32_t rounds, uint32_t first) {
             const uint32_t np_r = np - kRoundPreds * r < kRoundPreds ? np - kRoundPreds * r : kRoundPreds;
             const uint32_t nc_r = nc - kRoundCands * k < kRoundCands ? nc - kRoundCands * k : kRoundCands;
             const uint32_t nu = (np_r + 3u) >> 2, t = np_r - 4u * (nu - 1u);  // units, predecessors of the last one (1..4)
             const uint64_t cm = nc_r >= 16u ? ~0ull : (1ull << (4u * nc_r)) - 1ull;
             const uint32_t pat = t >= 4u ? 0xFFFFFFFFu : ((1u << t) - 1u) * 0x11111111u;  // phases below t, in every quad
-            return LPass{offK + ((p_beg + kRoundPreds * r) << 3), offC + ((c_beg + kRoundCands * k) << 3),
-                         np_r | (nc_r << 8) | (nu << 16) | (r + 1 == rounds ? 0x100000u : 0u) | (first ? 0x200000u : 0u), np | (nc << 16),
-                         cm, cm & (((uint64_t)pat << 32) | pat)};
+            const uint64_t lm = cm & (((uint64_t)pat << 32) | pat);
+            const uint32_t w0 = offK + ((p_beg + kRoundPreds * r) << 3), w1 = offC + ((c_beg + kRoundCands * k) << 3);
+            const uint32_t ps = np >= 4u ? 0xFFFFFFFFu : ((1u << np) - 1u) * 0x11111111u;  // phases that see a predecessor in some unit of the step
+            LPass& I = rec[P];
+            I.w0 = w0; I.w1 = w1;
+#pragma unroll
+            for (uint32_t i = 0; i < 4; ++i) I.m[i] = i + 1 < nu ? cm : (i + 1 == nu ? lm : 0ull);
+            rec_w3[P] = np | (first ? 0x8000u : 0u) | (nc << 16);
+            LPass& Cn = rec[P + kD];
+            Cn.w0c = w0;
+            Cn.w1c = w1 | (nu << 20) | (r == 0 ? 0x800000u : 0u) | (r + 1 == rounds ? 0x1000000u : 0u);
+            Cn.lm = lm;
+            Cn.vm = cm & (((uint64_t)ps << 32) | ps);
         };
         {
             uint64_t w = sw_w;
@@ -1804,7 +1823,7 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
                 if (SL + tot + 2 > sl_cap) overflow = true;
                 if (!overflow)
                     for (uint32_t q = 0, k = 0, r = 0; q < nsl; ++q) {
-                        rec[SL + ex + q] = make_pass(p_beg, np, c_beg, nc, k, r, rounds, q == 0);
+                        put_pass(SL + ex + q, p_beg, np, c_beg, nc, k, r, rounds, q == 0);
                         if (++r == rounds) { r = 0; ++k; }
                     }
                 SL += tot;
@@ -1822,19 +1841,27 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
             const uint32_t nsl = (np + kRoundPreds - 1) / kRoundPreds;
             if (SL + nsl + 2 > sl_cap) overflow = true;
             if (!overflow)
-                for (uint32_t q = ln; q < nsl; q += 64) rec[SL + q] = make_pass(p_beg, np, C, 1u, 0u, q, nsl, q == 0);
+                for (uint32_t q = ln; q < nsl; q += 64) put_pass(SL + q, p_beg, np, C, 1u, 0u, q, nsl, q == 0);
             eos_rec = SL;
             SL += nsl;
             ++S;
         } else if (sn_eos != n) { fail = 31; break; }  // cannot happen: no cut follows a space
         prof_SL += SL; prof_S += S;
         if (overflow || SL >= (1u << 18)) {  // more passes than estimated (gen_candidates bounds them per position)
-            if (budget > lds_bytes / 3) { budget -= lds_bytes / 4; __syncthreads(); continue; }
+            if (budget > lds_bytes / 3 && !whole) { budget -= lds_bytes / 4; __syncthreads(); continue; }  // (a sentence taken for whole keeps its records where a segmented one dumps its nodes: the next tier sweeps it)
             fail = 29; break;
         }
-        // empty passes behind the last one (no units, no lanes): the sweep loop runs in trips of kD passes and reads kD + 1 records
-        // ahead, i.e. up to record SL + 2 kD (whatever else lies there would be issued as gathers with garbage lane masks and indices)
-        if (ln < 2 * kD + 2) rec[SL + ln] = LPass{offK, offC, 0u, 0u, 0ull, 0ull};
+        // Empty passes behind the last one (no units, no lanes): the sweep loop runs in trips of kD passes and reads kD + 1 records
+        // ahead, i.e. up to record SL + 2 kD.  Their issue halves sit in the records [SL, SL + 2 kD + 2), their consume halves kD
+        // records further on (the consume halves in [SL, SL + kD) are those of the last kD real passes).
+        if (ln < 2 * kD + 2) {
+            LPass& I = rec[SL + ln];
+            I.w0 = offK; I.w1 = offC;
+#pragma unroll
+            for (uint32_t i = 0; i < 4; ++i) I.m[i] = 0ull;
+            LPass& Cn = rec[SL + kD + ln];
+            Cn.w0c = offK; Cn.w1c = offC; Cn.lm = 0ull; Cn.vm = 0ull;
+        }
         // the records are read back through the scalar cache: this wave's stores complete (workgroup scope: s_waitcnt vmcnt(0); the
         // vector L1 is write-through), then the scalar cache forgets whatever it holds of this region (an earlier segment's records)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1860,71 +1887,64 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
             constexpr uint64_t kPhase0 = 0x1111111111111111ull;  // the lanes that write a candidate's node: phase 0
             auto sel = [](uint64_t mask, uint32_t a, uint32_t b) { return __builtin_amdgcn_inverse_ballot_w64(mask) ? b : a; };  // bit ? b : a (v_cndmask on an SGPR mask)
             uint32_t word[kD][kUnits];      // VGPR ring: connection costs in flight (sign-extended), slot = pass % kD
-            uint32_t paddr[kD], caddr[kD];  // VGPR ring: LDS address of this lane's first predecessor record / of its candidate record
-            uint32_t s_w2[kD];              // SGPR rings: shape word of the pass, the lanes of its last unit
-            uint64_t s_lm[kD];
             uint32_t best_hi = 0xFFFFFFFFu, best_lo = 0xFFFFFFFFu;
-            // The pass records come through the scalar cache (s_load_dwordx8: constant address space).  The compiler treats such memory
+            // The pass records come through the scalar cache (s_load_dwordx16: constant address space).  The compiler treats such memory
             // as immutable, so the pointer is laundered behind the stores + s_dcache_inv above: no load of it can be moved in front of them.
-            typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
-            typedef __attribute__((address_space(4))) const u32x8 crec_t;
+            typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+            typedef __attribute__((address_space(4))) const u32x16 crec_t;
             uint64_t rbase = (uint64_t)reinterpret_cast<uintptr_t>(rec);
             rbase = uniform64(rbase);
             asm volatile("" : "+s"(rbase));
             const crec_t* const rq = reinterpret_cast<const crec_t*>(rbase);
             // issue side of a pass, part 1: this lane's addresses and the LDS reads the gathers need
-            struct Iss { uint32_t pa, ca, leftidx, lo[kUnits]; };
-            auto issue_reads = [&](const u32x8& pr) {
+            struct Iss { uint32_t leftidx, lo[kUnits]; };
+            auto issue_reads = [&](const u32x16& pr) {
                 Iss s;
-                s.pa = pr[0] + k8;
-                s.ca = pr[1] + cl8;
-                s.leftidx = *reinterpret_cast<lds_cu32*>(s.ca);
+                const uint32_t pa = pr[0] + k8, ca = pr[1] + cl8;
+                s.leftidx = *reinterpret_cast<lds_cu32*>(ca);
 #pragma unroll
-                for (uint32_t i = 0; i < kUnits; ++i) s.lo[i] = *reinterpret_cast<lds_cu32*>(s.pa + 32u * i);  // low half: right id of predecessor 4 i + k (garbage behind the list: masked below)
+                for (uint32_t i = 0; i < kUnits; ++i) s.lo[i] = *reinterpret_cast<lds_cu32*>(pa + 32u * i);  // low half: right id of predecessor 4 i + k (garbage behind the list: masked below)
                 return s;
             };
-            // part 2: the gathers into ring slot u.  Unit i runs under EXEC = cm while a later unit exists, = lm as the last one, = 0
-            // behind it: a load under EXEC = 0 moves nothing and writes no register, but it takes its place in vmcnt
-            // (tools/calib/exec0_vmcnt.hip: 128 000 of 128 000 trials on gfx950), so the count in flight stays static.  The empty passes
-            // behind the last one are never waited for: the counter is drained behind the loop, before the ring's registers go back to
-            // the compiler -- a load that lands late must not find its register reused (tools/check_ring_isa.py proves that on the
-            // compiled ISA).
-            auto issue_gathers = [&](uint32_t u, const Iss& s, const u32x8& pr) {
-                const uint32_t nu = (pr[2] >> 16) & 7u;
-                const uint64_t cm = ((uint64_t)pr[5] << 32) | pr[4], lm = ((uint64_t)pr[7] << 32) | pr[6];
+            // part 2: the gathers into ring slot u.  Unit i runs under the EXEC mask its record holds: the lanes of the candidates that
+            // exist while a later unit follows, the lanes that hold a pair as the last one, none behind it -- a load under EXEC = 0 moves
+            // nothing and writes no register, but it takes its place in vmcnt (tools/calib/exec0_vmcnt.hip: 128 000 of 128 000 trials on
+            // gfx950), so the count in flight stays static.  The empty passes behind the last one are never waited for: the counter is
+            // drained behind the loop, before the ring's registers go back to the compiler -- a load that lands late must not find its
+            // register reused (tools/check_ring_isa.py proves that on the compiled ISA).
+            auto issue_gathers = [&](uint32_t u, const Iss& s, const u32x16& pr) {
+                uint64_t m[kUnits];
                 uint32_t vo[kUnits];
 #pragma unroll
-                for (uint32_t i = 0; i < kUnits; ++i) vo[i] = (s.lo[i] & 0xFFFFu) + s.leftidx;
-#define VBT_LD(OP, I) OP " %[d" #I "], %[a" #I "], %[rs], 0 idxen\n\t"
+                for (uint32_t i = 0; i < kUnits; ++i) {
+                    m[i] = ((uint64_t)pr[5 + 2 * i] << 32) | pr[4 + 2 * i];
+                    vo[i] = (s.lo[i] & 0xFFFFu) + s.leftidx;
+                }
+#define VBT_LD(OP, I) "s_mov_b64 exec, %[m" #I "]\n\t" OP " %[d" #I "], %[a" #I "], %[rs], 0 idxen\n\t"
                 if constexpr (kUnits == 4) {
 #define VBT_GATHER(OP)                                                                                                        \
-                    asm volatile("s_cmp_gt_u32 %[nu], 1\n\ts_cselect_b64 exec, %[cm], %[lm]\n\t" VBT_LD(OP, 0)                  \
-                                 "s_cselect_b64 exec, %[lm], 0\n\ts_cmp_gt_u32 %[nu], 2\n\ts_cselect_b64 exec, %[cm], exec\n\t" VBT_LD(OP, 1) \
-                                 "s_cselect_b64 exec, %[lm], 0\n\ts_cmp_gt_u32 %[nu], 3\n\ts_cselect_b64 exec, %[cm], exec\n\t" VBT_LD(OP, 2) \
-                                 "s_cselect_b64 exec, %[lm], 0\n\t" VBT_LD(OP, 3) "s_mov_b64 exec, -1"                          \
+                    asm volatile(VBT_LD(OP, 0) VBT_LD(OP, 1) VBT_LD(OP, 2) VBT_LD(OP, 3) "s_mov_b64 exec, -1"                   \
                                  : [d0] "=&v"(word[u][0]), [d1] "=&v"(word[u][1]), [d2] "=&v"(word[u][kUnits - 2]), [d3] "=&v"(word[u][kUnits - 1]) \
                                  : [a0] "v"(vo[0]), [a1] "v"(vo[1]), [a2] "v"(vo[kUnits - 2]), [a3] "v"(vo[kUnits - 1]), [rs] "s"(rsrc),   \
-                                   [nu] "s"(nu), [cm] "s"(cm), [lm] "s"(lm) : "scc")
+                                   [m0] "s"(m[0]), [m1] "s"(m[1]), [m2] "s"(m[kUnits - 2]), [m3] "s"(m[kUnits - 1]))
                     if constexpr (kWide) VBT_GATHER("buffer_load_dword");
                     else VBT_GATHER("buffer_load_sshort");
 #undef VBT_GATHER
                 } else {
 #define VBT_GATHER(OP)                                                                                                        \
-                    asm volatile("s_cmp_gt_u32 %[nu], 1\n\ts_cselect_b64 exec, %[cm], %[lm]\n\t" VBT_LD(OP, 0)                  \
-                                 "s_cselect_b64 exec, %[lm], 0\n\t" VBT_LD(OP, 1) "s_mov_b64 exec, -1"                          \
+                    asm volatile(VBT_LD(OP, 0) VBT_LD(OP, 1) "s_mov_b64 exec, -1"                                               \
                                  : [d0] "=&v"(word[u][0]), [d1] "=&v"(word[u][1])                                               \
-                                 : [a0] "v"(vo[0]), [a1] "v"(vo[1]), [rs] "s"(rsrc), [nu] "s"(nu), [cm] "s"(cm), [lm] "s"(lm) : "scc")
+                                 : [a0] "v"(vo[0]), [a1] "v"(vo[1]), [rs] "s"(rsrc), [m0] "s"(m[0]), [m1] "s"(m[1]))
                     if constexpr (kWide) VBT_GATHER("buffer_load_dword");
                     else VBT_GATHER("buffer_load_sshort");
 #undef VBT_GATHER
                 }
 #undef VBT_LD
-                s_w2[u] = pr[2]; s_lm[u] = lm; paddr[u] = s.pa; caddr[u] = s.ca;
             };
-            u32x8 pr = rq[0];  // record of the pass whose gathers are issued next
+            u32x16 pr = rq[0];  // the record in hand: issue half of the pass whose gathers go out next, consume half of the pass kD before it
 #pragma unroll
             for (uint32_t p = 0; p < kD; ++p) {
-                const u32x8 nx = rq[p + 1];
+                const u32x16 nx = rq[p + 1];
                 const Iss s = issue_reads(pr);
                 issue_gathers(p, s, pr);
                 pr = nx;
@@ -1934,12 +1954,14 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
                 const crec_t* const rt = rq + s0;  // (the records of this trip sit at constant offsets from here)
 #pragma unroll
                 for (uint32_t u = 0; u < kD; ++u) {
-                    const uint32_t w2 = s_w2[u];
-                    const uint64_t lm = s_lm[u];
-                    const uint32_t nu = (w2 >> 16) & 7u;
-                    const uint32_t pa = paddr[u], ca = caddr[u];
-                    // ---- all LDS reads of the iteration: this pass's predecessor records first (the only ones its own chain
-                    // waits for), its candidate record, then what the issue side of pass si + kD needs; and the record behind that ----
+                    // iteration si = s0 + u: pr = record si + kD
+                    const uint32_t w2 = pr[3];
+                    const uint64_t lm = ((uint64_t)pr[13] << 32) | pr[12], vm = ((uint64_t)pr[15] << 32) | pr[14];
+                    const uint32_t nu = (w2 >> 20) & 7u;
+                    const uint32_t pa = pr[2] + k8, ca = (w2 & 0xFFFFFu) + cl8;
+                    // ---- all LDS reads of the iteration: what the issue side of pass si + kD needs, this pass's predecessor records, its
+                    // candidate record ----
+                    Iss is = issue_reads(pr);  // (first: the one place that waits for the record requested an iteration ago, with no LDS read in flight yet)
                     uint64_t kb[4];
                     kb[0] = *reinterpret_cast<lds_cu64*>(pa);
                     if (nu > 1u) {
@@ -1950,28 +1972,82 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
                                 kb[3] = *reinterpret_cast<lds_cu64*>(pa + 96u);
                             }
                     }
-                    const uint32_t cy = *reinterpret_cast<lds_cu32*>(ca + 4u);  // byte offset of the candidate's slot record | word cost << 16
-                    const Iss is = issue_reads(pr);
-                    const u32x8 nrec = rt[u + kD + 1];
+                    uint32_t cy = *reinterpret_cast<lds_cu32*>(ca + 4u);  // byte offset of the candidate's slot record | word cost << 16
                     // ---- the gathers of pass si have landed once at most those of the kD - 1 passes behind it are in flight ----
                     if constexpr (kUnits == 4)
                         asm volatile("s_waitcnt vmcnt(%4)" : "+v"(word[u][0]), "+v"(word[u][1]), "+v"(word[u][kUnits - 2]), "+v"(word[u][kUnits - 1]) : "n"(kUnits * (kD - 1)));
                     else
                         asm volatile("s_waitcnt vmcnt(%2)" : "+v"(word[u][0]), "+v"(word[u][1]) : "n"(kUnits * (kD - 1)));
+                    // Every LDS read of the iteration has to be back before the next pass record is requested: scalar loads and LDS reads
+                    // share one counter and return out of order with each other, so any later wait for LDS data would be a wait for the
+                    // scalar load as well -- its whole latency on the pass's chain.  (The reads were issued back to back: the last one is
+                    // a few cycles behind the first.)  Behind this point the iteration waits for nothing but the record itself, at the top
+                    // of the next one.
+                    if constexpr (kUnits == 4)
+                        asm volatile("" : "+v"(kb[0]), "+v"(kb[1]), "+v"(kb[2]), "+v"(kb[3]), "+v"(cy), "+v"(is.leftidx), "+v"(is.lo[0]), "+v"(is.lo[1]), "+v"(is.lo[kUnits - 2]), "+v"(is.lo[kUnits - 1]));
+                    else
+                        asm volatile("" : "+v"(kb[0]), "+v"(kb[1]), "+v"(cy), "+v"(is.leftidx), "+v"(is.lo[0]), "+v"(is.lo[1]));
+                    const u32x16 nrec = rt[u + kD + 1];
                     // ---- pass si ----
-                    if (nu) {
-                        // (the minimum of a lane's phase starts at the maximum: reset when its step is done, below; every unit before
-                        // the last is full, the last one holds a pair in the lanes lm -- lanes of candidates that do not exist are never read)
-                        auto unit = [&](uint32_t i) {
-                            const uint32_t nk_hi = (uint32_t)(kb[i] >> 32) + word[u][i < kUnits ? i : 0];  // wrapping i32 add of the connection cost (lattice.rs:139)
-                            const uint32_t nk_lo = (uint32_t)kb[i];                                         // the predecessor's own field | right id
-                            const uint64_t nk = ((uint64_t)nk_hi << 32) | nk_lo, bk = ((uint64_t)best_hi << 32) | best_lo;
-                            uint64_t lt = __builtin_amdgcn_ballot_w64(nk < bk) & (nu == i + 1u ? lm : ~0ull);
-                            if constexpr (kExact) lt &= __builtin_amdgcn_ballot_w64(nk_lo < 0xFFFF0000u);  // never inserted: field 0xFFFF
-                            best_hi = sel(lt, best_hi, nk_hi);
-                            best_lo = sel(lt, best_lo, nk_lo);
+                    // the four phases of a candidate: minimum cost over the lanes that saw a predecessor, then among the lanes that hold
+                    // it the smallest field (= the last inserted predecessor), by two quad-permute levels each; phase 0 adds the word
+                    // cost and writes the node
+                    auto finish_step = [&](uint32_t b_hi, uint32_t b_lo, uint64_t seen) {
+                        const uint32_t v_hi = sel(seen, 0xFFFFFFFFu, b_hi);
+                        const uint32_t m_hi = group_min_u32<2>(v_hi);
+                        const uint32_t m_lo = group_min_u32<2>(v_hi == m_hi ? b_lo : 0xFFFFFFFFu);
+                        // phase 0 of every candidate that exists writes: the node's cost into its slot record (+ word cost, lattice.rs:125),
+                        // the winner's field as its back pointer (the low half of its candidate record) and, where dead predecessors are told
+                        // by their field, its own field.  Inline assembly under an EXEC mask rather than a divergent `if`: with no
+                        // divergent branch in the loop the compiler leaves its (all wave-uniform) control flow alone.
+                        const uint64_t fm = vm & kPhase0;
+                        const uint32_t sa = offK + (cy & 0xFFFFu);
+                        const uint32_t cost = m_hi + (uint32_t)((int32_t)cy >> 16);
+                        if constexpr (kExact) {
+                            const uint32_t own = fld0 - ((ca - offC) >> 3);
+                            asm volatile("s_mov_b64 exec, %[m]\n\tds_write_b32 %[a], %[v] offset:4\n\tds_write_b16 %[a], %[o] offset:2\n\t"
+                                         "ds_write_b16_d16_hi %[c], %[b]\n\ts_mov_b64 exec, -1"
+                                         :: [m] "s"(fm), [a] "v"(sa), [v] "v"(cost), [o] "v"(own), [c] "v"(ca), [b] "v"(m_lo) : "memory");
+                        } else {
+                            asm volatile("s_mov_b64 exec, %[m]\n\tds_write_b32 %[a], %[v] offset:4\n\tds_write_b16_d16_hi %[c], %[b]\n\ts_mov_b64 exec, -1"
+                                         :: [m] "s"(fm), [a] "v"(sa), [v] "v"(cost), [c] "v"(ca), [b] "v"(m_lo) : "memory");
+                        }
+                    };
+                    if ((w2 >> 20) == (1u | 8u | 16u)) {
+                        // The common step -- at most 4 predecessors, at most 16 candidates: one unit that starts and ends the step -- straight
+                        // through: add the connection cost, combine the phases, write the nodes.
+                        const uint32_t hi = (uint32_t)(kb[0] >> 32) + word[u][0], lo = (uint32_t)kb[0];
+                        uint64_t seen = vm;
+                        if constexpr (kExact) seen &= __builtin_amdgcn_ballot_w64(lo < 0xFFFF0000u);
+                        finish_step(hi, lo, seen);
+                    } else if (nu) {
+                        // A lane keeps the 64-bit minimum (cost, field) over the predecessors of its phase.  The first unit of a step's first
+                        // round starts it in every lane -- a lane whose phase sees no predecessor in the whole step holds garbage until the
+                        // combine at the end of the step masks it (vm) -- so nothing is reset in between; every unit before the last is
+                        // full, the last one holds a pair in the lanes lm.
+                        auto pair = [&](uint32_t i, uint32_t& hi, uint32_t& lo, uint64_t& alive) {
+                            hi = (uint32_t)(kb[i] >> 32) + word[u][i < kUnits ? i : 0];  // wrapping i32 add of the connection cost (lattice.rs:139)
+                            lo = (uint32_t)kb[i];                                         // the predecessor's own field | right id
+                            alive = ~0ull;
+                            if constexpr (kExact) alive = __builtin_amdgcn_ballot_w64(lo < 0xFFFF0000u);  // never inserted: field 0xFFFF
                         };
-                        unit(0);
+                        auto unit = [&](uint32_t i) {
+                            uint32_t hi, lo;
+                            uint64_t alive;
+                            pair(i, hi, lo, alive);
+                            const uint64_t nk = ((uint64_t)hi << 32) | lo, bk = ((uint64_t)best_hi << 32) | best_lo;
+                            uint64_t lt = __builtin_amdgcn_ballot_w64(nk < bk) & (nu == i + 1u ? lm : ~0ull);
+                            if constexpr (kExact) lt &= alive;
+                            best_hi = sel(lt, best_hi, hi);
+                            best_lo = sel(lt, best_lo, lo);
+                        };
+                        if (w2 & 0x800000u) {
+                            uint32_t hi, lo;
+                            uint64_t alive;
+                            pair(0, hi, lo, alive);
+                            if constexpr (kExact) { best_hi = sel(alive, 0xFFFFFFFFu, hi); best_lo = sel(alive, 0xFFFFFFFFu, lo); }
+                            else { best_hi = hi; best_lo = lo; }
+                        } else unit(0);
                         if (nu > 1u) {
                             unit(1);
                             if constexpr (kUnits == 4)
@@ -1980,19 +2056,7 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
                                     if (nu > 3u) unit(3);
                                 }
                         }
-                        if (w2 & 0x100000u) {
-                            // the four phases of a candidate: minimum cost, then among the lanes that hold it the smallest field
-                            // (= the last inserted predecessor), by two quad-permute levels each
-                            const uint32_t m_hi = group_min_u32<2>(best_hi);
-                            const uint32_t m_lo = group_min_u32<2>(best_hi == m_hi ? best_lo : 0xFFFFFFFFu);
-                            best_hi = 0xFFFFFFFFu; best_lo = 0xFFFFFFFFu;
-                            if (__builtin_amdgcn_inverse_ballot_w64(lm & kPhase0)) {  // phase 0 of every candidate that exists
-                                const uint32_t sa = offK + (cy & 0xFFFFu);
-                                *reinterpret_cast<lds_u32*>(sa + 4u) = m_hi + (uint32_t)((int32_t)cy >> 16);  // + word cost (lattice.rs:125)
-                                if constexpr (kExact) *reinterpret_cast<lds_u16*>(sa + 2u) = (uint16_t)(fld0 - ((ca - offC) >> 3));  // inserted: its own field
-                                *reinterpret_cast<lds_u16*>(ca) = (uint16_t)(m_lo >> 16);  // back pointer: the winner's field
-                            }
-                        }
+                        if (w2 & 0x1000000u) finish_step(best_hi, best_lo, vm);
                     }
                     // LDS operations of one wave execute in order: a compiler-level fence is all the next pass needs
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -2029,9 +2093,10 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
             // fused kernel never counts a step twice.
             const uint32_t c_skip = counted >= nT ? CT : __builtin_amdgcn_readfirstlane(pcg[counted].x) & 0xFFFFu;  // candidates are in start order
             for (uint32_t k = 0; k < SL; ++k) {
-                const uint4 r = uniform4(*reinterpret_cast<const uint4*>(&rec[k]));
-                if (!(r.z & 0x200000u)) continue;  // one record per step: its first pass
-                const uint32_t c_beg = (r.y - offC) >> 3, nc = r.w >> 16, np = r.w & 0xFFFFu;
+                const uint32_t w3 = __builtin_amdgcn_readfirstlane(rec_w3[k]);
+                if (!(w3 & 0x8000u)) continue;  // one record per step: its first pass
+                const uint4 r = make_uint4(__builtin_amdgcn_readfirstlane(rec[k].w0), __builtin_amdgcn_readfirstlane(rec[k].w1), 0u, 0u);
+                const uint32_t c_beg = (r.y - offC) >> 3, nc = w3 >> 16, np = w3 & 0x7FFFu;
                 const bool eos_step = last_seg && k >= eos_rec;
                 if (eos_step ? counted > nT : seg_c + c_beg < c_skip) continue;
                 uint32_t p_beg = (r.x - offK) >> 3, p_end = p_beg + np;
@@ -2628,7 +2693,7 @@ Workspace::Workspace(const Tokenizer& t, uint64_t max_s, uint64_t max_b) : tok(t
     // LDS tiers (bytes per wave), ascending; the global-memory tier always follows
     {
         const char* e = std::getenv("VBT_TIERS");
-        std::string spec = e && *e ? e : (fused ? "16384,32768,65536" : env_u32("VBT_SEG_BYTES", 10240) ? "10240,49152,163840" : "8192,12288,16384,24576,32768,49152,65536,163840");
+        std::string spec = e && *e ? e : (fused ? "16384,32768,65536" : env_u32("VBT_SEG_BYTES", 8192) ? "8192,49152,163840" : "8192,12288,16384,24576,32768,49152,65536,163840");
         size_t pos = 0;
         while (pos < spec.size()) {
             size_t c = spec.find(',', pos);
@@ -2743,7 +2808,7 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
     a.lists = d_over; a.list_stride = (uint32_t)stride; a.n_tiers = (uint32_t)T;
     a.tier_prio = env_u32("VBT_TIER_PRIO", 3);
     {   // tier whose waves sweep longer sentences segment by segment (VBT_SEG_BYTES=0: off, sentences use the big tiers)
-        const uint32_t seg_bytes = env_u32("VBT_SEG_BYTES", 10240);
+        const uint32_t seg_bytes = env_u32("VBT_SEG_BYTES", 8192);
         a.seg_tier = 0xFFFFFFFFu;
         if (seg_bytes)
             for (size_t t = 0; t < T; ++t)
