@@ -572,7 +572,7 @@ def _worker_records(worker, text, offs):
 
 @pytest.mark.parametrize("ignore_space", [False, True])
 def test_worker_single_launch_path_matches_oracle(ignore_space):
-    """Worker::tokenize is ONE launch per sentence (Workspace::run_one): mixed lengths (short ones whole, 150+ characters in
+    """Worker::tokenize is served by a resident kernel (Workspace::serve): mixed lengths (short ones whole, 150+ characters in
     segments, 1000+ characters beyond the single wavefront's generator arrays or not), spaces, user lexicon -- every record equal to
     the oracle's, and the sentences the single launch cannot take come back through the batch pipeline with the same records."""
     sd = synth.SynthDict("small")
@@ -604,13 +604,53 @@ def test_worker_loop_benchmark_counts_tokens():
     to, tv = _oracle_and_product(sd)
     text, offs = sd.sentences(500, "lognormal_40")
     exp_tok, _ = to.new_worker().tokenize_batch(text, offs)
-    for spin in ("1", "0"):
-        os.environ["VBT_WORKER_SPIN"] = spin
+    # the resident kernel (default), one launch per call (the round-3 form), and a kernel that leaves after every few polls, so that
+    # calls keep finding it gone or on its way out (the doorbell / "has left" handshake)
+    for polls in (None, "0", "3"):
+        if polls is not None:
+            os.environ["VBT_WORKER_IDLE_POLLS"] = polls
         try:
             r = tv.new_worker().loop_benchmark(text, offs, rounds=2)
         finally:
-            del os.environ["VBT_WORKER_SPIN"]
+            os.environ.pop("VBT_WORKER_IDLE_POLLS", None)
         assert r["tokens"] == 2 * len(exp_tok) and r["us_per_call"] > 0
+
+
+def test_worker_resident_kernel_handshake_under_pauses():
+    """A Worker whose resident kernel leaves quickly (VBT_WORKER_IDLE_POLLS=3) with pauses between the calls -- some calls find the
+    kernel resident, some find it gone, some catch it leaving -- and a second Worker interleaved with it and with batch calls (which
+    allocate and free device memory, i.e. synchronise the device): every record equals the oracle's."""
+    import time
+    sd = synth.SynthDict("small")
+    to, tv = _oracle_and_product(sd)
+    text, offs = sd.sentences(300, "lognormal_40")
+    exp_tok, exp_off = to.new_worker().tokenize_batch(text, offs)
+    exp = np.stack([exp_tok[f].astype(np.int64) for f in V.TOKEN_DTYPE.names], axis=1)
+    os.environ["VBT_WORKER_IDLE_POLLS"] = "3"
+    try:
+        w1 = tv.new_worker()
+    finally:
+        os.environ.pop("VBT_WORKER_IDLE_POLLS", None)
+    w2 = tv.new_worker()
+    raw = bytes(text)
+    got1, got2 = [], []
+    for i in range(300):
+        sent = raw[int(offs[i]):int(offs[i + 1])]
+        for w, out in ((w1, got1), (w2, got2)):
+            w.reset_sentence(sent)
+            w.tokenize()
+            for k in range(w.num_tokens()):
+                t = w.token(k)
+                out.append((t.range_char[0], t.range_char[1], t.range_byte[0], t.range_byte[1], (t.lex_type << 30) | t.word_id, t.total_cost))
+        if i % 7 == 0:
+            time.sleep(0.0005 * (i % 5))
+        if i % 50 == 0:
+            b = tv.tokenize_batch(text=text[:int(offs[20])], offsets=offs[:21])
+            assert b.total_tokens() == int(exp_off[20])
+    for got in (got1, got2):
+        assert np.array_equal(np.array(got, dtype=np.int64).reshape(-1, 6), exp)
+    f1, s1 = w1.path_stats()
+    assert f1 == sum(1 for i in range(300) if offs[i + 1] > offs[i]) and s1 == 0
 
 
 @pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0]])

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Static check of the sweep kernel's gather ring in the compiled ISA (CPU only; also run by the CPU test suite).
 
-lattice_sentence issues its connection-cost gathers as inline assembly (engine.hip: `issue_gathers`) and waits for them with a
+lattice_sentence issues its connection-cost gathers as inline assembly (lattice.hip: `issue_gathers`) and waits for them with a
 hand-placed `s_waitcnt vmcnt(N)`, so the compiler does not know that the destination registers are written asynchronously.
 That is only sound if, between a gather and the instruction that consumes its result, nothing touches the destination
 register: no copy (register allocation splitting a live range), no spill, no reuse.  This script proves exactly that on
@@ -12,7 +12,7 @@ the assembly hipcc emits:
   at which G has provably landed (at least N inline gathers were issued behind G: loads return in order), or is the next
   gather into the same ring slot.
 
-usage: python tools/check_ring_isa.py [engine.s]      (without an argument: compiles engine.hip to assembly first)
+usage: python tools/check_ring_isa.py [lattice.s]      (without an argument: compiles lattice.hip to assembly first)
 """
 import os
 import re
@@ -21,7 +21,7 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNELS = ("lattice_lds", "tokenize_one")
+KERNELS = ("lattice_lds", "tokenize_serve")
 
 
 def mentions(text, reg):
@@ -123,7 +123,7 @@ def main():
     else:
         with tempfile.TemporaryDirectory() as d:
             out = os.path.join(d, "engine.s")
-            src = os.path.join(ROOT, "vibrato_amd", "csrc", "engine.hip")
+            src = os.path.join(ROOT, "vibrato_amd", "csrc", "lattice.hip")
             subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", "-S",
                                    "--cuda-device-only", "-o", out, "-x", "hip", src], stderr=subprocess.DEVNULL)
             asm = open(out).read()

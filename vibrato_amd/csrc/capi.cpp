@@ -154,23 +154,35 @@ struct vbt_worker {
     void* d_text = nullptr;
     uint64_t* d_offsets = nullptr;
     size_t cap = 0;  // bytes the workspace, d_text and the pinned block below hold
-    // latency path (Workspace::run_one): one pinned host block {text, padded to 16 | status, count | token records}, read and
-    // written by the kernel directly, and the worker's own stream
+    // latency path (Workspace::serve): one pinned host block {text, padded to 16 | 16 control words | token records}, read and written
+    // by a resident kernel directly (tokenize_serve in engine.hip: control word layout), and the worker's own stream, which that
+    // kernel occupies while it is resident
     void* h_block = nullptr;
     uint8_t* h_text = nullptr;
-    uint32_t* h_ctl = nullptr;  // [0] status, [1] token count
+    uint32_t* h_ctl = nullptr;  // kernel: [0] sequence served, [1] token count, [2] has left, [3] outcome; host: [4] doorbell, [5] bytes, [6] leave now
     vbt_token_rec* h_tokens = nullptr;
     uint8_t* hd_text = nullptr;  // device addresses of the same
     uint32_t* hd_ctl = nullptr;
     vbt_token_rec* hd_tokens = nullptr;
     hipStream_t stream = nullptr;
-    int spin = -1;  // wait for the status word in pinned memory instead of the stream's completion signal (VBT_WORKER_SPIN, default 1)
-    int single = 1;  // VBT_WORKER_SINGLE=0: every sentence through the batch pipeline (round-2 behaviour, kept for A/B)
-    uint64_t n_fast = 0, n_slow = 0;  // sentences served by the single launch / handed to the batch pipeline
+    int single = -1;   // VBT_WORKER_SINGLE=0: every sentence through the batch pipeline (round-2 behaviour, kept for A/B)
+    uint32_t idle_polls = 2000;  // VBT_WORKER_IDLE_POLLS: polls without a call after which the resident kernel leaves (~2 ms); 0 = one launch per call (round 3)
+    uint32_t seq = 0;       // sequence number of the last call handed to the kernel
+    bool serving = false;   // a resident kernel was started and has not been seen to leave
+    uint64_t n_fast = 0, n_slow = 0, n_launches = 0;  // sentences served by the resident kernel / handed to the batch pipeline; kernels started
+    // Tells a resident kernel to leave and waits for it (before the stream or the buffers it uses are touched by anything else).
+    void stop_serving() {
+        if (!serving) return;
+        __atomic_store_n(&h_ctl[6], 1u, __ATOMIC_RELEASE);
+        (void)hipStreamSynchronize(stream);
+        h_ctl[6] = 0; h_ctl[2] = 0;
+        serving = false;
+    }
     std::vector<vbt_token_rec> tokens;
     // ConnIdCounter of Worker::init_connid_counter (worker.rs:77-84, mapper.rs:87-106); empty = never initialised
     std::vector<uint64_t> lid_count, rid_count;
     void release() {
+        stop_serving();
         ws.reset();
         (void)hipFree(d_text); (void)hipFree(d_offsets);
         if (h_block) (void)hipHostFree(h_block);
@@ -591,9 +603,11 @@ int vbt_worker_reset_sentence(vbt_worker* w, const char* utf8, size_t len) {
     });
 }
 
-// Worker::tokenize (worker.rs:49-55).  One launch per sentence (Workspace::run_one): the kernel reads the text from the worker's
-// pinned block and writes the token records back into it; steady state allocates nothing and issues no copy.  Sentences the
-// single wavefront cannot take (status 1) and workers that count connection ids go through the batch pipeline.
+// Worker::tokenize (worker.rs:49-55).  No launch per sentence: a resident kernel (Workspace::serve / tokenize_serve) reads the text
+// from the worker's pinned block when the doorbell rings and writes the token records back into it; steady state allocates nothing,
+// launches nothing and issues no copy.  The kernel leaves after ~2 ms without a call (it must not sit on the GPU of an idle
+// process: anything that synchronises the device would wait for it) and is started again by the next call.  Sentences the single
+// wavefront cannot take (outcome 1) and workers that count connection ids go through the batch pipeline.
 int vbt_worker_tokenize(vbt_worker* w) {
     return guarded([&] {
         if (!w) throw Error(VBT_ERR_INVALID_ARGUMENT, "null argument");
@@ -603,14 +617,13 @@ int vbt_worker_tokenize(vbt_worker* w) {
         if (len >= 0xFFFFFFF0ull) throw Error(VBT_ERR_INVALID_ARGUMENT, "sentence too large");
         HIPX(hipSetDevice(w->tok->t->device()));
         if (!w->ws || w->cap < len) {
-            if (w->stream) HIPX(hipStreamSynchronize(w->stream));
-            w->release();
+            w->release();  // (stops a resident kernel first)
             const size_t cap = (std::max<size_t>(len * 2, 4096) + 15) & ~(size_t)15;
             w->ws = std::make_unique<Workspace>(*w->tok->t, 1, cap);
             if (!w->lid_count.empty()) w->ws->enable_connid_counts(true);
             HIPX(hipMalloc(&w->d_text, cap + 16));
             HIPX(hipMalloc(reinterpret_cast<void**>(&w->d_offsets), 16));
-            const size_t ctl_off = cap, tok_off = cap + 16;
+            const size_t ctl_off = cap, tok_off = cap + 64;
             HIPX(hipHostMalloc(&w->h_block, tok_off + (cap + 2) * sizeof(vbt_token_rec), hipHostMallocDefault));
             void* dev = nullptr;
             HIPX(hipHostGetDevicePointer(&dev, w->h_block, 0));
@@ -620,12 +633,14 @@ int vbt_worker_tokenize(vbt_worker* w) {
             w->hd_text = static_cast<uint8_t*>(dev);
             w->hd_ctl = reinterpret_cast<uint32_t*>(w->hd_text + ctl_off);
             w->hd_tokens = reinterpret_cast<vbt_token_rec*>(w->hd_text + tok_off);
+            std::memset(w->h_ctl, 0, 64);
+            w->h_ctl[0] = w->h_ctl[4] = w->seq;
             if (!w->stream) HIPX(hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking));
-            if (w->spin < 0) {
-                const char* e = std::getenv("VBT_WORKER_SPIN");
-                w->spin = e && *e ? std::atoi(e) : 1;
-                e = std::getenv("VBT_WORKER_SINGLE");
+            if (w->single < 0) {
+                const char* e = std::getenv("VBT_WORKER_SINGLE");
                 w->single = e && *e ? std::atoi(e) : 1;
+                e = std::getenv("VBT_WORKER_IDLE_POLLS");
+                if (e && *e) w->idle_polls = (uint32_t)std::strtoul(e, nullptr, 10);
             }
             w->cap = cap;
         }
@@ -633,24 +648,43 @@ int vbt_worker_tokenize(vbt_worker* w) {
         if (!counting && !w->ws->fused && w->single) {
             std::memcpy(w->h_text, w->text.data(), len);
             volatile uint32_t* ctl = w->h_ctl;
-            ctl[0] = 0xFFFFFFFFu; ctl[1] = 0;
-            w->ws->run_one(w->hd_text, (uint32_t)len, static_cast<uint8_t*>(w->d_text), w->d_offsets, w->hd_tokens, w->hd_ctl + 1, w->hd_ctl, w->stream);
+            const uint32_t seq = ++w->seq;
+            ctl[5] = (uint32_t)len;
+            __atomic_store_n(&w->h_ctl[4], seq, __ATOMIC_RELEASE);  // the doorbell: behind the text and its length
+            auto start = [&] {  // a kernel that serves from sequence number seq on
+                w->h_ctl[2] = 0;
+                w->ws->serve(w->hd_text, static_cast<uint8_t*>(w->d_text), w->d_offsets, w->hd_tokens, w->hd_ctl, seq - 1, w->idle_polls, w->stream);
+                w->serving = true;
+                ++w->n_launches;
+            };
+            if (!w->serving) start();
+            // the kernel's last store (system-scope release) is the status word; a kernel that left for idleness just before the doorbell
+            // rang raises ctl[2] instead: wait for it to be gone, start another
             bool seen = false;
-            if (w->spin) {  // the kernel's last store (system-scope release) is the status word
-                for (uint32_t it = 0; it < (1u << 22) && !seen; ++it) seen = __atomic_load_n(&w->h_ctl[0], __ATOMIC_ACQUIRE) != 0xFFFFFFFFu;
+            for (uint32_t spins = 0; !seen; ++spins) {
+                seen = __atomic_load_n(&w->h_ctl[0], __ATOMIC_ACQUIRE) == seq;
+                if (seen) break;
+                if (__atomic_load_n(&w->h_ctl[2], __ATOMIC_ACQUIRE) == 1u) {
+                    HIPX(hipStreamSynchronize(w->stream));
+                    w->serving = false;
+                    if (__atomic_load_n(&w->h_ctl[0], __ATOMIC_ACQUIRE) == seq) { seen = true; break; }  // (served on its way out)
+                    start();
+                } else if (spins > (1u << 26)) {  // (seconds: a kernel that never answers)
+                    w->stop_serving();
+                    throw Error(VBT_ERR_DEVICE, "worker: the resident tokenize kernel did not report back");
+                }
             }
-            if (!seen) HIPX(hipStreamSynchronize(w->stream));
-            const uint32_t status = __atomic_load_n(&w->h_ctl[0], __ATOMIC_ACQUIRE);
-            if (status == 0) {
+            if (w->idle_polls == 0) { HIPX(hipStreamSynchronize(w->stream)); w->serving = false; }  // (one launch per call: it has left)
+            const uint32_t outcome = w->h_ctl[3];
+            if (outcome == 0) {
                 const uint32_t cnt = w->h_ctl[1];
                 if (cnt > len) throw Error(VBT_ERR_INVALID_STATE, "worker: token count exceeds the sentence");
                 w->tokens.assign(w->h_tokens, w->h_tokens + cnt);
                 ++w->n_fast;
                 return;
             }
-            if (seen) HIPX(hipStreamSynchronize(w->stream));  // the batch pipeline reuses the workspace's buffers
-            if (status == 0xFFFFFFFFu) throw Error(VBT_ERR_DEVICE, "worker: the tokenize kernel did not report back");
         }
+        w->stop_serving();  // the batch pipeline uses the worker's stream and workspace
         ++w->n_slow;
         const uint64_t offs[2] = {0, len};
         HIPX(hipMemcpy(w->d_text, w->text.data(), len, hipMemcpyHostToDevice));

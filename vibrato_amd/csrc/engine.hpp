@@ -133,12 +133,13 @@ class Workspace {
     void run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n, uint64_t total_bytes, void* stream, bool defer_pack = false);
     void pack_to(vbt_token_rec* out_tokens, uint32_t* out_off, uint32_t* out_cnt, void* stream);
     void stats(vbt_call_stats* out);  // synchronizes the last stream used
-    // Worker::tokenize() latency path: one sentence of `nb` bytes at `h_text_dev` (device address of pinned host memory, padded to
-    // 16 bytes), ONE launch; `d_text` (>= nb + 16 bytes) / `d_offsets` (2 words) are device scratch of the caller; the token records,
-    // their count and a status word (0 = done, 1 = take the batch pipeline) are written through `tokens_out` / `count_out` /
-    // `status_out` (device addresses of pinned host memory).  Asynchronous on `stream`.
-    void run_one(const uint8_t* h_text_dev, uint32_t nb, uint8_t* d_text, uint64_t* d_offsets, vbt_token_rec* tokens_out, uint32_t* count_out,
-                 uint32_t* status_out, void* stream);
+    // Worker::tokenize() latency path: starts the resident kernel that serves one Worker out of its pinned host block (`h_text_dev`:
+    // device address of the block's text area, padded to 16 bytes; `ctl`: device address of its control words, see tokenize_serve in
+    // engine.hip; `tokens_out`: device address of its token records).  `d_text` (>= capacity + 16 bytes) / `d_offsets` (2 words) are
+    // device scratch of the caller.  `last_seq`: the sequence number already served; `idle_polls`: polls without work after which the
+    // kernel leaves (0: one sentence, then out).  Asynchronous on `stream`, which the kernel occupies until it leaves.
+    void serve(const uint8_t* h_text_dev, uint8_t* d_text, uint64_t* d_offsets, vbt_token_rec* tokens_out, uint32_t* ctl, uint32_t last_seq,
+               uint32_t idle_polls, void* stream);
 
     const Tokenizer& tok;
     uint64_t max_sentences, max_bytes;

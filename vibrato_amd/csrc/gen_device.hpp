@@ -1,0 +1,303 @@
+// gen_one: Sentence::compile + candidate enumeration of ONE sentence by ONE wavefront (the body of the bulk generator kernel in
+// gen.hip and of the resident Worker kernel in lattice.hip).
+#pragma once
+#include "device_common.hpp"
+
+namespace vbt {
+namespace {
+
+// Kernel 1 body: Sentence::compile + candidate enumeration of one sentence by one wavefront.
+// Per-character working arrays live in LDS (the vector L1 stalls on hit-under-miss, so nothing
+// is re-read from global while in flight); outputs: per-char records, byte offsets and the
+// candidates in reference insertion order, each tagged with its (start position, left_id) group:
+// search_min_node's result depends only on that pair (lattice.rs:129-151), so the lattice kernel
+// evaluates one row per group instead of one per candidate.
+// (Sentences that outgrow this wavefront's LDS -- ~26 bytes per character -- are handed to gen_long: one workgroup per sentence.)
+__device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, uint32_t sid, uint32_t lds_bytes) {
+    const uint32_t ln = threadIdx.x;
+    const uint64_t lt_mask = (1ull << ln) - 1ull;
+    uint64_t prof_t = A.prof ? clock64() : 0, prof_acc[3] = {};
+#define PROF_MARK(i) do { if (A.prof) { const uint64_t t_ = clock64(); prof_acc[i] += t_ - prof_t; prof_t = t_; } } while (0)
+    const uint64_t b0 = A.offsets[sid], nb64 = A.offsets[sid + 1] - b0;
+    const uint32_t fallback = A.n_tiers;
+    // gen routes a sentence by writing its list index; build_lists turns that into work lists with
+    // wave-aggregated atomics (a per-sentence atomic on a hot word caps the kernel at ~88 M/s)
+    auto route = [&](uint32_t t) {
+        if (A.direct_push) list_push(A, t, sid);  // (Worker's single launch: no build_lists behind it)
+        else if (ln == 0) A.s_tier[sid] = (uint8_t)t;
+    };
+    auto init = [&]() { if (ln == 0) { A.s_n[sid] = 0; A.s_C[sid] = 0; A.s_tier[sid] = 0xFF; } };
+    if (nb64 == 0) {
+        init();
+        if (ln == 0) A.tok_cnt[sid] = 0;
+        return;
+    }
+    if (nb64 >= 65535) { init(); route(fallback); return; }  // positions are u16 in the LDS lattice
+    const uint32_t nb = (uint32_t)nb64;
+    const uint8_t* __restrict__ txt = A.text + b0;
+    const size_t slot0 = sentence_slot(A, b0, sid);
+
+    const uint32_t n = count_chars(txt, nb);
+    if (n == 0) {
+        init();
+        if (ln == 0) A.tok_cnt[sid] = 0;
+        return;
+    }
+    const GenOneLds L = carve_gen_one(g_smem, lds_bytes, n, D.has_user != 0);
+    if (!L.ok) {
+        // Outgrows this wavefront: gen_long, one workgroup per sentence.
+        init();
+        route(A.n_tiers + 1 + gen_long_level(A, n, nb, D.has_user != 0));
+        return;
+    }
+    init();
+    uint64_t* const lens = L.lens;
+    uint32_t* const ci = L.ci;
+    uint32_t* const cand_off = L.cand_off;
+    auto set_lens = [&](uint32_t i, uint64_t v) { lens[i] = v; };
+    auto get_lens = [&](uint32_t i) -> uint64_t { return lens[i]; };
+    auto set_co = [&](uint32_t i, uint32_t v) { cand_off[i] = v; };
+    auto get_co = [&](uint32_t i) -> uint32_t { return cand_off[i]; };
+    uint16_t* const code = L.code;
+    uint16_t* const ucode = L.ucode;
+    uint16_t* const grp = L.grp;
+    uint32_t* const endc = L.endc;      // candidates ending at each position (bounds the pass count)
+    uint32_t* const hcount = L.hcount;  // hits staged so far
+    for (uint32_t i = ln; i < n + 1; i += 64) endc[i] = i == 0 ? 1u : 0u;  // BOS ends at 0
+
+    // decode (Sentence::compute_basic / compute_categories, sentence.rs:40-55); the 3 bytes after a
+    // lead byte come from neighbouring lanes (or the look-ahead chunk), not from memory again
+    {
+        uint16_t* c2b = A.g_c2b + slot0;
+        uint32_t cb = 0;
+        uint32_t cur = ln < nb ? txt[ln] : 0x80u;
+        for (uint32_t c0 = 0; c0 < nb; c0 += 64) {
+            const uint32_t bi = c0 + ln;
+            const uint32_t nxt = bi + 64 < nb ? txt[bi + 64] : 0x80u;
+            const uint32_t b = cur;
+            uint32_t t[3];
+#pragma unroll
+            for (int k = 1; k <= 3; ++k) {
+                const uint32_t src = (ln + k) & 63u;
+                const uint32_t a = __shfl(cur, src), c = __shfl(nxt, src);
+                t[k - 1] = ((ln + k < 64) ? a : c) & 0x3Fu;
+            }
+            const bool lead = bi < nb && (b & 0xC0) != 0x80;
+            const uint64_t m = __ballot(lead);
+            if (lead) {
+                const uint32_t idx = cb + (uint32_t)__popcll(m & lt_mask);
+                uint32_t cp;
+                if (b < 0x80) cp = b;
+                else if (b < 0xE0) cp = ((b & 0x1F) << 6) | t[0];
+                else if (b < 0xF0) cp = ((b & 0x0F) << 12) | (t[0] << 6) | t[1];
+                else cp = ((b & 0x07) << 18) | (t[0] << 12) | (t[1] << 6) | t[2];
+                ci[idx] = D.chr2inf[cp < 65536u ? cp : 0u];  // character.rs:112-116
+                code[idx] = cp < D.sys.mapper_len ? D.sys.mapper[cp] : (uint16_t)0;
+                if (D.has_user) ucode[idx] = cp < D.user.mapper_len ? D.user.mapper[cp] : (uint16_t)0;
+                c2b[idx] = (uint16_t)bi;
+            }
+            cb += (uint32_t)__popcll(m);
+            cur = nxt;
+        }
+        if (ln == 0) c2b[n] = (uint16_t)nb;
+    }
+    __syncthreads();
+    {   // groupable (sentence.rs:57-71)
+        uint32_t carry = 0;
+        for (int ch = (int)((n - 1) / 64); ch >= 0; --ch) {
+            const uint32_t i = (uint32_t)ch * 64 + ln;
+            const bool valid = i < n;
+            bool link = false;
+            if (valid && i + 1 < n) link = ((ci[i] & ci[i + 1]) & 0x3FFFFu) != 0;
+            const uint64_t brk = __ballot(valid && !link);
+            const uint64_t m = brk >> ln;
+            const uint32_t g = m ? (uint32_t)__builtin_ctzll(m) + 1 : (64 - ln) + carry;
+            if (valid) grp[i] = (uint16_t)g;
+            carry = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
+        }
+    }
+    __syncthreads();
+    PROF_MARK(0);
+
+    // One trie walk per start position (tokenizer.rs:155-198, unknown.rs:69-116).  The walk is a chain of
+    // dependent loads, so nothing else hangs on it: every hit -- a run of `c` dictionary entries ending at
+    // `end` -- is appended to a staging list in global memory as {first entry, c | lexicon << 16,
+    // end | start << 16, candidates of this start position before the hit} and expanded afterwards by
+    // independent lanes.
+    const uint64_t base = (uint64_t)A.node_factor * slot0;  // this sentence's node region (no allocation atomic)
+    const uint64_t region = (uint64_t)A.node_factor * (nb + kSentenceSlack);
+    uint4* __restrict__ hits = A.g_hits + base;
+    if (ln == 0) *hcount = 0;
+    __syncthreads();
+    uint32_t C = 0;
+    bool any_long = false;
+    for (uint32_t c0 = 0; c0 < n; c0 += 64) {
+        const uint32_t i = c0 + ln;
+        uint32_t cnt = 0;
+        uint64_t lmask = 0;
+        bool is_long = false;
+        if (i < n) {
+            auto seen = [&](uint32_t v, uint32_t c, uint32_t end, uint32_t lex) {
+                if (c == 0) return;  // a category without unknown-word entries contributes nothing (unknown.rs:118-130)
+                const uint32_t h = atomicAdd(hcount, 1u);
+                if (h < region) hits[h] = make_uint4(v, c | (lex << 16), end | (i << 16), cnt);
+                cnt += c;
+                const uint32_t len = end - i;
+                if (len <= 64) lmask |= 1ull << (len - 1); else is_long = true;
+                atomicAdd(&endc[end], c);
+            };
+            bool matched = false;
+            if (D.has_user) matched |= walk_trie(D.user, ucode, i, n, [&](uint32_t v, uint32_t c, uint32_t e) { seen(v, c, e, 1u); });
+            matched |= walk_trie(D.sys, code, i, n, [&](uint32_t v, uint32_t c, uint32_t e) { seen(v, c, e, 0u); });
+            const uint32_t cinfo = ci[i], cate = (cinfo >> 18) & 0xFFu;
+            const uint32_t u0 = D.unk_off[cate], nunk = D.unk_off[cate + 1] - u0;
+            unk_spans(cinfo, grp[i], i, matched, D.max_grouping_len, [&](uint32_t e) { seen(u0, nunk, e, 2u); });
+            set_lens(i, lmask);
+        }
+        uint32_t tot;
+        const uint32_t ex = wave_exscan(cnt, tot);
+        if (i < n) set_co(i, C + ex);
+        C += tot;
+        any_long |= __ballot(is_long) != 0;
+    }
+    // words > 64 chars need the generic pre-pass, > 65531 nodes need u32 indices: fused kernel
+    if (C >= 65532 || any_long) { route(fallback); return; }
+    if (ln == 0) set_co(n, C);
+    // End lists (`ends[e]` of lattice.rs:39-43) are laid out here once and for all: node slots are numbered by end
+    // position (BOS is slot 0, the only node ending at 0), so the lattice kernel reads every candidate with its slot
+    // attached and builds no lists.  endc[] turns from counts into running cursors: exclusive prefix now, after the
+    // expansion below the inclusive one (eo() recovers the exclusive offsets).  Order inside a list is arbitrary.
+    __syncthreads();
+    {
+        uint32_t running = 0;
+        for (uint32_t c0 = 0; c0 < n + 1; c0 += 64) {
+            const uint32_t p = c0 + ln;
+            const uint32_t cnt = p < n + 1 ? endc[p] : 0u;
+            uint32_t tot;
+            const uint32_t ex = wave_exscan(cnt, tot);
+            if (p < n + 1) endc[p] = running + ex;
+            running += tot;
+        }
+    }
+    __syncthreads();
+    if (C > region) { route(fallback); return; }  // denser than the region: fused path
+    // The staged hits are read back by this wave only: its stores have to be complete (workgroup scope:
+    // s_waitcnt vmcnt(0); the vector L1 is write-through and never held these lines).  An agent-scope
+    // release would write the whole L2 back (buffer_wbl2) once per sentence.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    PROF_MARK(1);
+
+    // expand the hits: lanes = hits, every entry load independent of every other; a candidate becomes ONE 16-byte record --
+    // {first cell of its left id's matrix row, (u16) word_cost | end-list slot << 16, word_idx, end_char | right_id << 16} -- at its
+    // place in the reference's insertion order (cand_off[start] + candidates of that start before the hit).  One scattered store
+    // per candidate: the generator is bound by the number of its scattered store requests (two 8-byte stores into separate arrays
+    // cost 5 % more; the sweep's load phase does not notice the wider record)
+    const uint32_t H = *hcount;  // <= C <= region
+    const uint32_t row_cells = D.num_right;  // a left id's row of the connection matrix starts at cell left_id * num_right
+    for (uint32_t h0 = 0; h0 < H; h0 += 64) {
+        const uint32_t h = h0 + ln;
+        const uint4 hr = h < H ? hits[h] : make_uint4(0, 0, 0, 0);
+        if (h < H) {
+            const uint32_t c = hr.y & 0xFFFFu, lex = hr.y >> 16, end = hr.z & 0xFFFFu, pos = hr.z >> 16;
+            const Entry* __restrict__ ent = lex == 0 ? D.sys.entries : lex == 1 ? D.user.entries : D.unk_entries;
+            const uint32_t dest = get_co(pos) + hr.w;
+            const uint32_t slot0 = atomicAdd(&endc[end], c);  // the hit's run of slots in ends[end]
+            for (uint32_t t0 = 0; t0 < c; t0 += 4) {
+                Entry e[4];
+#pragma unroll
+                for (uint32_t q = 0; q < 4; ++q) e[q] = ent[hr.x + (t0 + q < c ? t0 + q : t0)];
+#pragma unroll
+                for (uint32_t q = 0; q < 4; ++q) {
+                    if (t0 + q < c) {
+                        const uint32_t k = dest + t0 + q;
+                        A.g_cand[base + k] = make_uint4((e[q].left_right & 0xFFFFu) * row_cells, (e[q].cost & 0xFFFFu) | ((slot0 + t0 + q) << 16),
+                                                        (lex << 30) | e[q].word_id, end | (e[q].left_right & 0xFFFF0000u));
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // exclusive end-list offset of position p (0 .. n + 1): the cursors now hold the inclusive prefix
+    auto eo = [&](uint32_t p) { return p == 0 ? 0u : p == 1 ? 1u : endc[p - 1]; };
+    uint32_t passes = 0, maxcnt = 1;
+    {   // per-character records for the lattice kernel:
+        // {cand_off | end-list offset << 16, pass bound of the position's step | window end << 14 | space << 31,
+        //  length mask (64 bits; for a space position of ignore_space mode its groupable run instead: the sweep never
+        //  starts a word there, tokenizer.rs:113-125)}
+        // Window end of position i: the end-list offset behind the furthest end of any candidate of the positions <= i (with
+        // ignore_space, a visited space run hands its visit to the position behind the run, so such a run counts as spanning up
+        // to the furthest end of that position's candidates) -- the slots a sweep segment that ends behind i has to hold
+        // (lattice_lds may cut the sweep of a long sentence anywhere).
+        uint4* pc = A.g_pc + slot0;
+        uint32_t far = 0;  // furthest end of any candidate of the positions before this chunk
+        for (uint32_t c0 = 0; c0 < n; c0 += 64) {
+            const uint32_t i = c0 + ln;
+            uint32_t e = 0, space = 0, nsl = 0, cnt = 0, co_i = 0;
+            uint64_t lm = 0;
+            if (i < n) {
+                const uint32_t cinfo = ci[i];
+                space = (D.space_cateset && (cinfo & D.space_cateset)) ? 0x80000000u : 0u;
+                lm = get_lens(i);
+                e = lm ? i + 64u - (uint32_t)__builtin_clzll(lm) : i + 1;
+                co_i = get_co(i);
+                uint32_t nc = get_co(i + 1) - co_i;
+                if (space) {
+                    const uint32_t sw = i + grp[i];
+                    const uint64_t lw = sw < n ? get_lens(sw) : 0ull;
+                    const uint32_t e2 = sw < n ? (lw ? sw + 64u - (uint32_t)__builtin_clzll(lw) : sw + 1) : n;
+                    e = e2 > e ? e2 : e;
+                    nc = sw < n ? get_co(sw + 1) - get_co(sw) : 0u;  // the step taken from a space position starts its words behind the run
+                }
+                cnt = eo(i + 1) - eo(i);
+                nsl = step_passes(nc, cnt);
+            }
+            uint32_t m = e;  // inclusive prefix maximum over the lanes
+            m = wave_inscan_max_dpp(m);
+            if (i < n) {
+                const uint32_t upto = m > far ? m : far;  // furthest end of any candidate of the positions <= i (<= n)
+                const uint64_t third = space ? (uint64_t)grp[i] : lm;
+                const uint32_t yw = (nsl < 0x3FFFu ? nsl : 0x3FFFu) | (eo(upto + 1) << 14) | space;
+                pc[i] = make_uint4(co_i | (eo(i) << 16), yw, (uint32_t)third, (uint32_t)(third >> 32));
+            }
+            const uint32_t top = (uint32_t)__builtin_amdgcn_readlane((int)m, 63);
+            far = top > far ? top : far;
+            uint32_t mc = cnt;
+            nsl = wave_sum(nsl);
+            mc = wave_umax(mc);
+            passes += nsl;
+            maxcnt = mc > maxcnt ? mc : maxcnt;
+        }
+        {   // EOS connects to the end list of the last visited position: bounded by the longest list
+            const uint32_t last = eo(n + 1) - eo(n);
+            maxcnt = last > maxcnt ? last : maxcnt;
+            passes += step_passes(1u, maxcnt);
+        }
+        // terminator: totals (candidates, end-list slots)
+        if (ln == 0) pc[n] = make_uint4(C | (eo(n) << 16), 0, eo(n + 1), 0);
+    }
+    if (ln == 0) {
+        A.s_n[sid] = n; A.s_C[sid] = C; A.s_passes[sid] = passes;
+    }
+    // smallest tier whose LDS holds the lattice arrays (connection costs are never staged)
+    const uint64_t fixed = lattice_fixed_bytes(C, n, eo(n + 1));
+    uint32_t tier = fallback;
+    for (uint32_t t = 0; t < A.n_tiers; ++t)
+        if (fixed <= A.tier_bytes[t]) { tier = t; break; }
+    // longer sentences are swept in segments inside the segment tier instead of one huge LDS block (lattice_lds cuts anywhere;
+    // what it cannot sweep there -- a window of end lists wider than the tier -- it hands to the escape tiers itself)
+    if (A.seg_tier < A.n_tiers && tier > A.seg_tier) tier = A.seg_tier;
+    route(tier);
+    PROF_MARK(2);
+    if (A.prof && ln == 0) {
+        unsigned long long* pr_ = A.prof + (size_t)(sid & (kProfSlots - 1)) * kProfWords;
+        for (int i = 0; i < 3; ++i) atomicAdd(&pr_[i], (unsigned long long)prof_acc[i]);
+        atomicAdd(&pr_[kProfPhases], 1ull);
+    }
+#undef PROF_MARK
+}
+
+}  // namespace
+}  // namespace vbt
