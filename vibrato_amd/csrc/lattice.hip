@@ -768,6 +768,9 @@ __global__ void __launch_bounds__(64) tokenize_serve(DevDict D, BatchArgs A, uin
             continue;
         }
         idle = 0;
+        // (acquire at system scope: the vector L1 may still hold lines of the previous sentence's text -- the kernel never ends between
+        // two sentences, so nothing else invalidates them)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
         // ---- one sentence ----
         {
             const u32x4* __restrict__ src = reinterpret_cast<const u32x4*>(h_text);  // (the pinned block is padded to 16 bytes)
