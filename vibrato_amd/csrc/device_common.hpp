@@ -217,10 +217,16 @@ __device__ __forceinline__ void unk_spans(uint32_t cinfo, uint32_t g, uint32_t i
 // 4 predecessors x 16 candidates), keeps the minimum of its own phase in registers, and the four phases of a candidate are
 // combined with two quad-permute levels at the end of the step.  VBT_DEPTH = passes whose connection costs are in flight.
 #ifndef VBT_DEPTH
-#define VBT_DEPTH 3
+#define VBT_DEPTH 2
+#endif
+#ifndef VBT_LOOP_PROF
+#define VBT_LOOP_PROF 0  // developer aid (tools/phase_profile.py on a variant build): cycles parked at the sweep loop's two waits
+#endif
+#ifndef VBT_ASM_LOOP
+#define VBT_ASM_LOOP 1  // the sweep loop of the common build in assembly (sweep_asm.hpp; needs VBT_DEPTH 2); 0: the C++ loop everywhere
 #endif
 #ifndef VBT_LAT_WAVES
-#define VBT_LAT_WAVES 4
+#define VBT_LAT_WAVES 5
 #endif
 #ifndef VBT_ROUND_PREDS
 #define VBT_ROUND_PREDS 16

@@ -2,6 +2,7 @@
 // Reference: build_lattice_inner tokenizer.rs:94-139, Lattice::insert_node / search_min_node lattice.rs:103-151, insert_eos 85-101,
 // append_top_nodes lattice.rs:159-168, MatrixConnector::cost matrix_connector.rs:79-125, Worker::tokenize worker.rs:49-55.
 #include "gen_device.hpp"
+#include "sweep_asm.hpp"
 
 namespace vbt {
 namespace {
@@ -172,7 +173,11 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
             cnd[C] = make_uint2(0u, E << 3);
             e_rec[E] = make_uint2(((fld0 - C) & 0xFFFFu) << 16, kDeadHi);
         }
+#if !VBT_LOOP_PROF
         PROF_MARK(3);
+#else
+        if (A.prof) prof_t = clock64();
+#endif
 
         // ---- structural pre-pass (tokenizer.rs:106-138, control flow only) + pass records ----
         // Bit-serial sweep, all state in SGPRs.  w bit i <=> position p + 1 + i is the end of an inserted node;
@@ -387,6 +392,28 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
                 }
 #undef VBT_LD
             };
+            if constexpr (VBT_ASM_LOOP && !kExact && !kWide && kD == 2) {
+                // the loop in assembly (sweep_asm.hpp): same records, same LDS layout, same results
+                const uint32_t sl_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)SL);
+                const uint32_t offk_v = offK;
+#if VBT_LOOP_PROF
+                // cycles parked at the two waits, left in the (still unused) token path array
+                const uint32_t plds = lds0 + (uint32_t)(reinterpret_cast<char*>(path) - g_smem);
+                asm volatile(VBT_SWEEP_TEXT
+                             :: [rp] "s"(rbase), [sl] "s"(sl_s), [rs] "s"(rsrc), [k8] "v"(k8), [cl8] "v"(cl8), [offk] "v"(offk_v), [plds] "v"(plds)
+                             : VBT_SWEEP_CLOBBERS);
+                if (A.prof && ln == 0) {
+                    const uint64_t* q = reinterpret_cast<const uint64_t*>(path);
+                    atomicAdd(&pr_[5], (unsigned long long)q[0]); atomicAdd(&pr_[3], (unsigned long long)q[1]);
+                    atomicAdd(&pr_[0], (unsigned long long)q[2]); atomicAdd(&pr_[1], (unsigned long long)q[3]);  // (the generator's phase slots 0/1: the VALU chain / the tail of the common pass)
+                }
+#else
+                asm volatile(VBT_SWEEP_TEXT
+                             :: [rp] "s"(rbase), [sl] "s"(sl_s), [rs] "s"(rsrc), [k8] "v"(k8), [cl8] "v"(cl8), [offk] "v"(offk_v)
+                             : VBT_SWEEP_CLOBBERS);
+#endif
+                return;
+            }
             u32x16 pr = rq[0];  // the record in hand: issue half of the pass whose gathers go out next, consume half of the pass kD before it
 #pragma unroll
             for (uint32_t p = 0; p < kD; ++p) {
