@@ -7,10 +7,10 @@ That is only sound if, between a gather and the instruction that consumes its re
 register: no copy (register allocation splitting a live range), no spill, no reuse.  This script proves exactly that on
 the assembly hipcc emits:
 
-  for every `buffer_load_{sshort,dword}` G inside an inline-asm block of a kernel and every path through the control-flow
+  for every `buffer_load_{sshort,dword}` / `global_load_dwordx3` G inside an inline-asm block of a kernel and every path through the control-flow
   graph behind it, the first instruction that mentions G's destination register lies behind an inline `s_waitcnt vmcnt(N)`
-  at which G has provably landed (at least N inline gathers were issued behind G: loads return in order), or is the next
-  gather into the same ring slot.
+  at which G has provably landed (at least N inline loads were issued behind G: loads return in order), or is the next
+  load into the same ring slot.
 
 usage: python tools/check_ring_isa.py [lattice.s]      (without an argument: compiles lattice.hip to assembly first)
 """
@@ -80,13 +80,19 @@ def check_kernel(name, body):
         return [i + 1] if i + 1 < len(insts) else []
 
     errors, n_loads = [], 0
-    load_re = re.compile(r"^buffer_load_(sshort|dword)\s+v(\d+),")
-    for idx, (t, a) in enumerate(insts):
-        m = load_re.match(t)
-        if not (a and m):
-            continue
+    # the loads of the ring: the gathers (one register) and the broadcast fetch of a 16-byte pass record (three)
+    load_re = re.compile(r"^(?:buffer_load_(?:sshort|dword)|global_load_dwordx3)\s+v\[?(\d+)(?::(\d+)\])?,")
+
+    def dests(text):
+        m = load_re.match(text)
+        if not m:
+            return []
+        lo = int(m.group(1))
+        return list(range(lo, int(m.group(2)) + 1)) if m.group(2) else [lo]
+
+    targets = [(idx, reg) for idx, (t, a) in enumerate(insts) if a for reg in dests(t)]
+    for idx, reg in targets:
         n_loads += 1
-        reg = int(m.group(2))
         # Along every path from behind the gather G: `after` counts the inline gathers issued behind G.  An inline
         # `s_waitcnt vmcnt(N)` retires all but the N most recent loads (loads return in order), so G has landed there iff
         # after >= N.  The first instruction that mentions G's register must come behind such a wait -- or be another inline
@@ -104,8 +110,8 @@ def check_kernel(name, body):
             if aj and mw and after >= int(mw.group(1)):
                 landed = True
             if mentions(tj, reg):
-                if aj and load_re.match(tj) and int(load_re.match(tj).group(2)) == reg:
-                    continue  # overwritten by the next gather into this ring slot
+                if aj and reg in dests(tj):
+                    continue  # overwritten by the next load into this ring slot
                 if not landed:
                     verdict = f"v{reg}: touched by `{tj}` (#{j}) while the gather at #{idx} may still be in flight ({after} loads behind it)"
                 continue
