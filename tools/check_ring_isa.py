@@ -7,7 +7,7 @@ That is only sound if, between a gather and the instruction that consumes its re
 register: no copy (register allocation splitting a live range), no spill, no reuse.  This script proves exactly that on
 the assembly hipcc emits:
 
-  for every `buffer_load_{sshort,dword}` / `global_load_dwordx3` G inside an inline-asm block of a kernel and every path through the control-flow
+  for every `buffer_load_{sshort,dword}` / `global_load_dwordx2` G inside an inline-asm block of a kernel and every path through the control-flow
   graph behind it, the first instruction that mentions G's destination register lies behind an inline `s_waitcnt vmcnt(N)`
   at which G has provably landed (at least N inline loads were issued behind G: loads return in order), or is the next
   load into the same ring slot.
@@ -68,56 +68,68 @@ def check_kernel(name, body):
             continue
         insts.append((t.split(";")[0].strip(), in_asm))
 
-    def successors(i):
+    def successors_of(i):
         t = insts[i][0]
         op = t.split()[0]
         if op == "s_endpgm":
-            return []
+            return ()
         if op == "s_branch":
-            return [labels[t.split()[1]]]
+            return (labels[t.split()[1]],)
         if op.startswith("s_cbranch"):
-            return [labels[t.split()[1]], i + 1]
-        return [i + 1] if i + 1 < len(insts) else []
+            return (labels[t.split()[1]], i + 1)
+        return (i + 1,) if i + 1 < len(insts) else ()
 
-    errors, n_loads = [], 0
-    # the loads of the ring: the gathers (one register) and the broadcast fetch of a 16-byte pass record (three)
-    load_re = re.compile(r"^(?:buffer_load_(?:sshort|dword)|global_load_dwordx3)\s+v\[?(\d+)(?::(\d+)\])?,")
+    # the loads of the ring: the gathers (one register) and the broadcast fetch of an 8-byte pass record (two)
+    load_re = re.compile(r"^(?:buffer_load_(?:sshort|dword)|global_load_dwordx[23])\s+v\[?(\d+)(?::(\d+)\])?,")
 
     def dests(text):
         m = load_re.match(text)
         if not m:
-            return []
+            return ()
         lo = int(m.group(1))
-        return list(range(lo, int(m.group(2)) + 1)) if m.group(2) else [lo]
+        return tuple(range(lo, int(m.group(2)) + 1)) if m.group(2) else (lo,)
 
-    targets = [(idx, reg) for idx, (t, a) in enumerate(insts) if a for reg in dests(t)]
+    # per instruction, once: successors, VGPRs mentioned, registers loaded by an inline load, N of an inline s_waitcnt vmcnt(N)
+    succ = [successors_of(i) for i in range(len(insts))]
+    used, loaded, waits = [], [], []
+    for t, a in insts:
+        regs = set(int(m.group(1)) for m in re.finditer(r"\bv(\d+)\b", t))
+        for m in re.finditer(r"\bv\[(\d+):(\d+)\]", t):
+            regs.update(range(int(m.group(1)), int(m.group(2)) + 1))
+        used.append(regs)
+        loaded.append(dests(t) if a else ())
+        mw = re.match(r"^s_waitcnt\s+vmcnt\((\d+)\)", t) if a else None
+        waits.append(int(mw.group(1)) if mw else None)
+    cap = max([w for w in waits if w is not None] + [1])  # (more loads behind G than any wait asks for: no need to count on)
+
+    errors, n_loads = [], 0
+    targets = [(idx, reg) for idx in range(len(insts)) for reg in loaded[idx]]
     for idx, reg in targets:
         n_loads += 1
-        # Along every path from behind the gather G: `after` counts the inline gathers issued behind G.  An inline
+        # Along every path from behind the load G: `after` counts the inline loads issued behind G.  An inline
         # `s_waitcnt vmcnt(N)` retires all but the N most recent loads (loads return in order), so G has landed there iff
         # after >= N.  The first instruction that mentions G's register must come behind such a wait -- or be another inline
-        # gather into the same register (an unconsumed slot of a pass without that unit: in-order write after write).
-        stack = [(j, 0, False) for j in successors(idx)]
+        # load into the same register (an unconsumed slot of a pass without that unit: in-order write after write).
+        stack = [(j, 0, False) for j in succ[idx]]
         seen = set()
         verdict = None
         while stack and not verdict:
-            j, after, landed = stack.pop()
-            if (j, after, landed) in seen:
+            st = stack.pop()
+            if st in seen:
                 continue
-            seen.add((j, after, landed))
-            tj, aj = insts[j]
-            mw = re.match(r"^s_waitcnt\s+vmcnt\((\d+)\)", tj)
-            if aj and mw and after >= int(mw.group(1)):
-                landed = True
-            if mentions(tj, reg):
-                if aj and reg in dests(tj):
+            seen.add(st)
+            j, after, landed = st
+            if waits[j] is not None and after >= waits[j]:
+                landed, after = True, cap
+            if reg in used[j]:
+                if reg in loaded[j]:
                     continue  # overwritten by the next load into this ring slot
                 if not landed:
-                    verdict = f"v{reg}: touched by `{tj}` (#{j}) while the gather at #{idx} may still be in flight ({after} loads behind it)"
+                    verdict = f"v{reg}: touched by `{insts[j][0]}` (#{j}) while the load at #{idx} may still be in flight ({after} loads behind it)"
                 continue
-            if aj and load_re.match(tj):
-                after = min(after + 1, 64)
-            stack.extend((k, after, landed) for k in successors(j))
+            if loaded[j]:
+                after = min(after + 1, cap)
+            stack.extend((k, after, landed) for k in succ[j])
         if verdict:
             errors.append(verdict)
     return n_loads, errors

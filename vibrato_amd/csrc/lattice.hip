@@ -71,10 +71,10 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
         uint32_t* const rec_w3 = reinterpret_cast<uint32_t*>(rec + rec_cap);  // per pass: step totals for the connection-id counting
         // where a dead predecessor's sentinel cost could meet a live cost, every predecessor's own field is tested instead (kDeadHi)
         const bool exact = kWide || nT >= 8000u;
-        // the common build sweeps in assembly (sweep_asm.hpp) over 16-byte vector-fetched records {w0, w1, meta, -} in the same region;
+        // the common build sweeps in assembly (sweep_asm.hpp) over 8-byte vector-fetched records (16-bit LDS addresses) in the same region;
         // the 64-byte scalar records (LPass) feed the C++ loop of the other builds
-        const bool vrec_mode = VBT_ASM_LOOP && !kWide && !exact && kD == 2 && !A.lid_count;
-        uint4* const vrec = reinterpret_cast<uint4*>(rec);
+        const bool vrec_mode = VBT_ASM_LOOP && !kWide && !exact && kD == 2 && !A.lid_count && lds0 + lds_bytes <= 65536u;
+        uint2* const vrec = reinterpret_cast<uint2*>(rec);
         uint32_t seg_a = 0, seg_c = 0, seg_p = 0, sb = 0, m_in = 1, fail = 0;
         bool multi = false, done = false;
         uint32_t counted = A.lid_count ? __builtin_amdgcn_readfirstlane(A.s_counted[sid]) : 0u;
@@ -177,7 +177,11 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
             cnd[C] = make_uint2(0u, E << 3);
             e_rec[E] = make_uint2(((fld0 - C) & 0xFFFFu) << 16, kDeadHi);
         }
+#if !VBT_LOOP_PROF
         PROF_MARK(3);
+#else
+        if (A.prof) prof_t = clock64();  // (slot 3 is the loop's LDS wait in these builds)
+#endif
 
         // ---- structural pre-pass (tokenizer.rs:106-138, control flow only) + pass records ----
         // Bit-serial sweep, all state in SGPRs.  w bit i <=> position p + 1 + i is the end of an inserted node;
@@ -200,11 +204,11 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
             const uint32_t nc_r = nc - kRoundCands * k < kRoundCands ? nc - kRoundCands * k : kRoundCands;
             const uint32_t nu = (np_r + 3u) >> 2, t = np_r - 4u * (nu - 1u);  // units, predecessors of the last one (1..4)
             if (vrec_mode) {
-                // meta: candidates | predecessors of this round << 8 | (units | first round << 3 | last round << 4) << 16 | phases that
-                // see a predecessor in some unit of the step << 24
+                // {slot record of the first predecessor | phases that see a predecessor in some unit of the step << 16 | candidates << 24,
+                //  record of the first candidate | (units | first round << 3 | last round << 4) << 16 | predecessors of this round << 24}
                 const uint32_t fl = nu | (r == 0 ? 8u : 0u) | (r + 1 == rounds ? 16u : 0u);
-                vrec[P] = make_uint4(offK + ((p_beg + kRoundPreds * r) << 3), offC + ((c_beg + kRoundCands * k) << 3),
-                                     nc_r | (np_r << 8) | (fl << 16) | ((np < 4u ? np : 4u) << 24), 0u);
+                vrec[P] = make_uint2((offK + ((p_beg + kRoundPreds * r) << 3)) | ((np < 4u ? np : 4u) << 16) | (nc_r << 24),
+                                     (offC + ((c_beg + kRoundCands * k) << 3)) | (fl << 16) | (np_r << 24));
                 return;
             }
             const uint64_t cm = nc_r >= 16u ? ~0ull : (1ull << (4u * nc_r)) - 1ull;
@@ -314,7 +318,7 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
         // ahead, i.e. up to record SL + 2 kD.  Their issue halves sit in the records [SL, SL + 2 kD + 2), their consume halves kD
         // records further on (the consume halves in [SL, SL + kD) are those of the last kD real passes).
         if (vrec_mode) {
-            if (ln < 8) vrec[SL + ln] = make_uint4(offK, offC, 0u, 0u);  // (no candidates, no units: read up to record SL + 6)
+            if (ln < 10) vrec[SL + ln] = make_uint2(offK, offC);  // (no candidates, no units: records are read up to SL + 7)
         } else if (ln < 2 * kD + 2) {
             LPass& I = rec[SL + ln];
             I.w0 = offK; I.w1 = offC;
@@ -407,9 +411,21 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
                     // the loop in assembly (sweep_asm.hpp): same LDS layout, same results
                     const uint32_t sl_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)SL);
                     const uint32_t offk_v = offK;
+#if VBT_LOOP_PROF
+                    // (cycles parked at the loop's two waits, left in the still unused token path array: phase slots 5 and 3)
+                    const uint32_t plds = lds0 + (uint32_t)(reinterpret_cast<char*>(path) - g_smem);
+                    asm volatile(VBT_SWEEP_TEXT
+                                 :: [rp] "s"(rbase), [sl] "s"(sl_s), [rs] "s"(rsrc), [ln] "v"(ln), [offk] "v"(offk_v), [plds] "v"(plds)
+                                 : VBT_SWEEP_CLOBBERS);
+                    if (A.prof && ln == 0) {
+                        const uint64_t* q = reinterpret_cast<const uint64_t*>(path);
+                        atomicAdd(&pr_[5], (unsigned long long)q[0]); atomicAdd(&pr_[3], (unsigned long long)q[1]);
+                    }
+#else
                     asm volatile(VBT_SWEEP_TEXT
                                  :: [rp] "s"(rbase), [sl] "s"(sl_s), [rs] "s"(rsrc), [ln] "v"(ln), [offk] "v"(offk_v)
                                  : VBT_SWEEP_CLOBBERS);
+#endif
                     return;
                 }
             }
