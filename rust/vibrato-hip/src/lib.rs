@@ -31,7 +31,7 @@ pub mod token;
 pub mod tokenizer;
 
 pub use dictionary::{Dictionary, SystemDictionaryBuilder};
-pub use tokenizer::Tokenizer;
+pub use tokenizer::{BatchSentence, LineBatches, Tokenizer};
 
 /// Version number of this library (the reference API version it mirrors).
 pub const VERSION: &str = env!("CARGO_PKG_VERSION");

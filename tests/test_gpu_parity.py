@@ -616,6 +616,27 @@ def test_worker_loop_benchmark_counts_tokens():
         assert r["tokens"] == 2 * len(exp_tok) and r["us_per_call"] > 0
 
 
+def test_tokenize_lines_batches_behind_an_iterator():
+    """Tokenizer.tokenize_lines: the per-line loop over an iterable, batched behind the scenes (three batches here: the line limit, the
+    byte limit, the rest) -- every sentence comes back in input order with the oracle's records."""
+    sd = synth.SynthDict("small")
+    to, tv = _oracle_and_product(sd)
+    text, offs = sd.sentences(700, "lognormal_40")
+    exp_tok, exp_off = to.new_worker().tokenize_batch(text, offs)
+    buf = text.tobytes()
+    lines = [buf[int(offs[i]):int(offs[i + 1])].decode("utf-8") for i in range(len(offs) - 1)]
+    seen, batches = 0, set()
+    for s, (b, i) in enumerate(tv.tokenize_lines(iter(lines), batch_bytes=int(offs[300]), batch_lines=250)):
+        batches.add(id(b))
+        e = exp_tok[int(exp_off[s]):int(exp_off[s + 1])]
+        assert b.num_tokens(i) == len(e)
+        r = b.records(i)
+        for f in V.TOKEN_DTYPE.names:
+            assert np.array_equal(r[f], e[f]), (s, f)
+        seen += 1
+    assert seen == len(lines) and len(batches) >= 3
+
+
 def test_worker_resident_kernel_handshake_under_pauses():
     """A Worker whose resident kernel leaves quickly (VBT_WORKER_IDLE_POLLS=3) with pauses between the calls -- some calls find the
     kernel resident, some find it gone, some catch it leaving -- and a second Worker interleaved with it and with batch calls (which

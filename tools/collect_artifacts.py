@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
-"""Copies what tools/round_artifacts.sh <tag> (and tools/r03_final_bench.sh) left under gpurun_out/art_<tag>/ into profiles/:
+"""Copies what tools/round_artifacts.sh <tag> left under gpurun_out/art_<tag>/ into profiles/:
 the default bench line, the self-launched 2-rank line and the table of the other BASELINE configurations.
-  python tools/collect_artifacts.py r03"""
+  python tools/collect_artifacts.py r04"""
 import json
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 art = os.path.join(ROOT, "gpurun_out", f"art_{tag}")
 prof = os.path.join(ROOT, "profiles")
 
@@ -41,5 +41,5 @@ open(p_prev, "w").write(
     "`python bench.py --no-cpu-baseline --no-host-pipeline --no-suite --no-worker-loop --steps 10 <args>`; full JSON lines in "
     f"gpurun_out/art_{tag}/ (scratch).\nThe default `python bench.py` line (profiles/{tag}_bench_default.json) carries config 5 and the dense law as `suite` legs as well.\n\n"
     "| run | sentences/s | ms per step | generator ms | lattice ms (fork to join) | fallback + packing ms | nodes / dedup pairs per char | "
-    "sentences: 10 KiB tier, escape launches, fallback | bit-exact sample |\n|---|---|---|---|---|---|---|---|---|\n" + "\n".join(rows) + "\n" + notes)
+    "sentences: 8 KiB tier, escape launches, fallback | bit-exact sample |\n|---|---|---|---|---|---|---|---|---|\n" + "\n".join(rows) + "\n" + notes)
 print(open(p_prev).read())

@@ -296,6 +296,26 @@ class Tokenizer:
                                            len(offsets) - 1, C.byref(h)))
         return Batch(self, h)
 
+    def tokenize_lines(self, lines, batch_bytes=16 << 20, batch_lines=100000):
+        """The per-line loop of the reference's callers (tokenize/src/main.rs:78-95) over an iterable of lines, batched behind the
+        scenes: lines are collected until `batch_bytes` of text (or `batch_lines` lines) are in hand, tokenized as ONE device batch and
+        yielded one at a time, in input order, as (batch, index) -- batch.num_tokens(index), batch.token(index, i).  Worker.tokenize
+        costs ~35 us per call on the GPU, a batch ~17 ns per line: whoever has more than a handful of lines in hand wants this."""
+        buf, size = [], 0
+        for line in lines:
+            e = _b(line)
+            buf.append(e)
+            size += len(e)
+            if size >= batch_bytes or len(buf) >= batch_lines:
+                b = self.tokenize_batch(sentences=buf)
+                for i in range(len(buf)):
+                    yield b, i
+                buf, size = [], 0
+        if buf:
+            b = self.tokenize_batch(sentences=buf)
+            for i in range(len(buf)):
+                yield b, i
+
     def host_pipeline_benchmark(self, text, offsets, threads=2, rounds=4, repeats=3):
         """Host-to-host streaming throughput of vbt_tokenize_batch: `threads` host threads each push the whole batch through
         the thread-safe entry point `rounds` times, concurrently -- every call owns a pooled workspace, pinned staging and a
