@@ -261,7 +261,7 @@ __host__ __device__ __forceinline__ uint32_t step_passes(uint32_t nc, uint32_t n
 // E end-list slots: 8 bytes per slot, 8 per candidate, 2 per position (the token path).  Must over-estimate the Arena carve
 // there; gen_candidates routes sentences to LDS tiers with it.
 __host__ __device__ __forceinline__ uint64_t lattice_fixed_bytes(uint32_t C, uint32_t n, uint32_t E) {
-    return 8ull * (E + 2ull) + 8ull * (C + 2ull) + 2ull * (n + 4ull) + 48;
+    return 8ull * (E + 2ull) + 8ull * (C + 2ull) + 2ull * (n + 4ull) + 48;  // (+ the first three pass records of the assembly loop + alignment)
 }
 // Cost word of a slot whose node was never inserted (its start position is never visited).  Biased cost 0xC0000000 = +2^30: with
 // 16-bit connection and word costs a sentence of < 8000 characters keeps every live cost inside +-2^29, so such a predecessor

@@ -141,6 +141,7 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
         (void)ar.take<uint2>(E + 2);              // e_rec: the slot records
         uint2* cnd = ar.take<uint2>(C + 2);       // per candidate: {first cell of its matrix row (low half: its back pointer, once inserted), byte offset of its slot record | word_cost << 16}
         uint16_t* path = ar.take<uint16_t>(n + 4);  // the token path of the back-trace (tokens <= positions)
+        uint2* vhead = ar.take<uint2>(3);           // the first three pass records of the assembly loop (its prologue reads them from here: no round trip through global memory)
         const uint32_t sl_cap = rec_cap > 3 * kD + 4 ? rec_cap - (3 * kD + 2) : 0u;
         if (!ar.ok || sl_cap < 3) {  // the estimate was too low: try a shorter segment before giving up
             if (budget > lds_bytes / 3 && !whole) { budget -= lds_bytes / 4; __syncthreads(); continue; }  // (a sentence taken for whole keeps its records where a segmented one dumps its nodes: the next tier sweeps it)
@@ -207,8 +208,10 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
                 // {slot record of the first predecessor | phases that see a predecessor in some unit of the step << 16 | candidates << 24,
                 //  record of the first candidate | (units | first round << 3 | last round << 4) << 16 | predecessors of this round << 24}
                 const uint32_t fl = nu | (r == 0 ? 8u : 0u) | (r + 1 == rounds ? 16u : 0u);
-                vrec[P] = make_uint2((offK + ((p_beg + kRoundPreds * r) << 3)) | ((np < 4u ? np : 4u) << 16) | (nc_r << 24),
-                                     (offC + ((c_beg + kRoundCands * k) << 3)) | (fl << 16) | (np_r << 24));
+                const uint2 vr = make_uint2((offK + ((p_beg + kRoundPreds * r) << 3)) | ((np < 4u ? np : 4u) << 16) | (nc_r << 24),
+                                            (offC + ((c_beg + kRoundCands * k) << 3)) | (fl << 16) | (np_r << 24));
+                vrec[P] = vr;
+                if (P < 3) vhead[P] = vr;
                 return;
             }
             const uint64_t cm = nc_r >= 16u ? ~0ull : (1ull << (4u * nc_r)) - 1ull;
@@ -318,7 +321,10 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
         // ahead, i.e. up to record SL + 2 kD.  Their issue halves sit in the records [SL, SL + 2 kD + 2), their consume halves kD
         // records further on (the consume halves in [SL, SL + kD) are those of the last kD real passes).
         if (vrec_mode) {
-            if (ln < 10) vrec[SL + ln] = make_uint2(offK, offC);  // (no candidates, no units: records are read up to SL + 7)
+            if (ln < 10) {  // (no candidates, no units: records are read up to SL + 7)
+                vrec[SL + ln] = make_uint2(offK, offC);
+                if (SL + ln < 3) vhead[SL + ln] = make_uint2(offK, offC);
+            }
         } else if (ln < 2 * kD + 2) {
             LPass& I = rec[SL + ln];
             I.w0 = offK; I.w1 = offC;
@@ -331,7 +337,8 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
         // vector L1 is write-through), then the scalar cache forgets whatever it holds of this region (an earlier segment's records)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+        if (vrec_mode) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (vector loads read them back: nothing to invalidate)
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
         PROF_MARK(4);
 
         // ---- fused gather + cost recurrence (matrix_connector.rs:79-85, lattice.rs:103-151) ----
@@ -411,19 +418,23 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
                     // the loop in assembly (sweep_asm.hpp): same LDS layout, same results
                     const uint32_t sl_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)SL);
                     const uint32_t offk_v = offK;
+                    const uint32_t hd_v = lds0 + (uint32_t)(reinterpret_cast<char*>(vhead) - g_smem);
 #if VBT_LOOP_PROF
                     // (cycles parked at the loop's two waits, left in the still unused token path array: phase slots 5 and 3)
                     const uint32_t plds = lds0 + (uint32_t)(reinterpret_cast<char*>(path) - g_smem);
                     asm volatile(VBT_SWEEP_TEXT
-                                 :: [rp] "s"(rbase), [sl] "s"(sl_s), [rs] "s"(rsrc), [ln] "v"(ln), [offk] "v"(offk_v), [plds] "v"(plds)
+                                 :: [rp] "s"(rbase), [sl] "s"(sl_s), [rs] "s"(rsrc), [ln] "v"(ln), [offk] "v"(offk_v), [hd] "v"(hd_v), [plds] "v"(plds)
                                  : VBT_SWEEP_CLOBBERS);
                     if (A.prof && ln == 0) {
                         const uint64_t* q = reinterpret_cast<const uint64_t*>(path);
                         atomicAdd(&pr_[5], (unsigned long long)q[0]); atomicAdd(&pr_[3], (unsigned long long)q[1]);
+                        if (VBT_LOOP_PROF == 2) {  // (whole iterations by kind: slots 5 / 3 = cycles of the common / the other iterations, 0 / 1 = their counts)
+                            atomicAdd(&pr_[0], (unsigned long long)(uint32_t)q[2]); atomicAdd(&pr_[1], (unsigned long long)(q[2] >> 32));
+                        }
                     }
 #else
                     asm volatile(VBT_SWEEP_TEXT
-                                 :: [rp] "s"(rbase), [sl] "s"(sl_s), [rs] "s"(rsrc), [ln] "v"(ln), [offk] "v"(offk_v)
+                                 :: [rp] "s"(rbase), [sl] "s"(sl_s), [rs] "s"(rsrc), [ln] "v"(ln), [offk] "v"(offk_v), [hd] "v"(hd_v)
                                  : VBT_SWEEP_CLOBBERS);
 #endif
                     return;

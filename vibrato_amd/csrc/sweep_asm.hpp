@@ -58,10 +58,13 @@
 #define VBT_B2 " src0_sel:DWORD src1_sel:BYTE_2\n\t"
 #define VBT_B3 " src0_sel:DWORD src1_sel:BYTE_3\n\t"
 
-// developer aid (-DVBT_LOOP_PROF=1 builds, tools/loop_profile.sh): cycles an iteration is parked at its two waits, summed in
-// s[64:65] (the loads: gathers + record) and s[66:67] (the LDS reads), left in LDS at %[plds] behind the loop; s_memtime stamps
-// the moment it issues
-#if VBT_LOOP_PROF
+// developer aids (tools/loop_profile.sh; s_memtime stamps the moment it issues):
+//   -DVBT_LOOP_PROF=1: cycles an iteration is parked at its two waits, summed in s[64:65] (the loads: gathers + record) and s[66:67]
+//                      (the LDS reads);
+//   -DVBT_LOOP_PROF=2: whole iterations by kind -- s[78:79] / s80 cycles and count of the iterations that took the common pass,
+//                      s[82:83] / s81 of the others (an iteration's two stamps are summed behind the NEXT iteration's LDS wait).
+// The numbers are left in LDS at %[plds] behind the loop.
+#if VBT_LOOP_PROF == 1
 #define VBT_PROF_WAIT(ACC_LO, ACC_HI, WAIT)                                                          \
     "s_memtime s[62:63]\n\t" WAIT "s_memtime s[68:69]\n\ts_waitcnt lgkmcnt(0)\n\t"                   \
     "s_sub_u32 s62, s68, s62\n\ts_subb_u32 s63, s69, s63\n\t"                                        \
@@ -70,11 +73,35 @@
 #define VBT_PROF_OUT "v_mov_b32 v60, s64\n\tv_mov_b32 v61, s65\n\tv_mov_b32 v62, s66\n\tv_mov_b32 v63, s67\n\t"          \
                      "ds_write_b64 %[plds], v[60:61]\n\tds_write_b64 %[plds], v[62:63] offset:8\n\ts_waitcnt lgkmcnt(0)\n\t"
 #define VBT_PROF_CLOBBERS "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69",
+#define VBT_PROF2_START
+#define VBT_PROF2_ACC(KIND, THIS)
+#define VBT_PROF2_END
+#elif VBT_LOOP_PROF == 2
+#define VBT_PROF_WAIT(ACC_LO, ACC_HI, WAIT) WAIT
+#define VBT_PROF_INIT "s_mov_b64 s[70:71], 0\n\ts_mov_b64 s[72:73], 0\n\ts_mov_b32 s74, 0\n\ts_mov_b64 s[78:79], 0\n\ts_mov_b64 s[82:83], 0\n\t"  \
+                      "s_mov_b32 s80, 0\n\ts_mov_b32 s81, 0\n\t"
+#define VBT_PROF2_START "s_memtime s[76:77]\n\t"
+/* behind the iteration's LDS wait: the previous iteration's stamps (s[70:71] start, s[72:73] end, s74 its kind) are in; then this one's */
+#define VBT_PROF2_ACC(KIND, THIS)                                                                    \
+    "s_sub_u32 s62, s72, s70\n\ts_subb_u32 s63, s73, s71\n\t"                                        \
+    "s_cmp_eq_u32 s74, 0\n\ts_cbranch_scc0 .LBBvbt_pg%=_" KIND "\n\t"                                \
+    "s_add_u32 s78, s78, s62\n\ts_addc_u32 s79, s79, s63\n\ts_add_u32 s80, s80, 1\n\ts_branch .LBBvbt_pe%=_" KIND "\n"  \
+    "\n.LBBvbt_pg%=_" KIND ":\n\t"                                                                    \
+    "s_add_u32 s82, s82, s62\n\ts_addc_u32 s83, s83, s63\n\ts_add_u32 s81, s81, 1\n"                 \
+    "\n.LBBvbt_pe%=_" KIND ":\n\t"                                                                    \
+    "s_mov_b64 s[70:71], s[76:77]\n\ts_mov_b32 s74, " THIS "\n\t"
+#define VBT_PROF2_END "s_memtime s[72:73]\n\t"
+#define VBT_PROF_OUT "v_mov_b32 v60, s78\n\tv_mov_b32 v61, s79\n\tv_mov_b32 v62, s82\n\tv_mov_b32 v63, s83\n\tv_mov_b32 v64, s80\n\tv_mov_b32 v65, s81\n\t"  \
+                     "ds_write_b64 %[plds], v[60:61]\n\tds_write_b64 %[plds], v[62:63] offset:8\n\tds_write_b64 %[plds], v[64:65] offset:16\n\ts_waitcnt lgkmcnt(0)\n\t"
+#define VBT_PROF_CLOBBERS "s62", "s63", "s70", "s71", "s72", "s73", "s74", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83",
 #else
 #define VBT_PROF_WAIT(ACC_LO, ACC_HI, WAIT) WAIT
 #define VBT_PROF_INIT
 #define VBT_PROF_OUT
 #define VBT_PROF_CLOBBERS
+#define VBT_PROF2_START
+#define VBT_PROF2_ACC(KIND, THIS)
+#define VBT_PROF2_END
 #endif
 
 // combine the four phases of every candidate and write its node: in KLO / KHI the lane's (field | right id, cost + connection cost),
@@ -157,6 +184,7 @@
 #define VBT_ITER(U, V, VMC, W0, W1, W2, W3, PA, CA, META, M, FL, R0, R1, RLOAD, OFF, TAILN, TAILW)                          \
     "\n.LBBvbt_i" U V "_%=:\n\t"                                                                      \
     VBT_PROF_WAIT("s64", "s65", "s_waitcnt vmcnt(" VMC ")\n\t")  /* the gathers of the pass in hand, the record of the pass to issue */ \
+    VBT_PROF2_START                                                                                   \
     "ds_read_b64 v[60:61], " PA "\n\t"                           /* predecessor k of the pass in hand */ \
     "ds_read_b32 v68, " CA " offset:4\n\t"                       /* its candidate: slot offset | word cost */ \
     "s_cmp_lg_u32 " FL ", 25\n\t"                                /* one unit that starts and ends the step? */ \
@@ -165,6 +193,7 @@
     "s_cbranch_scc1 .LBBvbt_r" U V "_%=\n"                                                            \
     "\n.LBBvbt_b" U V "_%=:\n\t"                                                                      \
     VBT_PROF_WAIT("s66", "s67", "s_waitcnt lgkmcnt(0)\n\t")                                           \
+    VBT_PROF2_ACC("c" U V, "0")                                                                             \
     "global_load_dwordx2 " RLOAD ", v24, s[60:61] offset:" OFF "\n\t"   /* the record of six passes on */ \
     "v_add_u32 v61, v61, " W0 "\n\t"                             /* wrapping i32 add of the connection cost (lattice.rs:139) */ \
     VBT_FINISH("v60", "v61", M, CA, "v_add_u32_sdwa v55, v55, v54" VBT_SDWA_LO, VBT_META(META, R0, R1))                      \
@@ -176,6 +205,7 @@
     "s_mov_b64 exec, -1\n\t"                                                                          \
     "v_mov_b32 " CA ", v53\n\t"                                                                       \
     "s_mov_b64 " M ", s[48:49]\n\t"                                                                   \
+    VBT_PROF2_END                                                                                     \
     TAILN
 
 // the out-of-line blocks of an iteration: the general consume side (any number of units, rounds of a step, empty passes), the right
@@ -191,6 +221,7 @@
     VBT_WIDE_READS(PA)                                                                                \
     "\n.LBBvbt_n" U V "_%=:\n\t"                                                                      \
     VBT_PROF_WAIT("s66", "s67", "s_waitcnt lgkmcnt(0)\n\t")                                           \
+    VBT_PROF2_ACC("g" U V, "1")                                                                             \
     "global_load_dwordx2 " RLOAD ", v24, s[60:61] offset:" OFF "\n\t"                                 \
     "v_add_u32_sdwa v55, v55, v54" VBT_SDWA_LO                                                        \
     "v_cmp_lt_u32_sdwa s[50:51], v25, " META VBT_B3              /* candidates of the pass in hand */ \
@@ -237,6 +268,7 @@
     VBT_WIDE(W1, W2, W3, R0, R1)                                                                      \
     "v_mov_b32 " CA ", v53\n\t"                                                                       \
     "s_mov_b64 " M ", s[48:49]\n\t"                                                                   \
+    VBT_PROF2_END                                                                                     \
     TAILW
 
 // gather slots and record slots
@@ -310,10 +342,11 @@
     "s_mov_b32 s59, %[sl]\n\t"                                                                        \
     "s_mov_b32 s58, 0x07060302\n\t"                                                                   \
     VBT_PROF_INIT                                                                                     \
-    "global_load_dwordx2 v[76:77], v24, s[60:61]\n\t"                                                 \
-    "global_load_dwordx2 v[78:79], v24, s[60:61] offset:8\n\t"                                        \
-    "global_load_dwordx2 v[80:81], v24, s[60:61] offset:16\n\t"                                       \
-    "s_waitcnt vmcnt(0)\n\t"                                                                          \
+    /* the first three records out of LDS (the builder left a copy there: no round trip through global memory at the start) */ \
+    "ds_read_b64 v[76:77], %[hd]\n\t"                                                                 \
+    "ds_read_b64 v[78:79], %[hd] offset:8\n\t"                                                        \
+    "ds_read_b64 v[80:81], %[hd] offset:16\n\t"                                                       \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                        \
     /* prologue: the gathers of passes 0, 1 and 2 (behind the requests for the records of passes 3, 4 and 5) */ \
     VBT_PRO0                                                                                          \
     "s_cbranch_scc0 .LBBvbt_p0_%=\n\t"                                                                \
