@@ -14,18 +14,22 @@ namespace {
 // What lives in LDS per (segment of a) sentence: per end-list slot an 8-byte record {lo = (0xFFFE - sequence) << 16 | right id,
 // hi = min_cost biased to unsigned order} -- the low word is static and written by the load phase, the cost by the step that
 // inserts the node; per candidate 8 bytes {first cell of its matrix row, byte offset of its slot record | word cost << 16}
-// (the low half of the first word becomes the node's back pointer once its step is done); the pass records (16 B each).
+// (the low half of the first word becomes the node's back pointer once its step is done); the token path; the first three pass
+// records of the assembly loop.  The pass records themselves live in global memory (the sentence's dead hit-staging region).
 // Nothing per character: the per-character records of gen_candidates are consumed straight from global memory by the
 // reachability sweep, 64 positions at a time, and the end lists were laid out by gen_candidates (every candidate arrives
 // with its slot).
 //
-// The recurrence (lattice.rs:103-151) runs over PASSES of <= 16 candidates x <= 16 predecessors of one sweep step (LPass).
+// The recurrence (lattice.rs:103-151) runs over PASSES of <= 16 candidates x <= 16 predecessors of one sweep step.
 // Lane = (candidate cl = lane >> 2, phase k = lane & 3) walks the predecessors 4 i + k: it reads the predecessor's record
-// (four addresses per instruction, each broadcast to 16 lanes), adds the connection cost of its pair -- gathered VBT_DEPTH passes
+// (four addresses per instruction, each broadcast to 16 lanes), adds the connection cost of its pair -- gathered a few passes
 // ahead into a register ring -- and keeps the 64-bit minimum (cost, 0xFFFE - sequence of the predecessor): minimum cost, ties to
 // the last inserted predecessor = the `<=` of lattice.rs:141-146.  At the end of the step two quad-permute levels combine the
-// four phases, phase 0 adds the word cost and stores the node's cost into its slot record and the winner's field as its back
-// pointer.  LDS operations of one wave execute in order, so no barrier separates a pass from the next.
+// four phases, the word cost is added, the node's cost goes into its slot record and the winner's field becomes its back
+// pointer.  LDS operations of one wave execute in order, so no barrier separates a pass from the next.  Two loops state this:
+// the common build's in assembly over 8-byte vector-fetched records (sweep_asm.hpp: the one that is measured), and a C++ loop
+// over 64-byte scalar records with precomputed lane masks (LPass) for i32 cells, sentences >= 8000 characters, tiers of more
+// than 64 KiB and connection-id counting.
 //
 // A sentence whose lattice does not fit the tier's LDS is swept in segments cut at ANY position b (a multiple of 8 positions
 // behind the segment's start, not behind a space): slots are numbered by end position over the whole sentence, so the nodes
