@@ -62,7 +62,7 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
         const size_t node0 = (size_t)A.node_factor * slot0;
         const uint4* __restrict__ pcg = A.g_pc + slot0;   // per-character records (+ the terminator at nT)
         const uint4* __restrict__ ndg = A.g_cand + node0;  // candidate records in insertion order: {first cell of the matrix row, word cost | slot << 16, word_idx, end_char | right id << 16}
-        const uint32_t ET = __builtin_amdgcn_readfirstlane(pcg[nT].z);  // end-list slots of the sentence (BOS included)
+        const uint32_t ET = CT + 1u;  // end-list slots of the sentence: one per candidate + BOS (= the terminator record's pcg[nT].z: not worth a round trip)
         const uint32_t kBosSeq = CT + 1;
         // The sentence's hit-staging region (dead after gen_candidates; 16 bytes per node slot): its lower half holds (total cost,
         // back pointer) of every node of a sentence that is swept in segments, its upper half the pass records of the current segment.
