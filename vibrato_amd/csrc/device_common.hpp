@@ -219,6 +219,9 @@ __device__ __forceinline__ void unk_spans(uint32_t cinfo, uint32_t g, uint32_t i
 #ifndef VBT_DEPTH
 #define VBT_DEPTH 2
 #endif
+#ifndef VBT_NO_GATHER
+#define VBT_NO_GATHER 0  // ceiling experiment (sweep_asm.hpp): the assembly loop without its matrix gather, WRONG RESULTS by design
+#endif
 #ifndef VBT_LOOP_PROF
 #define VBT_LOOP_PROF 0  // developer aid (tools/phase_profile.py on a variant build): cycles parked at the assembly sweep loop's two waits
 #endif

@@ -54,6 +54,21 @@
 #define VBT_DPP2 " quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
 #define VBT_SDWA_LO " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD\n\t"
 #define VBT_SDWA_SEXT_HI " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
+// -DVBT_NO_GATHER=1 (ceiling experiment, WRONG RESULTS by design: what any staging of the connection matrix could buy at most): every
+// connection cost is 0, no gather is issued; an iteration then issues one load (its record request), so both variants wait with vmcnt(2)
+#if VBT_NO_GATHER == 1
+#define VBT_GLOAD(W, IDX) "v_mov_b32 " W ", 0\n\t"
+#define VBT_VMC_N "2"
+#define VBT_VMC_W "2"
+#elif VBT_NO_GATHER == 2  /* every lane gathers cell 0: the loads are issued and waited for, but they all hit one line */
+#define VBT_GLOAD(W, IDX) "buffer_load_sshort " W ", v24, %[rs], 0 idxen\n\t"
+#define VBT_VMC_N "4"
+#define VBT_VMC_W "7"
+#else
+#define VBT_GLOAD(W, IDX) "buffer_load_sshort " W ", " IDX ", %[rs], 0 idxen\n\t"
+#define VBT_VMC_N "4"
+#define VBT_VMC_W "7"
+#endif
 #define VBT_B1 " src0_sel:DWORD src1_sel:BYTE_1\n\t"
 #define VBT_B2 " src0_sel:DWORD src1_sel:BYTE_2\n\t"
 #define VBT_B3 " src0_sel:DWORD src1_sel:BYTE_3\n\t"
@@ -168,11 +183,11 @@
     "v_cmp_lt_u32_sdwa s[54:55], v28, " R1 VBT_B3                                                     \
     "v_cmp_lt_u32_sdwa s[56:57], v29, " R1 VBT_B3                                                     \
     "s_and_b64 exec, s[50:51], s[52:53]\n\t"                                                          \
-    "buffer_load_sshort " W1 ", v56, %[rs], 0 idxen\n\t"                                              \
+    VBT_GLOAD(W1, "v56")                                                                            \
     "s_and_b64 exec, s[50:51], s[54:55]\n\t"                                                          \
-    "buffer_load_sshort " W2 ", v57, %[rs], 0 idxen\n\t"                                              \
+    VBT_GLOAD(W2, "v57")                                                                            \
     "s_and_b64 exec, s[50:51], s[56:57]\n\t"                                                          \
-    "buffer_load_sshort " W3 ", v58, %[rs], 0 idxen\n\t"                                              \
+    VBT_GLOAD(W3, "v58")                                                                            \
     "s_mov_b64 exec, -1\n\t"
 // meta of the pass being issued, for the slot: predecessors of the round << 8 | phases << 16 | candidates << 24 (bytes 2, 3 of
 // the first record word over bytes 2, 3 of the second; s58 = the byte selector)
@@ -199,7 +214,7 @@
     VBT_FINISH("v60", "v61", M, CA, "v_add_u32_sdwa v55, v55, v54" VBT_SDWA_LO, VBT_META(META, R0, R1))                      \
     "\n.LBBvbt_j" U V "_%=:\n\t"                                                                      \
     "s_mov_b64 exec, s[48:49]\n\t"                                                                    \
-    "buffer_load_sshort " W0 ", v55, %[rs], 0 idxen\n\t"                                              \
+    VBT_GLOAD(W0, "v55")                                                                            \
     "s_cmp_lg_u32 s46, 0\n\t"                                    /* more units: a wide pass */        \
     "s_cbranch_scc1 .LBBvbt_w" U V "_%=\n\t"                                                          \
     "s_mov_b64 exec, -1\n\t"                                                                          \
@@ -320,7 +335,7 @@
     VBT_META(META, R0, R1)                                                                            \
     "s_mov_b64 " M ", s[48:49]\n\t"                                                                   \
     "s_mov_b64 exec, s[48:49]\n\t"                                                                    \
-    "buffer_load_sshort " W0 ", v55, %[rs], 0 idxen\n\t"                                              \
+    VBT_GLOAD(W0, "v55")                                                                            \
     "s_mov_b64 exec, -1\n\t"                                                                          \
     "s_cmp_lg_u32 s46, 0\n\t"
 #define VBT_PRO0 VBT_EXPAND(VBT_PRO, "0", VBT_G0, VBT_R0, "v[82:83]", "24")
@@ -361,30 +376,30 @@
     VBT_WIDE("v41", "v42", "v43", "v80", "v81")                                                       \
     "s_branch .LBBvbt_i0W_%=\n"                                                                       \
     /* the loop: the narrow variants in line */                                                       \
-    VBT_IT0(VBT_ITER, "N", "4", "", "")                                                               \
-    VBT_IT1(VBT_ITER, "N", "4", VBT_HALF_FALL, "")                                                    \
-    VBT_IT2(VBT_ITER, "N", "4", "", "")                                                               \
-    VBT_IT3(VBT_ITER, "N", "4", VBT_HALF_FALL, "")                                                    \
-    VBT_IT4(VBT_ITER, "N", "4", "", "")                                                               \
-    VBT_IT5(VBT_ITER, "N", "4", VBT_TRIP("N"), "")                                                    \
-    VBT_IT0(VBT_ITER, "W", "7", "s_branch .LBBvbt_i1N_%=\n", "")                                      \
-    VBT_IT1(VBT_ITER, "W", "7", VBT_HALF(".LBBvbt_i2N"), "")                                          \
-    VBT_IT2(VBT_ITER, "W", "7", "s_branch .LBBvbt_i3N_%=\n", "")                                      \
-    VBT_IT3(VBT_ITER, "W", "7", VBT_HALF(".LBBvbt_i4N"), "")                                          \
-    VBT_IT4(VBT_ITER, "W", "7", "s_branch .LBBvbt_i5N_%=\n", "")                                      \
-    VBT_IT5(VBT_ITER, "W", "7", VBT_TRIP("N"), "")                                                    \
-    VBT_IT0(VBT_ITER_OOL, "N", "4", "", "s_branch .LBBvbt_i1W_%=\n")                                  \
-    VBT_IT1(VBT_ITER_OOL, "N", "4", "", VBT_HALF(".LBBvbt_i2W"))                                      \
-    VBT_IT2(VBT_ITER_OOL, "N", "4", "", "s_branch .LBBvbt_i3W_%=\n")                                  \
-    VBT_IT3(VBT_ITER_OOL, "N", "4", "", VBT_HALF(".LBBvbt_i4W"))                                      \
-    VBT_IT4(VBT_ITER_OOL, "N", "4", "", "s_branch .LBBvbt_i5W_%=\n")                                  \
-    VBT_IT5(VBT_ITER_OOL, "N", "4", "", VBT_TRIP("W"))                                                \
-    VBT_IT0(VBT_ITER_OOL, "W", "7", "", "s_branch .LBBvbt_i1W_%=\n")                                  \
-    VBT_IT1(VBT_ITER_OOL, "W", "7", "", VBT_HALF(".LBBvbt_i2W"))                                      \
-    VBT_IT2(VBT_ITER_OOL, "W", "7", "", "s_branch .LBBvbt_i3W_%=\n")                                  \
-    VBT_IT3(VBT_ITER_OOL, "W", "7", "", VBT_HALF(".LBBvbt_i4W"))                                      \
-    VBT_IT4(VBT_ITER_OOL, "W", "7", "", "s_branch .LBBvbt_i5W_%=\n")                                  \
-    VBT_IT5(VBT_ITER_OOL, "W", "7", "", VBT_TRIP("W"))                                                \
+    VBT_IT0(VBT_ITER, "N", VBT_VMC_N, "", "")                                                               \
+    VBT_IT1(VBT_ITER, "N", VBT_VMC_N, VBT_HALF_FALL, "")                                                    \
+    VBT_IT2(VBT_ITER, "N", VBT_VMC_N, "", "")                                                               \
+    VBT_IT3(VBT_ITER, "N", VBT_VMC_N, VBT_HALF_FALL, "")                                                    \
+    VBT_IT4(VBT_ITER, "N", VBT_VMC_N, "", "")                                                               \
+    VBT_IT5(VBT_ITER, "N", VBT_VMC_N, VBT_TRIP("N"), "")                                                    \
+    VBT_IT0(VBT_ITER, "W", VBT_VMC_W, "s_branch .LBBvbt_i1N_%=\n", "")                                      \
+    VBT_IT1(VBT_ITER, "W", VBT_VMC_W, VBT_HALF(".LBBvbt_i2N"), "")                                          \
+    VBT_IT2(VBT_ITER, "W", VBT_VMC_W, "s_branch .LBBvbt_i3N_%=\n", "")                                      \
+    VBT_IT3(VBT_ITER, "W", VBT_VMC_W, VBT_HALF(".LBBvbt_i4N"), "")                                          \
+    VBT_IT4(VBT_ITER, "W", VBT_VMC_W, "s_branch .LBBvbt_i5N_%=\n", "")                                      \
+    VBT_IT5(VBT_ITER, "W", VBT_VMC_W, VBT_TRIP("N"), "")                                                    \
+    VBT_IT0(VBT_ITER_OOL, "N", VBT_VMC_N, "", "s_branch .LBBvbt_i1W_%=\n")                                  \
+    VBT_IT1(VBT_ITER_OOL, "N", VBT_VMC_N, "", VBT_HALF(".LBBvbt_i2W"))                                      \
+    VBT_IT2(VBT_ITER_OOL, "N", VBT_VMC_N, "", "s_branch .LBBvbt_i3W_%=\n")                                  \
+    VBT_IT3(VBT_ITER_OOL, "N", VBT_VMC_N, "", VBT_HALF(".LBBvbt_i4W"))                                      \
+    VBT_IT4(VBT_ITER_OOL, "N", VBT_VMC_N, "", "s_branch .LBBvbt_i5W_%=\n")                                  \
+    VBT_IT5(VBT_ITER_OOL, "N", VBT_VMC_N, "", VBT_TRIP("W"))                                                \
+    VBT_IT0(VBT_ITER_OOL, "W", VBT_VMC_W, "", "s_branch .LBBvbt_i1W_%=\n")                                  \
+    VBT_IT1(VBT_ITER_OOL, "W", VBT_VMC_W, "", VBT_HALF(".LBBvbt_i2W"))                                      \
+    VBT_IT2(VBT_ITER_OOL, "W", VBT_VMC_W, "", "s_branch .LBBvbt_i3W_%=\n")                                  \
+    VBT_IT3(VBT_ITER_OOL, "W", VBT_VMC_W, "", VBT_HALF(".LBBvbt_i4W"))                                      \
+    VBT_IT4(VBT_ITER_OOL, "W", VBT_VMC_W, "", "s_branch .LBBvbt_i5W_%=\n")                                  \
+    VBT_IT5(VBT_ITER_OOL, "W", VBT_VMC_W, "", VBT_TRIP("W"))                                                \
     "\n.LBBvbt_x_%=:\n\t"                                                                             \
     "s_waitcnt vmcnt(0)\n\t"                                                                          \
     VBT_PROF_OUT                                                                                      \
