@@ -206,3 +206,53 @@ def test_gather_ring_registers_are_untouched_in_the_compiled_isa():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_ring_isa.py")], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert r.stdout.count(" 0 violations") == 8, r.stdout
+
+
+def test_ring_checker_flags_seeded_violations():
+    """The checker itself: on a hand-written kernel body it accepts a ring whose consumer sits behind an exact wait, and flags (a) a
+    consumer in front of the wait, (b) a wait that lets one load too many stay in flight, (c) a copy of the destination register on
+    one of two paths, (d) a record load (register pair) whose second register is read early."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_ring_isa", os.path.join(ROOT, "tools", "check_ring_isa.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+
+    def run(lines):
+        body = ["\t;;#ASMSTART"] + ["\t" + ln if not ln.startswith(".L") else ln for ln in lines] + ["\t;;#ASMEND", "\ts_endpgm"]
+        return m.check_kernel("k", body)
+
+    good = ["buffer_load_sshort v40, v1, s[4:7], 0 idxen",      # G
+            "global_load_dwordx2 v[76:77], v24, s[60:61]",       # one load behind G
+            "buffer_load_sshort v41, v2, s[4:7], 0 idxen",       # two
+            "s_waitcnt vmcnt(2)",                                # all but the 2 youngest: G has landed
+            "v_add_u32 v3, v3, v40",
+            "s_waitcnt vmcnt(0)",
+            "v_add_u32 v3, v3, v41",
+            "v_add_u32 v3, v3, v76",
+            "v_add_u32 v3, v3, v77"]
+    n, errs = run(good)
+    assert n == 4 and errs == [], errs                            # (4 destination registers: v40, v76, v77, v41)
+    # (a) consumer in front of the wait
+    n, errs = run(good[:3] + ["v_add_u32 v3, v3, v40"] + good[3:])
+    assert any("v40" in e for e in errs), errs
+    # (b) the wait leaves three loads in flight, G may be one of them
+    bad = list(good)
+    bad[3] = "s_waitcnt vmcnt(3)"
+    n, errs = run(bad)
+    assert any("v40" in e for e in errs), errs
+    # (c) a branch around the wait on which the register is copied
+    n, errs = run(["buffer_load_sshort v40, v1, s[4:7], 0 idxen",
+                   "s_cbranch_scc1 .LBBx_1",
+                   "s_waitcnt vmcnt(0)",
+                   "s_branch .LBBx_2",
+                   ".LBBx_1:",
+                   "v_mov_b32 v9, v40",
+                   ".LBBx_2:",
+                   "s_waitcnt vmcnt(0)"])
+    assert any("v_mov_b32 v9, v40" in e for e in errs), errs
+    # (d) the second register of a record load read before the wait
+    n, errs = run(["global_load_dwordx2 v[76:77], v24, s[60:61]",
+                   "v_readfirstlane_b32 s45, v77",
+                   "s_waitcnt vmcnt(0)"])
+    assert any("v77" in e for e in errs) and not any("v76:" in e for e in errs), errs
+
