@@ -150,6 +150,18 @@ VBT_API int vbt_tokenizer_new(vbt_dict* dict, int ignore_space, uint32_t max_gro
 VBT_API int vbt_tokenizer_new_multi(vbt_dict* dict, int ignore_space, uint32_t max_grouping_len, const int* devices,
                                     uint32_t n_devices, vbt_tokenizer** out);
 VBT_API uint32_t vbt_tokenizer_num_devices(const vbt_tokenizer* tok);
+/* Connection-id locality, built in (the reference's `reorder` + `map` workflow -- map/src/reorder.rs:34-63,
+ * MatrixConnector::map_connection_ids matrix_connector.rs:99-116, Dictionary::map_connection_ids_from_iter dictionary.rs:245-259,
+ * docs/map.md -- without a caller action): the first batch of at least VBT_CONNID_MIN_SENTENCES (2048) sentences a tokenizer sees
+ * has its first VBT_CONNID_SAMPLE (16384) sentences swept once more with the connection-id counters on; the ids are sorted by
+ * count and every later launch reads a device image whose matrix rows / columns and entry id pairs are renumbered hot ids first.
+ * Results are bit-identical (a pure permutation) and nothing visible is in device ids: Token::left_id / right_id, vbt_dict_conn_cost,
+ * vbt_dict_write, the connection-id counters (vbt_workspace_connid_counts, vbt_worker_*connid*) all stay in the dictionary's
+ * numbering, and a mapping applied with vbt_dict_map_connection_ids before the tokenizer was created is kept underneath.
+ * VBT_CONNID_REORDER=0 turns it off.  out[8] = {epoch of the image in use (0 = the dictionary's numbering, 1 = renumbered),
+ * state (0 waiting for a large batch, 1 running, 2 done, 3 off), sentences sampled, the minimum batch size, microseconds the
+ * calibration took, left ids moved, right ids moved, 0}; of the tokenizer's first device. */
+VBT_API int vbt_tokenizer_connid_reorder_info(const vbt_tokenizer* tok, uint64_t out[8]);
 VBT_API void vbt_tokenizer_free(vbt_tokenizer* tok);
 VBT_API const vbt_dict* vbt_tokenizer_dictionary(const vbt_tokenizer* tok); /* Tokenizer::dictionary, tokenizer.rs:77 */
 

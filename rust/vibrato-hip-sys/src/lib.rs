@@ -109,6 +109,7 @@ extern "C" {
     pub fn vbt_tokenizer_new_multi(dict: *mut vbt_dict, ignore_space: c_int, max_grouping_len: u32, devices: *const c_int, n_devices: u32,
                                    out: *mut *mut vbt_tokenizer) -> c_int;
     pub fn vbt_tokenizer_num_devices(tok: *const vbt_tokenizer) -> u32;
+    pub fn vbt_tokenizer_connid_reorder_info(tok: *const vbt_tokenizer, out: *mut u64) -> c_int;
     pub fn vbt_tokenizer_free(tok: *mut vbt_tokenizer);
     pub fn vbt_tokenizer_dictionary(tok: *const vbt_tokenizer) -> *const vbt_dict;
 

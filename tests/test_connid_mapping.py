@@ -196,3 +196,160 @@ def test_connid_counts_survive_retries_and_escalation(tiers, seg, monkeypatch):
         assert ws.stats()["error_flags"] == 0
         glid, grid = ws.connid_counts(reset=True)
         assert np.array_equal(glid, lid) and np.array_equal(grid, rid)
+
+
+# ---- internal renumbering of the connection ids by measured usage (include/vibrato_hip.h: vbt_tokenizer_connid_reorder_info) ----
+
+def _oracle_counts(do, ignore_space, text, offs, lo, hi):
+    w = ora.Tokenizer(do, ignore_space, 0).new_worker()
+    lid = np.zeros(do.num_left, dtype=np.uint64)
+    rid = np.zeros(do.num_right, dtype=np.uint64)
+    for s in range(lo, hi):
+        w.reset_sentence(bytes(text[offs[s]:offs[s + 1]]))
+        w.tokenize()
+        w.add_connid_counts(lid, rid)
+    return lid, rid
+
+
+@pytest.mark.gpu
+def test_internal_connid_renumbering_is_invisible():
+    """The tokenizer's first large batch renumbers the connection ids of its device image by their measured usage (the reference's
+    reorder + map workflow -- map/src/reorder.rs:34-63, matrix_connector.rs:99-116, dictionary.rs:245-259 -- done internally).
+    Nothing a caller can see changes: token records, Token::left_id / right_id, conn_cost, Dictionary::write, the connection-id
+    counters (also when the image changes in the middle of a counting session), Worker::tokenize before and after."""
+    import torch
+    sd = synth.SynthDict("small")
+    text, offs = sd.sentences(4000, "lognormal_40", space_p=0.1)
+    do = ora.Dictionary.from_sources_binmatrix(sd.lex, sd.matrix, sd.num_right, sd.num_left, sd.char_def, sd.unk)
+    dv = V.SystemDictionaryBuilder.from_readers_binmatrix(sd.lex, sd.matrix, sd.num_right, sd.num_left, sd.char_def, sd.unk)
+    written_before = dv.write()
+    tok = V.Tokenizer(dv).ignore_space(True)
+    wo = ora.Tokenizer(do, True, 0).new_worker()
+
+    def check_worker(wv, sids):
+        for s in sids:
+            sent = bytes(text[offs[s]:offs[s + 1]])
+            wo.reset_sentence(sent); wo.tokenize()
+            wv.reset_sentence(sent); wv.tokenize()
+            assert wv.num_tokens() == wo.num_tokens()
+            for i in range(wo.num_tokens()):
+                a, b = wv.token(i), wo.token(i)
+                assert (a.surface, a.feature, list(a.range_char), a.lex_type, a.word_id, a.left_id, a.right_id, a.word_cost, a.total_cost) == \
+                       tuple(b[k] for k in ("surface", "feature", "range_char", "lex_type", "word_id", "left_id", "right_id", "word_cost", "total_cost"))
+
+    info = tok.connid_reorder_info()
+    assert info["epoch"] == 0 and info["state"] == "waiting" and info["min_sentences"] == 2048
+    wv = tok.new_worker()
+    check_worker(wv, range(0, 40))  # the dictionary's own numbering (a Worker's one-sentence batches never calibrate)
+    assert tok.connid_reorder_info()["epoch"] == 0
+
+    # a counting session that starts on the dictionary's numbering and goes on across the renumbering
+    ws = tok.workspace(4000, len(text))
+    ws.count_connids(True)
+    d_text = torch.from_numpy(text).cuda()
+    d_offs = torch.from_numpy(offs.astype(np.int64)).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    ws.run(d_text.data_ptr(), d_offs.data_ptr(), 1000, int(offs[1000]), st)  # < 2048 sentences: image 0
+    assert tok.connid_reorder_info()["epoch"] == 0
+    ws.run(d_text.data_ptr(), d_offs.data_ptr(), 4000, len(text), st)        # calibrates on its own first sentences, then runs on image 1
+    torch.cuda.synchronize()
+    info = tok.connid_reorder_info()
+    assert info["epoch"] == 1 and info["state"] == "done" and info["sample_sentences"] == 4000
+    assert info["moved_left"] > 0 and info["moved_right"] > 0
+    l0, r0 = _oracle_counts(do, True, text, offs, 0, 1000)
+    l1, r1 = _oracle_counts(do, True, text, offs, 0, 4000)
+    glid, grid = ws.connid_counts()
+    assert np.array_equal(glid, l0 + l1) and np.array_equal(grid, r0 + r1)
+    glid2, grid2 = ws.connid_counts(reset=True)  # reading twice does not fold twice
+    assert np.array_equal(glid2, glid) and np.array_equal(grid2, grid)
+    ws.run(d_text.data_ptr(), d_offs.data_ptr(), 1000, int(offs[1000]), st)
+    glid, grid = ws.connid_counts(reset=True)
+    assert np.array_equal(glid, l0) and np.array_equal(grid, r0)
+
+    # tokens of the renumbered image == oracle (batch API: every record and the host-side Token fields)
+    batch = tok.tokenize_batch(text=text, offsets=offs)
+    got, got_off = batch.tokens_in_order()
+    exp, exp_off = wo.tokenize_batch(text, offs)
+    assert np.array_equal(got_off, exp_off)
+    for f in V.TOKEN_DTYPE.names:
+        assert np.array_equal(got[f], exp[f]), f
+    for s in (0, 17, 3999):
+        sent = bytes(text[offs[s]:offs[s + 1]])
+        wo.reset_sentence(sent); wo.tokenize()
+        for i in range(wo.num_tokens()):
+            a, b = batch.token(s, i), wo.token(i)
+            assert (a.left_id, a.right_id, a.word_cost, a.total_cost, a.feature) == tuple(b[k] for k in ("left_id", "right_id", "word_cost", "total_cost", "feature"))
+    # the Worker that was resident on image 0 and a fresh one (image 1)
+    check_worker(wv, range(40, 80))
+    check_worker(tok.new_worker(), range(80, 120))
+    # the dictionary the caller sees is untouched
+    dd = tok.dictionary()
+    rng = random.Random(5)
+    for _ in range(200):
+        r, l = rng.randrange(sd.num_right), rng.randrange(sd.num_left)
+        assert dd.conn_cost(r, l) == do.conn_cost(r, l)
+    assert dd.write() == written_before
+
+
+@pytest.mark.gpu
+def test_internal_renumbering_off_and_on_top_of_a_callers_mapping(monkeypatch):
+    """VBT_CONNID_REORDER=0 keeps the dictionary's numbering; a mapping the caller applied with map_connection_ids_from_iter stays
+    underneath the internal one (counters come back in the caller's mapped ids)."""
+    import torch
+    sd = synth.SynthDict("small")
+    text, offs = sd.sentences(2500, "lognormal_40")
+    rng = random.Random(11)
+    lmap = list(range(1, sd.num_left)); rng.shuffle(lmap)
+    rmap = list(range(1, sd.num_right)); rng.shuffle(rmap)
+    do = ora.Dictionary.from_sources_binmatrix(sd.lex, sd.matrix, sd.num_right, sd.num_left, sd.char_def, sd.unk)
+    do.map_connection_ids_from_iter(lmap, rmap)
+    exp, exp_off = ora.Tokenizer(do).new_worker().tokenize_batch(text, offs)
+    lid, rid = _oracle_counts(do, False, text, offs, 0, 2500)
+    d_text = torch.from_numpy(text).cuda()
+    d_offs = torch.from_numpy(offs.astype(np.int64)).cuda()
+    for reorder in ("0", "1"):
+        monkeypatch.setenv("VBT_CONNID_REORDER", reorder)
+        dv = V.SystemDictionaryBuilder.from_readers_binmatrix(sd.lex, sd.matrix, sd.num_right, sd.num_left, sd.char_def, sd.unk)
+        dv.map_connection_ids_from_iter(lmap, rmap)
+        tok = V.Tokenizer(dv)
+        ws = tok.workspace(2500, len(text))
+        ws.count_connids(True)
+        ws.run(d_text.data_ptr(), d_offs.data_ptr(), 2500, len(text), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        info = tok.connid_reorder_info()
+        assert (info["epoch"], info["state"]) == ((0, "off") if reorder == "0" else (1, "done"))
+        glid, grid = ws.connid_counts()
+        assert np.array_equal(glid, lid) and np.array_equal(grid, rid)
+        got, got_off = tok.tokenize_batch(text=text, offsets=offs).tokens_in_order()
+        assert np.array_equal(got_off, exp_off) and all(np.array_equal(got[f], exp[f]) for f in V.TOKEN_DTYPE.names)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [0, 3])
+def test_tie_heavy_dictionaries_under_the_internal_renumbering(seed, monkeypatch):
+    """Equal-cost paths as the norm (the dictionaries of test_tie_heavy_random_dictionaries_match_oracle), with the calibration
+    threshold lowered so that these 600-sentence batches renumber their 2-5 connection ids: ties are broken by insertion
+    order (lattice.rs:141-146), never by id, so the permutation must not show."""
+    from tests.test_oracle_vs_python_restatement import make_dictionary, HIRA, KATA, ALPHA, NUM, OTHER
+    monkeypatch.setenv("VBT_CONNID_MIN_SENTENCES", "64")
+    monkeypatch.setenv("VBT_CONNID_SAMPLE", "300")
+    rng = random.Random(977 + seed)
+    d = make_dictionary(rng)
+    alphabet = HIRA * 3 + KATA * 2 + ALPHA * 2 + NUM + "   " + OTHER
+    sents = ["".join(rng.choice(alphabet) for _ in range(rng.choice([0, 1, 2, 5, 9, 14, 23, 40, 80, 200, 500, 1200]))) for _ in range(600)]
+    raw = [x.encode("utf-8") for x in sents]
+    text = np.frombuffer(b"".join(raw), dtype=np.uint8)
+    offs = np.zeros(len(raw) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([len(x) for x in raw])
+    for ignore_space, mgl in ((False, 0), (True, 3)):
+        do = ora.Dictionary.from_sources(d["lex"], d["matrix_def"], d["char_def"], d["unk"])
+        dv = V.SystemDictionaryBuilder.from_readers(d["lex"], d["matrix_def"], d["char_def"], d["unk"])
+        if d["user"] is not None:
+            do.reset_user_lexicon(d["user"])
+            dv.reset_user_lexicon_from_reader(d["user"])
+        tv = V.Tokenizer(dv).ignore_space(ignore_space).max_grouping_len(mgl)
+        exp, exp_off = ora.Tokenizer(do, ignore_space, mgl).new_worker().tokenize_batch(text, offs)
+        for _ in range(2):  # the calibrating batch and one that starts on the renumbered image
+            got, got_off = tv.tokenize_batch(text=text, offsets=offs).tokens_in_order()
+            assert np.array_equal(got_off, exp_off) and all(np.array_equal(got[f], exp[f]) for f in V.TOKEN_DTYPE.names)
+        assert tv.connid_reorder_info()["state"] == "done"

@@ -67,6 +67,7 @@ SIGNATURES = {
     "vbt_tokenizer_new": (_int, [_vp, _int, _u32, _int, _PP]),
     "vbt_tokenizer_new_multi": (_int, [_vp, _int, _u32, C.POINTER(C.c_int), _u32, _PP]),
     "vbt_tokenizer_num_devices": (_u32, [_vp]),
+    "vbt_tokenizer_connid_reorder_info": (_int, [_vp, C.POINTER(_u64)]),
     "vbt_tokenizer_free": (None, [_vp]),
     "vbt_tokenizer_dictionary": (_vp, [_vp]),
     "vbt_tokenizer_trim_pool": (_int, [_vp]),

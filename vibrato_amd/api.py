@@ -262,6 +262,14 @@ class Tokenizer:
         """Devices the tokenizer's batches are split over (1 unless created with `devices=[...]`)."""
         return int(N.lib().vbt_tokenizer_num_devices(self._handle()))
 
+    def connid_reorder_info(self):
+        """The internal renumbering of the connection ids by measured usage (include/vibrato_hip.h:
+        vbt_tokenizer_connid_reorder_info): which image is in use and what the calibration cost."""
+        out = (C.c_uint64 * 8)()
+        N.check(N.lib().vbt_tokenizer_connid_reorder_info(self._handle(), out))
+        return {"epoch": int(out[0]), "state": ("waiting", "running", "done", "off")[min(int(out[1]), 3)], "sample_sentences": int(out[2]),
+                "min_sentences": int(out[3]), "ms": out[4] / 1e3, "moved_left": int(out[5]), "moved_right": int(out[6])}
+
     def dictionary(self):
         """Tokenizer::dictionary (tokenizer.rs:77-79)."""
         self._handle()

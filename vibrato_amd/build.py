@@ -14,7 +14,8 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # host code, then the kernels: gen.hip (validate_batch, generators, work lists), lattice.hip (the sweep, the resident Worker
 # kernel), fused.hip (the single-kernel fallback), pack.hip (token compaction, connector expansion), engine.hip (Tokenizer, Workspace)
 SOURCES = ["dict.cpp", "connector.cpp", "dictio.cpp", "capi.cpp", "engine.hip", "gen.hip", "lattice.hip", "fused.hip", "pack.hip"]
-HEADERS = ["dict.hpp", "engine.hpp", "kernels.hpp", "device_common.hpp", "gen_device.hpp", "../../include/vibrato_hip.h"]
+# every header under csrc/ (sweep_asm.hpp -- the hottest code -- was once missing from a hand-written list) + the C ABI
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".hpp")) + ["../../include/vibrato_hip.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-result", "-Wno-unused-function"]
 
 

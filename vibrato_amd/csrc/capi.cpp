@@ -570,6 +570,15 @@ int vbt_tokenizer_new(vbt_dict* dict, int ignore_space, uint32_t max_grouping_le
 
 uint32_t vbt_tokenizer_num_devices(const vbt_tokenizer* tok) { return tok ? (uint32_t)tok->reps.size() : 0; }
 
+int vbt_tokenizer_connid_reorder_info(const vbt_tokenizer* tok, uint64_t out[8]) {
+    return guarded([&] {
+        if (!tok || !out) throw Error(VBT_ERR_INVALID_ARGUMENT, "null argument");
+        const ConnidReorderInfo r = tok->t->reorder_info();
+        out[0] = r.epoch; out[1] = r.state; out[2] = r.sample_sentences; out[3] = r.min_sentences;
+        out[4] = (uint64_t)(r.ms * 1e3); out[5] = r.moved_left; out[6] = r.moved_right; out[7] = 0;
+    });
+}
+
 void vbt_tokenizer_free(vbt_tokenizer* tok) {
     if (!tok) return;
     for (auto& r : tok->reps) r->pool.clear();
@@ -660,7 +669,13 @@ int vbt_worker_tokenize(vbt_worker* w) {
             if (!w->serving) start();
             // the kernel's last store (system-scope release) is the status word; a kernel that left for idleness just before the doorbell
             // rang raises ctl[2] instead: wait for it to be gone, start another
-            bool seen = false;
+            // A kernel that starts late (a GPU busy with batch kernels or another process, a profiler, more Workers than hardware queues
+            // behind another Worker's resident kernel) is not an error: after kWorkerPatience without an answer the kernel is told to
+            // leave and the stream is waited for -- it serves a doorbell that already rang on its way out -- and only a failing
+            // stream reports VBT_ERR_DEVICE; a sentence that is still unserved then goes through the batch pipeline below.
+            constexpr auto kWorkerPatience = std::chrono::seconds(5);
+            bool seen = false, gave_up = false;
+            auto deadline = std::chrono::steady_clock::time_point{};
             for (uint32_t spins = 0; !seen; ++spins) {
                 seen = __atomic_load_n(&w->h_ctl[0], __ATOMIC_ACQUIRE) == seq;
                 if (seen) break;
@@ -669,13 +684,23 @@ int vbt_worker_tokenize(vbt_worker* w) {
                     w->serving = false;
                     if (__atomic_load_n(&w->h_ctl[0], __ATOMIC_ACQUIRE) == seq) { seen = true; break; }  // (served on its way out)
                     start();
-                } else if (spins > (1u << 26)) {  // (seconds: a kernel that never answers)
-                    w->stop_serving();
-                    throw Error(VBT_ERR_DEVICE, "worker: the resident tokenize kernel did not report back");
+                } else if ((spins & 0xFFFFu) == 0xFFFFu) {  // (a clock read every 64 k polls)
+                    const auto now = std::chrono::steady_clock::now();
+                    if (deadline == std::chrono::steady_clock::time_point{}) deadline = now + kWorkerPatience;
+                    else if (now > deadline) {
+                        __atomic_store_n(&w->h_ctl[6], 1u, __ATOMIC_RELEASE);
+                        HIPX(hipStreamSynchronize(w->stream));  // (the only failure that is reported as one)
+                        w->h_ctl[6] = 0; w->h_ctl[2] = 0;
+                        w->serving = false;
+                        seen = __atomic_load_n(&w->h_ctl[0], __ATOMIC_ACQUIRE) == seq;
+                        gave_up = !seen;
+                        break;
+                    }
                 }
             }
-            if (w->idle_polls == 0) { HIPX(hipStreamSynchronize(w->stream)); w->serving = false; }  // (one launch per call: it has left)
-            const uint32_t outcome = w->h_ctl[3];
+            if (w->idle_polls == 0 && w->serving) { HIPX(hipStreamSynchronize(w->stream)); w->serving = false; }  // (one launch per call: it has left)
+            const uint32_t outcome = gave_up ? 1u : w->h_ctl[3];
+            if (gave_up) { w->h_ctl[0] = w->h_ctl[4] = seq; }  // the batch pipeline below serves this sequence number: the next kernel starts behind it
             if (outcome == 0) {
                 const uint32_t cnt = w->h_ctl[1];
                 if (cnt > len) throw Error(VBT_ERR_INVALID_STATE, "worker: token count exceeds the sentence");
@@ -1103,13 +1128,22 @@ int vbt_batch_format(const vbt_batch* b, int mode, char** out, size_t* len) {
         std::mutex fail_mu;
         auto in_parallel = [&](auto&& body) {  // body(k) for every chunk; exceptions (a word id outside the dictionary) are carried out
             std::vector<std::thread> th;
+            { std::lock_guard<std::mutex> g(fail_mu); failure.clear(); }
             auto run = [&](unsigned k) {
                 try { body(k); }
                 catch (const std::exception& e) { std::lock_guard<std::mutex> g(fail_mu); failure = e.what(); }
             };
-            for (unsigned k = 1; k < T; ++k) th.emplace_back(run, k);
+            unsigned started = 1;  // chunks that have a thread (chunk 0 is this thread's)
+            try {
+                th.reserve(T);
+                for (; started < T; ++started) th.emplace_back(run, started);
+            } catch (const std::exception&) {
+                // the host is out of threads (EAGAIN): what could not be started runs here, nothing is left joinable
+            }
             run(0);
+            for (unsigned k = started; k < T; ++k) run(k);
             for (auto& t : th) t.join();
+            std::lock_guard<std::mutex> g(fail_mu);
             if (!failure.empty()) throw Error(VBT_ERR_INVALID_STATE, failure);
         };
         in_parallel([&](unsigned k) {

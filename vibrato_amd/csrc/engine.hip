@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -72,6 +73,8 @@ Tokenizer::Tokenizer(const Dictionary* dict, bool ignore_space, uint32_t max_gro
     if (device >= count) throw Error(VBT_ERR_INVALID_ARGUMENT, "device: index out of range");
     HIP_CHECK(hipSetDevice(device));
     device_ = device;
+    auto img0 = std::make_unique<DevImage>();
+    DevDict& dev_ = img0->dev;  // image 0: the dictionary's own connection ids
     hipDeviceProp_t prop;
     HIP_CHECK(hipGetDeviceProperties(&prop, device));
     if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
@@ -168,6 +171,13 @@ Tokenizer::Tokenizer(const Dictionary* dict, bool ignore_space, uint32_t max_gro
         for (void* p : allocs_) (void)hipFree(p);
         throw;
     }
+    // internal renumbering of the connection ids by measured usage (maybe_calibrate): on unless VBT_CONNID_REORDER=0
+    if (env_u32("VBT_CONNID_REORDER", 1) == 0) calib_state_.store(3);
+    calib_min_ = std::max<uint32_t>(1, env_u32("VBT_CONNID_MIN_SENTENCES", 2048));
+    calib_sample_ = std::max<uint32_t>(1, env_u32("VBT_CONNID_SAMPLE", 16384));
+    info_.min_sentences = calib_min_;
+    cur_.store(img0.get(), std::memory_order_release);
+    images_.push_back(std::move(img0));
 }
 
 void Tokenizer::upload_lexicon(const Lexicon& lx, DevLexicon& out) {
@@ -179,7 +189,74 @@ void Tokenizer::upload_lexicon(const Lexicon& lx, DevLexicon& out) {
 }
 
 Tokenizer::~Tokenizer() {
+    (void)hipSetDevice(device_);
+    for (auto& im : images_)
+        for (void* p : im->allocs) (void)hipFree(p);
     for (void* p : allocs_) (void)hipFree(p);
+}
+
+const DevImage& Tokenizer::image_of(uint32_t epoch) const {
+    std::lock_guard<std::mutex> g(img_mu_);
+    for (const auto& im : images_)
+        if (im->epoch == epoch) return *im;
+    throw Error(VBT_ERR_INVALID_STATE, "no device image of that epoch");
+}
+
+ConnidReorderInfo Tokenizer::reorder_info() const {
+    std::lock_guard<std::mutex> g(img_mu_);
+    ConnidReorderInfo r = info_;
+    r.state = (uint32_t)calib_state_.load(std::memory_order_acquire);
+    r.epoch = image().epoch;
+    return r;
+}
+
+// A copy of image 0 under a renumbering of the connection ids (perm_*[dictionary id] = device id; id 0 -- BOS / EOS -- stays 0):
+// the matrix with rows and columns permuted on the device, the entry arrays with their id pairs translated on the host.
+std::unique_ptr<DevImage> Tokenizer::renumbered_image(const std::vector<uint16_t>& pl, const std::vector<uint16_t>& pr, void* stream_) const {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    const DevImage& base = *images_[0];
+    auto im = std::make_unique<DevImage>();
+    im->dev = base.dev;
+    im->perm_left = pl; im->perm_right = pr;
+    try {
+        auto entries = [&](const std::vector<Entry>& src) {
+            std::vector<Entry> v(src);
+            for (Entry& e : v) {
+                const uint32_t l = e.left_right & 0xFFFFu, r = e.left_right >> 16;
+                if (l >= pl.size() || r >= pr.size()) throw Error(VBT_ERR_INVALID_STATE, "entry with a connection id outside the matrix");
+                e.left_right = (uint32_t)pl[l] | ((uint32_t)pr[r] << 16);
+            }
+            return dev_upload(v, im->allocs);
+        };
+        im->dev.sys.entries = entries(dict_->system.entries);
+        im->dev.user.entries = dict_->has_user ? entries(dict_->user.entries) : im->dev.sys.entries;
+        im->dev.unk_entries = entries(dict_->unk_entries);
+        std::vector<uint16_t> il(pl.size()), ir(pr.size());  // device id -> dictionary id
+        for (size_t i = 0; i < pl.size(); ++i) il[pl[i]] = (uint16_t)i;
+        for (size_t i = 0; i < pr.size(); ++i) ir[pr[i]] = (uint16_t)i;
+        std::vector<void*> tmp;
+        try {
+            const uint16_t* d_il = dev_upload(il, tmp);
+            const uint16_t* d_ir = dev_upload(ir, tmp);
+            const size_t cell = base.dev.matrix_wide ? 4 : 2;
+            const size_t cells = (size_t)dict_->num_left * dict_->num_right;
+            void* m = nullptr;
+            HIP_CHECK(hipMalloc(&m, (cells + 1) * cell));
+            im->allocs.push_back(m);
+            HIP_CHECK(hipMemset(static_cast<char*>(m) + cells * cell, 0, cell));
+            kern::permute_matrix(stream, base.dev.matrix, m, base.dev.matrix_wide != 0, d_il, d_ir, dict_->num_left, dict_->num_right);
+            HIP_CHECK(hipStreamSynchronize(stream));  // (not the device: a resident Worker kernel of another thread must not hold this up)
+            im->dev.matrix = static_cast<const int16_t*>(m);
+            for (void* p : tmp) (void)hipFree(p);
+        } catch (...) {
+            for (void* p : tmp) (void)hipFree(p);
+            throw;
+        }
+    } catch (...) {
+        for (void* p : im->allocs) (void)hipFree(p);
+        throw;
+    }
+    return im;
 }
 
 // ------------------------------------------------------------------ Workspace
@@ -289,6 +366,13 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
     if (n > max_sentences || total_bytes > max_bytes) throw Error(VBT_ERR_INVALID_ARGUMENT, "batch exceeds the workspace capacity");
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     HIP_CHECK(hipSetDevice(tok.device()));
+    // the tokenizer's first large batch renumbers the connection ids of the device image by their measured usage (once)
+    if (!fused) tok.maybe_calibrate(d_text, d_offsets, n, stream_);
+    const DevImage& image = tok.image();  // one image for every launch of this batch
+    if (count_connids && image.epoch != count_epoch) {  // the counters on the device are in another image's ids: fold them first
+        if (last_stream) fold_connid_counts();
+        count_epoch = image.epoch;
+    }
     last_n = n;
     last_stream = stream_;
     HIP_CHECK(hipMemsetAsync(d_ctrl, 0, (kCtrlWords + (size_t)kBlockCtrlWords) * 4, stream));  // ctrl + cctrl
@@ -316,7 +400,7 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
     a.s_counted = count_connids ? d_counted : nullptr;
     if (count_connids) HIP_CHECK(hipMemsetAsync(d_counted, 0, n * 4, stream));
     for (size_t t = 0; t < T; ++t) a.tier_bytes[t] = tiers[t];
-    const DevDict& D = tok.dev();
+    const DevDict& D = image.dev;
     auto rec = [&](int i) { if (timing) HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(ev[i]), stream)); };
     auto over = [&](size_t t) { return d_over + t * stride; };
     auto waves_for = [&](uint32_t lds, uint64_t items) {
@@ -429,8 +513,10 @@ void Workspace::serve(const uint8_t* h_text_dev, uint8_t* d_text, uint64_t* d_of
     a.lid_count = nullptr; a.rid_count = nullptr; a.s_counted = nullptr;
     constexpr uint32_t kOneLds = 65536;  // generator arrays (~26 B per character), then the lattice (whole up to ~400 characters, in segments beyond)
     a.tier_bytes[0] = kOneLds;
-    const DevDict& D = tok.dev();
-    kern::tokenize_serve(kOneLds, stream, D, a, h_text_dev, ctl, last_seq, idle_polls);
+    const DevDict& D = tok.dev();  // (the image of the moment: a kernel that is started later may use a newer one)
+    // (VBT_WORKER_MAX_SERVED: sentences after which the resident kernel leaves and is started again by the next call -- ~0.15 s of
+    // residency at 35 us per call; 0 = unbounded)
+    kern::tokenize_serve(kOneLds, stream, D, a, h_text_dev, ctl, last_seq, idle_polls, env_u32("VBT_WORKER_MAX_SERVED", 4096));
     HIP_CHECK(hipGetLastError());
 }
 
@@ -493,21 +579,118 @@ void Workspace::enable_connid_counts(bool on) {
     count_connids = on;
 }
 
+// Device counters (device ids of image `count_epoch`) -> dictionary ids, added to out_*.
+static void add_unmapped(const DevImage& im, const std::vector<uint64_t>& dl, const std::vector<uint64_t>& dr, uint64_t* lid, uint64_t* rid) {
+    for (size_t i = 0; i < dl.size(); ++i) lid[i] += dl[im.perm_left.empty() ? i : im.perm_left[i]];
+    for (size_t i = 0; i < dr.size(); ++i) rid[i] += dr[im.perm_right.empty() ? i : im.perm_right[i]];
+}
+
+void Workspace::fold_connid_counts() {
+    if (!d_connid) return;
+    HIP_CHECK(hipSetDevice(tok.device()));
+    if (last_stream) HIP_CHECK(hipStreamSynchronize(reinterpret_cast<hipStream_t>(last_stream)));
+    const size_t nl = tok.dict().num_left, nr = tok.dict().num_right;
+    std::vector<uint64_t> dl(nl), dr(nr);
+    HIP_CHECK(hipMemcpy(dl.data(), d_connid, nl * 8, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(dr.data(), d_connid + nl, nr * 8, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemset(d_connid, 0, (nl + nr) * 8));
+    acc_lid.resize(nl, 0); acc_rid.resize(nr, 0);
+    add_unmapped(tok.image_of(count_epoch), dl, dr, acc_lid.data(), acc_rid.data());
+}
+
 void Workspace::read_connid_counts(uint64_t* lid, uint64_t* rid, bool reset) {
     HIP_CHECK(hipSetDevice(tok.device()));
     if (!d_connid) throw Error(VBT_ERR_INVALID_STATE, "connection-id counting was never enabled");
-    HIP_CHECK(hipStreamSynchronize(reinterpret_cast<hipStream_t>(last_stream)));
+    if (last_stream) HIP_CHECK(hipStreamSynchronize(reinterpret_cast<hipStream_t>(last_stream)));
     const size_t nl = tok.dict().num_left, nr = tok.dict().num_right;
-    HIP_CHECK(hipMemcpy(lid, d_connid, nl * 8, hipMemcpyDeviceToHost));
-    HIP_CHECK(hipMemcpy(rid, d_connid + nl, nr * 8, hipMemcpyDeviceToHost));
-    if (reset) HIP_CHECK(hipMemset(d_connid, 0, (nl + nr) * 8));
+    std::vector<uint64_t> dl(nl), dr(nr);
+    HIP_CHECK(hipMemcpy(dl.data(), d_connid, nl * 8, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(dr.data(), d_connid + nl, nr * 8, hipMemcpyDeviceToHost));
+    // what the caller sees is in the dictionary's ids, whatever numbering the image that counted uses
+    for (size_t i = 0; i < nl; ++i) lid[i] = i < acc_lid.size() ? acc_lid[i] : 0;
+    for (size_t i = 0; i < nr; ++i) rid[i] = i < acc_rid.size() ? acc_rid[i] : 0;
+    add_unmapped(tok.image_of(count_epoch), dl, dr, lid, rid);
+    if (reset) {
+        HIP_CHECK(hipMemset(d_connid, 0, (nl + nr) * 8));
+        acc_lid.clear(); acc_rid.clear();
+    }
 }
 
 void Workspace::reset_connid_counts() {
     HIP_CHECK(hipSetDevice(tok.device()));
     if (!d_connid) return;
-    HIP_CHECK(hipStreamSynchronize(reinterpret_cast<hipStream_t>(last_stream)));
+    if (last_stream) HIP_CHECK(hipStreamSynchronize(reinterpret_cast<hipStream_t>(last_stream)));
     HIP_CHECK(hipMemset(d_connid, 0, ((size_t)tok.dict().num_left + tok.dict().num_right) * 8));
+    acc_lid.clear(); acc_rid.clear();
+}
+
+// ------------------------------------------------------------------ connection ids by usage
+
+void Tokenizer::maybe_calibrate(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n, void* stream) const {
+    if (n < calib_min_ || calib_state_.load(std::memory_order_acquire) != 0) return;
+    int idle = 0;
+    if (!calib_state_.compare_exchange_strong(idle, 1)) return;  // another thread is at it: this batch runs on the current image
+    bool done = false;
+    try {
+        done = calibrate(d_text, d_offsets, n, stream);
+        calib_state_.store(done ? 2 : 0, std::memory_order_release);  // (not done: the sample was rejected -- a later batch tries again)
+    } catch (const std::exception& e) {
+        // an optimisation that cannot run (no memory for the sample's workspace, ...) must not fail the caller's batch: the image
+        // stays as it is, for good
+        if (std::getenv("VBT_DEBUG")) std::fprintf(stderr, "[vbt] connection-id renumbering given up: %s\n", e.what());
+        (void)hipGetLastError();
+        calib_state_.store(3, std::memory_order_release);
+    }
+}
+
+bool Tokenizer::calibrate(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n, void* stream_) const {
+    const auto t0 = std::chrono::steady_clock::now();
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    HIP_CHECK(hipSetDevice(device_));
+    HIP_CHECK(hipStreamSynchronize(stream));  // the caller's text and offsets are complete
+    const uint64_t ns = std::min<uint64_t>(n, calib_sample_);
+    uint64_t o0 = 0, o1 = 0;
+    HIP_CHECK(hipMemcpy(&o0, d_offsets, 8, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(&o1, d_offsets + ns, 8, hipMemcpyDeviceToHost));
+    if (o1 < o0 || o1 - o0 >= 0xFFFFFFF0ull) return false;  // (the batch's own run reports what is wrong with it)
+    const size_t nl = dict_->num_left, nr = dict_->num_right;
+    std::vector<uint64_t> lid(nl), rid(nr);
+    {
+        Workspace ws(*this, ns, o1 - o0);  // (its run() comes back here and finds the state "running")
+        ws.enable_connid_counts(true);
+        ws.run(d_text, d_offsets, ns, o1 - o0, stream_);
+        vbt_call_stats st;
+        ws.stats(&st);
+        if (st.error_flags) return false;
+        ws.read_connid_counts(lid.data(), rid.data(), false);
+    }
+    // ids by descending count, then ascending id (ConnIdCounter::compute_probs, mapper.rs:108-146); id 0 (BOS / EOS) stays
+    auto order = [](const std::vector<uint64_t>& cnt, std::vector<uint16_t>& perm) {
+        std::vector<uint32_t> ids(cnt.size() > 0 ? cnt.size() - 1 : 0);
+        for (size_t i = 0; i < ids.size(); ++i) ids[i] = (uint32_t)i + 1;
+        std::stable_sort(ids.begin(), ids.end(), [&](uint32_t a, uint32_t b) { return cnt[a] > cnt[b]; });
+        perm.assign(cnt.size(), 0);
+        uint32_t moved = 0;
+        for (size_t k = 0; k < ids.size(); ++k) { perm[ids[k]] = (uint16_t)(k + 1); moved += ids[k] != k + 1; }
+        return moved;
+    };
+    std::vector<uint16_t> pl, pr;
+    const uint32_t ml = order(lid, pl), mr = order(rid, pr);
+    std::unique_ptr<DevImage> im;
+    if (ml || mr) {
+        im = renumbered_image(pl, pr, stream_);
+        im->epoch = 1;
+    }
+    std::lock_guard<std::mutex> g(img_mu_);
+    info_.sample_sentences = ns;
+    info_.moved_left = ml; info_.moved_right = mr;
+    if (im) {
+        const DevImage* p = im.get();
+        images_.push_back(std::move(im));
+        cur_.store(p, std::memory_order_release);
+    }
+    info_.ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return true;
 }
 
 void Workspace::read_profile(uint64_t* out, bool reset) {

@@ -1,8 +1,10 @@
 // Device engine of the MI355X tokenizer (product code): device dictionary image,
 // batch workspace and the kernel launch sequence.  See DESIGN.md for the layout.
 #pragma once
+#include <atomic>
 #include <cstdint>
 #include <memory>
+#include <mutex>
 #include <vector>
 
 #include "dict.hpp"
@@ -105,6 +107,30 @@ constexpr int kProfPhases = 8;  // decode, count, fill, end lists, pre-pass, gat
 // kErrOffsets / kErrUtf8 are set by validate_batch; the batch is then skipped (no kernel touches the per-sentence regions)
 enum DevError { kErrTokCap = 1, kErrScratch = 2, kErrTooLong = 4, kErrOffsets = 8, kErrUtf8 = 16, kErrFatal = kErrOffsets | kErrUtf8 };
 
+// What a kernel launch reads of the dictionary.  The connection ids inside it -- the rows and columns of the matrix, the id pairs of
+// the entry arrays -- are DEVICE ids: image 0 numbers them as the dictionary does; the image a tokenizer builds from the usage
+// counts of its first large batch (Tokenizer::maybe_calibrate) numbers them by descending frequency, the reference's own locality
+// lever (map/src/reorder.rs:34-63, matrix_connector.rs:99-116, dictionary.rs:245-259) applied internally.  Nothing a caller sees is
+// in device ids: token records carry word ids, the connection-id counters are translated back on their way out.
+struct DevImage {
+    DevDict dev{};
+    uint32_t epoch = 0;
+    std::vector<uint16_t> perm_left, perm_right;  // dictionary id -> device id (empty: identity)
+    std::vector<void*> allocs;                    // what this image owns on the device
+};
+
+// vbt_tokenizer_connid_reorder_info
+struct ConnidReorderInfo {
+    uint32_t epoch = 0;              // 0: the dictionary's own numbering, 1: renumbered by measured usage
+    uint32_t state = 0;              // 0 waiting for a batch of >= min_sentences, 1 running, 2 done, 3 off (VBT_CONNID_REORDER=0 or a failed attempt)
+    uint64_t sample_sentences = 0;   // sentences the usage counts were taken on
+    uint64_t min_sentences = 0;
+    double ms = 0;                   // wall time of the calibration (counting run, sort, new image)
+    uint32_t moved_left = 0, moved_right = 0;  // ids whose device id differs from their dictionary id
+};
+
+class Workspace;
+
 class Tokenizer {
   public:
     // Builds the device image of `dict` (borrowed until adopt() hands over ownership).
@@ -112,16 +138,32 @@ class Tokenizer {
     ~Tokenizer();
     void adopt(std::unique_ptr<Dictionary> d) { owned_ = std::move(d); }
     const Dictionary& dict() const { return *dict_; }
-    const DevDict& dev() const { return dev_; }
+    // the image new launches use (an image lives as long as the tokenizer: launches in flight and resident Worker kernels keep reading theirs)
+    const DevImage& image() const { return *cur_.load(std::memory_order_acquire); }
+    const DevImage& image_of(uint32_t epoch) const;
+    const DevDict& dev() const { return image().dev; }
     int device() const { return device_; }
+    // Called by Workspace::run in front of every batch: the first batch of >= min_sentences gets its first sentences (at most
+    // VBT_CONNID_SAMPLE, default 16384) swept once more with the connection-id counters on (the reorder tool's statistics,
+    // worker.rs:77-93, lattice.rs:170-183); the ids are sorted by count (mapper.rs:108-146) and a renumbered image -- permuted
+    // matrix, permuted id pairs in the entries -- replaces the current one for every later launch.  Synchronises `stream` once.
+    void maybe_calibrate(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n, void* stream) const;
+    ConnidReorderInfo reorder_info() const;
 
   private:
     void upload_lexicon(const Lexicon& lx, DevLexicon& out);
+    bool calibrate(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n, void* stream) const;
+    std::unique_ptr<DevImage> renumbered_image(const std::vector<uint16_t>& perm_left, const std::vector<uint16_t>& perm_right, void* stream) const;
     const Dictionary* dict_;
     std::unique_ptr<Dictionary> owned_;
-    DevDict dev_{};
     int device_ = 0;
-    std::vector<void*> allocs_;
+    std::vector<void*> allocs_;  // what every image shares: tries, code mappers, character classes, unknown-word offsets
+    mutable std::mutex img_mu_;
+    mutable std::vector<std::unique_ptr<DevImage>> images_;  // [0] = the dictionary's numbering
+    mutable std::atomic<const DevImage*> cur_{nullptr};
+    mutable std::atomic<int> calib_state_{0};
+    mutable ConnidReorderInfo info_;
+    uint64_t calib_min_ = 2048, calib_sample_ = 16384;
 };
 
 class Workspace {
@@ -153,12 +195,15 @@ class Workspace {
     std::vector<void*> tier_events;
     void* ev_fork2 = nullptr;
     bool fused = false;              // VBT_FUSED=1: the single fused kernel per sentence (A/B reference)
-    unsigned long long* d_connid = nullptr;  // [num_left + num_right] usage counters, allocated on first use
+    unsigned long long* d_connid = nullptr;  // [num_left + num_right] usage counters (DEVICE ids of image `count_epoch`), allocated on first use
     uint32_t* d_counted = nullptr;           // per-sentence watermark of the counted steps
     bool count_connids = false;
+    uint32_t count_epoch = 0;                // the image whose numbering d_connid is in
+    std::vector<uint64_t> acc_lid, acc_rid;  // counts of earlier images, already in dictionary ids (the image changed while counting)
     void enable_connid_counts(bool on);
-    void read_connid_counts(uint64_t* lid, uint64_t* rid, bool reset);
+    void read_connid_counts(uint64_t* lid, uint64_t* rid, bool reset);  // dictionary ids
     void reset_connid_counts();
+    void fold_connid_counts();               // device counters -> acc_* (dictionary ids), device counters zeroed
     unsigned long long* d_prof = nullptr;
     char* d_scratch = nullptr;
     uint64_t scratch_bytes = 0;

@@ -30,7 +30,7 @@ void gen_set_max_lds(int bytes);  // hipFuncAttributeMaxDynamicSharedMemorySize 
 void lattice_lds(uint32_t workgroups, uint32_t lds_bytes, hipStream_t stream, const DevDict& D, const BatchArgs& a, uint32_t tier, uint32_t persistent);
 void lattice_set_max_lds(int bytes);
 void tokenize_serve(uint32_t lds_bytes, hipStream_t stream, const DevDict& D, const BatchArgs& a, const uint8_t* h_text, uint32_t* ctl, uint32_t last_seq,
-                    uint32_t idle_polls);
+                    uint32_t idle_polls, uint32_t max_served);
 
 // ---- fused.hip: the single-kernel fallback (global-memory lattice) and its LDS form (VBT_FUSED=1)
 void fused_lds(uint32_t workgroups, uint32_t lds_bytes, hipStream_t stream, const DevDict& D, const BatchArgs& a, const uint32_t* in_list, const uint32_t* in_count,
@@ -45,6 +45,8 @@ void compact_tokens_out(uint32_t workgroups, hipStream_t stream, const BatchArgs
                         uint32_t* out_off, uint32_t* out_cnt);
 void expand_connector_i16(dim3 grid, const DevConnector& c, int16_t* out, uint32_t num_right, uint32_t num_left, uint32_t* range_flag);
 void expand_connector_i32(dim3 grid, const DevConnector& c, int32_t* out, uint32_t num_right, uint32_t num_left, uint32_t* range_flag);
+// dst[l][r] = src[inv_left[l]][inv_right[r]] (i16 cells, or i32 when `wide`): the matrix under a renumbering of the connection ids
+void permute_matrix(hipStream_t stream, const void* src, void* dst, bool wide, const uint16_t* inv_left, const uint16_t* inv_right, uint32_t num_left, uint32_t num_right);
 
 }  // namespace kern
 }  // namespace vbt

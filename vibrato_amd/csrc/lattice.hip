@@ -794,7 +794,7 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
 // starts the kernel again (capi.cpp).  `idle_polls` = 0: one sentence, then out (the launch-per-call form of round 3, kept for A/B).
 template <bool kSpaceMode, bool kWide>
 __global__ void __launch_bounds__(64) tokenize_serve(DevDict D, BatchArgs A, uint32_t lds_bytes, const uint8_t* h_text, uint32_t* ctl, uint32_t last_seq,
-                                                       uint32_t idle_polls) {
+                                                       uint32_t idle_polls, uint32_t max_served) {
     const uint32_t ln = threadIdx.x;
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     // (one 16-byte read of the host's group: the doorbell is the word the host writes last, so a new doorbell comes with its length)
@@ -806,7 +806,7 @@ __global__ void __launch_bounds__(64) tokenize_serve(DevDict D, BatchArgs A, uin
         return make_uint4((uint32_t)__builtin_amdgcn_readfirstlane((int)g.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)g.y),
                           (uint32_t)__builtin_amdgcn_readfirstlane((int)g.z), 0u);
     };
-    uint32_t idle = 0;
+    uint32_t idle = 0, served = 0;
     for (;;) {
         // ---- wait for the doorbell (lane 0 polls pinned host memory; everything below is wave-uniform) ----
         const uint4 hg = poll();
@@ -860,6 +860,14 @@ __global__ void __launch_bounds__(64) tokenize_serve(DevDict D, BatchArgs A, uin
             __hip_atomic_store(&ctl[0], bell, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         if (idle_polls == 0) return;
+        // Residency is bounded: a Worker that is called in a tight loop would otherwise keep this kernel on the device for ever, and
+        // every device-synchronising call of another thread (hipFree of a pooled workspace, hipHostFree, a caller's own
+        // hipDeviceSynchronize) waits for it.  After max_served sentences the kernel raises "has left" and goes; the next call
+        // finds the word set and starts another (capi.cpp: the same handshake as leaving for idleness).
+        if (max_served && ++served >= max_served) {
+            if (ln == 0) __hip_atomic_store(&ctl[2], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            return;
+        }
         __syncthreads();
     }
 }
@@ -885,9 +893,9 @@ void lattice_set_max_lds(int bytes) {
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(vbt::lattice_lds<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
 }
 void tokenize_serve(uint32_t lds_bytes, hipStream_t stream, const DevDict& D, const BatchArgs& a, const uint8_t* h_text, uint32_t* ctl, uint32_t last_seq,
-                    uint32_t idle_polls) {
+                    uint32_t idle_polls, uint32_t max_served) {
     auto k = pick(D, [](auto s, auto w) { return &vbt::tokenize_serve<decltype(s)::value, decltype(w)::value>; });
-    hipLaunchKernelGGL(k, dim3(1), dim3(64), lds_bytes, stream, D, a, lds_bytes, h_text, ctl, last_seq, idle_polls);
+    hipLaunchKernelGGL(k, dim3(1), dim3(64), lds_bytes, stream, D, a, lds_bytes, h_text, ctl, last_seq, idle_polls, max_served);
 }
 
 }  // namespace kern

@@ -156,9 +156,26 @@ __global__ void __launch_bounds__(256) expand_connector(DevConnector c, CellT* o
     out[(size_t)left * num_right + right] = (CellT)v;
 }
 
+// The connection matrix under a renumbering of the ids (Tokenizer::renumbered_image; the reference's MatrixConnector::
+// map_connection_ids, matrix_connector.rs:99-116, on the device): one thread per destination cell, stores coalesced, the loads of a
+// workgroup gather from one source row (31 KB for unidic: it stays in L2 while the row is being read).
+template <typename CellT>
+__global__ void __launch_bounds__(256) permute_matrix(const CellT* __restrict__ src, CellT* __restrict__ dst, const uint16_t* __restrict__ inv_left,
+                                                      const uint16_t* __restrict__ inv_right, uint32_t num_right) {
+    const uint32_t r = blockIdx.x * 256 + threadIdx.x, l = blockIdx.y;
+    if (r >= num_right) return;
+    dst[(size_t)l * num_right + r] = src[(size_t)inv_left[l] * num_right + inv_right[r]];
+}
+
 }  // namespace
 
 namespace kern {
+
+void permute_matrix(hipStream_t stream, const void* src, void* dst, bool wide, const uint16_t* inv_left, const uint16_t* inv_right, uint32_t num_left, uint32_t num_right) {
+    const dim3 grid((num_right + 255) / 256, num_left);
+    if (wide) hipLaunchKernelGGL(vbt::permute_matrix<int32_t>, grid, dim3(256), 0, stream, static_cast<const int32_t*>(src), static_cast<int32_t*>(dst), inv_left, inv_right, num_right);
+    else hipLaunchKernelGGL(vbt::permute_matrix<int16_t>, grid, dim3(256), 0, stream, static_cast<const int16_t*>(src), static_cast<int16_t*>(dst), inv_left, inv_right, num_right);
+}
 
 uint32_t pack_split() { return kPackSplit; }
 void tok_tile_scan(hipStream_t stream, const BatchArgs& a, uint32_t* tile_sums, uint32_t n_tiles) {

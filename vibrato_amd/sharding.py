@@ -95,12 +95,13 @@ def gather_packed(send, world_out=None, group=None, async_op=False):
 def gather_to_root(send, root_out=None, root=0, group=None, async_op=False):
     """The path's final exchange as a true GATHER (north star: "RCCL over xGMI only for the final gather"): every rank sends its
     packed slot to `root` only -- grouped send/recv under RCCL, 1/world of the all-gather's inbound traffic per non-root rank, and
-    nothing at all lands on them.  `root_out` ([world * slot_bytes] uint8, device-resident) is needed on the root only.
+    nothing at all lands on them.  `root` is a GLOBAL rank (what torch's `dst` means, also with a sub-group).  `root_out`
+    ([world * slot_bytes] uint8, device-resident) is needed on the root only.
     Returns (out tensor [world, slot_bytes] on the root, None elsewhere; work or None)."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
-    is_root = dist.get_rank(group) == root
+    is_root = dist.get_rank() == root
     parts = None
     if is_root:
         if root_out is None:
