@@ -282,6 +282,11 @@ def main():
     if st["error_flags"]:
         raise SystemExit(f"device error flags {st['error_flags']}")
     total_tokens = int(st["n_tokens"])
+    if reorder_info is None:
+        # the tokenizer renumbers the connection ids of its device image by the usage it measures on its first large batch
+        # (the warm-up step above): include/vibrato_hip.h, vbt_tokenizer_connid_reorder_info.  VBT_CONNID_REORDER=0: off (A/B).
+        ri = tok.connid_reorder_info()
+        reorder_info = ("internal" if ri["epoch"] else "off") if world > 1 else {"mode": "internal" if ri["epoch"] else "off", **ri}
     gathered_ok = None
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -518,6 +523,7 @@ def main():
                               "error_flags": int(stx["error_flags"]),
                               "lattice_density_sample": {"nodes_per_char": round(cx["n_nodes"] / max(cx["n_chars"], 1), 2),
                                                          "dedup_pairs_per_char": round(cx["n_pairs_dedup"] / max(cx["n_chars"], 1), 1)},
+                              "connection_ids_reordered": "internal" if tokx.connid_reorder_info()["epoch"] else "off",
                               "parity_vs_oracle_sample": okx, "parity_sample_sentences": nsx, "leg_s": round(time.time() - t_leg, 1)}
                 del tokx, dvx, dox, wx, tx, ox
 

@@ -370,11 +370,12 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
     if (!fused) tok.maybe_calibrate(d_text, d_offsets, n, stream_);
     const DevImage& image = tok.image();  // one image for every launch of this batch
     if (count_connids && image.epoch != count_epoch) {  // the counters on the device are in another image's ids: fold them first
-        if (last_stream) fold_connid_counts();
+        if (has_run) fold_connid_counts();  // (not "last_stream != nullptr": the null stream is a stream)
         count_epoch = image.epoch;
     }
     last_n = n;
     last_stream = stream_;
+    has_run = true;
     HIP_CHECK(hipMemsetAsync(d_ctrl, 0, (kCtrlWords + (size_t)kBlockCtrlWords) * 4, stream));  // ctrl + cctrl
     if (n == 0) return;
     const size_t T = tiers.size();
@@ -588,7 +589,7 @@ static void add_unmapped(const DevImage& im, const std::vector<uint64_t>& dl, co
 void Workspace::fold_connid_counts() {
     if (!d_connid) return;
     HIP_CHECK(hipSetDevice(tok.device()));
-    if (last_stream) HIP_CHECK(hipStreamSynchronize(reinterpret_cast<hipStream_t>(last_stream)));
+    if (has_run) HIP_CHECK(hipStreamSynchronize(reinterpret_cast<hipStream_t>(last_stream)));
     const size_t nl = tok.dict().num_left, nr = tok.dict().num_right;
     std::vector<uint64_t> dl(nl), dr(nr);
     HIP_CHECK(hipMemcpy(dl.data(), d_connid, nl * 8, hipMemcpyDeviceToHost));
@@ -601,7 +602,7 @@ void Workspace::fold_connid_counts() {
 void Workspace::read_connid_counts(uint64_t* lid, uint64_t* rid, bool reset) {
     HIP_CHECK(hipSetDevice(tok.device()));
     if (!d_connid) throw Error(VBT_ERR_INVALID_STATE, "connection-id counting was never enabled");
-    if (last_stream) HIP_CHECK(hipStreamSynchronize(reinterpret_cast<hipStream_t>(last_stream)));
+    if (has_run) HIP_CHECK(hipStreamSynchronize(reinterpret_cast<hipStream_t>(last_stream)));
     const size_t nl = tok.dict().num_left, nr = tok.dict().num_right;
     std::vector<uint64_t> dl(nl), dr(nr);
     HIP_CHECK(hipMemcpy(dl.data(), d_connid, nl * 8, hipMemcpyDeviceToHost));
@@ -619,7 +620,7 @@ void Workspace::read_connid_counts(uint64_t* lid, uint64_t* rid, bool reset) {
 void Workspace::reset_connid_counts() {
     HIP_CHECK(hipSetDevice(tok.device()));
     if (!d_connid) return;
-    if (last_stream) HIP_CHECK(hipStreamSynchronize(reinterpret_cast<hipStream_t>(last_stream)));
+    if (has_run) HIP_CHECK(hipStreamSynchronize(reinterpret_cast<hipStream_t>(last_stream)));
     HIP_CHECK(hipMemset(d_connid, 0, ((size_t)tok.dict().num_left + tok.dict().num_right) * 8));
     acc_lid.clear(); acc_rid.clear();
 }

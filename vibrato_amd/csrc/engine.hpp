@@ -214,6 +214,7 @@ class Workspace {
     uint64_t last_n = 0;
     BatchArgs last_args{};  // of the last run(): what pack_to() packs
     void* last_stream = nullptr;
+    bool has_run = false;  // (last_stream == nullptr is the null stream, not "never ran")
     void* ev[4] = {nullptr, nullptr, nullptr, nullptr};
 
   private:
