@@ -256,3 +256,27 @@ def test_ring_checker_flags_seeded_violations():
                    "s_waitcnt vmcnt(0)"])
     assert any("v77" in e for e in errs) and not any("v76:" in e for e in errs), errs
 
+    # (e) LDS reads (the pass records of the default build, the loop's own reads): landed behind s_waitcnt lgkmcnt(0) only
+    n, errs = run(["ds_read_b64 v[76:77], v59 offset:48",
+                   "ds_read_b32 v54, v53",
+                   "s_waitcnt lgkmcnt(0)",
+                   "v_add_u32 v3, v54, v76",
+                   "v_add_u32 v3, v3, v77"])
+    assert n == 3 and errs == [], errs
+    n, errs = run(["ds_read_b64 v[76:77], v59 offset:48",
+                   "s_waitcnt vmcnt(0)",                      # the wrong counter
+                   "v_readfirstlane_b32 s45, v77",
+                   "s_waitcnt lgkmcnt(0)"])
+    assert any("v77" in e for e in errs), errs
+    n, errs = run(["ds_read_b64 v[76:77], v59 offset:48",   # a path around the wait
+                   "s_cbranch_scc1 .LBBy_1",
+                   "s_waitcnt lgkmcnt(0)",
+                   ".LBBy_1:",
+                   "v_mov_b32 v9, v76"])
+    assert any("v_mov_b32 v9, v76" in e for e in errs), errs
+    # (f) the block that holds the ring must begin by draining the compiler's own loads
+    ring = ["buffer_load_sshort v40, v1, s[4:7], 0 idxen", "s_waitcnt vmcnt(0)", "v_add_u32 v3, v3, v40"] + ["s_nop 0"] * 20
+    n, errs = run(["s_waitcnt vmcnt(0) lgkmcnt(0)"] + ring)
+    assert errs == [], errs
+    n, errs = run(["v_mov_b32 v24, 0"] + ring)
+    assert any("begins with" in e for e in errs), errs

@@ -10,7 +10,11 @@ the assembly hipcc emits:
   for every `buffer_load_{sshort,dword}` / `global_load_dwordx2` G inside an inline-asm block of a kernel and every path through the control-flow
   graph behind it, the first instruction that mentions G's destination register lies behind an inline `s_waitcnt vmcnt(N)`
   at which G has provably landed (at least N inline loads were issued behind G: loads return in order), or is the next
-  load into the same ring slot.
+  load into the same ring slot;
+
+  and the same for every inline `ds_read_*` (the loop's LDS reads and, in the default build, the fetch of a pass record out of
+  LDS): the first mention of its destination lies behind an inline `s_waitcnt lgkmcnt(0)`, or is the next read into the same
+  register.  (Inside the loop nothing but LDS operations counts in lgkmcnt, and those complete in order.)
 
 usage: python tools/check_ring_isa.py [lattice.s]      (without an argument: compiles lattice.hip to assembly first)
 """
@@ -89,9 +93,35 @@ def check_kernel(name, body):
         lo = int(m.group(1))
         return tuple(range(lo, int(m.group(2)) + 1)) if m.group(2) else (lo,)
 
-    # per instruction, once: successors, VGPRs mentioned, registers loaded by an inline load, N of an inline s_waitcnt vmcnt(N)
+    # every inline-asm block that holds ring loads (the sweep loop) must BEGIN by draining what the compiler has in flight: a
+    # load nobody went on to use is never waited for by compiled code and could land in a register the block owns
+    entry_errors = []
+    blk = None
+    for l in body:
+        t = l.strip()
+        if t.startswith(";;#ASMSTART"):
+            blk = []
+        elif t.startswith(";;#ASMEND"):
+            if blk and any(load_re.match(x) for x in blk) and len(blk) > 20:
+                if not re.match(r"^s_waitcnt\s+vmcnt\(0\)\s+lgkmcnt\(0\)", blk[0]):
+                    entry_errors.append(f"an inline-asm block with ring loads begins with `{blk[0]}`, not with s_waitcnt vmcnt(0) lgkmcnt(0)")
+            blk = None
+        elif blk is not None and t and not t.startswith(";") and not t.startswith(".") and not re.match(r"^\.?\w+:", t):
+            blk.append(t.split(";")[0].strip())
+
+    lds_re = re.compile(r"^ds_read\w*\s+v\[?(\d+)(?::(\d+)\])?,")
+
+    def lds_dests(text):
+        m = lds_re.match(text)
+        if not m:
+            return ()
+        lo = int(m.group(1))
+        return tuple(range(lo, int(m.group(2)) + 1)) if m.group(2) else (lo,)
+
+    # per instruction, once: successors, VGPRs mentioned, registers loaded by an inline load, N of an inline s_waitcnt vmcnt(N);
+    # the same for inline LDS reads and s_waitcnt lgkmcnt(0)
     succ = [successors_of(i) for i in range(len(insts))]
-    used, loaded, waits = [], [], []
+    used, loaded, waits, lds_loaded, lds_wait = [], [], [], [], []
     for t, a in insts:
         regs = set(int(m.group(1)) for m in re.finditer(r"\bv(\d+)\b", t))
         for m in re.finditer(r"\bv\[(\d+):(\d+)\]", t):
@@ -100,9 +130,11 @@ def check_kernel(name, body):
         loaded.append(dests(t) if a else ())
         mw = re.match(r"^s_waitcnt\s+vmcnt\((\d+)\)", t) if a else None
         waits.append(int(mw.group(1)) if mw else None)
+        lds_loaded.append(lds_dests(t) if a else ())
+        lds_wait.append(bool(a and re.match(r"^s_waitcnt\s+(?:vmcnt\(\d+\)\s+)?lgkmcnt\(0\)", t)))
     cap = max([w for w in waits if w is not None] + [1])  # (more loads behind G than any wait asks for: no need to count on)
 
-    errors, n_loads = [], 0
+    errors, n_loads = list(entry_errors), 0
     targets = [(idx, reg) for idx in range(len(insts)) for reg in loaded[idx]]
     for idx, reg in targets:
         n_loads += 1
@@ -132,6 +164,28 @@ def check_kernel(name, body):
             stack.extend((k, after, landed) for k in succ[j])
         if verdict:
             errors.append(verdict)
+    # the inline LDS reads: landed at the first inline s_waitcnt lgkmcnt(0) behind them
+    for idx in range(len(insts)):
+        for reg in lds_loaded[idx]:
+            n_loads += 1
+            stack = list(succ[idx])
+            seen = set()
+            verdict = None
+            while stack and not verdict:
+                j = stack.pop()
+                if j in seen:
+                    continue
+                seen.add(j)
+                if lds_wait[j]:
+                    continue  # landed on this path
+                if reg in used[j]:
+                    if reg in lds_loaded[j]:
+                        continue  # the next read into the same register (in order)
+                    verdict = f"v{reg}: touched by `{insts[j][0]}` (#{j}) before an s_waitcnt lgkmcnt(0) behind the LDS read at #{idx}"
+                    continue
+                stack.extend(succ[j])
+            if verdict:
+                errors.append(verdict)
     return n_loads, errors
 
 
@@ -150,7 +204,7 @@ def main():
     for name, body in kernel_bodies(asm):
         n, errs = check_kernel(name, body)
         total += n
-        print(f"{name[:90]}: {n} ring gathers, {len(errs)} violations")
+        print(f"{name[:90]}: {n} inline loads / LDS reads, {len(errs)} violations")
         for e in errs[:20]:
             print("   ", e)
         bad += len(errs)

@@ -231,6 +231,18 @@ __device__ __forceinline__ void unk_spans(uint32_t cinfo, uint32_t g, uint32_t i
 #ifndef VBT_LAT_WAVES
 #define VBT_LAT_WAVES 5
 #endif
+#ifndef VBT_LDS_REC
+#define VBT_LDS_REC 1  // the assembly loop's 8-byte pass records in the sentence's LDS (sweep_asm.hpp); 0: round 4's records in global memory
+#endif
+#ifndef VBT_GUARD
+#define VBT_GUARD 0  // developer aid: 64 guard bytes between the token path and the pass records, checked at four points (ctrl[20..23])
+#endif
+#ifndef VBT_C2B_LDS
+#define VBT_C2B_LDS 1  // a whole sentence's character -> byte offsets are pulled into LDS with its candidates: emit's records need no second round trip
+#endif
+#ifndef VBT_EARLY_LOADS
+#define VBT_EARLY_LOADS 4  // candidate records per lane requested in front of the reachability sweep and consumed behind it (0: load phase first, as in round 4)
+#endif
 #ifndef VBT_ROUND_PREDS
 #define VBT_ROUND_PREDS 16
 #endif
@@ -260,11 +272,13 @@ static_assert(sizeof(LPass) == 64, "one s_load_dwordx16 per pass");
 __host__ __device__ __forceinline__ uint32_t step_passes(uint32_t nc, uint32_t np) {
     return ((np + kRoundPreds - 1) / kRoundPreds) * ((nc + kRoundCands - 1) / kRoundCands);
 }
-// LDS bytes of the lattice arrays of lattice_lds for a (segment of a) sentence of n positions with C candidates and a window of
-// E end-list slots: 8 bytes per slot, 8 per candidate, 2 per position (the token path).  Must over-estimate the Arena carve
-// there; gen_candidates routes sentences to LDS tiers with it.
-__host__ __device__ __forceinline__ uint64_t lattice_fixed_bytes(uint32_t C, uint32_t n, uint32_t E) {
-    return 8ull * (E + 2ull) + 8ull * (C + 2ull) + 2ull * (n + 4ull) + 48;  // (+ the first three pass records of the assembly loop + alignment)
+// LDS bytes of the lattice arrays of lattice_lds for a (segment of a) sentence of n positions with C candidates, a window of
+// E end-list slots and at most `passes` sweep passes: 8 bytes per slot, 8 per candidate, 2 + 2 per position (the token path, the
+// byte offsets of the characters), 8 per pass record (+ the empty ones behind the last).  Must over-estimate the Arena carve there; gen_candidates routes sentences to LDS
+// tiers with it.
+__host__ __device__ __forceinline__ uint64_t lattice_fixed_bytes(uint32_t C, uint32_t n, uint32_t E, uint32_t passes) {
+    return 8ull * (E + 2ull) + 8ull * (C + 2ull) + (VBT_C2B_LDS ? 4ull : 2ull) * (n + 4ull) + 48  // (+ alignment; VBT_LDS_REC=0: the first three pass records of the assembly loop)
+           + (VBT_LDS_REC ? 8ull * (passes + 10ull) : 0ull) + (VBT_GUARD ? 72ull : 0ull);
 }
 // Cost word of a slot whose node was never inserted (its start position is never visited).  Biased cost 0xC0000000 = +2^30: with
 // 16-bit connection and word costs a sentence of < 8000 characters keeps every live cost inside +-2^29, so such a predecessor

@@ -316,15 +316,13 @@ Workspace::Workspace(const Tokenizer& t, uint64_t max_s, uint64_t max_b) : tok(t
     for (auto& e : ev) HIP_CHECK(hipEventCreate(reinterpret_cast<hipEvent_t*>(&e)));
     // two-kernel pipeline buffers
     const size_t slots = nbts + kSentenceSlack * ns + 1;
-    pipe.s_n = static_cast<uint32_t*>(alloc(ns * 4));
-    pipe.s_C = static_cast<uint32_t*>(alloc(ns * 4));
+    pipe.s_hdr = static_cast<uint4*>(alloc(ns * 16));
     if (!fused) {
         pipe.g_c2b = static_cast<uint16_t*>(alloc(slots * 2));
         pipe.g_pc = static_cast<uint4*>(alloc(slots * 16));
         pipe.node_factor = std::max<uint32_t>(1, env_u32("VBT_NODE_FACTOR", 8));  // candidate slots per input byte
         pipe.g_cand = static_cast<uint4*>(alloc((size_t)pipe.node_factor * slots * 16));
         pipe.g_hits = static_cast<uint4*>(alloc((size_t)pipe.node_factor * slots * 16));
-        pipe.s_passes = static_cast<uint32_t*>(alloc(ns * 4));
         pipe.s_tier = static_cast<uint8_t*>(alloc(ns));
         for (size_t t = 0; t < tiers.size(); ++t) {
             hipStream_t st;
@@ -553,6 +551,7 @@ void Workspace::stats(vbt_call_stats* out) {
     if (std::getenv("VBT_DEBUG")) {
         std::fprintf(stderr, "[vbt] lattice fallbacks: arena=%u window=%u passes=%u no-cut=%u space-tail=%u interface/backtrace=%u; lists:", ctrl[26], ctrl[27], ctrl[29], ctrl[30], ctrl[31], ctrl[28]);
         for (size_t t = 0; t < T + kListsBehindTiers; ++t) std::fprintf(stderr, " %u", cc[2 * t]);
+        std::fprintf(stderr, "; guard (VBT_GUARD builds): %u %u %u %u", ctrl[20], ctrl[21], ctrl[22], ctrl[23]);
         std::fprintf(stderr, "\n");
     }
     if (timing && last_n) {

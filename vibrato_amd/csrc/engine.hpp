@@ -55,10 +55,10 @@ struct BatchArgs {
     // optional per-phase cycle counters (kProfSlots x kProfWords u64), nullptr = off
     unsigned long long* prof;
     // ---- two-kernel pipeline: gen_candidates -> lattice_lds (per LDS tier) ----
-    // per sentence
-    uint32_t* s_n;      // characters
-    uint32_t* s_C;      // lattice candidates
-    uint32_t* s_passes; // upper bound of the lattice passes
+    // per sentence: ONE 16-byte header written by the generator {characters | bytes << 16, lattice candidates | LDS tier << 16,
+    // upper bound of the lattice passes, byte offset relative to the batch}: everything lattice_lds needs to find the sentence's
+    // regions, in one load
+    uint4* s_hdr;
     // per character slot (sentence s, char i -> slot offsets[s] - offsets[0] + kSentenceSlack * s + i; nb + kSentenceSlack slots per sentence)
     uint16_t* g_c2b;
     uint4* g_pc;        // {cand_off | end-list offset << 16, pass bound | window end << 14 | is_space << 31, lens lo, lens hi}

@@ -87,7 +87,7 @@ __device__ __forceinline__ void gen_long(const DevDict& D, const BatchArgs& A, u
     (void)level;
     // (thread 0 appends: no build_lists behind these launches.  The fallback list is the batch's, everything else this launch's own.)
     auto route = [&](uint32_t t) { if (t == fallback) list_push_fb(A, sid); else list_push(A, t, sid); };
-    if (tid == 0) { A.s_n[sid] = 0; A.s_C[sid] = 0; }
+    if (tid == 0) A.s_hdr[sid] = make_uint4(0u, 0xFFu << 16, 0u, 0u);
     if (nb64 == 0) {
         if (tid == 0) A.tok_cnt[sid] = 0;
         return;
@@ -360,16 +360,14 @@ __device__ __forceinline__ void gen_long(const DevDict& D, const BatchArgs& A, u
         maxcnt = last > maxcnt ? last : maxcnt;
         passes += step_passes(1u, maxcnt);
     }
-    if (tid == 0) {
-        A.g_pc[slot0 + n] = make_uint4(C | (eo(n) << 16), 0, eo(n + 1), 0);  // terminator: totals (candidates, end-list slots)
-        A.s_n[sid] = n; A.s_C[sid] = C; A.s_passes[sid] = passes;
-    }
+    if (tid == 0) A.g_pc[slot0 + n] = make_uint4(C | (eo(n) << 16), 0, eo(n + 1), 0);  // terminator: totals (candidates, end-list slots)
     // smallest tier whose LDS holds the lattice arrays, else the segment tier (see gen_one)
-    const uint64_t fixed = lattice_fixed_bytes(C, n, eo(n + 1));
+    const uint64_t fixed = lattice_fixed_bytes(C, n, eo(n + 1), passes);
     uint32_t tier = fallback;
     for (uint32_t t = 0; t < A.n_tiers; ++t)
         if (fixed <= A.tier_bytes[t]) { tier = t; break; }
     if (A.seg_tier < A.n_tiers && tier > A.seg_tier) tier = A.seg_tier;
+    if (tid == 0) A.s_hdr[sid] = make_uint4(n | (nb << 16), C | (tier << 16), passes, (uint32_t)(b0 - uniform64(A.offsets[0])));
     route(tier);
 }
 

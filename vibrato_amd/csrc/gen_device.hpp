@@ -26,7 +26,8 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
         if (A.direct_push) list_push(A, t, sid);  // (Worker's single launch: no build_lists behind it)
         else if (ln == 0) A.s_tier[sid] = (uint8_t)t;
     };
-    auto init = [&]() { if (ln == 0) { A.s_n[sid] = 0; A.s_C[sid] = 0; A.s_tier[sid] = 0xFF; } };
+    // (header with tier 0xFF: nothing for lattice_lds -- the final header is written with the routing decision, by gen_long for what is filed there)
+    auto init = [&]() { if (ln == 0) { A.s_hdr[sid] = make_uint4(0u, 0xFFu << 16, 0u, 0u); A.s_tier[sid] = 0xFF; } };
     if (nb64 == 0) {
         init();
         if (ln == 0) A.tok_cnt[sid] = 0;
@@ -278,17 +279,15 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
         // terminator: totals (candidates, end-list slots)
         if (ln == 0) pc[n] = make_uint4(C | (eo(n) << 16), 0, eo(n + 1), 0);
     }
-    if (ln == 0) {
-        A.s_n[sid] = n; A.s_C[sid] = C; A.s_passes[sid] = passes;
-    }
     // smallest tier whose LDS holds the lattice arrays (connection costs are never staged)
-    const uint64_t fixed = lattice_fixed_bytes(C, n, eo(n + 1));
+    const uint64_t fixed = lattice_fixed_bytes(C, n, eo(n + 1), passes);
     uint32_t tier = fallback;
     for (uint32_t t = 0; t < A.n_tiers; ++t)
         if (fixed <= A.tier_bytes[t]) { tier = t; break; }
     // longer sentences are swept in segments inside the segment tier instead of one huge LDS block (lattice_lds cuts anywhere;
     // what it cannot sweep there -- a window of end lists wider than the tier -- it hands to the escape tiers itself)
     if (A.seg_tier < A.n_tiers && tier > A.seg_tier) tier = A.seg_tier;
+    if (ln == 0) A.s_hdr[sid] = make_uint4(n | (nb << 16), C | (tier << 16), passes, (uint32_t)(b0 - uniform64(A.offsets[0])));
     route(tier);
     PROF_MARK(2);
     if (A.prof && ln == 0) {

@@ -36,8 +36,9 @@ namespace {
 // of the finished segment that end behind the cut are final and sit in the slot range [eo(b), window end); that range is
 // moved to the front of the slot window and the next segment carries on -- its load phase touches only the slots of its own
 // candidates, the reachability state (three scalars) stays in registers.
+// `h`: the sentence's header (BatchArgs::s_hdr), wave-uniform.
 template <bool kSpaceMode, bool kWide>
-__device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const BatchArgs& A, uint32_t tier, uint32_t sid) {
+__device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const BatchArgs& A, uint32_t tier, uint32_t sid, uint4 h) {
     typedef __attribute__((address_space(3))) const uint64_t lds_cu64;
     typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -56,9 +57,8 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
         uint64_t prof_t = A.prof ? clock64() : 0;
         unsigned long long* const pr_ = A.prof ? A.prof + (size_t)(sid & (kProfSlots - 1)) * kProfWords : nullptr;
 #define PROF_MARK(i) do { if (A.prof) { const uint64_t t_ = clock64(); if (ln == 0) atomicAdd(&pr_[i], (unsigned long long)(t_ - prof_t)); prof_t = t_; } } while (0)
-        const uint32_t nT = __builtin_amdgcn_readfirstlane(A.s_n[sid]), CT = __builtin_amdgcn_readfirstlane(A.s_C[sid]);
-        const uint32_t passesT = __builtin_amdgcn_readfirstlane(A.s_passes[sid]);
-        const size_t slot0 = sentence_slot(A, uniform64(A.offsets[sid]), sid);
+        const uint32_t nT = h.x & 0xFFFFu, CT = h.y & 0xFFFFu, passesT = h.z;
+        const size_t slot0 = (size_t)h.w + (size_t)kSentenceSlack * sid;  // (sentence_slot: the header holds the byte offset relative to the batch)
         const size_t node0 = (size_t)A.node_factor * slot0;
         const uint4* __restrict__ pcg = A.g_pc + slot0;   // per-character records (+ the terminator at nT)
         const uint4* __restrict__ ndg = A.g_cand + node0;  // candidate records in insertion order: {first cell of the matrix row, word cost | slot << 16, word_idx, end_char | right id << 16}
@@ -66,18 +66,20 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
         const uint32_t kBosSeq = CT + 1;
         // The sentence's hit-staging region (dead after gen_candidates; 16 bytes per node slot): its lower half holds (total cost,
         // back pointer) of every node of a sentence that is swept in segments, its upper half the pass records of the current segment.
-        const uint32_t nbT = (uint32_t)(uniform64(A.offsets[sid + 1]) - uniform64(A.offsets[sid]));
+        const uint32_t nbT = h.x >> 16;
         const uint32_t half_bytes = 8u * A.node_factor * (nbT + kSentenceSlack);
+        // where a dead predecessor's sentinel cost could meet a live cost, every predecessor's own field is tested instead (kDeadHi)
+        const bool exact = kWide || nT >= 8000u;
+        // the common build sweeps in assembly (sweep_asm.hpp) over 8-byte records (16-bit LDS addresses) -- in the sentence's LDS, or
+        // (VBT_LDS_REC=0) vector-fetched from the region below; the 64-byte scalar records (LPass) feed the C++ loop of the other builds
+        const bool vrec_mode = VBT_ASM_LOOP && !kWide && !exact && kD == 2 && !A.lid_count && lds0 + lds_bytes <= 65536u;
+        constexpr bool kLdsRec = VBT_LDS_REC != 0;
+        const bool lds_rec = kLdsRec && vrec_mode;  // the pass records live in LDS: nothing bounds them but the tier
         // (a sentence that is swept whole dumps nothing: its records take the whole region)
-        const bool whole = lattice_fixed_bytes(CT, nT, ET) <= lds_bytes && passesT + 3 * kD + 4 <= 2 * half_bytes / (uint32_t)(sizeof(LPass) + 4);
+        const bool whole = lattice_fixed_bytes(CT, nT, ET, passesT) <= lds_bytes && (lds_rec || passesT + 3 * kD + 4 <= 2 * half_bytes / (uint32_t)(sizeof(LPass) + 4));
         LPass* const rec = reinterpret_cast<LPass*>(reinterpret_cast<char*>(A.g_hits + node0) + (whole ? 0u : half_bytes));
         const uint32_t rec_cap = (whole ? 2 * half_bytes : half_bytes) / (uint32_t)(sizeof(LPass) + 4);
         uint32_t* const rec_w3 = reinterpret_cast<uint32_t*>(rec + rec_cap);  // per pass: step totals for the connection-id counting
-        // where a dead predecessor's sentinel cost could meet a live cost, every predecessor's own field is tested instead (kDeadHi)
-        const bool exact = kWide || nT >= 8000u;
-        // the common build sweeps in assembly (sweep_asm.hpp) over 8-byte vector-fetched records (16-bit LDS addresses) in the same region;
-        // the 64-byte scalar records (LPass) feed the C++ loop of the other builds
-        const bool vrec_mode = VBT_ASM_LOOP && !kWide && !exact && kD == 2 && !A.lid_count && lds0 + lds_bytes <= 65536u;
         uint2* const vrec = reinterpret_cast<uint2*>(rec);
         uint32_t seg_a = 0, seg_c = 0, seg_p = 0, sb = 0, m_in = 1, fail = 0;
         bool multi = false, done = false;
@@ -94,7 +96,7 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
         while (!done) {
         uint32_t seg_b = nT, seg_pass = passesT - seg_p, wend = ET;
         // (pass records of a segment live in global memory: rec_cap of them, the empty ones behind the last included)
-        if (lattice_fixed_bytes(CT - seg_c, nT - seg_a, ET - sb) > budget || passesT - seg_p + 3 * kD + 4 > rec_cap) {
+        if (lattice_fixed_bytes(CT - seg_c, nT - seg_a, ET - sb, passesT - seg_p) > budget || (!lds_rec && passesT - seg_p + 3 * kD + 4 > rec_cap)) {
             // furthest admissible cut within 256 positions whose segment fits: any position a multiple of 8 behind the segment's
             // start (the bit-serial sweep below runs in groups of 8 positions) that does not follow a space (a visited space run and
             // the word it hands its visit to stay in one segment, tokenizer.rs:113-125)
@@ -114,7 +116,7 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
                 const uint32_t incl = wave_exscan(nsl, tot) + nsl + run;
                 const uint32_t est = b == nT ? passesT - seg_p : incl;  // (the sentence's bound includes the EOS step)
                 const uint32_t wsl = b == nT ? ET : we;
-                const bool fits = b <= nT && lattice_fixed_bytes((cx - seg_c) & 0xFFFFu, b - seg_a, wsl - sb) <= budget && est + 3 * kD + 4 <= rec_cap;
+                const bool fits = b <= nT && lattice_fixed_bytes((cx - seg_c) & 0xFFFFu, b - seg_a, wsl - sb, est) <= budget && (lds_rec || est + 3 * kD + 4 <= rec_cap);
                 const uint64_t m = __ballot(fits && (b == nT || (!sp && ((ln + 1) & 7u) == 0)));
                 if (m) {
                     const uint32_t top = 63u - (uint32_t)__builtin_clzll(m);
@@ -145,43 +147,86 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
         (void)ar.take<uint2>(E + 2);              // e_rec: the slot records
         uint2* cnd = ar.take<uint2>(C + 2);       // per candidate: {first cell of its matrix row (low half: its back pointer, once inserted), byte offset of its slot record | word_cost << 16}
         uint16_t* path = ar.take<uint16_t>(n + 4);  // the token path of the back-trace (tokens <= positions)
-        uint2* vhead = ar.take<uint2>(3);           // the first three pass records of the assembly loop (its prologue reads them from here: no round trip through global memory)
-        const uint32_t sl_cap = rec_cap > 3 * kD + 4 ? rec_cap - (3 * kD + 2) : 0u;
+        // byte offsets of the characters (gen_candidates' c2b) of a sentence that is swept whole: requested with the candidates, read by emit
+        uint16_t* c2bl = ar.take<uint16_t>(VBT_C2B_LDS ? n + 4 : 0);
+        const bool c2b_lds = VBT_C2B_LDS && !multi && last_seg;
+#if VBT_GUARD
+        uint32_t* guard = ar.take<uint32_t>(16);
+#define VBT_GUARD_CHECK(k) do { if (ar.ok && ln < 16 && guard[ln] != 0xDEADBEEFu + ln) atomicAdd(&A.ctrl[20 + (k)], 1u); } while (0)
+#else
+#define VBT_GUARD_CHECK(k) do { } while (0)
+#endif
+        // the pass records of the assembly loop: all of them (seg_pass bounds the segment's passes; + the empty ones behind the last), or
+        // (VBT_LDS_REC=0) the first three, which its prologue reads from here instead of waiting for them to come back from global memory
+        uint2* vhead = ar.take<uint2>(kLdsRec ? (seg_pass < (1u << 20) ? seg_pass : (1u << 20)) + 10u : 3u);
+        const uint32_t sl_cap = lds_rec ? seg_pass + 2u : rec_cap > 3 * kD + 4 ? rec_cap - (3 * kD + 2) : 0u;
         if (!ar.ok || sl_cap < 3) {  // the estimate was too low: try a shorter segment before giving up
             if (budget > lds_bytes / 3 && !whole) { budget -= lds_bytes / 4; __syncthreads(); continue; }  // (a sentence taken for whole keeps its records where a segmented one dumps its nodes: the next tier sweeps it)
             fail = 26; break;
         }
         const uint32_t offC = lds0 + (uint32_t)(reinterpret_cast<char*>(cnd) - g_smem);
+#if VBT_GUARD
+        if (ln < 16) guard[ln] = 0xDEADBEEFu + ln;
+#endif
 
         // the per-character records of the first 64 positions are requested now, ahead of the candidate loads: by the time the
         // reachability sweep wants them they have arrived (the sweep of a chunk then prefetches the next chunk's)
         uint4 rc_next = pc[ln < n ? ln : n], rn_next = pc[ln < n ? ln + 1 : n];
         // ---- load: candidates from global (every record carries its slot); EOS ----
+        // The first kEarly records per lane are only REQUESTED here: the reachability sweep below needs nothing of them, so their
+        // round trip runs under it and they are put into LDS behind it (load_rest); what is left follows there.
         const uint32_t fld0 = 0xFFFEu - seg_c;  // own field of candidate c of this segment: fld0 - c
-        for (uint32_t c0 = 0; c0 < C; c0 += 64 * 4) {  // 4 independent 16-byte loads per lane in flight
-            uint4 r[4];
+        auto put_cand = [&](uint32_t c, const uint4& r) {
+            const uint32_t es = (r.y >> 16) - sb;
+            // never inserted until a sweep step reaches its start position (exact mode: the field says so, the step writes it)
+            const uint32_t fld = exact ? 0xFFFFu : ((fld0 - c) & 0xFFFFu);
+            e_rec[es] = make_uint2((fld << 16) | (r.w >> 16), kDeadHi);
+            cnd[c] = make_uint2(r.x, (es << 3) | (r.y << 16));
+        };
+        constexpr uint32_t kEarly = VBT_EARLY_LOADS;
+        const uint16_t* __restrict__ c2bg = A.g_c2b + slot0;
+        uint32_t cb_early[2] = {0u, 0u};
+        if (c2b_lds) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const uint32_t c = c0 + u * 64 + ln;
-                r[u] = nd[c < C ? c : 0u];
+            for (uint32_t u = 0; u < 2; ++u) { const uint32_t i = u * 64 + ln; cb_early[u] = c2bg[i <= n ? i : n]; }
+        }
+        uint4 r_early[kEarly ? kEarly : 1];
+#pragma unroll
+        for (uint32_t u = 0; u < kEarly; ++u) {
+            const uint32_t c = u * 64 + ln;
+            r_early[u] = nd[c < C ? c : 0u];
+        }
+        auto load_rest = [&]() {
+            if (c2b_lds) {
+#pragma unroll
+                for (uint32_t u = 0; u < 2; ++u) { const uint32_t i = u * 64 + ln; if (i <= n) c2bl[i] = (uint16_t)cb_early[u]; }
+                for (uint32_t i = 128 + ln; i <= n; i += 64) c2bl[i] = c2bg[i];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const uint32_t c = c0 + u * 64 + ln;
-                if (c < C) {
-                    const uint32_t es = (r[u].y >> 16) - sb;
-                    // never inserted until a sweep step reaches its start position (exact mode: the field says so, the step writes it)
-                    const uint32_t fld = exact ? 0xFFFFu : ((fld0 - c) & 0xFFFFu);
-                    e_rec[es] = make_uint2((fld << 16) | (r[u].w >> 16), kDeadHi);
-                    cnd[c] = make_uint2(r[u].x, (es << 3) | (r[u].y << 16));
+            for (uint32_t u = 0; u < kEarly; ++u) {
+                const uint32_t c = u * 64 + ln;
+                if (c < C) put_cand(c, r_early[u]);
+            }
+            for (uint32_t c0 = 64 * kEarly; c0 < C; c0 += 64 * 4) {  // 4 independent 16-byte loads per lane in flight
+                uint4 r[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t c = c0 + u * 64 + ln;
+                    r[u] = nd[c < C ? c : 0u];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t c = c0 + u * 64 + ln;
+                    if (c < C) put_cand(c, r[u]);
                 }
             }
-        }
-        if (last_seg && ln == 0) {
-            // EOS pseudo candidate (insert_eos, lattice.rs:85-101): left_id 0 (matrix row 0), word cost 0
-            cnd[C] = make_uint2(0u, E << 3);
-            e_rec[E] = make_uint2(((fld0 - C) & 0xFFFFu) << 16, kDeadHi);
-        }
+            if (last_seg && ln == 0) {
+                // EOS pseudo candidate (insert_eos, lattice.rs:85-101): left_id 0 (matrix row 0), word cost 0
+                cnd[C] = make_uint2(0u, E << 3);
+                e_rec[E] = make_uint2(((fld0 - C) & 0xFFFFu) << 16, kDeadHi);
+            }
+        };
+        if constexpr (kEarly == 0) load_rest();
 #if !VBT_LOOP_PROF
         PROF_MARK(3);
 #else
@@ -214,8 +259,8 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
                 const uint32_t fl = nu | (r == 0 ? 8u : 0u) | (r + 1 == rounds ? 16u : 0u);
                 const uint2 vr = make_uint2((offK + ((p_beg + kRoundPreds * r) << 3)) | ((np < 4u ? np : 4u) << 16) | (nc_r << 24),
                                             (offC + ((c_beg + kRoundCands * k) << 3)) | (fl << 16) | (np_r << 24));
-                vrec[P] = vr;
-                if (P < 3) vhead[P] = vr;
+                if constexpr (kLdsRec) vhead[P] = vr;
+                else { vrec[P] = vr; if (P < 3) vhead[P] = vr; }
                 return;
             }
             const uint64_t cm = nc_r >= 16u ? ~0ull : (1ull << (4u * nc_r)) - 1ull;
@@ -326,8 +371,8 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
         // records further on (the consume halves in [SL, SL + kD) are those of the last kD real passes).
         if (vrec_mode) {
             if (ln < 10) {  // (no candidates, no units: records are read up to SL + 7)
-                vrec[SL + ln] = make_uint2(offK, offC);
-                if (SL + ln < 3) vhead[SL + ln] = make_uint2(offK, offC);
+                if constexpr (kLdsRec) vhead[SL + ln] = make_uint2(offK, offC);
+                else { vrec[SL + ln] = make_uint2(offK, offC); if (SL + ln < 3) vhead[SL + ln] = make_uint2(offK, offC); }
             }
         } else if (ln < 2 * kD + 2) {
             LPass& I = rec[SL + ln];
@@ -339,11 +384,25 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
         }
         // the records are read back through the scalar cache: this wave's stores complete (workgroup scope: s_waitcnt vmcnt(0); the
         // vector L1 is write-through), then the scalar cache forgets whatever it holds of this region (an earlier segment's records)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        if (vrec_mode) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (vector loads read them back: nothing to invalidate)
-        else asm volatile("s_waitcnt vmcnt(0)\n\ts_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
         PROF_MARK(4);
+        VBT_GUARD_CHECK(0);
+        if constexpr (kEarly != 0) load_rest();
+        VBT_GUARD_CHECK(1);
+        if (lds_rec) {
+            // records in LDS: the LDS operations of one wave execute in order -- a compiler-level fence is all the loop needs
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        } else {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            if (vrec_mode) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (vector loads read them back: nothing to invalidate)
+            else asm volatile("s_waitcnt vmcnt(0)\n\ts_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+#if !VBT_LOOP_PROF
+        PROF_MARK(3);  // (the candidates' way into LDS counts as load time wherever it happens)
+#else
+        if (A.prof) prof_t = clock64();
+#endif
 
         // ---- fused gather + cost recurrence (matrix_connector.rs:79-85, lattice.rs:103-151) ----
         auto recurrence = [&](auto exact_c) {
@@ -423,11 +482,16 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
                     const uint32_t sl_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)SL);
                     const uint32_t offk_v = offK;
                     const uint32_t hd_v = lds0 + (uint32_t)(reinterpret_cast<char*>(vhead) - g_smem);
+#if VBT_LDS_REC
+#define VBT_REC_OPERANDS [rp] "v"(hd_v)
+#else
+#define VBT_REC_OPERANDS [rp] "s"(rbase), [hd] "v"(hd_v)
+#endif
 #if VBT_LOOP_PROF
                     // (cycles parked at the loop's two waits, left in the still unused token path array: phase slots 5 and 3)
                     const uint32_t plds = lds0 + (uint32_t)(reinterpret_cast<char*>(path) - g_smem);
                     asm volatile(VBT_SWEEP_TEXT
-                                 :: [rp] "s"(rbase), [sl] "s"(sl_s), [rs] "s"(rsrc), [ln] "v"(ln), [offk] "v"(offk_v), [hd] "v"(hd_v), [plds] "v"(plds)
+                                 :: VBT_REC_OPERANDS, [sl] "s"(sl_s), [rs] "s"(rsrc), [ln] "v"(ln), [offk] "v"(offk_v), [plds] "v"(plds)
                                  : VBT_SWEEP_CLOBBERS);
                     if (A.prof && ln == 0) {
                         const uint64_t* q = reinterpret_cast<const uint64_t*>(path);
@@ -438,7 +502,7 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
                     }
 #else
                     asm volatile(VBT_SWEEP_TEXT
-                                 :: [rp] "s"(rbase), [sl] "s"(sl_s), [rs] "s"(rsrc), [ln] "v"(ln), [offk] "v"(offk_v), [hd] "v"(hd_v)
+                                 :: VBT_REC_OPERANDS, [sl] "s"(sl_s), [rs] "s"(rsrc), [ln] "v"(ln), [offk] "v"(offk_v)
                                  : VBT_SWEEP_CLOBBERS);
 #endif
                     return;
@@ -579,6 +643,7 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
         };
         if (exact) recurrence(std::true_type{}); else recurrence(std::false_type{});
         PROF_MARK(6);
+        VBT_GUARD_CHECK(2);
 
         // a node of this segment: its cost word and its back pointer (sequence of its best predecessor)
         auto node_cost = [&](uint32_t c) { return e_rec[(cnd[c].y & 0xFFFFu) >> 3].y ^ 0x80000000u; };
@@ -669,7 +734,8 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
                 const uint32_t stp = start_of(prev_end), en = r.w & 0xFFFFu;
                 vbt_token_rec o;
                 o.start_char = stp; o.end_char = en;
-                o.start_byte = c2b[stp]; o.end_byte = c2b[en];
+                if (c2b_lds) { o.start_byte = c2bl[stp]; o.end_byte = c2bl[en]; }
+                else { o.start_byte = c2b[stp]; o.end_byte = c2b[en]; }
                 o.word_idx = r.z;
                 o.total_cost = (int32_t)node_cost(c);
                 A.tok_stage[slot0 + t] = o;  // the sentence's own staging region: no allocation atomic (compact_tokens packs them)
@@ -753,6 +819,10 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
     // Work distribution: one list entry per workgroup (the grid covers the batch; a returning atomic on a hot word costs
     // ~11 ns of a serial resource, which bounds a kernel at ~88 M entries/s however fast the waves are), or -- escape tiers,
     // whose lists are short -- persistent waves that draw entries from a cursor.
+    // (Round 5 tried to do without the list for the bulk of a batch -- workgroup -> sentence id -> header, two dependent round trips
+    // fewer in front of the candidate loads: no faster at 5 waves per SIMD, and 5 % SLOWER when the sentences are visited in their
+    // linear order -- the ~5000 in flight then neighbours in memory -- than in the order build_lists files them, blocks of 1024 in
+    // the order their workgroups happen to finish; profiles/EXPERIMENTS.md.)
     bool first_item = true;
     for (;;) {
         uint32_t item = blockIdx.x;  // (persistent waves too: their first item is their own index, see tokenize_global)
@@ -765,7 +835,9 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
         // newest entries first: the large-LDS generator levels append their (long, slow) sentences last, level by level,
         // so reading the list backwards starts the longest sentences first instead of leaving them as the tail
         const uint32_t sid = __builtin_amdgcn_readfirstlane(list[count - 1 - item]);
-        const uint32_t fail = lattice_sentence<kSpaceMode, kWide>(D, A, tier, sid);
+        const uint4 hq = A.s_hdr[sid];  // ONE load: sizes, pass bound, where the sentence's regions are
+        const uint4 h = make_uint4(__builtin_amdgcn_readfirstlane(hq.x), __builtin_amdgcn_readfirstlane(hq.y), __builtin_amdgcn_readfirstlane(hq.z), __builtin_amdgcn_readfirstlane(hq.w));
+        const uint32_t fail = lattice_sentence<kSpaceMode, kWide>(D, A, tier, sid, h);
         if (fail) {
             // Could not be swept here (no admissible cut, estimates too low, ...): the next escape tier -- more LDS,
             // launched behind this one -- retries; after the last one the fused kernel with the global-memory
@@ -846,7 +918,9 @@ __global__ void __launch_bounds__(64) tokenize_serve(DevDict D, BatchArgs A, uin
             __syncthreads();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             const uint32_t tier = __builtin_amdgcn_readfirstlane((uint32_t)A.s_tier[0]);
-            if (tier == 0u) st = lattice_sentence<kSpaceMode, kWide>(D, A, 0u, 0u) ? 1u : 0u;
+            const uint4 hq = A.s_hdr[0];
+            const uint4 h = make_uint4(__builtin_amdgcn_readfirstlane(hq.x), __builtin_amdgcn_readfirstlane(hq.y), __builtin_amdgcn_readfirstlane(hq.z), __builtin_amdgcn_readfirstlane(hq.w));
+            if (tier == 0u) st = lattice_sentence<kSpaceMode, kWide>(D, A, 0u, 0u, h) ? 1u : 0u;
             else if (tier != 0xFFu) st = 1u;  // 0xFF: an empty sentence, tok_cnt = 0 is already written
         } else if (ln == 0) A.tok_cnt[0] = 0;
         // every lane's token stores have to be visible to the host before the status word is (the host spins on it):

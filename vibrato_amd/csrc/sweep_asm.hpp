@@ -47,7 +47,8 @@
 //   v74:75  the lane's running minimum (field | right id, cost) across units and rounds of a step; all ones between steps
 //   v[76:77] .. v[86:87]  record slots 0..5
 //   s[36:37] / s[38:39] / s[40:41]  slot 0 / 1 / 2: lanes of unit 0 of the pass in the slot     s42 / s43 / s44 its flags
-//   s45-s57 scratch (record word, flags, masks)   s58 byte selector of meta   s59 passes left   s[60:61] address of the record of the trip's first pass
+//   s45-s57 scratch (record word, flags, masks)   s58 byte selector of meta   s59 passes left
+//   v59 LDS address of the record of the trip's first pass (VBT_LDS_REC=0: s[60:61], its address in global memory)
 #pragma once
 
 #define VBT_DPP1 " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
@@ -56,18 +57,48 @@
 #define VBT_SDWA_SEXT_HI " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
 // -DVBT_NO_GATHER=1 (ceiling experiment, WRONG RESULTS by design: what any staging of the connection matrix could buy at most): every
 // connection cost is 0, no gather is issued; an iteration then issues one load (its record request), so both variants wait with vmcnt(2)
+// -DVBT_LDS_REC=1 (the default build): the pass records of a (segment of a) sentence sit in its LDS, behind the lattice arrays --
+// 8 bytes per pass, ~0.5 KiB for the mean sentence -- instead of its region of global memory: the builder's stores are ds_writes,
+// nothing has to be drained before the loop, the fetch of a record is a broadcast ds_read_b64 (v59 = LDS address of the first record
+// of the trip) that the iteration's own LDS wait covers long before the record is used, and the gathers are the only vector loads
+// left: an iteration issues 1 or 4, so the waits at the top are vmcnt(2) / vmcnt(5).  VBT_LDS_REC=0: round 4's records in global
+// memory (a global_load_dwordx2 that every lane aims at one address; one load more per iteration in vmcnt).
+#if VBT_LDS_REC
+#define VBT_RECLOAD(RLOAD, OFF) "ds_read_b64 " RLOAD ", v59 offset:" OFF "\n\t"
+#define VBT_REC_LOADS 0
+#else
+#define VBT_RECLOAD(RLOAD, OFF) "global_load_dwordx2 " RLOAD ", v24, s[60:61] offset:" OFF "\n\t"
+#define VBT_REC_LOADS 1
+#endif
 #if VBT_NO_GATHER == 1
 #define VBT_GLOAD(W, IDX) "v_mov_b32 " W ", 0\n\t"
-#define VBT_VMC_N "2"
-#define VBT_VMC_W "2"
+#define VBT_GATHERS_N 0
+#define VBT_GATHERS_W 0
 #elif VBT_NO_GATHER == 2  /* every lane gathers cell 0: the loads are issued and waited for, but they all hit one line */
 #define VBT_GLOAD(W, IDX) "buffer_load_sshort " W ", v24, %[rs], 0 idxen\n\t"
+#define VBT_GATHERS_N 1
+#define VBT_GATHERS_W 4
+#else
+#define VBT_GLOAD(W, IDX) "buffer_load_sshort " W ", " IDX ", %[rs], 0 idxen\n\t"
+#define VBT_GATHERS_N 1
+#define VBT_GATHERS_W 4
+#endif
+// loads that may stay in flight at the top of an iteration: those of the iteration before it (narrow or wide: the variant) and of the
+// one before that (counted as narrow), each + its record request where the records come from global memory
+#if VBT_GATHERS_N == 0
+#if VBT_REC_LOADS
+#define VBT_VMC_N "2"
+#define VBT_VMC_W "2"
+#else
+#define VBT_VMC_N "0"
+#define VBT_VMC_W "0"
+#endif
+#elif VBT_REC_LOADS
 #define VBT_VMC_N "4"
 #define VBT_VMC_W "7"
 #else
-#define VBT_GLOAD(W, IDX) "buffer_load_sshort " W ", " IDX ", %[rs], 0 idxen\n\t"
-#define VBT_VMC_N "4"
-#define VBT_VMC_W "7"
+#define VBT_VMC_N "2"
+#define VBT_VMC_W "5"
 #endif
 #define VBT_B1 " src0_sel:DWORD src1_sel:BYTE_1\n\t"
 #define VBT_B2 " src0_sel:DWORD src1_sel:BYTE_2\n\t"
@@ -209,7 +240,7 @@
     "\n.LBBvbt_b" U V "_%=:\n\t"                                                                      \
     VBT_PROF_WAIT("s66", "s67", "s_waitcnt lgkmcnt(0)\n\t")                                           \
     VBT_PROF2_ACC("c" U V, "0")                                                                             \
-    "global_load_dwordx2 " RLOAD ", v24, s[60:61] offset:" OFF "\n\t"   /* the record of six passes on */ \
+    VBT_RECLOAD(RLOAD, OFF)                                      /* the record of six passes on */ \
     "v_add_u32 v61, v61, " W0 "\n\t"                             /* wrapping i32 add of the connection cost (lattice.rs:139) */ \
     VBT_FINISH("v60", "v61", M, CA, "v_add_u32_sdwa v55, v55, v54" VBT_SDWA_LO, VBT_META(META, R0, R1))                      \
     "\n.LBBvbt_j" U V "_%=:\n\t"                                                                      \
@@ -237,7 +268,7 @@
     "\n.LBBvbt_n" U V "_%=:\n\t"                                                                      \
     VBT_PROF_WAIT("s66", "s67", "s_waitcnt lgkmcnt(0)\n\t")                                           \
     VBT_PROF2_ACC("g" U V, "1")                                                                             \
-    "global_load_dwordx2 " RLOAD ", v24, s[60:61] offset:" OFF "\n\t"                                 \
+    VBT_RECLOAD(RLOAD, OFF)                                                                           \
     "v_add_u32_sdwa v55, v55, v54" VBT_SDWA_LO                                                        \
     "v_cmp_lt_u32_sdwa s[50:51], v25, " META VBT_B3              /* candidates of the pass in hand */ \
     "s_and_b32 s45, s47, 7\n\t"                                  /* units (0: an empty pass -- unit 0 under no lanes) */ \
@@ -306,9 +337,13 @@
     "s_sub_i32 s59, s59, 2\n\t"                                                                       \
     "s_cmp_gt_i32 s59, 0\n\t"                                                                         \
     "s_cbranch_scc0 .LBBvbt_x_%=\n\t"
+#if VBT_LDS_REC
+#define VBT_TRIP_ADVANCE "v_add_u32 v59, 48, v59\n\t"
+#else
+#define VBT_TRIP_ADVANCE "s_add_u32 s60, s60, 48\n\ts_addc_u32 s61, s61, 0\n\t"
+#endif
 #define VBT_TRIP(NEXT)                                                                               \
-    "s_add_u32 s60, s60, 48\n\t"                                                                      \
-    "s_addc_u32 s61, s61, 0\n\t"                                                                      \
+    VBT_TRIP_ADVANCE                                                                                  \
     "s_sub_i32 s59, s59, 2\n\t"                                                                       \
     "s_cmp_gt_i32 s59, 0\n\t"                                                                         \
     "s_cbranch_scc1 .LBBvbt_i0" NEXT "_%=\n\t"                                                        \
@@ -325,7 +360,7 @@
 
 // the prologue's issue of pass P (record slot P, gather slot P): the record of pass P + 3 is requested first
 #define VBT_PRO(P, W0, W1, W2, W3, PA, CA, META, M, FL, R0, R1, RLOAD, OFF)                          \
-    "global_load_dwordx2 " RLOAD ", v24, s[60:61] offset:" OFF "\n\t"                                 \
+    VBT_RECLOAD(RLOAD, OFF)                                                                           \
     VBT_ISSUE_HEAD(PA, CA, R0, R1, FL)                                                                \
     "s_cbranch_scc0 .LBBvbt_pn" P "_%=\n\t"                                                           \
     VBT_WIDE_READS(PA)                                                                                \
@@ -342,7 +377,19 @@
 #define VBT_PRO1 VBT_EXPAND(VBT_PRO, "1", VBT_G1, VBT_R1, "v[84:85]", "32")
 #define VBT_PRO2 VBT_EXPAND(VBT_PRO, "2", VBT_G2, VBT_R2, "v[86:87]", "40")
 
+#if VBT_LDS_REC
+#define VBT_REC_BASE "v_mov_b32 v59, %[rp]\n\t"
+#define VBT_REC_HEAD "v59"
+#else
+#define VBT_REC_BASE "s_mov_b64 s[60:61], %[rp]\n\t"
+#define VBT_REC_HEAD "%[hd]"
+#endif
 #define VBT_SWEEP_TEXT                                                                               \
+    /* Nothing the compiler issued may still be in flight: a load whose result no lane went on to use (the candidate records */ \
+    /* requested ahead of the reachability sweep, for lanes behind the last candidate) is never waited for by compiled code, */ \
+    /* and its destination may be one of the registers this block owns -- it would land in the middle of the loop.  (Round 4  */ \
+    /* had this wait by accident: the drain of the record stores.  Found in round 5 as wrong tokens in one build variant.)   */ \
+    "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"                                                               \
     "v_mov_b32 v24, 0\n\t"                                                                            \
     "v_lshrrev_b32 v25, 2, %[ln]\n\t"                                                                 \
     "v_and_b32 v26, 3, %[ln]\n\t"                                                                     \
@@ -353,14 +400,14 @@
     "v_lshlrev_b32 v31, 3, v25\n\t"                                                                   \
     "v_mov_b32 v74, -1\n\t"                                                                           \
     "v_mov_b32 v75, -1\n\t"                                                                           \
-    "s_mov_b64 s[60:61], %[rp]\n\t"                                                                   \
+    VBT_REC_BASE                                                                                      \
     "s_mov_b32 s59, %[sl]\n\t"                                                                        \
     "s_mov_b32 s58, 0x07060302\n\t"                                                                   \
     VBT_PROF_INIT                                                                                     \
-    /* the first three records out of LDS (the builder left a copy there: no round trip through global memory at the start) */ \
-    "ds_read_b64 v[76:77], %[hd]\n\t"                                                                 \
-    "ds_read_b64 v[78:79], %[hd] offset:8\n\t"                                                        \
-    "ds_read_b64 v[80:81], %[hd] offset:16\n\t"                                                       \
+    /* the first three records out of LDS (global records: the builder left a copy there, no round trip at the start) */ \
+    "ds_read_b64 v[76:77], " VBT_REC_HEAD "\n\t"                                                      \
+    "ds_read_b64 v[78:79], " VBT_REC_HEAD " offset:8\n\t"                                             \
+    "ds_read_b64 v[80:81], " VBT_REC_HEAD " offset:16\n\t"                                            \
     "s_waitcnt lgkmcnt(0)\n\t"                                                                        \
     /* prologue: the gathers of passes 0, 1 and 2 (behind the requests for the records of passes 3, 4 and 5) */ \
     VBT_PRO0                                                                                          \
@@ -402,13 +449,14 @@
     VBT_IT5(VBT_ITER_OOL, "W", VBT_VMC_W, "", VBT_TRIP("W"))                                                \
     "\n.LBBvbt_x_%=:\n\t"                                                                             \
     "s_waitcnt vmcnt(0)\n\t"                                                                          \
+    "s_waitcnt lgkmcnt(0)\n\t"           /* (record reads of the empty passes behind the last: their registers go back to the compiler) */ \
     VBT_PROF_OUT                                                                                      \
     "s_mov_b64 exec, -1"
 
 #define VBT_SWEEP_CLOBBERS                                                                           \
     "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39",                \
     "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57",   \
-    "v58", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75",          \
+    "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75",          \
     "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87",                                             \
     "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51",               \
     "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", VBT_PROF_CLOBBERS "vcc", "scc", "memory"
