@@ -194,6 +194,25 @@ def test_config4_sized_batch_on_one_gpu_equals_its_shards():
     sd = synth.SynthDict("ipadic")
     to, tv = _oracle_and_product(sd)
     text, offs = sd.sentences(1000000, "lognormal_40")
+    _config4_checks(sd, to, tv, text, offs)
+
+
+def test_config4_on_unidic_through_the_multi_device_tokenizer():
+    """BASELINE config 4 as it is named -- unidic, 1 M sentences, sharded -- behind the C ABI: one tokenizer over two replicas of the
+    458.6 MiB image (vbt_tokenizer_new_multi with device list {0, 0}: what a one-GPU box admits), every batch cut into shards whose
+    results land in the caller's one pinned block.  Same checks as on ipadic: the 1 M-sentence batch equals its 8 contiguous shards,
+    the first 20 000 sentences equal the oracle's, tokens tile every sentence."""
+    sd = synth.SynthDict("unidic")
+    do = ora.Dictionary.from_sources_binmatrix(sd.lex, sd.matrix, sd.num_right, sd.num_left, sd.char_def, sd.unk)
+    dv = V.SystemDictionaryBuilder.from_readers_binmatrix(sd.lex, sd.matrix, sd.num_right, sd.num_left, sd.char_def, sd.unk)
+    to, tv = ora.Tokenizer(do), V.Tokenizer(dv, devices=[0, 0])
+    text, offs = sd.sentences(1000000, "lognormal_40")
+    _config4_checks(sd, to, tv, text, offs)
+    assert tv.num_devices() == 2 and tv.connid_reorder_info()["epoch"] == 1
+
+
+def _config4_checks(sd, to, tv, text, offs):
+    from vibrato_amd import sharding
     whole = tv.tokenize_batch(text=text, offsets=offs)
     toks, off, cnt = whole.arrays()
     assert len(cnt) == 1000000 and int(cnt.sum()) == len(toks) > 20_000_000
@@ -263,6 +282,53 @@ def test_very_long_sentences_take_every_generator_level_and_the_fallback():
     text = np.frombuffer(b"".join(enc), dtype=np.uint8)
     assert max(len(e) for e in enc) > 50000
     batch, _ = _assert_batch_equal(to, tv, text, offs)
+
+
+@pytest.mark.parametrize("ignore_space", [False, True])
+def test_sentences_of_8000_to_11000_characters_take_the_exact_instance_of_the_sweep(ignore_space):
+    """Sentences of ~8 200, ~9 000 and ~10 500 characters: the whole-CU level of gen_long generates them and lattice_lds sweeps them in
+    its segment tier, but with >= 8 000 characters the dead-predecessor sentinel of the common build no longer bounds a live cost, so the
+    `exact` instance of the C++ loop runs (every predecessor's own field is tested) -- on i16 cells, which no other test reaches (round-4
+    review).  None of them may fall through to the global-memory kernel.  (What this test found when it was written: every sentence of
+    more than 32 767 lattice nodes -- 6 500+ characters here -- lost the tail of its path: the end-list offset of the EOS step was
+    shifted as a signed int.  The oracle counts 38 000 - 50 000 nodes for these.)"""
+    import torch
+    sd = synth.SynthDict("small")
+    to, tv = _oracle_and_product(sd, ignore_space=ignore_space)
+    base, offs0 = sd.sentences(1200, "lognormal_40", space_p=0.05 if ignore_space else 0.0)
+    raw = bytes(base)
+    chars = np.cumsum([len(raw[int(offs0[i]):int(offs0[i + 1])].decode("utf-8")) for i in range(1200)])
+    cuts = [int(np.searchsorted(chars, c)) for c in (8200, 9000, 10500)]
+    assert all(8000 <= chars[k] < 11000 for k in cuts)
+    enc = [raw[:int(offs0[k + 1])] for k in cuts] + [raw[int(offs0[5]):int(offs0[6])]]
+    offs = np.zeros(len(enc) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([len(e) for e in enc])
+    text = np.frombuffer(b"".join(enc), dtype=np.uint8)
+    _assert_batch_equal(to, tv, text, offs)
+    ws = tv.workspace(len(enc), len(text))
+    d_text = torch.from_numpy(text.copy()).cuda()
+    d_offs = torch.from_numpy(offs.astype(np.int64)).cuda()
+    ws.run(d_text.data_ptr(), d_offs.data_ptr(), len(enc), len(text), torch.cuda.current_stream().cuda_stream)
+    st = ws.stats()
+    # (the long ones are routed to the segment tier and escalate from there to the escape tier for their back-trace window: counted in both)
+    assert st["error_flags"] == 0 and st["n_tier2"] == 0 and st["n_tier0"] == len(enc) and st["n_tier1"] >= 3, st
+
+
+def test_the_cpp_sweep_loop_on_common_shapes():
+    """lattice_lds states its recurrence twice: the assembly loop (the default build's common shapes) and a C++ loop that the default
+    build only runs on rare shapes (i32 cells, >= 8000 characters, connection-id counting).  The `cpploop` library variant
+    (-DVBT_ASM_LOOP=0, built by build()) runs the C++ loop on EVERYTHING: the differential, tie-heavy, segmented and config-5-shaped
+    tests once more against it, in a process of its own (the library is chosen when it is loaded)."""
+    import subprocess
+    import sys
+    sel = "differential or tie_heavy or dense_stretches or dense_lattice_law or group_spans or edge_cases or very_long or golden_vectors_batch"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k", sel, "-p", "no:cacheprovider"],
+                       env=dict(os.environ, VBT_LIB_VARIANT="cpploop"), capture_output=True, text=True, timeout=1500,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-3000:] + r.stderr[-1500:]
+    assert "libvibrato_hip_cpploop.so" in subprocess.run(
+        [sys.executable, "-c", "from vibrato_amd import _native; print(_native.lib()._name)"], env=dict(os.environ, VBT_LIB_VARIANT="cpploop"),
+        capture_output=True, text=True, timeout=300, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))).stdout
 
 
 def test_cli_output_formats(fixture_sources):

@@ -1216,6 +1216,16 @@ int vbt_workspace_profile(vbt_workspace* ws, uint64_t out[12], int reset) {
     return guarded([&] { ws->w->read_profile(out, reset != 0); });
 }
 
+#ifdef VBT_DEBUG_API
+// Developer aid (debug build variants only, not part of the ABI): device addresses of a workspace's intermediate arrays.
+__attribute__((visibility("default"))) int vbt_debug_ptrs(vbt_workspace* ws, uint64_t out[8]) {
+    const BatchArgs& p = ws->w->pipe;
+    out[0] = (uint64_t)(uintptr_t)p.s_hdr; out[1] = (uint64_t)(uintptr_t)p.g_pc; out[2] = (uint64_t)(uintptr_t)p.g_cand;
+    out[3] = (uint64_t)(uintptr_t)p.g_hits; out[4] = (uint64_t)(uintptr_t)p.g_c2b; out[5] = p.node_factor; out[6] = kSentenceSlack; out[7] = 0;
+    return VBT_OK;
+}
+#endif
+
 int vbt_workspace_stats(vbt_workspace* ws, vbt_call_stats* out) {
     return guarded([&] { ws->w->stats(out); });
 }

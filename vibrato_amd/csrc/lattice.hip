@@ -37,6 +37,11 @@ namespace {
 // moved to the front of the slot window and the next segment carries on -- its load phase touches only the slots of its own
 // candidates, the reachability state (three scalars) stays in registers.
 // `h`: the sentence's header (BatchArgs::s_hdr), wave-uniform.
+#ifdef VBT_SEG_TRACE
+#define SEG_TRACE(...) do { if (ln == 0) printf(__VA_ARGS__); } while (0)
+#else
+#define SEG_TRACE(...) do { } while (0)
+#endif
 template <bool kSpaceMode, bool kWide>
 __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const BatchArgs& A, uint32_t tier, uint32_t sid, uint4 h) {
     typedef __attribute__((address_space(3))) const uint64_t lds_cu64;
@@ -132,11 +137,13 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
             multi = true;
         }
         const bool last_seg = seg_b == nT;
+        SEG_TRACE("tier %u seg [%u,%u) of %u: seg_c %u sb %u wend %u seg_pass %u budget %u m_in %u multi %d\n", tier, seg_a, seg_b, nT, seg_c, sb, wend, seg_pass, budget, m_in, (int)multi);
         const uint32_t n = seg_b - seg_a;
         const uint4* __restrict__ pc = pcg + seg_a;
         const uint4 rend = uniform4(pcg[seg_b]);  // record of the segment's end position (the terminator for the last segment)
         const uint32_t C = ((rend.x & 0xFFFFu) - seg_c) & 0xFFFFu;
         const uint32_t E = wend - sb;  // slots of the window [eo(seg_a), wend); slot E is the EOS node's (last segment)
+        if (E >= 8190u || m_in > E) SEG_TRACE("   retry/fail: E %u m_in %u\n", E, m_in);
         if (E >= 8190u || m_in > E) {  // the candidate records hold a slot's byte offset (slot * 8) in 16 bits: a shorter segment, or the next tier / the fused kernel
             if (budget > lds_bytes / 3 && !whole) { budget -= lds_bytes / 4; __syncthreads(); continue; }  // (a sentence taken for whole keeps its records where a segmented one dumps its nodes: the next tier sweeps it)
             fail = 26; break;
@@ -160,6 +167,7 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
         // (VBT_LDS_REC=0) the first three, which its prologue reads from here instead of waiting for them to come back from global memory
         uint2* vhead = ar.take<uint2>(kLdsRec ? (seg_pass < (1u << 20) ? seg_pass : (1u << 20)) + 10u : 3u);
         const uint32_t sl_cap = lds_rec ? seg_pass + 2u : rec_cap > 3 * kD + 4 ? rec_cap - (3 * kD + 2) : 0u;
+        if (!ar.ok || sl_cap < 3) SEG_TRACE("   retry/fail: arena ok %d used %u sl_cap %u (C %u E %u n %u)\n", (int)ar.ok, (uint32_t)ar.used, sl_cap, C, E, n);
         if (!ar.ok || sl_cap < 3) {  // the estimate was too low: try a shorter segment before giving up
             if (budget > lds_bytes / 3 && !whole) { budget -= lds_bytes / 4; __syncthreads(); continue; }  // (a sentence taken for whole keeps its records where a segmented one dumps its nodes: the next tier sweeps it)
             fail = 26; break;
@@ -350,8 +358,11 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
         uint32_t eos_rec = 0;  // first pass record of the EOS step
         if (last_seg) {
             // + the EOS step (insert_eos(start_node), tokenizer.rs:138): predecessors = ends[sn_eos]
-            const uint32_t y0 = __builtin_amdgcn_readfirstlane(pc[sn_eos].x) >> 16;
-            const uint32_t y1 = sn_eos < n ? __builtin_amdgcn_readfirstlane(pc[sn_eos + 1].x) >> 16 : ET;
+            // (the builtin returns int: shifted as it comes, an end-list offset of 32 768 or more -- a sentence of more than 32 767
+            // lattice nodes -- would be sign-extended and EOS would be connected to garbage; found in round 5 by the first test with
+            // sentences of 6 500+ characters that stay in the pipeline)
+            const uint32_t y0 = (uint32_t)__builtin_amdgcn_readfirstlane(pc[sn_eos].x) >> 16;
+            const uint32_t y1 = sn_eos < n ? (uint32_t)__builtin_amdgcn_readfirstlane(pc[sn_eos + 1].x) >> 16 : ET;
             const uint32_t p_beg = y0 - sb, np = y1 - y0;
             const uint32_t nsl = (np + kRoundPreds - 1) / kRoundPreds;
             if (SL + nsl + 2 > sl_cap) overflow = true;
@@ -362,6 +373,7 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
             ++S;
         } else if (sn_eos != n) { fail = 31; break; }  // cannot happen: no cut follows a space
         prof_SL += SL; prof_S += S;
+        SEG_TRACE("   S %u SL %u overflow %d sn_eos %u\n", S, SL, (int)overflow, sn_eos);
         if (overflow || SL >= (1u << 18)) {  // more passes than estimated (gen_candidates bounds them per position)
             if (budget > lds_bytes / 3 && !whole) { budget -= lds_bytes / 4; __syncthreads(); continue; }  // (a sentence taken for whole keeps its records where a segmented one dumps its nodes: the next tier sweeps it)
             fail = 29; break;
