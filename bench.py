@@ -238,21 +238,22 @@ def main():
         max_s = sharding.agree_max(n, device="cuda")
         max_t = sharding.agree_max(ntok_local, device="cuda")
         slot = sharding.packed_bytes(max_s, max_t)
-        views = sharding.workspace_views(ws, n, ntok_local)
         to_all = args.gather == "all"
         gather = {"send": [torch.empty(slot, dtype=torch.uint8, device="cuda") for _ in range(2)],
                   "out": [torch.empty(world * slot, dtype=torch.uint8, device="cuda") if (to_all or rank == 0) else None for _ in range(2)],
                   "work": [None, None], "comm": torch.cuda.Stream(), "slot": slot, "max_s": max_s, "k": 0}
 
     def step():
-        ws.run(d_text.data_ptr(), d_offs.data_ptr(), n, nbytes, stream)
         if gather is None:
+            ws.run(d_text.data_ptr(), d_offs.data_ptr(), n, nbytes, stream)
             return
         b = gather["k"] & 1
         gather["k"] += 1
         if gather["work"][b] is not None:
             gather["work"][b].wait()  # the collective that last read send[b] (two steps ago): orders this stream behind it
-        sharding.pack_results(gather["send"][b], n, ntok_local, views["total"], views["tok_off"], views["tok_cnt"], views["tokens"], gather["max_s"])
+        # the kernels write this step's results straight into send[b], laid out as the rank's slot (no pack / copy kernels)
+        ws.set_packed_output(gather["send"][b].data_ptr(), gather["slot"], gather["max_s"])
+        ws.run(d_text.data_ptr(), d_offs.data_ptr(), n, nbytes, stream)
         ready = torch.cuda.Event()
         ready.record()
         with torch.cuda.stream(gather["comm"]):
@@ -310,6 +311,15 @@ def main():
         h2h = {"one_call": tok.host_pipeline_benchmark(text, offs, threads=1, rounds=1),
                "pipelined": tok.host_pipeline_benchmark(text, offs, threads=4, rounds=4),
                "pipelined_8_threads": tok.host_pipeline_benchmark(text, offs, threads=8, rounds=4)}
+        # one tokenizer over several replicas of the image (vbt_tokenizer_new_multi; this box has one GPU, so device 0 is listed 4 and 8
+        # times): what the host side of a multi-device call costs -- one host thread per device -- before 8 real devices are
+        for k_dev in (4, 8):
+            dvm = V.SystemDictionaryBuilder.from_readers_binmatrix(sd.lex, sd.matrix, sd.num_right, sd.num_left, sd.char_def, sd.unk)
+            if user_csv is not None:
+                dvm.reset_user_lexicon_from_reader(user_csv)
+            tokm = V.Tokenizer(dvm, devices=[local_rank] * k_dev).ignore_space(args.ignore_space).max_grouping_len(args.max_grouping_len)
+            h2h[f"one_call_device_list_0x{k_dev}"] = tokm.host_pipeline_benchmark(text, offs, threads=1, rounds=1)
+            del tokm, dvm
 
     result = None
     if rank == 0:
@@ -467,6 +477,8 @@ def main():
             t_tok = time.perf_counter() - t_e
             out_b, t_fmt = bt.format_bytes("mecab")
             t_e2e = time.perf_counter() - t_e
+            fmt_calls = [t_fmt] + [bt.format_bytes("mecab")[1] for _ in range(4)]  # (the same batch again: output buffer and threads are reused)
+            t_fmt = sorted(fmt_calls)[len(fmt_calls) // 2]
             n_f = min(n, 20000)
             f_offs = offs[:n_f + 1]
             f_text = text[:int(f_offs[-1])]
@@ -476,13 +488,17 @@ def main():
             t_cpu = time.perf_counter() - t_c
             same = bool(out_b[:got_n] == obuf[:got_n].tobytes())  # the oracle's bytes for the first n_f sentences are a prefix of the product's
             parity = parity and same
-            fmt = {"mode": "mecab", "output_bytes": len(out_b), "format_ms": round(t_fmt * 1e3, 3), "format_MB_per_s": round(len(out_b) / t_fmt / 1e6, 1),
+            piped = tok.text_pipeline_benchmark(text, offs, batches=8, mode="mecab")
+            fmt = {"mode": "mecab", "output_bytes": len(out_b), "format_ms": round(t_fmt * 1e3, 3), "format_ms_five_calls": [round(x * 1e3, 3) for x in fmt_calls], "format_MB_per_s": round(len(out_b) / t_fmt / 1e6, 1),
                    "tokenize_batch_ms": round(t_tok * 1e3, 3), "text_in_to_text_out_ms": round((t_tok + t_fmt) * 1e3, 3),
-                   "text_in_to_text_out_sentences_per_s": round(n / (t_tok + t_fmt), 1),
+                   "text_in_to_text_out_sentences_per_s": piped["sentences_per_s"],
+                   "text_in_to_text_out_pipelined": piped,
+                   "text_in_to_text_out_one_unpipelined_batch_sentences_per_s": round(n / (t_tok + t_fmt), 1),
                    "python_wall_incl_copy_out_ms": round(t_e2e * 1e3, 3),
-                   "what": "vbt_tokenize_batch (host text in, token records in pinned host memory) then vbt_batch_format(MECAB): two parallel passes "
-                           "over chunks of sentences (sizes, prefix, render in place); text_in_to_text_out = the two library calls (one unpipelined "
-                           "batch); python_wall adds the copy of the output bytes out of the library into a python object",
+                   "what": "vbt_tokenize_batch (host text in, token records in pinned host memory) then vbt_batch_format(MECAB): sizes and "
+                           "rendering on one set of threads over chunks of sentences, feature strings from a flat table; text_in_to_text_out = a stream "
+                           "of batches, the formatter of batch k under the kernels of batch k + 1 (how vibrato_amd.cli runs); the unpipelined figure is the "
+                           "two library calls back to back; python_wall adds the copy of the output bytes out of the library into a python object",
                    "cpu_port_1thread": {"sample_sentences": n_f, "sentences_per_s": round(n_f / t_cpu, 1), "output_MB_per_s": round(got_n / t_cpu / 1e6, 2),
                                         "what": "oracle: tokenize + print per line, the loop of tokenize/src/main.rs:78-95, one thread"},
                    "bytes_identical_to_oracle_sample": same}

@@ -262,6 +262,16 @@ VBT_API int vbt_tokenize_batch_device(vbt_workspace* ws, const uint8_t* d_text, 
  *   total    : u32[1]  total tokens written */
 VBT_API int vbt_workspace_results(const vbt_workspace* ws, const vbt_token_rec** d_tokens, const uint32_t** d_tok_off,
                                   const uint32_t** d_tok_cnt, const uint32_t** d_total);
+/* The final exchange of a multi-GPU job without copy kernels: every later vbt_tokenize_batch_device call of this workspace leaves
+ * its results in ONE caller-owned device buffer laid out as a rank's slot of the gather (vibrato_amd/sharding.py; north_star:
+ * "RCCL over xGMI only for the final gather"):
+ *   [32-byte header {n_sentences u64, n_tokens u32, 0}] [tok_off u32 x max_sentences] [tok_cnt u32 x max_sentences] [vbt_token_rec x n_tokens]
+ * -- tok_cnt written by the sweep, tok_off and the records by the packing kernel, the header with its total -- so the collective
+ * (ncclSend / all-gather of the slot) starts from what the tokenizer wrote.  d_slot: 8-byte aligned device memory of slot_bytes >=
+ * 32 + 8 max_sentences + 24 x (tokens of the largest batch); a batch whose tokens do not fit sets error flag 1.  d_slot = NULL:
+ * back to the workspace's own buffers.  vbt_workspace_results then points into the slot.  The caller alternates two slots to
+ * overlap the gather of batch k with the kernels of batch k + 1. */
+VBT_API int vbt_workspace_set_packed_output(vbt_workspace* ws, void* d_slot, uint64_t slot_bytes, uint64_t max_sentences);
 /* Per-call statistics (synchronizes the stream of the last call): how many sentences were routed
  * to the smallest LDS tier of the lattice kernel (n_tier0), to the larger LDS tiers (n_tier1) and to
  * the global-memory fallback kernel (n_tier2; a re-routed sentence is counted twice), tokens

@@ -151,6 +151,7 @@ extern "C" {
                                      hip_stream: *mut c_void) -> c_int;
     pub fn vbt_workspace_results(ws: *const vbt_workspace, d_tokens: *mut *const vbt_token_rec, d_tok_off: *mut *const u32,
                                  d_tok_cnt: *mut *const u32, d_total: *mut *const u32) -> c_int;
+    pub fn vbt_workspace_set_packed_output(ws: *mut vbt_workspace, d_slot: *mut c_void, slot_bytes: u64, max_sentences: u64) -> c_int;
     pub fn vbt_workspace_set_timing(ws: *mut vbt_workspace, enabled: c_int) -> c_int;
     pub fn vbt_workspace_count_connids(ws: *mut vbt_workspace, enabled: c_int) -> c_int;
     pub fn vbt_workspace_connid_counts(ws: *mut vbt_workspace, lid: *mut u64, rid: *mut u64, reset: c_int) -> c_int;

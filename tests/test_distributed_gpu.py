@@ -41,9 +41,11 @@ def _worker(rank, world, port, q):
         assert st["error_flags"] == 0
         max_s = sharding.agree_max(n_local, device="cuda")
         max_t = sharding.agree_max(st["n_tokens"], device="cuda")
-        v = sharding.workspace_views(ws, n_local, st["n_tokens"])
+        # the kernels write the rank's slot themselves (vbt_workspace_set_packed_output): no pack step in front of the collective
         send = torch.zeros(sharding.packed_bytes(max_s, max_t), dtype=torch.uint8, device="cuda")
-        sharding.pack_results(send, n_local, st["n_tokens"], v["total"], v["tok_off"], v["tok_cnt"], v["tokens"], max_s)
+        ws.set_packed_output(send.data_ptr(), send.numel(), max_s)
+        ws.run(d_text.data_ptr(), d_offs.data_ptr(), n_local, nbytes, torch.cuda.current_stream().cuda_stream)
+        assert ws.stats()["error_flags"] == 0
         out, _ = sharding.gather_packed(send)
         torch.cuda.synchronize()
         assert out.is_cuda
@@ -162,7 +164,6 @@ def _rccl_worker(port, q):
         max_s = sharding.agree_max(n_local, device="cuda")   # all_reduce(MAX) over RCCL
         max_t = sharding.agree_max(ntok, device="cuda")
         assert (max_s, max_t) == (n_local, ntok)
-        v = sharding.workspace_views(ws, n_local, ntok)
         slot = sharding.packed_bytes(max_s, max_t)
         send = [torch.empty(slot, dtype=torch.uint8, device="cuda") for _ in range(2)]
         out = [torch.empty(slot, dtype=torch.uint8, device="cuda") for _ in range(2)]
@@ -172,11 +173,11 @@ def _rccl_worker(port, q):
         # communication stream, double-buffered; three steps so that both buffers are reused once
         for k in range(4):
             b = k & 1
-            ws.run(d_text.data_ptr(), d_offs.data_ptr(), n_local, nbytes, stream)
             if work[b] is not None:
                 work[b].wait()
             send[b].zero_()
-            sharding.pack_results(send[b], n_local, ntok, v["total"], v["tok_off"], v["tok_cnt"], v["tokens"], max_s)
+            ws.set_packed_output(send[b].data_ptr(), slot, max_s)  # the kernels write the slot: no pack step
+            ws.run(d_text.data_ptr(), d_offs.data_ptr(), n_local, nbytes, stream)
             ready = torch.cuda.Event()
             ready.record()
             with torch.cuda.stream(comm):
@@ -196,20 +197,21 @@ def _rccl_worker(port, q):
         def timed(with_gather):
             torch.cuda.synchronize()
             t0 = _time.perf_counter()
-            pending = None
+            pending = [None, None]
             for k in range(20):
+                if with_gather and pending[k & 1] is not None:
+                    pending[k & 1].wait()
+                ws.set_packed_output(send[k & 1].data_ptr(), slot, max_s)
                 ws.run(d_text.data_ptr(), d_offs.data_ptr(), n_local, nbytes, stream)
                 if with_gather:
-                    if pending is not None:
-                        pending.wait()
-                    sharding.pack_results(send[0], n_local, ntok, v["total"], v["tok_off"], v["tok_cnt"], v["tokens"], max_s)
                     ready = torch.cuda.Event()
                     ready.record()
                     with torch.cuda.stream(comm):
                         comm.wait_event(ready)
-                        _, pending = sharding.gather_to_root(send[0], out[0], root=0, async_op=True)
-            if pending is not None:
-                pending.wait()
+                        _, pending[k & 1] = sharding.gather_to_root(send[k & 1], out[k & 1], root=0, async_op=True)
+            for p_ in pending:
+                if p_ is not None:
+                    p_.wait()
             torch.cuda.synchronize()
             return (_time.perf_counter() - t0) / 20
         timed(False); timed(True)
@@ -237,7 +239,7 @@ def _rccl_worker(port, q):
 def test_rccl_backend_world_size_one_gather_on_the_communication_stream():
     """The collective calls bench.py issues at N > 1 -- init_process_group("nccl", device_id=...), all_reduce(MAX) for the slot
     sizes, pack_results, asynchronous all_gather_into_tensor on the communication stream with the double buffer, barrier --
-    executed on the real RCCL backend (world size 1: what one GPU admits); the gathered records equal the oracle's."""
+    (the kernels write every rank's slot themselves: vbt_workspace_set_packed_output) executed on the real RCCL backend (world size 1: what one GPU admits); the gathered records equal the oracle's."""
     import torch.multiprocessing as mp
     from oracle import oracle as ora
     from tools import synth

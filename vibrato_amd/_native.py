@@ -99,6 +99,7 @@ SIGNATURES = {
     "vbt_workspace_free": (None, [_vp]),
     "vbt_tokenize_batch_device": (_int, [_vp, _vp, _vp, _u64, _u64, _vp]),
     "vbt_workspace_results": (_int, [_vp, _PP, _PP, _PP, _PP]),
+    "vbt_workspace_set_packed_output": (_int, [_vp, _vp, _u64, _u64]),
     "vbt_workspace_set_timing": (_int, [_vp, _int]),
     "vbt_workspace_count_connids": (_int, [_vp, _int]),
     "vbt_workspace_connid_counts": (_int, [_vp, _vp, _vp, _int]),

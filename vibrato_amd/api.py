@@ -362,6 +362,63 @@ class Tokenizer:
                 "tokens_per_batch": int(tokens), "pool": self.pool_stats(),
                 "includes": "host copy of the text into the batch, H2D, kernels, D2H of token records into pinned host memory"}
 
+    def text_pipeline_benchmark(self, text, offsets, batches=8, mode="mecab"):
+        """Text in -> `tokenize` output text out (tokenize/src/main.rs:76-95) as a stream of batches: one host thread pushes batch
+        k + 1 through vbt_tokenize_batch while another renders batch k with vbt_batch_format (both calls release the GIL), which
+        is how vibrato_amd.cli runs.  Wall time of `batches` batches of the given text, output bytes counted, nothing copied
+        into Python objects."""
+        import queue
+        import threading
+        import time
+        text = np.ascontiguousarray(text, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        m = {"mecab": 0, "wakati": 1, "detail": 2}[mode]
+        L, h = N.lib(), self._handle()
+
+        def tokenize():
+            b = C.c_void_p()
+            N.check(L.vbt_tokenize_batch(h, text.ctypes.data, offsets.ctypes.data, n, C.byref(b)))
+            return b
+
+        def render(b):
+            p, ln = C.c_void_p(), C.c_size_t()
+            try:
+                N.check(L.vbt_batch_format(b, m, C.byref(p), C.byref(ln)))
+                L.vbt_free(p)
+            finally:
+                L.vbt_batch_free(b)
+            return ln.value
+
+        render(tokenize())  # warm-up: pools, the flat feature table
+        q = queue.Queue(maxsize=2)
+        err = []
+
+        def producer():
+            try:
+                for _ in range(batches):
+                    q.put(tokenize())
+            except Exception as e:  # noqa: BLE001 -- handed to the consumer
+                err.append(e)
+            q.put(None)
+
+        t0 = time.perf_counter()
+        th = threading.Thread(target=producer)
+        th.start()
+        out_bytes = 0
+        while True:
+            b = q.get()
+            if b is None:
+                break
+            out_bytes += render(b)
+        th.join()
+        dt = time.perf_counter() - t0
+        if err:
+            raise err[0]
+        return {"sentences_per_s": round(n * batches / dt, 1), "ms_per_batch": round(dt / batches * 1e3, 3), "batches": batches,
+                "batch_sentences": n, "output_MB_per_s": round(out_bytes / dt / 1e6, 1), "mode": mode,
+                "what": "two host threads: vbt_tokenize_batch of batch k + 1 under vbt_batch_format of batch k"}
+
     def workspace(self, max_sentences, max_bytes):
         return Workspace(self, max_sentences, max_bytes)
 
@@ -530,6 +587,23 @@ def _batch_format_bytes(self, mode="mecab"):
 Batch.format_bytes = _batch_format_bytes
 
 
+def _batch_format_into(self, write, mode="mecab"):
+    """Renders the batch and hands the library's buffer to `write` (e.g. a binary file's write) as a memoryview: no copy into a
+    Python object.  Returns the number of bytes."""
+    m = {"mecab": 0, "wakati": 1, "detail": 2}[mode]
+    p, n = C.c_void_p(), C.c_size_t()
+    N.check(N.lib().vbt_batch_format(self._h, m, C.byref(p), C.byref(n)))
+    try:
+        if n.value:
+            write(memoryview((C.c_char * n.value).from_address(p.value)))
+        return n.value
+    finally:
+        N.lib().vbt_free(p)
+
+
+Batch.format_into = _batch_format_into
+
+
 def compute_connid_probs(lid_count, rid_count):
     """ConnIdCounter::compute_probs (mapper.rs:108-146): per side, (id, count / sum) without id 0, sorted by
     probability descending then id ascending -- the content of the reference's *.lmap / *.rmap files."""
@@ -570,6 +644,12 @@ class Workspace:
     def run(self, d_text_ptr, d_offsets_ptr, n, total_bytes, stream=0):
         """Enqueue on `stream` (raw hipStream_t as int). Pointers are raw device addresses."""
         N.check(N.lib().vbt_tokenize_batch_device(self._h, d_text_ptr, d_offsets_ptr, n, total_bytes, stream or None))
+
+    def set_packed_output(self, slot_ptr, slot_bytes, max_sentences):
+        """Results of every later run() go straight into the caller's device buffer `slot_ptr`, laid out as a rank's slot of the
+        final gather (sharding.packed_bytes / unpack_results): no copy kernels between the tokenizer and the collective.
+        slot_ptr=None: back to the workspace's own buffers."""
+        N.check(N.lib().vbt_workspace_set_packed_output(self._h, slot_ptr or None, int(slot_bytes), int(max_sentences)))
 
     def result_ptrs(self):
         p = [C.c_void_p() for _ in range(4)]

@@ -51,10 +51,44 @@ def main(argv=None, stdin=None, stdout=None):
     tok = api.Tokenizer(d, device=args.device).ignore_space(args.ignore_space).max_grouping_len(args.max_grouping_len or 0)
     print("Ready to tokenize", file=sys.stderr)
 
-    def flush(lines):
-        if lines:
-            stdout.write(tok.tokenize_batch(lines).format(args.output_mode).encode("utf-8"))
+    # Three stages, each on its own thread (the library calls release the GIL): this thread reads lines and cuts blocks, one thread
+    # pushes block k + 1 through the GPU (vbt_tokenize_batch), one renders block k (vbt_batch_format) and writes it -- the formatter
+    # of one block runs under the kernels and copies of the next.  Output order = input order (one block at a time per stage).
+    import queue
+    import threading
+    blocks, batches = queue.Queue(maxsize=2), queue.Queue(maxsize=2)
+    failure = []
 
+    def tokenize_stage():
+        try:
+            while True:
+                lines = blocks.get()
+                if lines is None:
+                    break
+                if not failure:
+                    batches.put(tok.tokenize_batch(lines))
+        except BaseException as e:  # noqa: BLE001 -- reported by the main thread
+            failure.append(e)
+            while blocks.get() is not None:  # (keep draining: the reader must not block on a full queue)
+                pass
+        batches.put(None)
+
+    def output_stage():
+        try:
+            while True:
+                b = batches.get()
+                if b is None:
+                    break
+                if not failure:
+                    b.format_into(stdout.write, args.output_mode)
+        except BaseException as e:  # noqa: BLE001
+            failure.append(e)
+            while batches.get() is not None:
+                pass
+
+    stages = [threading.Thread(target=tokenize_stage), threading.Thread(target=output_stage)]
+    for t in stages:
+        t.start()
     block = []
     for raw in stdin:
         if raw.endswith(b"\n"):
@@ -63,9 +97,15 @@ def main(argv=None, stdin=None, stdout=None):
                 raw = raw[:-1]
         block.append(raw)
         if len(block) >= args.block:
-            flush(block)
+            blocks.put(block)
             block = []
-    flush(block)
+    if block:
+        blocks.put(block)
+    blocks.put(None)
+    for t in stages:
+        t.join()
+    if failure:
+        raise failure[0]
     stdout.flush()
     return 0
 

@@ -2,6 +2,8 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -131,6 +133,10 @@ struct vbt_tokenizer {
     std::mutex pool_mu;
     std::vector<std::unique_ptr<PinnedBlock>> host_pool;  // idle pinned blocks
     uint64_t pool_created = 0, pool_reused = 0;
+    // feature strings of the three lexicons (system, user, unknown) back to back + offsets per word id: what vbt_batch_format reads
+    // instead of 877 k separately allocated std::strings (built at the first format call)
+    struct FlatFeatures { std::vector<uint32_t> off; std::vector<char> blob; } flat[3];
+    std::once_flag flat_once;
     std::atomic<int> out_mode{-1};      // VBT_H2H_OUT: 0 = the packing kernel stores into the pinned block, 1 = SDMA copies (default); published with release once the replicas' Sdma exist
     ~vbt_tokenizer() { for (auto& r : reps) r->pool.clear(); }  // before the Tokenizers (workspaces reference them)
 };
@@ -396,6 +402,109 @@ void pool_give(vbt_tokenizer* tok, Replica& rep, std::unique_ptr<PooledWorkspace
     if (drop) { (void)hipSetDevice(rep.t->device()); drop.reset(); }
 }
 
+// Buffers the library hands out and vbt_free takes back (vbt_batch_format's text, vbt_dict_write's bytes).  A 16-byte header in
+// front of the caller's pointer holds the capacity; the last few big ones are kept instead of freed: 100 MB of `tokenize` output per
+// batch would otherwise be mapped, faulted in page by page (the kernel zeroes every page first: that, not the copying, bounded the
+// formatter at ~10 GB/s on 64 threads) and unmapped again for every batch.
+struct OutHeader { uint64_t magic, cap; };
+constexpr uint64_t kOutMagic = 0x7662745F6F757462ull;
+constexpr size_t kOutCacheSlots = 4;
+constexpr uint64_t kOutCacheMinBytes = 1u << 20, kOutCacheMaxTotal = 2048ull << 20;
+std::mutex g_out_mu;
+std::vector<OutHeader*> g_out_cache;
+
+void* out_alloc(size_t bytes) {
+    if (bytes >= kOutCacheMinBytes) {
+        std::lock_guard<std::mutex> g(g_out_mu);
+        size_t best = g_out_cache.size();
+        for (size_t i = 0; i < g_out_cache.size(); ++i)
+            if (g_out_cache[i]->cap >= bytes && g_out_cache[i]->cap <= 2 * bytes + (1u << 20) && (best == g_out_cache.size() || g_out_cache[i]->cap < g_out_cache[best]->cap)) best = i;
+        if (best != g_out_cache.size()) {
+            OutHeader* h = g_out_cache[best];
+            g_out_cache.erase(g_out_cache.begin() + (long)best);
+            return h + 1;
+        }
+    }
+    const size_t cap = bytes >= kOutCacheMinBytes ? bytes + bytes / 8 : (bytes ? bytes : 1);  // (head room: the next batch's output is about as long)
+    OutHeader* h = static_cast<OutHeader*>(std::malloc(sizeof(OutHeader) + cap));
+    if (!h) return nullptr;
+    h->magic = kOutMagic; h->cap = cap;
+    return h + 1;
+}
+
+void out_free(void* p) {
+    if (!p) return;
+    OutHeader* h = static_cast<OutHeader*>(p) - 1;
+    if (h->magic != kOutMagic) { std::free(p); return; }  // (not ours: a caller's own malloc -- be forgiving)
+    if (h->cap >= kOutCacheMinBytes) {
+        std::lock_guard<std::mutex> g(g_out_mu);
+        uint64_t held = h->cap;
+        for (const OutHeader* q : g_out_cache) held += q->cap;
+        if (g_out_cache.size() < kOutCacheSlots && held <= kOutCacheMaxTotal) { g_out_cache.push_back(h); return; }
+    }
+    h->magic = 0;
+    std::free(h);
+}
+
+// Persistent host threads for the formatter (starting 63 threads per call cost 2-3 ms of a 10 ms call).  run(T, body): body(k) for
+// k = 0 .. T - 1, k = 0 on the calling thread, the others on pool threads (created on demand, parked on a condition variable
+// between calls); returns how many chunks ran concurrently = T, or fewer if the host refused more threads (then the caller is told
+// BEFORE any body runs, through `granted`).  One job at a time (callers serialise on job_mu): the formatter is memory-bound, two
+// at once gain nothing.
+class HostPool {
+  public:
+    static HostPool& get() { static HostPool* p = new HostPool; return *p; }  // (leaked on purpose: parked threads at process exit)
+    // reserves up to `want` workers (this thread included); returns the number granted; run() must follow with exactly that T
+    unsigned begin(unsigned want) {
+        job_mu_.lock();
+        std::lock_guard<std::mutex> g(mu_);
+        while (threads_ + 1 < want) {
+            try { std::thread([this, idx = threads_ + 1] { loop(idx); }).detach(); ++threads_; }
+            catch (const std::exception&) { break; }
+        }
+        return std::min<unsigned>(want, threads_ + 1);
+    }
+    template <typename F>
+    void run(unsigned T, F&& body) {
+        std::function<void(unsigned)> fn = body;
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            fn_ = &fn; active_ = T; pending_ = T - 1; ++gen_;
+        }
+        cv_.notify_all();
+        fn(0);
+        std::unique_lock<std::mutex> g(mu_);
+        done_cv_.wait(g, [&] { return pending_ == 0; });
+        fn_ = nullptr;
+        g.unlock();
+        job_mu_.unlock();
+    }
+    void cancel() { job_mu_.unlock(); }  // begin() without run()
+
+  private:
+    void loop(unsigned idx) {
+        uint64_t seen = 0;
+        for (;;) {
+            std::function<void(unsigned)>* fn;
+            {
+                std::unique_lock<std::mutex> g(mu_);
+                cv_.wait(g, [&] { return gen_ != seen; });
+                seen = gen_;
+                if (idx >= active_) continue;
+                fn = fn_;
+            }
+            (*fn)(idx);
+            std::lock_guard<std::mutex> g(mu_);
+            if (--pending_ == 0) done_cv_.notify_all();
+        }
+    }
+    std::mutex mu_, job_mu_;
+    std::condition_variable cv_, done_cv_;
+    std::function<void(unsigned)>* fn_ = nullptr;
+    unsigned threads_ = 0, active_ = 0, pending_ = 0;
+    uint64_t gen_ = 0;
+};
+
 const Dictionary& dict_of(const vbt_dict* dict) {
     if (!dict || !dict->d) throw Error(VBT_ERR_INVALID_ARGUMENT, "dict: null or consumed by vbt_tokenizer_new");
     return *dict->d;
@@ -450,7 +559,7 @@ int vbt_dict_write(const vbt_dict* dict, int zstd_level, uint8_t** out, size_t* 
         if (!out || !len) throw Error(VBT_ERR_INVALID_ARGUMENT, "null argument");
         std::vector<uint8_t> bytes = write_dictionary(dict_of(dict));
         if (zstd_level >= 0) bytes = zstd_compress(bytes.data(), bytes.size(), zstd_level);
-        uint8_t* p = static_cast<uint8_t*>(std::malloc(bytes.size() ? bytes.size() : 1));
+        uint8_t* p = static_cast<uint8_t*>(out_alloc(bytes.size()));
         if (!p) throw std::bad_alloc();
         std::memcpy(p, bytes.data(), bytes.size());
         *out = p;
@@ -872,15 +981,13 @@ int vbt_tokenize_batch(const vbt_tokenizer* tok_, const uint8_t* text, const uin
         const size_t text_end = (n + 1) * 8 + ((bytes + 7) & ~(uint64_t)7);
         b.in_blk = host_take(tok, text_end + 8 * R + (R > 1 ? (n + R) * 8 : 0) + 24);
         uint64_t* offs = static_cast<uint64_t*>(b.in_blk->p);
-        for (uint64_t i = 0; i <= n; ++i) offs[i] = offsets[i] - lo;
         uint8_t* txt = reinterpret_cast<uint8_t*>(offs + n + 1);
-        if (bytes) std::memcpy(txt, text + lo, bytes);
         b.offsets = offs;
         b.text = txt;
         uint32_t* tails = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(b.in_blk->p) + text_end);  // per shard {n_tokens, error flags}
         uint64_t* shard_offs = reinterpret_cast<uint64_t*>(tails + 2 * R);
         std::vector<uint64_t> bounds;
-        shard_bounds(offs, n, R, bounds);
+        shard_bounds(offsets, n, R, bounds);  // (on the caller's offsets: the rule only looks at differences)
         // How the results reach the host (VBT_H2H_OUT): 1 (default) = packed on the device, then copied by the GPU's SDMA engines
         // (Sdma above); 0 = the packing kernel stores them straight into this batch's pinned block.  Either way the total and the
         // error flags come back first, in 8 bytes, so that the pinned block is sized exactly.
@@ -899,17 +1006,40 @@ int vbt_tokenize_batch(const vbt_tokenizer* tok_, const uint8_t* text, const uin
         }
         const bool use_sdma = tok->out_mode.load(std::memory_order_acquire) == 1;
         h.sh.resize(R);
-        for (uint32_t k = 0; k < R; ++k) {
+        // Every device is driven by ITS OWN host thread (a single-device tokenizer: the calling thread): the thread rebases its shard's
+        // offsets, copies its shard of the text into the pinned block, enqueues the H2D copies and the launch sequence on its device
+        // and waits for the 8 bytes of totals -- so eight devices cost one shard's host work, not eight in a row (round-4 review).
+        auto in_shard_threads = [&](auto&& body) {
+            if (R == 1) { body(0u); return; }
+            std::vector<std::exception_ptr> errs(R);
+            std::vector<std::thread> th;
+            auto run = [&](uint32_t k) { try { body(k); } catch (...) { errs[k] = std::current_exception(); } };
+            uint32_t started = 1;
+            try {
+                th.reserve(R);
+                for (; started < R; ++started) th.emplace_back(run, started);
+            } catch (const std::exception&) {}  // (out of threads: the rest runs here)
+            run(0);
+            for (uint32_t k = started; k < R; ++k) run(k);
+            for (auto& t : th) t.join();
+            for (auto& e : errs) if (e) std::rethrow_exception(e);
+        };
+        in_shard_threads([&](uint32_t k) {
             Shard& s = h.sh[k];
-            s.s0 = bounds[k]; s.s1 = bounds[k + 1]; s.b0 = offs[s.s0]; s.b1 = offs[s.s1];
+            s.s0 = bounds[k]; s.s1 = bounds[k + 1];
+            s.b0 = offsets[s.s0] - lo; s.b1 = offsets[s.s1] - lo;
             s.tail = tails + 2 * k;
             s.tail[0] = s.tail[1] = 0;
             const uint64_t ns = s.s1 - s.s0, nb = s.b1 - s.b0;
-            if (ns == 0) continue;
+            // this shard's part of the batch's own copy of the input (the last shard also writes offs[n])
+            for (uint64_t i = s.s0; i < s.s1; ++i) offs[i] = offsets[i] - lo;
+            if (k + 1 == R) offs[n] = bytes;
+            if (nb) std::memcpy(txt + s.b0, text + lo + s.b0, nb);
+            if (ns == 0) return;
             const uint64_t* so = offs;  // a single shard reads the batch's offsets as they are
             if (R > 1) {
                 uint64_t* q = shard_offs + s.s0 + k;
-                for (uint64_t i = 0; i <= ns; ++i) q[i] = offs[s.s0 + i] - s.b0;
+                for (uint64_t i = 0; i <= ns; ++i) q[i] = offsets[s.s0 + i] - lo - s.b0;
                 so = q;
             }
             HIPX(hipSetDevice(tok->reps[k]->t->device()));
@@ -919,14 +1049,13 @@ int vbt_tokenize_batch(const vbt_tokenizer* tok_, const uint8_t* text, const uin
             HIPX(hipMemcpyAsync(p.d_off, so, (ns + 1) * 8, hipMemcpyHostToDevice, p.stream));
             p.ws->run(static_cast<const uint8_t*>(p.d_text), p.d_off, ns, nb, p.stream, /*defer_pack=*/!use_sdma);
             HIPX(hipMemcpyAsync(s.tail, p.ws->d_ctrl, 8, hipMemcpyDeviceToHost, p.stream));
-        }
+            HIPX(hipStreamSynchronize(p.stream));
+        });
         uint32_t error_flags = 0;
         uint64_t total = 0;
         for (uint32_t k = 0; k < R; ++k) {
             Shard& s = h.sh[k];
             if (!s.p) continue;
-            HIPX(hipSetDevice(tok->reps[k]->t->device()));
-            HIPX(hipStreamSynchronize(s.p->stream));
             error_flags |= s.tail[1];
             s.tok_base = total;
             total += s.tail[0];
@@ -946,36 +1075,33 @@ int vbt_tokenize_batch(const vbt_tokenizer* tok_, const uint8_t* text, const uin
         b.tok_off = o;
         b.tok_cnt = o + n;
         b.tokens = otok;
-        std::vector<hsa_signal_t> sigs;
-        bool copies_ok = true;
-        for (uint32_t k = 0; k < R; ++k) {
+        // the results: every device's own thread has its DMA engines (or its packing kernel) write its shard into the one block at
+        // the shard's place, waits for them, rebases the shard's token offsets to the batch and hands its workspace back
+        in_shard_threads([&](uint32_t k) {
             Shard& s = h.sh[k];
-            if (!s.p) continue;
+            if (!s.p) return;
             const uint64_t ns = s.s1 - s.s0;
             PooledWorkspace& p = *s.p;
             if (use_sdma) {
                 const void* src[3] = {p.ws->d_tok_off, p.ws->d_tok_cnt, p.ws->d_tokens};
                 void* dst[3] = {o + s.s0, o + n + s.s0, otok + s.tok_base};
                 const size_t len[3] = {(size_t)ns * 4, (size_t)ns * 4, (size_t)s.tail[0] * sizeof(vbt_token_rec)};
-                copies_ok = tok->reps[k]->sdma->issue(src, dst, len, 3, sigs) && copies_ok;
+                std::vector<hsa_signal_t> sigs;
+                bool ok = tok->reps[k]->sdma->issue(src, dst, len, 3, sigs);
+                ok = Sdma::wait(sigs) && ok;
+                if (!ok) throw Error(VBT_ERR_DEVICE, "device -> host copy of the results failed (hsa_amd_memory_async_copy)");
             } else {
                 HIPX(hipSetDevice(tok->reps[k]->t->device()));
                 void* dev = nullptr;
                 HIPX(hipHostGetDevicePointer(&dev, o, 0));
                 uint32_t* od = static_cast<uint32_t*>(dev);
                 p.ws->pack_to(reinterpret_cast<vbt_token_rec*>(od + 2 * n) + s.tok_base, od + s.s0, od + n + s.s0, p.stream);
+                HIPX(hipStreamSynchronize(p.stream));
             }
-        }
-        copies_ok = Sdma::wait(sigs) && copies_ok;
-        if (!copies_ok) throw Error(VBT_ERR_DEVICE, "device -> host copy of the results failed (hsa_amd_memory_async_copy)");
-        for (uint32_t k = 0; k < R; ++k) {
-            Shard& s = h.sh[k];
-            if (!s.p) continue;
-            if (!use_sdma) { HIPX(hipSetDevice(tok->reps[k]->t->device())); HIPX(hipStreamSynchronize(s.p->stream)); }
             if (s.tok_base)  // a shard's token offsets start at 0: rebase them to the batch
                 for (uint64_t i = s.s0; i < s.s1; ++i) o[i] += (uint32_t)s.tok_base;
             pool_give(tok, *tok->reps[k], std::move(s.p));
-        }
+        });
         *out = h.b.release();
     });
 }
@@ -1088,13 +1214,38 @@ int vbt_batch_format(const vbt_batch* b, int mode, char** out, size_t* len) {
         if (mode < VBT_FORMAT_MECAB || mode > VBT_FORMAT_DETAIL) throw Error(VBT_ERR_INVALID_ARGUMENT, "mode: unknown output mode");
         const Dictionary& d = b->tok->t->dict();
         const uint64_t n = b->n;
+        // The feature strings, flat: one blob per lexicon + a u32 offset per word id (3.5 MB of offsets for unidic: they stay in the
+        // host's caches, where 877 k separately allocated std::strings cost a cache miss per token for the length alone).
+        vbt_tokenizer* tk = b->tok;
+        std::call_once(tk->flat_once, [&] {
+            auto flatten = [](const std::vector<std::string>& f, vbt_tokenizer::FlatFeatures& o) {
+                size_t total = 0;
+                for (const auto& x : f) total += x.size();
+                if (total >= 0xFFFFFFFFull) throw Error(VBT_ERR_UNSUPPORTED, "format: more than 4 GiB of feature strings");
+                o.off.resize(f.size() + 1);
+                o.blob.resize(total);
+                size_t at = 0;
+                for (size_t i = 0; i < f.size(); ++i) { o.off[i] = (uint32_t)at; std::memcpy(o.blob.data() + at, f[i].data(), f[i].size()); at += f[i].size(); }
+                o.off[f.size()] = (uint32_t)at;
+            };
+            flatten(d.system.features, tk->flat[VBT_LEX_SYSTEM]);
+            if (d.has_user) flatten(d.user.features, tk->flat[VBT_LEX_USER]); else tk->flat[VBT_LEX_USER].off.assign(1, 0);
+            flatten(d.unk_features, tk->flat[VBT_LEX_UNKNOWN]);
+        });
+        const vbt_tokenizer::FlatFeatures* flat = tk->flat;
         // chunks of sentences balanced by tokens (tok_off is non-decreasing in sentence order)
         unsigned want = std::thread::hardware_concurrency();
         if (want == 0) want = 1;
-        if (want > 32) want = 32;
+        if (want > 64) want = 64;
         if (const char* e = std::getenv("VBT_FORMAT_THREADS")) { const int v = std::atoi(e); if (v > 0) want = (unsigned)std::min(v, 256); }
-        const uint64_t est = b->n_tokens * 80 + n * 4;
-        const unsigned T = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(want, est / (2u << 20) + 1));
+        const uint64_t est = b->n_tokens * 40 + n * 4;
+        unsigned T = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(want, est / (1u << 20) + 1));
+        // persistent workers (HostPool): the number granted (a host out of threads grants fewer) decides how many chunks there are,
+        // so the barrier between the two passes below counts exactly the threads that take part
+        HostPool& pool = HostPool::get();
+        T = pool.begin(T);
+        struct PoolGuard { HostPool& p; bool ran = false; ~PoolGuard() { if (!ran) p.cancel(); } } pool_guard{pool};
+        std::function<void(unsigned)> chunk_body;
         std::vector<uint64_t> first(T + 1, n);
         first[0] = 0;
         for (unsigned k = 1; k < T; ++k) {
@@ -1102,22 +1253,51 @@ int vbt_batch_format(const vbt_batch* b, int mode, char** out, size_t* len) {
             first[k] = (uint64_t)(std::lower_bound(b->tok_off, b->tok_off + n, target) - b->tok_off);
             if (first[k] < first[k - 1]) first[k] = first[k - 1];
         }
+        // feature string of a record (mecab mode): two reads of the cached offset array; a word id outside the dictionary is an error
+        auto feature_of = [&](const vbt_token_rec& r, const char*& p, size_t& l) {
+            const uint32_t lex = r.word_idx >> 30, wid = r.word_idx & 0x3FFFFFFFu;
+            if (lex > VBT_LEX_UNKNOWN || (size_t)wid + 1 >= flat[lex].off.size()) throw std::runtime_error("format: a token's word id lies outside its lexicon");
+            const uint32_t a = flat[lex].off[wid];
+            p = flat[lex].blob.data() + a;
+            l = flat[lex].off[wid + 1] - a;
+        };
         auto sentence_size = [&](uint64_t si) {
-            const uint8_t* sent = b->text + b->offsets[si];
             const uint32_t nt = b->tok_cnt[si];
+            const vbt_token_rec* recs = b->tokens + b->tok_off[si];
             size_t sz = mode == VBT_FORMAT_WAKATI ? (nt ? nt - 1 : 0) + 1 : 4;  // separators + '\n' | "EOS\n" (tokenize/src/main.rs:91,96-103)
-            vbt_token t;
-            for (uint32_t i = 0; i < nt; ++i) { fill_token(d, sent, b->tokens[b->tok_off[si] + i], &t); sz += format_size(t, mode); }
+            if (mode == VBT_FORMAT_DETAIL) {
+                const uint8_t* sent = b->text + b->offsets[si];
+                vbt_token t;
+                for (uint32_t i = 0; i < nt; ++i) { fill_token(d, sent, recs[i], &t); sz += format_size(t, mode); }
+            } else if (mode == VBT_FORMAT_WAKATI) {
+                for (uint32_t i = 0; i < nt; ++i) sz += recs[i].end_byte - recs[i].start_byte;
+            } else {
+                const char* fp; size_t fl;
+                for (uint32_t i = 0; i < nt; ++i) { feature_of(recs[i], fp, fl); sz += (recs[i].end_byte - recs[i].start_byte) + fl + 2; }
+            }
             return sz;
         };
         auto render = [&](uint64_t si, char* p) {
             const uint8_t* sent = b->text + b->offsets[si];
             const uint32_t nt = b->tok_cnt[si];
-            vbt_token t;
-            for (uint32_t i = 0; i < nt; ++i) {
-                fill_token(d, sent, b->tokens[b->tok_off[si] + i], &t);
-                if (mode == VBT_FORMAT_WAKATI && i) *p++ = ' ';
-                p = format_token(p, t, mode);
+            const vbt_token_rec* recs = b->tokens + b->tok_off[si];
+            if (mode == VBT_FORMAT_DETAIL) {
+                vbt_token t;
+                for (uint32_t i = 0; i < nt; ++i) { fill_token(d, sent, recs[i], &t); p = format_token(p, t, mode); }
+            } else if (mode == VBT_FORMAT_WAKATI) {
+                for (uint32_t i = 0; i < nt; ++i) {
+                    if (i) *p++ = ' ';
+                    p = put_s(p, reinterpret_cast<const char*>(sent) + recs[i].start_byte, recs[i].end_byte - recs[i].start_byte);
+                }
+            } else {  // surface \t feature \n (tokenize/src/main.rs:83-91)
+                const char* fp; size_t fl;
+                for (uint32_t i = 0; i < nt; ++i) {
+                    feature_of(recs[i], fp, fl);
+                    p = put_s(p, reinterpret_cast<const char*>(sent) + recs[i].start_byte, recs[i].end_byte - recs[i].start_byte);
+                    *p++ = '\t';
+                    p = put_s(p, fp, fl);
+                    *p++ = '\n';
+                }
             }
             if (mode == VBT_FORMAT_WAKATI) *p++ = '\n';
             else p = put_s(p, "EOS\n", 4);
@@ -1126,54 +1306,53 @@ int vbt_batch_format(const vbt_batch* b, int mode, char** out, size_t* len) {
         std::vector<size_t> chunk_bytes(T, 0);
         std::string failure;
         std::mutex fail_mu;
-        auto in_parallel = [&](auto&& body) {  // body(k) for every chunk; exceptions (a word id outside the dictionary) are carried out
-            std::vector<std::thread> th;
-            { std::lock_guard<std::mutex> g(fail_mu); failure.clear(); }
-            auto run = [&](unsigned k) {
-                try { body(k); }
-                catch (const std::exception& e) { std::lock_guard<std::mutex> g(fail_mu); failure = e.what(); }
-            };
-            unsigned started = 1;  // chunks that have a thread (chunk 0 is this thread's)
-            try {
-                th.reserve(T);
-                for (; started < T; ++started) th.emplace_back(run, started);
-            } catch (const std::exception&) {
-                // the host is out of threads (EAGAIN): what could not be started runs here, nothing is left joinable
-            }
-            run(0);
-            for (unsigned k = started; k < T; ++k) run(k);
-            for (auto& t : th) t.join();
-            std::lock_guard<std::mutex> g(fail_mu);
-            if (!failure.empty()) throw Error(VBT_ERR_INVALID_STATE, failure);
-        };
-        in_parallel([&](unsigned k) {
-            size_t sz = 0;
-            for (uint64_t si = first[k]; si < first[k + 1]; ++si) sz += sentence_size(si);
-            chunk_bytes[k] = sz;
-        });
+        // Both passes on the one set of threads: sizes, then -- behind a barrier at which the last arrival takes the prefix over the
+        // chunks and allocates -- every thread renders its own chunk in place (and first-touches its part of the output).
         size_t total = 0;
         std::vector<size_t> at(T + 1, 0);
-        for (unsigned k = 0; k < T; ++k) { at[k] = total; total += chunk_bytes[k]; }
-        at[T] = total;
-        char* buf = static_cast<char*>(std::malloc(total + 1));
-        if (!buf) throw std::bad_alloc();
-        try {
-            in_parallel([&](unsigned k) {
+        char* buf = nullptr;
+        std::mutex bar_mu;
+        std::condition_variable bar_cv;
+        unsigned arrived = 0;
+        bool ready = false, alloc_failed = false;
+        auto fail_with = [&](const char* what) { std::lock_guard<std::mutex> g(fail_mu); failure = what; };
+        chunk_body = [&](unsigned k) {
+            size_t sz = 0;
+            bool ok = true;
+            try { for (uint64_t si = first[k]; si < first[k + 1]; ++si) sz += sentence_size(si); }
+            catch (const std::exception& e) { ok = false; fail_with(e.what()); }
+            {
+                std::unique_lock<std::mutex> g(bar_mu);
+                chunk_bytes[k] = sz;
+                if (++arrived == T) {
+                    for (unsigned q = 0; q < T; ++q) { at[q] = total; total += chunk_bytes[q]; }
+                    at[T] = total;
+                    bool failed;
+                    { std::lock_guard<std::mutex> f(fail_mu); failed = !failure.empty(); }
+                    if (!failed) buf = static_cast<char*>(out_alloc(total + 1));
+                    alloc_failed = !failed && !buf;
+                    ready = true;
+                    bar_cv.notify_all();
+                } else bar_cv.wait(g, [&] { return ready; });
+            }
+            if (!ok || !buf) return;
+            try {
                 char* p = buf + at[k];
                 for (uint64_t si = first[k]; si < first[k + 1]; ++si) p = render(si, p);
-                if (p != buf + at[k + 1]) throw std::runtime_error("format: size pass and render pass disagree");
-            });
-        } catch (...) {
-            std::free(buf);
-            throw;
-        }
+                if (p != buf + at[k + 1]) fail_with("format: size pass and render pass disagree");
+            } catch (const std::exception& e) { fail_with(e.what()); }
+        };
+        pool_guard.ran = true;
+        pool.run(T, chunk_body);
+        if (!failure.empty()) { out_free(buf); throw Error(VBT_ERR_INVALID_STATE, failure); }
+        if (alloc_failed) throw std::bad_alloc();
         buf[total] = 0;
         *out = buf;
         *len = total;
     });
 }
 
-void vbt_free(void* p) { std::free(p); }
+void vbt_free(void* p) { out_free(p); }
 
 int vbt_workspace_new(const vbt_tokenizer* tok, uint64_t max_sentences, uint64_t max_bytes, vbt_workspace** out) {
     return guarded([&] {
@@ -1192,10 +1371,19 @@ int vbt_tokenize_batch_device(vbt_workspace* ws, const uint8_t* d_text, const ui
 int vbt_workspace_results(const vbt_workspace* ws, const vbt_token_rec** d_tokens, const uint32_t** d_tok_off, const uint32_t** d_tok_cnt,
                           const uint32_t** d_total) {
     return guarded([&] {
-        if (d_tokens) *d_tokens = ws->w->d_tokens;
-        if (d_tok_off) *d_tok_off = ws->w->d_tok_off;
-        if (d_tok_cnt) *d_tok_cnt = ws->w->d_tok_cnt;
-        if (d_total) *d_total = ws->w->d_ctrl;
+        const Workspace& w = *ws->w;
+        char* slot = static_cast<char*>(w.packed_slot);  // (with a packed output slot set: where inside it the arrays are)
+        if (d_tokens) *d_tokens = slot ? reinterpret_cast<const vbt_token_rec*>(slot + 32 + 8 * w.packed_max_s) : w.d_tokens;
+        if (d_tok_off) *d_tok_off = slot ? reinterpret_cast<const uint32_t*>(slot + 32) : w.d_tok_off;
+        if (d_tok_cnt) *d_tok_cnt = slot ? reinterpret_cast<const uint32_t*>(slot + 32 + 4 * w.packed_max_s) : w.d_tok_cnt;
+        if (d_total) *d_total = w.d_ctrl;
+    });
+}
+
+int vbt_workspace_set_packed_output(vbt_workspace* ws, void* d_slot, uint64_t slot_bytes, uint64_t max_sentences) {
+    return guarded([&] {
+        if (!ws) throw Error(VBT_ERR_INVALID_ARGUMENT, "null argument");
+        ws->w->set_packed_output(d_slot, slot_bytes, max_sentences);
     });
 }
 

@@ -375,13 +375,26 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
     last_stream = stream_;
     has_run = true;
     HIP_CHECK(hipMemsetAsync(d_ctrl, 0, (kCtrlWords + (size_t)kBlockCtrlWords) * 4, stream));  // ctrl + cctrl
-    if (n == 0) return;
+    if (packed_slot && n > packed_max_s) throw Error(VBT_ERR_INVALID_ARGUMENT, "batch has more sentences than the packed output slot holds");
+    if (n == 0) {
+        if (packed_slot) HIP_CHECK(hipMemsetAsync(packed_slot, 0, 32, stream));  // header of an empty result
+        return;
+    }
     const size_t T = tiers.size();
     const size_t stride = 2 * std::max<uint64_t>(max_sentences, 1);
     BatchArgs a = pipe;
     a.text = d_text; a.offsets = d_offsets; a.n = (uint32_t)n;
     a.tokens = d_tokens; a.tok_stage = d_tok_stage; a.tok_cap = (uint32_t)std::max<uint64_t>(max_bytes, 1);
     a.tok_off = d_tok_off; a.tok_cnt = d_tok_cnt; a.ctrl = d_ctrl; a.tile_sums = d_tile_sums;
+    a.out_header = nullptr;
+    if (packed_slot) {  // results straight into the caller's slot (set_packed_output)
+        char* base = static_cast<char*>(packed_slot);
+        a.out_header = reinterpret_cast<uint32_t*>(base);
+        a.tok_off = reinterpret_cast<uint32_t*>(base + 32);
+        a.tok_cnt = reinterpret_cast<uint32_t*>(base + 32 + 4 * packed_max_s);
+        a.tokens = reinterpret_cast<vbt_token_rec*>(base + 32 + 8 * packed_max_s);
+        a.tok_cap = (uint32_t)std::min<uint64_t>((packed_bytes - 32 - 8 * packed_max_s) / sizeof(vbt_token_rec), 0xFFFFFFFFull);
+    }
     a.scratch = d_scratch; a.scratch_bytes = scratch_bytes;
     a.prof = profile ? d_prof : nullptr;
     a.lists = d_over; a.list_stride = (uint32_t)stride; a.n_tiers = (uint32_t)T;
@@ -517,6 +530,15 @@ void Workspace::serve(const uint8_t* h_text_dev, uint8_t* d_text, uint64_t* d_of
     // residency at 35 us per call; 0 = unbounded)
     kern::tokenize_serve(kOneLds, stream, D, a, h_text_dev, ctl, last_seq, idle_polls, env_u32("VBT_WORKER_MAX_SERVED", 4096));
     HIP_CHECK(hipGetLastError());
+}
+
+void Workspace::set_packed_output(void* slot, uint64_t slot_bytes, uint64_t max_s) {
+    if (slot) {
+        if (fused) throw Error(VBT_ERR_UNSUPPORTED, "packed output needs the two-kernel pipeline (unset VBT_FUSED)");
+        if ((reinterpret_cast<uintptr_t>(slot) & 7u) != 0) throw Error(VBT_ERR_INVALID_ARGUMENT, "packed output: the slot must be 8-byte aligned");
+        if (slot_bytes < 32 + 8 * max_s) throw Error(VBT_ERR_INVALID_ARGUMENT, "packed output: the slot is smaller than its header and per-sentence arrays");
+    }
+    packed_slot = slot; packed_bytes = slot ? slot_bytes : 0; packed_max_s = slot ? max_s : 0;
 }
 
 void Workspace::pack_to(vbt_token_rec* out_tokens, uint32_t* out_off, uint32_t* out_cnt, void* stream_) {

@@ -46,6 +46,7 @@ struct BatchArgs {
     uint32_t tok_cap;
     uint32_t* tok_off;
     uint32_t* tok_cnt;
+    uint32_t* out_header;  // optional: {n_sentences (u64), n_tokens (u32), 0 ...} of a packed result slot (Workspace::set_packed_output), written with the total
     uint32_t* tile_sums;  // tokens per tile of kScanTile sentences, added up by the kernels that write tok_cnt (zeroed by validate_batch)
     // control block (device, kCtrlWords u32): see CtrlSlot
     uint32_t* ctrl;
@@ -174,6 +175,13 @@ class Workspace {
     // the packed records wherever the caller wants them (vbt_tokenize_batch: straight into its pinned host block)
     void run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n, uint64_t total_bytes, void* stream, bool defer_pack = false);
     void pack_to(vbt_token_rec* out_tokens, uint32_t* out_off, uint32_t* out_cnt, void* stream);
+    // The results of every later run() go straight into ONE caller-owned device buffer, laid out as a rank's slot of the final gather
+    // (vibrato_amd/sharding.py): [32-byte header {n_sentences u64, n_tokens u32, 0}] [tok_off u32 x max_sentences] [tok_cnt u32 x
+    // max_sentences] [24-byte token records] -- tok_cnt by the sweep, tok_off and the records by compact_tokens, the header with its
+    // total: no copy kernels between the tokenizer and the collective.  slot == nullptr: back to the workspace's own buffers.
+    void set_packed_output(void* slot, uint64_t slot_bytes, uint64_t max_sentences);
+    void* packed_slot = nullptr;
+    uint64_t packed_bytes = 0, packed_max_s = 0;
     void stats(vbt_call_stats* out);  // synchronizes the last stream used
     // Worker::tokenize() latency path: starts the resident kernel that serves one Worker out of its pinned host block (`h_text_dev`:
     // device address of the block's text area, padded to 16 bytes; `ctl`: device address of its control words, see tokenize_serve in

@@ -35,7 +35,10 @@ __global__ void __launch_bounds__(1024) tok_tile_scan(BatchArgs A, uint32_t* til
         if (t < n_tiles) tile_sums[t] = running + ex;
         running += tot;
     }
-    if (threadIdx.x == 0) A.ctrl[kTotal] = running;
+    if (threadIdx.x == 0) {
+        A.ctrl[kTotal] = running;
+        if (A.out_header) { A.out_header[0] = A.n; A.out_header[1] = 0u; A.out_header[2] = running; A.out_header[3] = 0u; }
+    }
 }
 // kPackSplit (8) workgroups share a tile: each redoes the tile's (cheap) offset scan and copies every kPackSplit-th stripe of its
 // tokens -- the copy is a chain of dependent round trips per token (which sentence, where its slot starts, the record), so it
@@ -76,7 +79,10 @@ __global__ void __launch_bounds__(kScanBlock) compact_tokens(BatchArgs A, const 
         before = all = 0;
         for (uint32_t w = 0; w < kScanBlock / 64; ++w) { before += red[0][w]; all += red[1][w]; }
         base = before;
-        if (blockIdx.x == 0 && threadIdx.x == 0) A.ctrl[kTotal] = all;
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            A.ctrl[kTotal] = all;
+            if (A.out_header) { A.out_header[0] = A.n; A.out_header[1] = 0u; A.out_header[2] = all; A.out_header[3] = 0u; }  // {n_sentences u64, n_tokens u32, 0}
+        }
     }
     for (uint32_t i = 0; i < kScanItems; ++i) {
         offs[threadIdx.x * kScanItems + i] = ex;
@@ -92,6 +98,7 @@ __global__ void __launch_bounds__(kScanBlock) compact_tokens(BatchArgs A, const 
         while (lo + 1 < hi) { const uint32_t mid = (lo + hi) >> 1; if (offs[mid] <= k) lo = mid; else hi = mid; }
         const size_t from = (size_t)slot[lo] + (k - offs[lo]);
         const size_t to = (size_t)base + k;
+        if (to >= A.tok_cap) { atomicOr(&A.ctrl[kError], (uint32_t)kErrTokCap); break; }  // (a caller's slot that is too small for this batch)
 #pragma unroll
         for (int w = 0; w < 3; ++w) dst[3 * to + w] = src[3 * from + w];
     }
