@@ -234,6 +234,9 @@ __device__ __forceinline__ void unk_spans(uint32_t cinfo, uint32_t g, uint32_t i
 #ifndef VBT_LDS_REC
 #define VBT_LDS_REC 1  // the assembly loop's 8-byte pass records in the sentence's LDS (sweep_asm.hpp); 0: round 4's records in global memory
 #endif
+#ifndef VBT_LDS_HITS
+#define VBT_LDS_HITS 1  // gen_one stages its trie hits in what is left of its LDS (8-byte packed records) and only the overflow in global memory
+#endif
 #ifndef VBT_GUARD
 #define VBT_GUARD 0  // developer aid: 64 guard bytes between the token path and the pass records, checked at four points (ctrl[20..23])
 #endif
@@ -318,6 +321,8 @@ struct GenOneLds {
     uint32_t *ci, *cand_off;
     uint16_t *code, *ucode, *grp;
     uint32_t *endc, *hcount;
+    uint2* lhits;     // what is left of the wavefront's LDS: staged trie hits, 8 bytes each (gen_one)
+    uint32_t lcap;    // hits it holds
     bool ok;
 };
 __device__ __forceinline__ GenOneLds carve_gen_one(char* base, uint32_t lds_bytes, uint32_t n, bool has_user) {
@@ -332,6 +337,8 @@ __device__ __forceinline__ GenOneLds carve_gen_one(char* base, uint32_t lds_byte
     L.endc = ar.take<uint32_t>(n + 1);
     L.hcount = ar.take<uint32_t>(1);
     L.ok = ar.ok;
+    L.lhits = ar.take<uint2>(0);
+    L.lcap = VBT_LDS_HITS && ar.ok && lds_bytes > ar.used ? (uint32_t)((lds_bytes - ar.used) / sizeof(uint2)) : 0u;
     return L;
 }
 // the smallest level of gen_long whose LDS holds the sentence

@@ -128,10 +128,18 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
     const uint64_t base = (uint64_t)A.node_factor * slot0;  // this sentence's node region (no allocation atomic)
     const uint64_t region = (uint64_t)A.node_factor * (nb + kSentenceSlack);
     uint4* __restrict__ hits = A.g_hits + base;
+    // Hit h sits in LDS when it can: 8 bytes {first entry (21 bits) | entries (9) | lexicon (2), start (12) | length - 1 (6) | candidates
+    // of the start position before it (14)}, as many as the wavefront's LDS has room for behind the per-character arrays (the mean
+    // sentence's ~230 hits fit the bulk generator's 4 KiB).  What does not fit -- the tail of a long sentence, a field out of range --
+    // is staged in the sentence's region of global memory as before, with an all-ones marker in its LDS slot; only then does the
+    // expansion below have to wait for this wave's stores.  (Was: every hit through global memory -- 16 bytes written, drained and read
+    // back: 0.74 GB of the step's traffic and two dependent round trips per sentence.)
+    uint2* const lhits = L.lhits;
+    const uint32_t lcap = L.lcap;
     if (ln == 0) *hcount = 0;
     __syncthreads();
     uint32_t C = 0;
-    bool any_long = false;
+    bool any_long = false, any_global = false;
     for (uint32_t c0 = 0; c0 < n; c0 += 64) {
         const uint32_t i = c0 + ln;
         uint32_t cnt = 0;
@@ -141,9 +149,15 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
             auto seen = [&](uint32_t v, uint32_t c, uint32_t end, uint32_t lex) {
                 if (c == 0) return;  // a category without unknown-word entries contributes nothing (unknown.rs:118-130)
                 const uint32_t h = atomicAdd(hcount, 1u);
-                if (h < region) hits[h] = make_uint4(v, c | (lex << 16), end | (i << 16), cnt);
-                cnt += c;
                 const uint32_t len = end - i;
+                const bool packed = h < lcap && v < (1u << 21) && c < 512u && i < 4096u && len <= 64u && cnt < 16383u;  // (16383: an all-ones second word is the "not here" marker)
+                if (packed) lhits[h] = make_uint2(v | (c << 21) | (lex << 30), i | ((len - 1u) << 12) | (cnt << 18));
+                else {
+                    if (h < lcap) lhits[h] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+                    if (h < region) hits[h] = make_uint4(v, c | (lex << 16), end | (i << 16), cnt);
+                    any_global = true;
+                }
+                cnt += c;
                 if (len <= 64) lmask |= 1ull << (len - 1); else is_long = true;
                 atomicAdd(&endc[end], c);
             };
@@ -161,6 +175,7 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
         C += tot;
         any_long |= __ballot(is_long) != 0;
     }
+    any_global = __ballot(any_global) != 0;  // (wave-uniform from here on)
     // words > 64 chars need the generic pre-pass, > 65531 nodes need u32 indices: fused kernel
     if (C >= 65532 || any_long) { route(fallback); return; }
     if (ln == 0) set_co(n, C);
@@ -185,9 +200,11 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
     // The staged hits are read back by this wave only: its stores have to be complete (workgroup scope:
     // s_waitcnt vmcnt(0); the vector L1 is write-through and never held these lines).  An agent-scope
     // release would write the whole L2 back (buffer_wbl2) once per sentence.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (any_global) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    } else __syncthreads();  // (hits in LDS only: the LDS operations of one wave execute in order)
     PROF_MARK(1);
 
     // expand the hits: lanes = hits, every entry load independent of every other; a candidate becomes ONE 16-byte record --
@@ -199,7 +216,14 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
     const uint32_t row_cells = D.num_right;  // a left id's row of the connection matrix starts at cell left_id * num_right
     for (uint32_t h0 = 0; h0 < H; h0 += 64) {
         const uint32_t h = h0 + ln;
-        const uint4 hr = h < H ? hits[h] : make_uint4(0, 0, 0, 0);
+        uint4 hr = make_uint4(0, 0, 0, 0);
+        if (h < H) {
+            const uint2 q = h < lcap ? lhits[h] : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+            if (q.y != 0xFFFFFFFFu) {  // packed in LDS (an all-ones second word would be start 4095, length 64, 16383 candidates before it: never packed)
+                const uint32_t pos = q.y & 0xFFFu;
+                hr = make_uint4(q.x & 0x1FFFFFu, ((q.x >> 21) & 0x1FFu) | ((q.x >> 30) << 16), (pos + ((q.y >> 12) & 63u) + 1u) | (pos << 16), q.y >> 18);
+            } else hr = hits[h];
+        }
         if (h < H) {
             const uint32_t c = hr.y & 0xFFFFu, lex = hr.y >> 16, end = hr.z & 0xFFFFu, pos = hr.z >> 16;
             const Entry* __restrict__ ent = lex == 0 ? D.sys.entries : lex == 1 ? D.user.entries : D.unk_entries;
