@@ -314,6 +314,20 @@ __device__ __forceinline__ uint32_t count_chars(const uint8_t* __restrict__ txt,
     return n;
 }
 
+// A staged trie hit in LDS: 8 bytes {first entry (21 bits) | entries (9) | lexicon (2), start position (14) | length - 1 (6) | candidates of
+// the start position before the hit (12)}; the 16-byte form in global memory is {first entry, entries | lexicon << 16, end | start << 16,
+// candidates before}.  An all-ones second word marks "this hit is in global memory" (start 16383 + length 64 + 4095 candidates: never packed).
+__device__ __forceinline__ bool hit_packs(uint32_t first, uint32_t c, uint32_t start, uint32_t len, uint32_t before) {
+    return first < (1u << 21) && c < 512u && start < (1u << 14) && len <= 64u && before < 4095u;
+}
+__device__ __forceinline__ uint2 pack_hit(uint32_t first, uint32_t c, uint32_t lex, uint32_t start, uint32_t len, uint32_t before) {
+    return make_uint2(first | (c << 21) | (lex << 30), start | ((len - 1u) << 14) | (before << 20));
+}
+__device__ __forceinline__ uint4 unpack_hit(uint2 q) {
+    const uint32_t pos = q.y & 0x3FFFu;
+    return make_uint4(q.x & 0x1FFFFFu, ((q.x >> 21) & 0x1FFu) | ((q.x >> 30) << 16), (pos + ((q.y >> 14) & 63u) + 1u) | (pos << 16), q.y >> 20);
+}
+
 // gen_one's per-character working arrays in its wavefront's LDS (~26 bytes per character).  `ok` = they fit: the test by which
 // gen_one files what does not fit for gen_long.
 struct GenOneLds {

@@ -135,6 +135,9 @@ __device__ __forceinline__ void gen_long(const DevDict& D, const BatchArgs& A, u
     uint32_t* endc = ar.take<uint32_t>(n + 1);  // candidates ending at each position: counts, then running cursors (see gen_one)
     if (!ar.ok) { route(next_level); return; }
     uint4* const pcw = A.g_pc + slot0;  // .z/.w = length mask until the records are finalised (as gen_one<kLarge>)
+    // what is left of the workgroup's LDS stages the trie hits (8 bytes each: pack_hit; see gen_one), the overflow goes to global memory
+    uint2* const lhits = ar.take<uint2>(0);
+    const uint32_t lcap = VBT_LDS_HITS && lds_bytes > ar.used ? (uint32_t)((lds_bytes - ar.used) / sizeof(uint2)) : 0u;
     for (uint32_t i = tid; i < n + 1; i += nthreads) endc[i] = i == 0 ? 1u : 0u;  // BOS ends at 0
 
     // decode (sentence.rs:40-55): every chunk loads its 64 bytes and the 64 behind them (the 3 bytes after a lead byte)
@@ -198,9 +201,13 @@ __device__ __forceinline__ void gen_long(const DevDict& D, const BatchArgs& A, u
             auto seen = [&](uint32_t v, uint32_t c, uint32_t end, uint32_t lex) {
                 if (c == 0) return;  // a category without unknown-word entries contributes nothing (unknown.rs:118-130)
                 const uint32_t h = atomicAdd(&red[kHits], 1u);
-                if (h < region) hits[h] = make_uint4(v, c | (lex << 16), end | (i << 16), cnt);
-                cnt += c;
                 const uint32_t len = end - i;
+                if (h < lcap && hit_packs(v, c, i, len, cnt)) lhits[h] = pack_hit(v, c, lex, i, len, cnt);
+                else {
+                    if (h < lcap) lhits[h] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+                    if (h < region) hits[h] = make_uint4(v, c | (lex << 16), end | (i << 16), cnt);
+                }
+                cnt += c;
                 if (len <= 64) lmask |= 1ull << (len - 1); else is_long = true;
                 atomicAdd(&endc[end], c);
             };
@@ -251,11 +258,15 @@ __device__ __forceinline__ void gen_long(const DevDict& D, const BatchArgs& A, u
     // expand the hits: threads = hits (see gen_one)
     // (the next round's hit records are requested before this round's entries: one round trip per round instead of two; in
     // gen_one, with three rounds per sentence, the same was measured slightly slower)
-    uint4 hr_next = tid < H ? hits[tid] : make_uint4(0, 0, 0, 0);
+    auto hit_at = [&](uint32_t h) {
+        const uint2 q = h < lcap ? lhits[h] : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+        return q.y != 0xFFFFFFFFu ? unpack_hit(q) : hits[h];
+    };
+    uint4 hr_next = tid < H ? hit_at(tid) : make_uint4(0, 0, 0, 0);
     const uint32_t row_cells = D.num_right;  // (see gen_one)
     for (uint32_t h = tid; h < H; h += nthreads) {
         const uint4 hr = hr_next;
-        if (h + nthreads < H) hr_next = hits[h + nthreads];
+        if (h + nthreads < H) hr_next = hit_at(h + nthreads);
         const uint32_t c = hr.y & 0xFFFFu, lex = hr.y >> 16, end = hr.z & 0xFFFFu, pos = hr.z >> 16;
         const Entry* __restrict__ ent = lex == 0 ? D.sys.entries : lex == 1 ? D.user.entries : D.unk_entries;
         const uint32_t dest = (uint32_t)co[pos] + hr.w;

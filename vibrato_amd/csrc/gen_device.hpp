@@ -128,8 +128,8 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
     const uint64_t base = (uint64_t)A.node_factor * slot0;  // this sentence's node region (no allocation atomic)
     const uint64_t region = (uint64_t)A.node_factor * (nb + kSentenceSlack);
     uint4* __restrict__ hits = A.g_hits + base;
-    // Hit h sits in LDS when it can: 8 bytes {first entry (21 bits) | entries (9) | lexicon (2), start (12) | length - 1 (6) | candidates
-    // of the start position before it (14)}, as many as the wavefront's LDS has room for behind the per-character arrays (the mean
+    // Hit h sits in LDS when it can: 8 bytes {first entry (21 bits) | entries (9) | lexicon (2), start (14) | length - 1 (6) | candidates
+    // of the start position before it (12)} (pack_hit / unpack_hit), as many as the wavefront's LDS has room for behind the per-character arrays (the mean
     // sentence's ~230 hits fit the bulk generator's 4 KiB).  What does not fit -- the tail of a long sentence, a field out of range --
     // is staged in the sentence's region of global memory as before, with an all-ones marker in its LDS slot; only then does the
     // expansion below have to wait for this wave's stores.  (Was: every hit through global memory -- 16 bytes written, drained and read
@@ -150,8 +150,8 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
                 if (c == 0) return;  // a category without unknown-word entries contributes nothing (unknown.rs:118-130)
                 const uint32_t h = atomicAdd(hcount, 1u);
                 const uint32_t len = end - i;
-                const bool packed = h < lcap && v < (1u << 21) && c < 512u && i < 4096u && len <= 64u && cnt < 16383u;  // (16383: an all-ones second word is the "not here" marker)
-                if (packed) lhits[h] = make_uint2(v | (c << 21) | (lex << 30), i | ((len - 1u) << 12) | (cnt << 18));
+                const bool packed = h < lcap && hit_packs(v, c, i, len, cnt);
+                if (packed) lhits[h] = pack_hit(v, c, lex, i, len, cnt);
                 else {
                     if (h < lcap) lhits[h] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
                     if (h < region) hits[h] = make_uint4(v, c | (lex << 16), end | (i << 16), cnt);
@@ -219,10 +219,7 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
         uint4 hr = make_uint4(0, 0, 0, 0);
         if (h < H) {
             const uint2 q = h < lcap ? lhits[h] : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
-            if (q.y != 0xFFFFFFFFu) {  // packed in LDS (an all-ones second word would be start 4095, length 64, 16383 candidates before it: never packed)
-                const uint32_t pos = q.y & 0xFFFu;
-                hr = make_uint4(q.x & 0x1FFFFFu, ((q.x >> 21) & 0x1FFu) | ((q.x >> 30) << 16), (pos + ((q.y >> 12) & 63u) + 1u) | (pos << 16), q.y >> 18);
-            } else hr = hits[h];
+            hr = q.y != 0xFFFFFFFFu ? unpack_hit(q) : hits[h];
         }
         if (h < H) {
             const uint32_t c = hr.y & 0xFFFFu, lex = hr.y >> 16, end = hr.z & 0xFFFFu, pos = hr.z >> 16;
