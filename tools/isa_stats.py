@@ -57,6 +57,22 @@ def main():
     print(f"{name}: {len(insts)} instructions  " + "  ".join(f"{k}={v}" for k, v in sorted(mix.items())))
     spills = sum(1 for _, op, t in insts if op.startswith("scratch_"))
     print(f"  scratch (spill) instructions: {spills}")
+    # the compiler's own metadata for this kernel (.amdgpu_metadata at the end of the file): registers and spill counts
+    meta = re.search(r"\.name:\s+" + re.escape(name.split(":")[0].strip()) + r"\n(.*?)(?=\n  - \.|\Z)", "\n".join(lines), re.S)
+    if meta:
+        g = lambda k: (re.search(r"\." + k + r":\s+(\d+)", meta.group(1)) or [None, "?"])[1]
+        print(f"  compiler metadata: vgpr_count {g('vgpr_count')}  vgpr_spill_count {g('vgpr_spill_count')}  sgpr_count {g('sgpr_count')}  "
+              f"sgpr_spill_count {g('sgpr_spill_count')}  private_segment_fixed_size {g('private_segment_fixed_size')} bytes")
+    # where the scratch instructions sit relative to the inline-assembly sweep loop (the compiler cannot spill inside an asm block)
+    asm_lines = [i for i, l in enumerate(lines[start:end], start) if "ASMSTART" in l or "ASMEND" in l]
+    big = None
+    for a, b in zip(asm_lines[0::2], asm_lines[1::2]):
+        if big is None or b - a > big[1] - big[0]:
+            big = (a, b)
+    if big:
+        inside = sum(1 for ln_, op, _ in insts if op.startswith("scratch_") and big[0] < ln_ - 1 < big[1])
+        wl = sum(1 for ln_, op, _ in insts if op.startswith("v_writelane") and big[0] < ln_ - 1 < big[1])
+        print(f"  largest inline-asm block (the sweep loop): lines {big[0] + 1}-{big[1] + 1}; scratch instructions inside it: {inside}; v_writelane (SGPR spills) inside it: {wl}")
     loops = []
     for idx, (ln, op, t) in enumerate(insts):
         if op.startswith("s_cbranch") or op == "s_branch":
