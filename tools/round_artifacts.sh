@@ -1,9 +1,9 @@
 #!/bin/bash
-# Everything the round's committed artefacts come from, in one GPU call: tools/round_artifacts.sh r04
+# Everything the round's committed artefacts come from, in one GPU call: tools/round_artifacts.sh r05
 #   parity suite, default bench line (CPU legs, suite, Worker loop, host-to-host), rocprofv3 evidence, the other BASELINE
 #   configurations, config-5 kernel timeline, phase profile, host-to-host timeline, the self-launched 2-rank bench line
 ulimit -c 0
-TAG=${1:-r04}; OUT=gpurun_out/art_$TAG; mkdir -p $OUT
+TAG=${1:-r05}; OUT=gpurun_out/art_$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 timeout 1200 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log; tail -3 $OUT/pytest_gpu.log
 timeout 900 python bench.py > $OUT/bench_default.json 2>$OUT/bench_default.err; tail -c 300 $OUT/bench_default.err
@@ -21,6 +21,10 @@ timeout 200 python tools/phase_profile.py > $OUT/phase.txt 2>&1; tail -12 $OUT/p
 [ -f vibrato_amd/lib/libvibrato_hip_lp.so ] && bash tools/loop_profile.sh > $OUT/loop_profile.txt 2>&1
 timeout 300 python tools/worker_latency.py 2>&1 | grep -v amdgpu > $OUT/worker_latency.txt; cat $OUT/worker_latency.txt
 [ -x tools/calib/exec0_vmcnt ] && timeout 60 tools/calib/exec0_vmcnt > $OUT/exec0_vmcnt.txt 2>&1
+# what the connection-matrix gather still costs (nogather / samecell variant builds), a batch of long sentences per character, the formatter call by call
+[ -f vibrato_amd/lib/libvibrato_hip_nogather.so ] && bash tools/ceiling_nogather.sh > /dev/null 2>&1 && cp gpurun_out/ceiling_nogather.txt $OUT/
+bash tools/long_profile.sh > /dev/null 2>&1; cp gpurun_out/long_profile.txt $OUT/ 2>/dev/null
+timeout 300 python tools/format_bench.py 32 64 128 2>&1 | grep threads > $OUT/format_bench.txt; cat $OUT/format_bench.txt
 cp gpurun_out/rccl_ws1_overlap.json $OUT/ 2>/dev/null
 # config 5, kernel by kernel
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/cfg5_stats -o stats -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-pipeline --no-suite --no-worker-loop $CFG5 > $OUT/cfg5_stats.log 2>&1
