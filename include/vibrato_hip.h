@@ -175,9 +175,12 @@ VBT_API uint32_t vbt_worker_num_tokens(const vbt_worker* w);                    
 VBT_API int vbt_worker_token(const vbt_worker* w, uint32_t i, vbt_token* out);    /* Worker::token(i) */
 /* vbt_worker_reset_sentence fails with VBT_ERR_UTF8 when the bytes are not a Rust `str` (the reference takes &str,
  * worker.rs:34); the worker then holds the empty sentence. */
-/* vbt_worker_tokenize is ONE kernel launch per sentence: the kernel reads the text from the worker's pinned host block and
- * writes the token records back into it (no copy engine, no allocation in steady state); the call returns when the kernel's
- * status word has landed.  Sentences a single wavefront cannot take (longer than ~2500 characters, a dictionary word of more
+/* vbt_worker_tokenize costs no launch in steady state: a resident one-wavefront kernel polls a doorbell in the worker's pinned host block,
+ * reads the text out of it and writes the token records back into it (no copy engine, no allocation); the call returns when the
+ * kernel's status word has landed.  The kernel leaves after ~2 ms without a call (VBT_WORKER_IDLE_POLLS) and, so that it never holds
+ * the device against other threads' synchronising calls, after VBT_WORKER_MAX_SERVED (4096) sentences; the next call starts it again.  A kernel
+ * that answers late (a busy GPU, a profiler) is waited for up to 5 s, then told to leave; only a failing stream is an error.
+ * Sentences a single wavefront cannot take (longer than ~2500 characters, a dictionary word of more
  * than 64 characters, ...) and workers that count connection ids go through the batch pipeline instead.
  * vbt_worker_path_stats: sentences served by the single launch / by the batch pipeline so far. */
 VBT_API int vbt_worker_path_stats(const vbt_worker* w, uint64_t* fast, uint64_t* slow);
