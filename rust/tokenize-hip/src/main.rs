@@ -66,20 +66,52 @@ fn run(o: Options) -> Result<(), Box<dyn Error>> {
     tokenizer.build_device_image()?; // "no MI355X" is an error message here, not a panic in new_worker()
     eprintln!("Ready to tokenize");
 
-    let stdout = io::stdout();
-    let mut out = BufWriter::new(stdout.lock());
-    let mut block: Vec<String> = Vec::with_capacity(o.block);
-    for line in io::stdin().lock().lines() {
-        block.push(line?);
-        if block.len() == o.block {
-            out.write_all(tokenizer.tokenize_batch(&block)?.format(o.mode)?.as_bytes())?;
-            block.clear();
+    // Three stages (as vibrato_amd/cli.py): this thread reads lines and cuts blocks, one thread pushes block k + 1 through the GPU
+    // (vbt_tokenize_batch), one renders block k (vbt_batch_format) and writes it -- the formatter of one block runs under the kernels
+    // and copies of the next.  Bounded channels of depth 2 keep the order and the memory.
+    let (block_tx, block_rx) = std::sync::mpsc::sync_channel::<Vec<String>>(2);
+    let (batch_tx, batch_rx) = std::sync::mpsc::sync_channel(2);
+    let mode = o.mode;
+    let result: Result<(), Box<dyn std::error::Error + Send + Sync>> = std::thread::scope(|sc| {
+        let tok = &tokenizer;
+        let tokenize = sc.spawn(move || -> Result<(), Box<dyn std::error::Error + Send + Sync>> {
+            for block in block_rx {
+                if batch_tx.send(tok.tokenize_batch(&block)?).is_err() {
+                    break; // the output stage is gone: its error is the one to report
+                }
+            }
+            Ok(())
+        });
+        let output = sc.spawn(move || -> Result<(), Box<dyn std::error::Error + Send + Sync>> {
+            let stdout = io::stdout();
+            let mut out = BufWriter::new(stdout.lock());
+            for batch in batch_rx {
+                out.write_all(batch.format(mode)?.as_bytes())?;
+            }
+            out.flush()?;
+            Ok(())
+        });
+        let mut block: Vec<String> = Vec::with_capacity(o.block);
+        let mut read_err = None;
+        for line in io::stdin().lock().lines() {
+            match line {
+                Ok(l) => block.push(l),
+                Err(e) => { read_err = Some(e); break; }
+            }
+            if block.len() == o.block && block_tx.send(std::mem::replace(&mut block, Vec::with_capacity(o.block))).is_err() {
+                break;
+            }
         }
-    }
-    if !block.is_empty() {
-        out.write_all(tokenizer.tokenize_batch(&block)?.format(o.mode)?.as_bytes())?;
-    }
-    out.flush()?;
+        if read_err.is_none() && !block.is_empty() {
+            let _ = block_tx.send(block);
+        }
+        drop(block_tx);
+        let a = tokenize.join().expect("tokenize stage panicked");
+        let b = output.join().expect("output stage panicked");
+        if let Some(e) = read_err { return Err(e.into()); }
+        a.and(b)
+    });
+    result.map_err(|e| -> Box<dyn std::error::Error> { e })?;
     Ok(())
 }
 

@@ -308,7 +308,7 @@ class Tokenizer:
         """The per-line loop of the reference's callers (tokenize/src/main.rs:78-95) over an iterable of lines, batched behind the
         scenes: lines are collected until `batch_bytes` of text (or `batch_lines` lines) are in hand, tokenized as ONE device batch and
         yielded one at a time, in input order, as (batch, index) -- batch.num_tokens(index), batch.token(index, i).  Worker.tokenize
-        costs ~35 us per call on the GPU, a batch ~17 ns per line: whoever has more than a handful of lines in hand wants this."""
+        costs ~39 us per call on the GPU, a batch ~17 ns per line: whoever has more than a handful of lines in hand wants this."""
         buf, size = [], 0
         for line in lines:
             e = _b(line)
