@@ -7,10 +7,10 @@ A "step" is one pass of the tokenize() hot path over one device-resident batch o
                       100k sentences, text and offsets resident in HBM, results left in HBM.
   --gpus N > 1        BASELINE config 4: ONE corpus of 1M sentences (same law, same seed on every rank), split into
                       N contiguous shards balanced by bytes (vibrato_amd.sharding); one process per GPU tokenizes
-                      its shard and joins the path's only collective, the final gather of the results
-                      (all_gather_into_tensor over RCCL/xGMI of the packed token records, device-resident, issued on
-                      a communication stream so that it overlaps the next step's kernels).  Fixed total work:
-                      "scaling": "strong".
+                      its shard -- the kernels write the results straight into the rank's slot of the gather
+                      (vbt_workspace_set_packed_output) -- and joins the path's only collective, the final gather to
+                      rank 0 over RCCL/xGMI (device-resident, issued on a communication stream so that it overlaps the
+                      next step's kernels; --gather all: all_gather_into_tensor).  Fixed total work: "scaling": "strong".
 
 Launching: `python bench.py --gpus N` with no WORLD_SIZE in the environment starts its own N ranks (it re-executes itself
 under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`); started under

@@ -4,7 +4,9 @@ dictionary is immutable), so there is no data-path collective.  The only exchang
 gather of the per-rank results, which stays device-resident: every rank's padded slot -- its totals,
 per-sentence token ranges and 24-byte token records -- goes to the root (`gather_to_root`: grouped
 send/recv under RCCL over xGMI when the backend is "nccl"; RCCL has no gatherv) or, on request, to
-every rank (`gather_packed`: one `all_gather_into_tensor`)."""
+every rank (`gather_packed`: one `all_gather_into_tensor`).  On the GPU the kernels write a rank's slot themselves
+(`Workspace.set_packed_output`: `vbt_workspace_set_packed_output`); `pack_results` lays the same slot out with tensor copies for
+the CPU (gloo) tests and for callers that already hold results in a workspace's own buffers."""
 import numpy as np
 
 TOKEN_BYTES = 24
