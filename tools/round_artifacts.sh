@@ -25,6 +25,8 @@ timeout 300 python tools/worker_latency.py 2>&1 | grep -v amdgpu > $OUT/worker_l
 [ -f vibrato_amd/lib/libvibrato_hip_nogather.so ] && bash tools/ceiling_nogather.sh > /dev/null 2>&1 && cp gpurun_out/ceiling_nogather.txt $OUT/
 bash tools/long_profile.sh > /dev/null 2>&1; cp gpurun_out/long_profile.txt $OUT/ 2>/dev/null
 timeout 300 python tools/format_bench.py 32 64 128 2>&1 | grep threads > $OUT/format_bench.txt; cat $OUT/format_bench.txt
+# occupancy A/B: the default build (4 waves per SIMD, 10 KiB tier) against 5 waves per SIMD with an 8 KiB tier (the w5 variant build), same box
+[ -f vibrato_amd/lib/libvibrato_hip_w5.so ] && bash tools/ab_variants.sh "base w5:VBT_TIERS=8192,49152,163840:VBT_SEG_BYTES=8192 base w5:VBT_TIERS=8192,49152,163840:VBT_SEG_BYTES=8192" --no-host-pipeline --no-worker-loop 2>&1 | grep -v amdgpu > $OUT/occupancy_ab.txt; cat $OUT/occupancy_ab.txt
 cp gpurun_out/rccl_ws1_overlap.json $OUT/ 2>/dev/null
 # config 5, kernel by kernel
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/cfg5_stats -o stats -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-pipeline --no-suite --no-worker-loop $CFG5 > $OUT/cfg5_stats.log 2>&1

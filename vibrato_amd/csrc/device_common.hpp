@@ -229,7 +229,10 @@ __device__ __forceinline__ void unk_spans(uint32_t cinfo, uint32_t g, uint32_t i
 #define VBT_ASM_LOOP 1  // the sweep loop of the common build in assembly (sweep_asm.hpp; needs VBT_DEPTH 2); 0: the C++ loop everywhere
 #endif
 #ifndef VBT_LAT_WAVES
-#define VBT_LAT_WAVES 5
+// waves per SIMD lattice_lds is compiled for.  4 (128 VGPRs: no VGPR spills around the assembly loop) with a 10 KiB tier beats 5 (96 VGPRs, 18 spilled)
+// with an 8 KiB tier since round 5 took the loop's memory waits away: 0.830 vs 0.874 ms on the headline, 2.17 vs 2.72 ms on the dense law
+// (profiles/EXPERIMENTS.md; round 4 measured the opposite, 1.064 vs 1.127 ms, when the loop still waited for its pass records)
+#define VBT_LAT_WAVES 4
 #endif
 #ifndef VBT_LDS_REC
 #define VBT_LDS_REC 1  // the assembly loop's 8-byte pass records in the sentence's LDS (sweep_asm.hpp); 0: round 4's records in global memory

@@ -269,7 +269,8 @@ Workspace::Workspace(const Tokenizer& t, uint64_t max_s, uint64_t max_b) : tok(t
     // LDS tiers (bytes per wave), ascending; the global-memory tier always follows
     {
         const char* e = std::getenv("VBT_TIERS");
-        std::string spec = e && *e ? e : (fused ? "16384,32768,65536" : env_u32("VBT_SEG_BYTES", 8192) ? "8192,49152,163840" : "8192,12288,16384,24576,32768,49152,65536,163840");
+        // (default: ONE 10 KiB tier that is also the segment tier -- 16 waves per CU, 4 per SIMD: lattice_lds is built for 128 VGPRs -- + two escape tiers)
+        std::string spec = e && *e ? e : (fused ? "16384,32768,65536" : env_u32("VBT_SEG_BYTES", kSegTierBytes) ? "10240,49152,163840" : "8192,12288,16384,24576,32768,49152,65536,163840");
         size_t pos = 0;
         while (pos < spec.size()) {
             size_t c = spec.find(',', pos);
@@ -400,7 +401,7 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
     a.lists = d_over; a.list_stride = (uint32_t)stride; a.n_tiers = (uint32_t)T;
     a.tier_prio = env_u32("VBT_TIER_PRIO", 3);
     {   // tier whose waves sweep longer sentences segment by segment (VBT_SEG_BYTES=0: off, sentences use the big tiers)
-        const uint32_t seg_bytes = env_u32("VBT_SEG_BYTES", 8192);
+        const uint32_t seg_bytes = env_u32("VBT_SEG_BYTES", kSegTierBytes);
         a.seg_tier = 0xFFFFFFFFu;
         if (seg_bytes)
             for (size_t t = 0; t < T; ++t)

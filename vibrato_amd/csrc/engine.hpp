@@ -97,6 +97,7 @@ struct BatchArgs {
 // ctrl[kNodeCursor] bump pointer of the candidate arrays
 enum CtrlSlot { kTotal = 0, kError = 1, kBump = 2, kNodeCursor = 4, kTierCtrl = 6, kCtrlWords = 32 };
 constexpr int kMaxTiers = 8;
+constexpr uint32_t kSegTierBytes = 10240;  // default LDS of the sweep's one tier: 16 wavefronts per CU (4 per SIMD, 128 VGPRs each) x 10 KiB = the CU's 160 KiB
 constexpr uint32_t kScanBlock = 256, kScanTile = 256;  // token packing: sentences per tile (small tiles: the copy needs the parallelism)
 constexpr uint32_t kSentenceSlack = 24;  // character slots per sentence on top of its bytes (see sentence_slot in engine.hip)
 constexpr int kGenLevels = 3;  // large-LDS instances of the generator behind the bulk one (32 KiB, 64 KiB, whole CU)
