@@ -41,5 +41,5 @@ open(p_prev, "w").write(
     "`python bench.py --no-cpu-baseline --no-host-pipeline --no-suite --no-worker-loop --steps 10 <args>`; full JSON lines in "
     f"gpurun_out/art_{tag}/ (scratch).\nThe default `python bench.py` line (profiles/{tag}_bench_default.json) carries config 5 and the dense law as `suite` legs as well.\n\n"
     "| run | sentences/s | ms per step | generator ms | lattice ms (fork to join) | fallback + packing ms | nodes / dedup pairs per char | "
-    "sentences: 8 KiB tier, escape launches, fallback | bit-exact sample |\n|---|---|---|---|---|---|---|---|---|\n" + "\n".join(rows) + "\n" + notes)
+    "sentences: segment tier, escape launches, fallback | bit-exact sample |\n|---|---|---|---|---|---|---|---|---|\n" + "\n".join(rows) + "\n" + notes)
 print(open(p_prev).read())

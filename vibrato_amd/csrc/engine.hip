@@ -8,7 +8,7 @@
 // categories and groupable runs -- Sentence::compile, sentence.rs:34-71 -- and candidate generation by double-array common-prefix
 // search + unknown-word rules -- Tokenizer::add_lattice_edges tokenizer.rs:141-199, UnkHandler::gen_unk_words unknown.rs:69-137)
 // -> build_lists -> gen_candidates_large (gen_long: one WORKGROUP per sentence that outgrew the bulk generator's LDS) ->
-// lattice_lds (ONE 8 KiB tier; one wavefront per sentence: the position sweep with per-node min-cost search over the connection
+// lattice_lds (ONE 10 KiB tier; one wavefront per sentence: the position sweep with per-node min-cost search over the connection
 // matrix -- build_lattice_inner tokenizer.rs:94-139, Lattice::insert_node / search_min_node lattice.rs:103-151, insert_eos 85-101
 // -- and the back-trace, append_top_nodes lattice.rs:159-168; the lattice lives in LDS, longer sentences are swept in segments
 // cut at any position, the window of open end lists handed over; escape tiers behind it for a window wider than the tier)
