@@ -225,6 +225,9 @@ __device__ __forceinline__ void unk_spans(uint32_t cinfo, uint32_t g, uint32_t i
 #ifndef VBT_LOOP_PROF
 #define VBT_LOOP_PROF 0  // developer aid (tools/phase_profile.py on a variant build): cycles parked at the assembly sweep loop's two waits
 #endif
+#ifndef VBT_GENLONG_PROF
+#define VBT_GENLONG_PROF 0  // developer aid (tools/dbg/genlong_profile.py on a variant build): gen_long's wall cycles between its barriers
+#endif
 #ifndef VBT_ASM_LOOP
 #define VBT_ASM_LOOP 1  // the sweep loop of the common build in assembly (sweep_asm.hpp; needs VBT_DEPTH 2); 0: the C++ loop everywhere
 #endif

@@ -307,8 +307,8 @@ Workspace::Workspace(const Tokenizer& t, uint64_t max_s, uint64_t max_b) : tok(t
             pos = c + 1;
         }
     }
-    d_prof = static_cast<unsigned long long*>(alloc(kProfSlots * kProfWords * 8));
-    HIP_CHECK(hipMemset(d_prof, 0, kProfSlots * kProfWords * 8));
+    d_prof = static_cast<unsigned long long*>(alloc(2 * kProfSlots * kProfWords * 8));  // (second half: gen_long's phases in a VBT_GENLONG_PROF build)
+    HIP_CHECK(hipMemset(d_prof, 0, 2 * kProfSlots * kProfWords * 8));
     const uint64_t mb = env_u32("VBT_SCRATCH_MB", 0);
     // (fused fallback only: rare sentences; a one-sentence Worker must not pin 256 MiB)
     scratch_bytes = mb ? mb << 20 : std::max<uint64_t>(std::min<uint64_t>(256ull << 20, (16ull << 20) + 512 * nbts), 64 * nbts);
@@ -462,7 +462,8 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
         // get onto a CU before the bulk launch has been dispatched: profiles/r03_long_first_experiment.md.)
         for (uint32_t lv = 1; lv <= (uint32_t)kGenLevels; ++lv) {
             const uint32_t lds = gen_level_lds[lv - 1];
-            const uint32_t nw = lds > 65536 ? 16u : std::max<uint32_t>(1, std::min<uint32_t>(16, lv == 1 ? env_u32("VBT_GEN_WAVES1", env_u32("VBT_GEN_WAVES", 4)) : env_u32("VBT_GEN_WAVES", 4)));
+            // (4 wavefronts per workgroup at the first level, 8 above it: 32 waves on a CU at either; config 5's generator 1.55 -> 1.45-1.48 ms against 4 everywhere)
+            const uint32_t nw = lds > 65536 ? 16u : std::max<uint32_t>(1, std::min<uint32_t>(16, lv == 1 ? env_u32("VBT_GEN_WAVES1", 4) : env_u32("VBT_GEN_WAVES", 8)));
             const uint32_t per_cu = std::max<uint32_t>(1, std::min<uint32_t>(32 / nw, 163840 / lds));
             kern::gen_candidates_large(std::max<uint32_t>(1, std::min<uint32_t>(cn, per_cu * 256)), nw, lds, stream, D, a, lv);
         }
@@ -720,11 +721,12 @@ void Workspace::read_profile(uint64_t* out, bool reset) {
     HIP_CHECK(hipSetDevice(tok.device()));
     HIP_CHECK(hipStreamSynchronize(reinterpret_cast<hipStream_t>(last_stream)));
     std::vector<uint64_t> h((size_t)kProfSlots * kProfWords);
-    HIP_CHECK(hipMemcpy(h.data(), d_prof, h.size() * 8, hipMemcpyDeviceToHost));
+    unsigned long long* const half = d_prof + (env_u32("VBT_PROF_HALF", 0) ? h.size() : 0);
+    HIP_CHECK(hipMemcpy(h.data(), half, h.size() * 8, hipMemcpyDeviceToHost));
     for (int i = 0; i < kProfWords; ++i) out[i] = 0;
     for (int k = 0; k < kProfSlots; ++k)
         for (int i = 0; i < kProfWords; ++i) out[i] += h[(size_t)k * kProfWords + i];
-    if (reset) HIP_CHECK(hipMemset(d_prof, 0, h.size() * 8));
+    if (reset) HIP_CHECK(hipMemset(half, 0, h.size() * 8));
 }
 
 }  // namespace vbt

@@ -88,6 +88,12 @@ __device__ __forceinline__ void gen_long(const DevDict& D, const BatchArgs& A, u
     // (thread 0 appends: no build_lists behind these launches.  The fallback list is the batch's, everything else this launch's own.)
     auto route = [&](uint32_t t) { if (t == fallback) list_push_fb(A, sid); else list_push(A, t, sid); };
     if (tid == 0) A.s_hdr[sid] = make_uint4(0u, 0xFFu << 16, 0u, 0u);
+#if VBT_GENLONG_PROF  // developer aid (tools/dbg/genlong_profile.py): wall cycles of the workgroup between its barriers
+    uint64_t gl_t = clock64(), gl_acc[10] = {};
+#define GL_MARK(i) do { const uint64_t t_ = clock64(); gl_acc[i] += t_ - gl_t; gl_t = t_; } while (0)
+#else
+#define GL_MARK(i) do { } while (0)
+#endif
     if (nb64 == 0) {
         if (tid == 0) A.tok_cnt[sid] = 0;
         return;
@@ -122,6 +128,7 @@ __device__ __forceinline__ void gen_long(const DevDict& D, const BatchArgs& A, u
         if (ln == 0) { red[kN] = running; red[kHits] = 0; red[kLong] = 0; red[kPasses] = 0; red[kMaxCnt] = 1; }
     }
     __syncthreads();
+    GL_MARK(0);
     const uint32_t n = __builtin_amdgcn_readfirstlane(red[kN]);
     if (n == 0) {
         if (tid == 0) A.tok_cnt[sid] = 0;
@@ -172,6 +179,7 @@ __device__ __forceinline__ void gen_long(const DevDict& D, const BatchArgs& A, u
         if (tid == 0) c2b[n] = (uint16_t)nb;
     }
     __syncthreads();
+    GL_MARK(1);
     if (wv == 0) {  // groupable (sentence.rs:57-71): right to left, the run length carried across chunks
         uint32_t carry = 0;
         for (int ch = (int)((n - 1) / 64); ch >= 0; --ch) {
@@ -187,6 +195,7 @@ __device__ __forceinline__ void gen_long(const DevDict& D, const BatchArgs& A, u
         }
     }
     __syncthreads();
+    GL_MARK(2);
 
     // one trie walk per start position (tokenizer.rs:155-198, unknown.rs:69-116): hits staged in global memory exactly as in gen_one
     const uint64_t base = (uint64_t)A.node_factor * slot0;
@@ -224,6 +233,7 @@ __device__ __forceinline__ void gen_long(const DevDict& D, const BatchArgs& A, u
         if (__ballot(is_long) != 0 && ln == 0) atomicOr(&red[kLong], 1u);
     }
     __syncthreads();
+    GL_MARK(3);
     if (wv == 0) {  // candidates before a position (CSR offsets), then the end-list offsets
         uint32_t running = 0;
         for (uint32_t c0 = 0; c0 < n; c0 += 64) {
@@ -254,6 +264,7 @@ __device__ __forceinline__ void gen_long(const DevDict& D, const BatchArgs& A, u
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    GL_MARK(4);
 
     // expand the hits: threads = hits (see gen_one)
     // (the next round's hit records are requested before this round's entries: one round trip per round instead of two; in
@@ -286,6 +297,7 @@ __device__ __forceinline__ void gen_long(const DevDict& D, const BatchArgs& A, u
         }
     }
     __syncthreads();
+    GL_MARK(5);
     auto eo = [&](uint32_t p) { return p == 0 ? 0u : p == 1 ? 1u : endc[p - 1]; };  // exclusive end-list offset: the cursors hold the inclusive prefix now
     auto get_lens = [&](uint32_t i) -> uint64_t { const uint4 r = pcw[i]; return ((uint64_t)r.w << 32) | r.z; };
     // per-character records (layout and meaning: gen_one).  Per position: e = the furthest end of its candidates (for a space
@@ -343,6 +355,7 @@ __device__ __forceinline__ void gen_long(const DevDict& D, const BatchArgs& A, u
         }
     }
     __syncthreads();
+    GL_MARK(6);
     {
         uint4* pc = A.g_pc + slot0;
         for (uint32_t ch = wv; ch < npc; ch += nw) {
@@ -365,6 +378,7 @@ __device__ __forceinline__ void gen_long(const DevDict& D, const BatchArgs& A, u
         }
     }
     __syncthreads();
+    GL_MARK(7);
     uint32_t passes = __builtin_amdgcn_readfirstlane(red[kPasses]), maxcnt = __builtin_amdgcn_readfirstlane(red[kMaxCnt]);
     {   // EOS connects to the end list of the last visited position: bounded by the longest list
         const uint32_t last = eo(n + 1) - eo(n);
@@ -380,6 +394,15 @@ __device__ __forceinline__ void gen_long(const DevDict& D, const BatchArgs& A, u
     if (A.seg_tier < A.n_tiers && tier > A.seg_tier) tier = A.seg_tier;
     if (tid == 0) A.s_hdr[sid] = make_uint4(n | (nb << 16), C | (tier << 16), passes, (uint32_t)(b0 - uniform64(A.offsets[0])));
     route(tier);
+#if VBT_GENLONG_PROF
+    GL_MARK(8);
+    if (A.prof && tid == 0) {
+        unsigned long long* pr_ = A.prof + ((size_t)kProfSlots + (sid & (kProfSlots - 1))) * kProfWords;  // the second half of the buffer
+        for (int i = 0; i < 9; ++i) atomicAdd(&pr_[i], (unsigned long long)gl_acc[i]);
+        atomicAdd(&pr_[9], 1ull); atomicAdd(&pr_[10], (unsigned long long)n); atomicAdd(&pr_[11], (unsigned long long)H);
+    }
+#endif
+#undef GL_MARK
 }
 
 // Turns the per-sentence routing decisions into work lists: one atomic per (wave, list) instead of
