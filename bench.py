@@ -304,6 +304,26 @@ def main():
 
     kernel_ms = st["ms_tier0"] + st["ms_tier12"] + st["ms_pack"]
 
+    # two batches in flight (two workspaces on two streams, the same resident input): what a caller that streams batches gets when the
+    # tail of one batch's kernels runs under the head of the next one's.  Outside the timed region and never `value`: a step of
+    # `value` is one batch at a time on one stream, which is also what the roofline's kernel durations are measured on.
+    two_in_flight = None
+    if world == 1 and not args.no_suite:
+        wsp = [tok.workspace(n, nbytes) for _ in range(2)]
+        stp = [torch.cuda.Stream() for _ in range(2)]
+        for i in range(4):
+            wsp[i & 1].run(d_text.data_ptr(), d_offs.data_ptr(), n, nbytes, stp[i & 1].cuda_stream)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for i in range(args.steps):
+            wsp[i & 1].run(d_text.data_ptr(), d_offs.data_ptr(), n, nbytes, stp[i & 1].cuda_stream)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter() - t2
+        stx = [w.stats() for w in wsp]
+        two_in_flight = {"sentences_per_s": round(n * args.steps / t2, 1), "ms_per_batch": round(t2 / args.steps * 1e3, 4), "batches": args.steps,
+                         "same_tokens_as_the_timed_steps": all(int(x["n_tokens"]) == total_tokens and not x["error_flags"] for x in stx)}
+        del wsp, stp
+
     # host-to-host leg, outside the timed region and never `value`: what a caller of the batched entry
     # point pays -- the copy of the text into the batch, H2D, kernels, D2H of the token records into host memory
     h2h = None
@@ -562,7 +582,7 @@ def main():
                         "delivered_all_shards": bool(gathered_ok)} if world > 1 else None),
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all,
             "speedup_vs_cpu_1thread": round(value / cpu["value"], 1) if cpu else None,
-            "suite": suite, "worker_loop": worker_loop,
+            "suite": suite, "worker_loop": worker_loop, "two_batches_in_flight": two_in_flight,
             "host_to_host": h2h, "format": fmt,
             "setup_s": round(t_setup, 1),
         }
