@@ -225,6 +225,9 @@ __device__ __forceinline__ void unk_spans(uint32_t cinfo, uint32_t g, uint32_t i
 #ifndef VBT_LOOP_PROF
 #define VBT_LOOP_PROF 0  // developer aid (tools/phase_profile.py on a variant build): cycles parked at the assembly sweep loop's two waits
 #endif
+#ifndef VBT_GEN_RECORDS
+#define VBT_GEN_RECORDS 1  // the bulk generator lays out the sweep's pass records for the sentences lattice_lds sweeps whole (gen_device.hpp)
+#endif
 #ifndef VBT_GENLONG_PROF
 #define VBT_GENLONG_PROF 0  // developer aid (tools/dbg/genlong_profile.py on a variant build): gen_long's wall cycles between its barriers
 #endif

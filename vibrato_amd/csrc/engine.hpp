@@ -58,7 +58,8 @@ struct BatchArgs {
     // ---- two-kernel pipeline: gen_candidates -> lattice_lds (per LDS tier) ----
     // per sentence: ONE 16-byte header written by the generator {characters | bytes << 16, lattice candidates | LDS tier << 16,
     // upper bound of the lattice passes, byte offset relative to the batch}: everything lattice_lds needs to find the sentence's
-    // regions, in one load
+    // regions, in one load.  Bit 31 of the third word: the generator laid out the sweep's pass records as well (a sentence that is
+    // swept whole; the word is then the exact pass count, the records sit at the start of the sentence's hit-staging region)
     uint4* s_hdr;
     // per character slot (sentence s, char i -> slot offsets[s] - offsets[0] + kSentenceSlack * s + i; nb + kSentenceSlack slots per sentence)
     uint16_t* g_c2b;

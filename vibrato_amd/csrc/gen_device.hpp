@@ -245,6 +245,104 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
     // exclusive end-list offset of position p (0 .. n + 1): the cursors now hold the inclusive prefix
     auto eo = [&](uint32_t p) { return p == 0 ? 0u : p == 1 ? 1u : endc[p - 1]; };
     uint32_t passes = 0, maxcnt = 1;
+#if VBT_GEN_RECORDS
+    // The sweep's structural pre-pass done HERE for a sentence that lattice_lds will sweep whole: which (start node, start word) steps
+    // the position sweep takes depends only on where words end (tokenizer.rs:106-138, control flow only), so the 8-byte pass
+    // records of the assembly sweep loop (sweep_asm.hpp) can be laid out by the wave that holds the length masks in LDS anyway -- and
+    // that runs in a kernel waiting for memory three quarters of its time, while lattice_lds is bound by what its waves issue.
+    // Same state machine, same records as the pre-pass in lattice_sentence (which keeps doing it for what is swept in segments,
+    // for the builds and modes without the assembly loop, and in the escape tiers): w bit i <=> a node ends at p + 1 + i, cur <=>
+    // position p is reachable, a visited space run hands its visit to the position behind it.  LDS addresses in the records are
+    // relative to the wave's arena (slot records at 0, candidate records behind the ET + 2 slot records); they are written to the
+    // sentence's dead hit-staging region, and the header's third word becomes the exact pass count | 1 << 31.
+    struct PreState { bool on, windowed; uint32_t stop, cur, pend, sn_eos, SL, offC, cap; uint64_t w; uint2* recs; };
+    PreState pre;
+    pre.on = VBT_ASM_LOOP && VBT_LDS_REC && !A.lid_count && !A.direct_push && !D.matrix_wide && n < 8000u;
+    pre.windowed = true; pre.stop = 0; pre.cur = 1; pre.pend = 0; pre.sn_eos = n; pre.SL = 0; pre.w = 0;
+    pre.offC = 8u * (eo(n + 1) + 2u);
+    pre.recs = reinterpret_cast<uint2*>(A.g_hits + base);
+    pre.cap = (uint32_t)(region < 0x7FFFFFu ? 2u * region : 0xFFFFFFu);  // 8-byte records in 16-byte hit slots
+    if (pre.offC + 8u * (C + 2u) > 65535u) pre.on = false;  // (16-bit LDS addresses; such a sentence is not swept whole anyway)
+    {   // nothing to lay out for a sentence that no tier up to the segment tier holds whole, however few passes it takes
+        const uint32_t t_max = A.seg_tier < A.n_tiers ? A.seg_tier : A.n_tiers - 1u;
+        if (lattice_fixed_bytes(C, n, eo(n + 1), 1u) > A.tier_bytes[t_max]) pre.on = false;
+    }
+    auto put_rec = [&](uint32_t P, uint32_t p_beg, uint32_t np, uint32_t c_beg, uint32_t nc, uint32_t k, uint32_t r, uint32_t rounds) {
+        const uint32_t np_r = np - kRoundPreds * r < kRoundPreds ? np - kRoundPreds * r : kRoundPreds;
+        const uint32_t nc_r = nc - kRoundCands * k < kRoundCands ? nc - kRoundCands * k : kRoundCands;
+        const uint32_t nu = (np_r + 3u) >> 2;
+        const uint32_t fl = nu | (r == 0 ? 8u : 0u) | (r + 1 == rounds ? 16u : 0u);
+        pre.recs[P] = make_uint2(((p_beg + kRoundPreds * r) << 3) | ((np < 4u ? np : 4u) << 16) | (nc_r << 24),
+                                 (pre.offC + ((c_beg + kRoundCands * k) << 3)) | (fl << 16) | (np_r << 24));
+    };
+    // (lm, space, co_i, nc, eo_i, np: what the record loop below holds of position i anyway)
+    auto pre_chunk = [&](auto space_c, uint32_t c0, uint64_t lm, uint32_t space, uint32_t co_i, uint32_t nc_i, uint32_t eo_i, uint32_t np_i) {
+        constexpr bool kSp = decltype(space_c)::value;
+        const uint32_t i = c0 + ln;
+        const bool in = i < n;
+        const bool is_space = kSp && in && space != 0;
+        const uint64_t lmi = (in && !is_space) ? lm : 0ull;
+        const uint32_t l_lo = (uint32_t)lmi, l_hi = (uint32_t)(lmi >> 32);
+        const uint32_t gf = is_space ? (uint32_t)grp[i] : 0u;  // groupable run of a space position
+        const uint64_t spm = kSp ? __ballot(is_space) : 0ull;
+        const uint32_t cnt = n - c0 < 64 ? n - c0 : 64;
+        uint64_t w = pre.w, vis = 0, visp = 0;
+        uint32_t cur = pre.cur, pend = pre.pend, stop = 0;
+        // (groups of 8 positions, the lane index of v_readlane in an SGPR: unrolled 64 times as in lattice_sentence the two instances
+        // of this loop made the kernel 90 KB of code -- more than the instruction cache two CUs share -- and every phase of it slower)
+        for (uint32_t k0 = 0; k0 < cnt; k0 += 8)
+#pragma unroll
+        for (uint32_t kj = 0; kj < 8; ++kj) {
+            const uint32_t k = k0 + kj;
+            const uint64_t bit = 1ull << k;
+            const uint64_t m = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(l_hi, k) << 32) | (uint32_t)__builtin_amdgcn_readlane(l_lo, k);
+            if constexpr (kSp) {
+                if (cur && !pend && (spm & bit)) {  // rare: a reachable space run
+                    const uint32_t r = __builtin_amdgcn_readlane(gf, k);
+                    if (c0 + k + r >= n) { pre.sn_eos = c0 + k; stop = 1; w = 0; }  // only spaces left: EOS connects here
+                    else if (r > 63) { pre.windowed = false; stop = 1; w = 0; }
+                    else {
+                        visp |= bit;
+                        w = (w & ~((1ull << r) - 1ull)) | (1ull << (r - 1));
+                        pend = 1;
+                    }
+                } else {
+                    w |= cur ? m : 0ull;
+                    vis |= (cur && !pend) ? bit : 0ull;
+                    pend = cur ? 0u : pend;
+                }
+            } else {
+                w |= cur ? m : 0ull;
+                vis |= cur ? bit : 0ull;
+            }
+            cur = (uint32_t)w & 1u;
+            w >>= 1;
+        }
+        if (cnt < 64) { vis &= (1ull << cnt) - 1ull; visp &= (1ull << cnt) - 1ull; }
+        pre.w = w; pre.cur = cur; pre.pend = pend; pre.stop = stop;
+        const uint64_t any = vis | visp;
+        const bool step = (any >> ln) & 1ull;  // lanes = the visited positions of the chunk: step (start node i, start word sw)
+        uint32_t nsl = 0, p_beg = 0, np = 0, c_beg = 0, nc = 0, rounds = 0;
+        if (step) {
+            p_beg = eo_i; np = np_i;
+            c_beg = co_i; nc = nc_i;  // (a space position's count is that of the position behind its run already)
+            if (kSp && ((visp >> ln) & 1ull)) c_beg = get_co(i + gf);  // (< n: a run that reaches the end stops the sweep above)
+            rounds = (np + kRoundPreds - 1) / kRoundPreds;
+            nsl = rounds * ((nc + kRoundCands - 1) / kRoundCands);
+        }
+        uint32_t tot;
+        const uint32_t ex = wave_exscan(nsl, tot);
+        if (pre.SL + tot + 64u > pre.cap) { pre.on = false; return; }  // (wave-uniform; the region is 16 bytes per candidate slot: never in practice)
+        for (uint32_t q = 0, k = 0, r = 0; q < nsl; ++q) {
+            put_rec(pre.SL + ex + q, p_beg, np, c_beg, nc, k, r, rounds);
+            if (++r == rounds) { r = 0; ++k; }
+        }
+        pre.SL += tot;
+    };
+#else
+    struct { bool on; uint32_t stop; } pre{false, 0};
+    auto pre_chunk = [&](auto, uint32_t, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t) {};
+#endif
     {   // per-character records for the lattice kernel:
         // {cand_off | end-list offset << 16, pass bound of the position's step | window end << 14 | space << 31,
         //  length mask (64 bits; for a space position of ignore_space mode its groupable run instead: the sweep never
@@ -259,6 +357,7 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
             const uint32_t i = c0 + ln;
             uint32_t e = 0, space = 0, nsl = 0, cnt = 0, co_i = 0;
             uint64_t lm = 0;
+            uint32_t nc_i = 0, eo_i = 0;
             if (i < n) {
                 const uint32_t cinfo = ci[i];
                 space = (D.space_cateset && (cinfo & D.space_cateset)) ? 0x80000000u : 0u;
@@ -266,6 +365,7 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
                 e = lm ? i + 64u - (uint32_t)__builtin_clzll(lm) : i + 1;
                 co_i = get_co(i);
                 uint32_t nc = get_co(i + 1) - co_i;
+                eo_i = eo(i);
                 if (space) {
                     const uint32_t sw = i + grp[i];
                     const uint64_t lw = sw < n ? get_lens(sw) : 0ull;
@@ -273,8 +373,13 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
                     e = e2 > e ? e2 : e;
                     nc = sw < n ? get_co(sw + 1) - get_co(sw) : 0u;  // the step taken from a space position starts its words behind the run
                 }
-                cnt = eo(i + 1) - eo(i);
+                cnt = eo(i + 1) - eo_i;
                 nsl = step_passes(nc, cnt);
+                nc_i = nc;
+            }
+            if (pre.on && !pre.stop) {
+                if (D.space_cateset) pre_chunk(std::true_type{}, c0, lm, space, co_i, nc_i, eo_i, cnt);
+                else pre_chunk(std::false_type{}, c0, lm, space, co_i, nc_i, eo_i, cnt);
             }
             uint32_t m = e;  // inclusive prefix maximum over the lanes
             m = wave_inscan_max_dpp(m);
@@ -282,7 +387,7 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
                 const uint32_t upto = m > far ? m : far;  // furthest end of any candidate of the positions <= i (<= n)
                 const uint64_t third = space ? (uint64_t)grp[i] : lm;
                 const uint32_t yw = (nsl < 0x3FFFu ? nsl : 0x3FFFu) | (eo(upto + 1) << 14) | space;
-                pc[i] = make_uint4(co_i | (eo(i) << 16), yw, (uint32_t)third, (uint32_t)(third >> 32));
+                pc[i] = make_uint4(co_i | (eo_i << 16), yw, (uint32_t)third, (uint32_t)(third >> 32));
             }
             const uint32_t top = (uint32_t)__builtin_amdgcn_readlane((int)m, 63);
             far = top > far ? top : far;
@@ -300,15 +405,35 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
         // terminator: totals (candidates, end-list slots)
         if (ln == 0) pc[n] = make_uint4(C | (eo(n) << 16), 0, eo(n + 1), 0);
     }
-    // smallest tier whose LDS holds the lattice arrays (connection costs are never staged)
-    const uint64_t fixed = lattice_fixed_bytes(C, n, eo(n + 1), passes);
-    uint32_t tier = fallback;
-    for (uint32_t t = 0; t < A.n_tiers; ++t)
-        if (fixed <= A.tier_bytes[t]) { tier = t; break; }
-    // longer sentences are swept in segments inside the segment tier instead of one huge LDS block (lattice_lds cuts anywhere;
-    // what it cannot sweep there -- a window of end lists wider than the tier -- it hands to the escape tiers itself)
-    if (A.seg_tier < A.n_tiers && tier > A.seg_tier) tier = A.seg_tier;
-    if (ln == 0) A.s_hdr[sid] = make_uint4(n | (nb << 16), C | (tier << 16), passes, (uint32_t)(b0 - uniform64(A.offsets[0])));
+    uint32_t tier = fallback, pre_flag = 0u;
+#if VBT_GEN_RECORDS
+    if (pre.on && pre.windowed) {
+        // + the EOS step (insert_eos(start_node), tokenizer.rs:138): predecessors = ends[sn_eos]
+        const uint32_t y0 = eo(pre.sn_eos), y1 = pre.sn_eos < n ? eo(pre.sn_eos + 1) : eo(n + 1);
+        const uint32_t np = y1 - y0, nsl = (np + kRoundPreds - 1) / kRoundPreds;
+        const uint32_t exact = pre.SL + nsl;  // (<= the bound `passes`: every step was counted with its position's bound)
+        // the records count only for a sentence that fits a tier up to the segment tier WHOLE (with its exact pass count), in LDS
+        // the records' 16-bit addresses reach; everything else keeps the bound (a segmented sweep budgets its segments with it)
+        const uint64_t fixed_x = lattice_fixed_bytes(C, n, eo(n + 1), exact);
+        uint32_t tx = fallback;
+        for (uint32_t t = 0; t < A.n_tiers; ++t)
+            if (fixed_x <= A.tier_bytes[t]) { tx = t; break; }
+        if (pre.SL + nsl + 64u <= pre.cap && tx < A.n_tiers && (A.seg_tier >= A.n_tiers || tx <= A.seg_tier) && A.tier_bytes[tx] <= 65536u) {
+            for (uint32_t q = ln; q < nsl; q += 64) put_rec(pre.SL + q, y0, np, C, 1u, 0u, q, nsl);
+            tier = tx; passes = exact; pre_flag = 0x80000000u;
+        }
+    }
+#endif
+    if (!pre_flag) {
+        // smallest tier whose LDS holds the lattice arrays (connection costs are never staged)
+        const uint64_t fixed = lattice_fixed_bytes(C, n, eo(n + 1), passes);
+        for (uint32_t t = 0; t < A.n_tiers; ++t)
+            if (fixed <= A.tier_bytes[t]) { tier = t; break; }
+        // longer sentences are swept in segments inside the segment tier instead of one huge LDS block (lattice_lds cuts anywhere;
+        // what it cannot sweep there -- a window of end lists wider than the tier -- it hands to the escape tiers itself)
+        if (A.seg_tier < A.n_tiers && tier > A.seg_tier) tier = A.seg_tier;
+    }
+    if (ln == 0) A.s_hdr[sid] = make_uint4(n | (nb << 16), C | (tier << 16), passes | pre_flag, (uint32_t)(b0 - uniform64(A.offsets[0])));
     route(tier);
     PROF_MARK(2);
     if (A.prof && ln == 0) {

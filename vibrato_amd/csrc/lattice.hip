@@ -62,7 +62,7 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
         uint64_t prof_t = A.prof ? clock64() : 0;
         unsigned long long* const pr_ = A.prof ? A.prof + (size_t)(sid & (kProfSlots - 1)) * kProfWords : nullptr;
 #define PROF_MARK(i) do { if (A.prof) { const uint64_t t_ = clock64(); if (ln == 0) atomicAdd(&pr_[i], (unsigned long long)(t_ - prof_t)); prof_t = t_; } } while (0)
-        const uint32_t nT = h.x & 0xFFFFu, CT = h.y & 0xFFFFu, passesT = h.z;
+        const uint32_t nT = h.x & 0xFFFFu, CT = h.y & 0xFFFFu, passesT = h.z & 0x7FFFFFFFu;
         const size_t slot0 = (size_t)h.w + (size_t)kSentenceSlack * sid;  // (sentence_slot: the header holds the byte offset relative to the batch)
         const size_t node0 = (size_t)A.node_factor * slot0;
         const uint4* __restrict__ pcg = A.g_pc + slot0;   // per-character records (+ the terminator at nT)
@@ -82,6 +82,10 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
         const bool lds_rec = kLdsRec && vrec_mode;  // the pass records live in LDS: nothing bounds them but the tier
         // (a sentence that is swept whole dumps nothing: its records take the whole region)
         const bool whole = lattice_fixed_bytes(CT, nT, ET, passesT) <= lds_bytes && (lds_rec || passesT + 3 * kD + 4 <= 2 * half_bytes / (uint32_t)(sizeof(LPass) + 4));
+        // The generator laid out the pass records of a sentence that is swept whole (gen_device.hpp: header word 2, bit 31; the word
+        // is then the exact pass count): no per-character record is read, no pre-pass runs -- the records come in with the candidates.
+        // Only where this instance would have built the same records itself: the assembly loop over records in LDS.
+        const bool pre = VBT_GEN_RECORDS && (h.z >> 31) != 0 && lds_rec && whole;
         LPass* const rec = reinterpret_cast<LPass*>(reinterpret_cast<char*>(A.g_hits + node0) + (whole ? 0u : half_bytes));
         const uint32_t rec_cap = (whole ? 2 * half_bytes : half_bytes) / (uint32_t)(sizeof(LPass) + 4);
         uint32_t* const rec_w3 = reinterpret_cast<uint32_t*>(rec + rec_cap);  // per pass: step totals for the connection-id counting
@@ -140,7 +144,8 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
         SEG_TRACE("tier %u seg [%u,%u) of %u: seg_c %u sb %u wend %u seg_pass %u budget %u m_in %u multi %d\n", tier, seg_a, seg_b, nT, seg_c, sb, wend, seg_pass, budget, m_in, (int)multi);
         const uint32_t n = seg_b - seg_a;
         const uint4* __restrict__ pc = pcg + seg_a;
-        const uint4 rend = uniform4(pcg[seg_b]);  // record of the segment's end position (the terminator for the last segment)
+        // record of the segment's end position (the terminator for the last segment; pre: all that is used of it is the candidate total)
+        const uint4 rend = pre ? make_uint4(CT, 0u, 0u, 0u) : uniform4(pcg[seg_b]);
         const uint32_t C = ((rend.x & 0xFFFFu) - seg_c) & 0xFFFFu;
         const uint32_t E = wend - sb;  // slots of the window [eo(seg_a), wend); slot E is the EOS node's (last segment)
         if (E >= 8190u || m_in > E) SEG_TRACE("   retry/fail: E %u m_in %u\n", E, m_in);
@@ -179,7 +184,15 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
 
         // the per-character records of the first 64 positions are requested now, ahead of the candidate loads: by the time the
         // reachability sweep wants them they have arrived (the sweep of a chunk then prefetches the next chunk's)
-        uint4 rc_next = pc[ln < n ? ln : n], rn_next = pc[ln < n ? ln + 1 : n];
+        uint4 rc_next = make_uint4(0, 0, 0, 0), rn_next = rc_next;
+        if (!pre) { rc_next = pc[ln < n ? ln : n]; rn_next = pc[ln < n ? ln + 1 : n]; }
+        // (pre: the first two records per lane are requested with the candidates)
+        const uint2* __restrict__ grec = reinterpret_cast<const uint2*>(A.g_hits + node0);
+        uint2 pr_early[2] = {make_uint2(0, 0), make_uint2(0, 0)};
+        if (pre) {
+#pragma unroll
+            for (uint32_t u = 0; u < 2; ++u) { const uint32_t P = u * 64 + ln; pr_early[u] = grec[P < seg_pass ? P : 0u]; }
+        }
         // ---- load: candidates from global (every record carries its slot); EOS ----
         // The first kEarly records per lane are only REQUESTED here: the reachability sweep below needs nothing of them, so their
         // round trip runs under it and they are put into LDS behind it (load_rest); what is left follows there.
@@ -205,6 +218,12 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
             r_early[u] = nd[c < C ? c : 0u];
         }
         auto load_rest = [&]() {
+            if (pre) {  // the generator's records: LDS addresses relative to the arena
+                const uint2 adj = make_uint2(lds0, lds0);
+#pragma unroll
+                for (uint32_t u = 0; u < 2; ++u) { const uint32_t P = u * 64 + ln; if (P < seg_pass) vhead[P] = make_uint2(pr_early[u].x + adj.x, pr_early[u].y + adj.y); }
+                for (uint32_t P = 128 + ln; P < seg_pass; P += 64) { const uint2 r = grec[P]; vhead[P] = make_uint2(r.x + adj.x, r.y + adj.y); }
+            }
             if (c2b_lds) {
 #pragma unroll
                 for (uint32_t u = 0; u < 2; ++u) { const uint32_t i = u * 64 + ln; if (i <= n) c2bl[i] = (uint16_t)cb_early[u]; }
@@ -287,7 +306,7 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
             Cn.lm = lm;
             Cn.vm = cm & (((uint64_t)ps << 32) | ps);
         };
-        {
+        if (!pre) {
             uint64_t w = sw_w;
             uint32_t cur = sw_cur, pend = sw_pend, stop = 0;
             for (uint32_t chunk = 0; chunk < n && !stop; chunk += 64) {
@@ -356,7 +375,8 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
         }
         if (!windowed) { fail = 27; break; }  // > 63 skipped spaces in a row: generic pre-pass of the fused kernel
         uint32_t eos_rec = 0;  // first pass record of the EOS step
-        if (last_seg) {
+        if (pre) SL = seg_pass;  // (exact; the EOS step's records are among them)
+        else if (last_seg) {
             // + the EOS step (insert_eos(start_node), tokenizer.rs:138): predecessors = ends[sn_eos]
             // (the builtin returns int: shifted as it comes, an end-list offset of 32 768 or more -- a sentence of more than 32 767
             // lattice nodes -- would be sign-extended and EOS would be connected to garbage; found in round 5 by the first test with
