@@ -17,6 +17,8 @@ run cfg5_unidic_user_S_M24_mixed $CFG5
 run dense_unidic --dict unidic-dense
 run unidic_short_uniform_5_20 --law uniform_5_20
 timeout 200 python tools/phase_profile.py > $OUT/phase.txt 2>&1; tail -12 $OUT/phase.txt
+timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
+[ -n "$QUICK" ] && exit 0   # QUICK=1: suite, default line, rocprofv3 evidence, the other configurations, phase profile, smoke -- and no more
 # where the assembly sweep loop is parked (needs the lp variant build in vibrato_amd/lib), Worker latency by length, the EXEC = 0 probe, the RCCL overlap ratio
 [ -f vibrato_amd/lib/libvibrato_hip_lp.so ] && bash tools/loop_profile.sh > $OUT/loop_profile.txt 2>&1
 timeout 300 python tools/worker_latency.py 2>&1 | grep -v amdgpu > $OUT/worker_latency.txt; cat $OUT/worker_latency.txt
