@@ -5,12 +5,13 @@
 ulimit -c 0
 TAG=${1:-r05}; OUT=gpurun_out/art_$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+CFG5="--law mixed --ignore-space --max-grouping-len 24 --user-lexicon 1000"
+if [ -z "$REST" ]; then   # REST=1: only what QUICK=1 leaves out (the two together = one full run)
 timeout 1200 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log; tail -3 $OUT/pytest_gpu.log
 timeout 900 python bench.py > $OUT/bench_default.json 2>$OUT/bench_default.err; tail -c 300 $OUT/bench_default.err
 bash tools/profile_round.sh $TAG > $OUT/profile.log 2>&1
 run() { name=$1; shift; timeout 300 python bench.py --no-cpu-baseline --no-host-pipeline --no-suite --no-worker-loop --steps 10 "$@" 2>/dev/null | grep '^{' | tail -1 > $OUT/$name.json; python -c "
 import json; d=json.load(open('$OUT/$name.json')); r=d['roofline']; print('$name', d['value'], d['ms_per_step'], 'gen', r['gen_candidates']['kernel_ms'], 'lat', r['kernel_ms'], d['parity_vs_oracle_sample'], r['tiers'])"; }
-CFG5="--law mixed --ignore-space --max-grouping-len 24 --user-lexicon 1000"
 run cfg2_ipadic --dict ipadic
 run cfg3_unidic
 run cfg5_unidic_user_S_M24_mixed $CFG5
@@ -18,6 +19,7 @@ run dense_unidic --dict unidic-dense
 run unidic_short_uniform_5_20 --law uniform_5_20
 timeout 200 python tools/phase_profile.py > $OUT/phase.txt 2>&1; tail -12 $OUT/phase.txt
 timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
+fi
 [ -n "$QUICK" ] && exit 0   # QUICK=1: suite, default line, rocprofv3 evidence, the other configurations, phase profile, smoke -- and no more
 # where the assembly sweep loop is parked (needs the lp variant build in vibrato_amd/lib), Worker latency by length, the EXEC = 0 probe, the RCCL overlap ratio
 [ -f vibrato_amd/lib/libvibrato_hip_lp.so ] && bash tools/loop_profile.sh > $OUT/loop_profile.txt 2>&1
