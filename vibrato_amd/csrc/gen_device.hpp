@@ -257,7 +257,8 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
     // sentence's dead hit-staging region, and the header's third word becomes the exact pass count | 1 << 31.
     struct PreState { bool on, windowed; uint32_t stop, cur, pend, sn_eos, SL, offC, cap; uint64_t w; uint2* recs; };
     PreState pre;
-    pre.on = VBT_ASM_LOOP && VBT_LDS_REC && !A.lid_count && !A.direct_push && !D.matrix_wide && n < 8000u;
+    constexpr bool kSweepTakesRecords = (VBT_ASM_LOOP != 0) && (VBT_LDS_REC != 0);  // (the assembly loop over records in LDS: the only consumer)
+    pre.on = kSweepTakesRecords && !A.lid_count && !A.direct_push && !D.matrix_wide && n < 8000u;
     pre.windowed = true; pre.stop = 0; pre.cur = 1; pre.pend = 0; pre.sn_eos = n; pre.SL = 0; pre.w = 0;
     pre.offC = 8u * (eo(n + 1) + 2u);
     pre.recs = reinterpret_cast<uint2*>(A.g_hits + base);

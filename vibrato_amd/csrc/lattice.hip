@@ -85,7 +85,7 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
         // The generator laid out the pass records of a sentence that is swept whole (gen_device.hpp: header word 2, bit 31; the word
         // is then the exact pass count): no per-character record is read, no pre-pass runs -- the records come in with the candidates.
         // Only where this instance would have built the same records itself: the assembly loop over records in LDS.
-        const bool pre = VBT_GEN_RECORDS && (h.z >> 31) != 0 && lds_rec && whole;
+        const bool pre = (VBT_GEN_RECORDS != 0) && (h.z >> 31) != 0 && lds_rec && whole;
         LPass* const rec = reinterpret_cast<LPass*>(reinterpret_cast<char*>(A.g_hits + node0) + (whole ? 0u : half_bytes));
         const uint32_t rec_cap = (whole ? 2 * half_bytes : half_bytes) / (uint32_t)(sizeof(LPass) + 4);
         uint32_t* const rec_w3 = reinterpret_cast<uint32_t*>(rec + rec_cap);  // per pass: step totals for the connection-id counting
