@@ -291,34 +291,41 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
         uint32_t cur = pre.cur, pend = pre.pend, stop = 0;
         // (groups of 8 positions, the lane index of v_readlane in an SGPR: unrolled 64 times as in lattice_sentence the two instances
         // of this loop made the kernel 90 KB of code -- more than the instruction cache two CUs share -- and every phase of it slower)
-        for (uint32_t k0 = 0; k0 < cnt; k0 += 8)
+        auto bits = [&](auto sp2_c) {
+            constexpr bool kS = decltype(sp2_c)::value;
+            for (uint32_t k0 = 0; k0 < cnt; k0 += 8)
 #pragma unroll
-        for (uint32_t kj = 0; kj < 8; ++kj) {
-            const uint32_t k = k0 + kj;
-            const uint64_t bit = 1ull << k;
-            const uint64_t m = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(l_hi, k) << 32) | (uint32_t)__builtin_amdgcn_readlane(l_lo, k);
-            if constexpr (kSp) {
-                if (cur && !pend && (spm & bit)) {  // rare: a reachable space run
-                    const uint32_t r = __builtin_amdgcn_readlane(gf, k);
-                    if (c0 + k + r >= n) { pre.sn_eos = c0 + k; stop = 1; w = 0; }  // only spaces left: EOS connects here
-                    else if (r > 63) { pre.windowed = false; stop = 1; w = 0; }
-                    else {
-                        visp |= bit;
-                        w = (w & ~((1ull << r) - 1ull)) | (1ull << (r - 1));
-                        pend = 1;
+            for (uint32_t kj = 0; kj < 8; ++kj) {
+                const uint32_t k = k0 + kj;
+                const uint64_t bit = 1ull << k;
+                const uint64_t m = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(l_hi, k) << 32) | (uint32_t)__builtin_amdgcn_readlane(l_lo, k);
+                if constexpr (kS) {
+                    if (cur && !pend && (spm & bit)) {  // rare: a reachable space run
+                        const uint32_t r = __builtin_amdgcn_readlane(gf, k);
+                        if (c0 + k + r >= n) { pre.sn_eos = c0 + k; stop = 1; w = 0; }  // only spaces left: EOS connects here
+                        else if (r > 63) { pre.windowed = false; stop = 1; w = 0; }
+                        else {
+                            visp |= bit;
+                            w = (w & ~((1ull << r) - 1ull)) | (1ull << (r - 1));
+                            pend = 1;
+                        }
+                    } else {
+                        w |= cur ? m : 0ull;
+                        vis |= (cur && !pend) ? bit : 0ull;
+                        pend = cur ? 0u : pend;
                     }
                 } else {
                     w |= cur ? m : 0ull;
-                    vis |= (cur && !pend) ? bit : 0ull;
-                    pend = cur ? 0u : pend;
+                    vis |= cur ? bit : 0ull;
                 }
-            } else {
-                w |= cur ? m : 0ull;
-                vis |= cur ? bit : 0ull;
+                cur = (uint32_t)w & 1u;
+                w >>= 1;
             }
-            cur = (uint32_t)w & 1u;
-            w >>= 1;
-        }
+        };
+        if constexpr (kSp) {
+            // (a chunk without a space position and with no hand-over pending sweeps exactly as with ignore_space off)
+            if (spm != 0 || pend) bits(std::true_type{}); else bits(std::false_type{});
+        } else bits(std::false_type{});
         if (cnt < 64) { vis &= (1ull << cnt) - 1ull; visp &= (1ull << cnt) - 1ull; }
         pre.w = w; pre.cur = cur; pre.pend = pend; pre.stop = stop;
         const uint64_t any = vis | visp;
