@@ -122,6 +122,7 @@ def lib():
         L.ora_worker_reset_sentence.restype = C.c_int
         L.ora_worker_reset_sentence.argtypes = [vp, u8p, sz]
         L.ora_worker_add_connid_counts.argtypes = [vp, vp, vp]
+        L.ora_worker_add_corner_hist.argtypes = [vp, vp, vp, vp, C.c_uint32, vp]
         L.ora_worker_tokenize.argtypes = [vp]
         L.ora_worker_tokenize_counted.argtypes = [vp]
         L.ora_worker_num_tokens.restype = u32
@@ -332,6 +333,11 @@ class Worker:
     def add_connid_counts(self, lid, rid):
         """Worker::update_connid_counts for the sentence just tokenized; lid/rid are np.uint64 arrays."""
         lib().ora_worker_add_connid_counts(self._h, lid.ctypes.data, rid.ctypes.data)
+
+    def add_corner_hist(self, rank_left, rank_right, bounds, hist):
+        """Statistics (not part of the reference): histogram of max(rank_left[left id], rank_right[right id]) over the (node, predecessor)
+        pairs of the sentence just tokenized; np.uint32 ranks and bounds, np.uint64 hist of len(bounds) + 1."""
+        lib().ora_worker_add_corner_hist(self._h, rank_left.ctypes.data, rank_right.ctypes.data, bounds.ctypes.data, len(bounds), hist.ctypes.data)
 
     def counters(self):
         buf = (C.c_uint64 * len(COUNTER_FIELDS))()

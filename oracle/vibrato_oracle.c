@@ -1378,6 +1378,36 @@ ORA_API uint32_t ora_worker_lattice_shape(const ora_worker *w, uint32_t *np_out,
     return w->len_char;
 }
 
+/* Where the gathered matrix cells fall (statistics for DESIGN.md 3.6, the "hot corner in LDS" question; not part of the
+ * reference): for every (node, predecessor) pair search_min_node evaluated in the sentence just tokenized -- the cells a sweep
+ * gathers, lattice.rs:137-147 -- m = max(rank_left[node.left_id], rank_right[pred.right_id]) is the smallest k for which the cell
+ * lies inside the top-k x top-k corner of a matrix renumbered by those ranks; hist[b] += 1 for the first bound with m < bounds[b]
+ * (hist[n_bounds]: beyond all).  EOS (left id 0) against ends[eos.start_node] included. */
+ORA_API void ora_worker_add_corner_hist(const ora_worker *w, const uint32_t *rank_left, const uint32_t *rank_right,
+                                        const uint32_t *bounds, uint32_t n_bounds, uint64_t *hist) {
+    if (w->len_char == 0) return;
+    for (uint32_t end_char = 1; end_char <= w->len_char; end_char++) {
+        const node_vec *e = &w->ends[end_char];
+        for (uint32_t a = 0; a < e->n; a++) {
+            const node_vec *le = &w->ends[e->v[a].start_node];
+            const uint32_t rl = rank_left[e->v[a].left_id];
+            for (uint32_t b = 0; b < le->n; b++) {
+                const uint32_t rr = rank_right[le->v[b].right_id], m = rl > rr ? rl : rr;
+                uint32_t k = 0;
+                while (k < n_bounds && m >= bounds[k]) k++;
+                hist[k] += 1;
+            }
+        }
+    }
+    const node_vec *le = &w->ends[w->eos.start_node];
+    for (uint32_t b = 0; b < le->n; b++) {
+        const uint32_t rr = rank_right[le->v[b].right_id], m = rank_left[0] > rr ? rank_left[0] : rr;
+        uint32_t k = 0;
+        while (k < n_bounds && m >= bounds[k]) k++;
+        hist[k] += 1;
+    }
+}
+
 ORA_API void ora_worker_tokenize(ora_worker *w) { tokenize_impl(w, 0); }
 ORA_API void ora_worker_tokenize_counted(ora_worker *w) { tokenize_impl(w, 1); }
 ORA_API uint32_t ora_worker_num_tokens(const ora_worker *w) { return w->n_top; }
