@@ -102,6 +102,9 @@ def timed_leg(tok, text, offs, steps, warmup, torch):
     n, nbytes = len(offs) - 1, int(len(text))
     d_text = torch.from_numpy(text).cuda()
     d_offs = torch.from_numpy(offs.astype(np.int64)).cuda()
+    # the tokenizer's renumbering of its connection ids by measured usage, done up front (vbt_tokenizer_calibrate): left to the first
+    # large batch it runs on a background thread and would share the GPU with the timed steps
+    tok.calibrate(text=text, offsets=offs)
     ws = tok.workspace(n, nbytes)
     ws.set_timing(True)
     stream = torch.cuda.current_stream().cuda_stream
@@ -214,6 +217,9 @@ def main():
         del wst, tt, dt, dtt, dto
 
     tok = V.Tokenizer(dv, device=local_rank).ignore_space(args.ignore_space).max_grouping_len(args.max_grouping_len)
+    # the tokenizer's internal renumbering of the connection ids by measured usage, done up front on this rank's own text
+    # (vbt_tokenizer_calibrate; left alone it runs on a background thread behind the first large batch, next to the timed steps)
+    tok.calibrate(text=text, offsets=offs)
     d_text = torch.from_numpy(text).cuda()
     d_offs = torch.from_numpy(offs.astype(np.int64)).cuda()
     ws = tok.workspace(n, nbytes)
@@ -284,8 +290,8 @@ def main():
         raise SystemExit(f"device error flags {st['error_flags']}")
     total_tokens = int(st["n_tokens"])
     if reorder_info is None:
-        # the tokenizer renumbers the connection ids of its device image by the usage it measures on its first large batch
-        # (the warm-up step above): include/vibrato_hip.h, vbt_tokenizer_connid_reorder_info.  VBT_CONNID_REORDER=0: off (A/B).
+        # the tokenizer renumbers the connection ids of its device image by the usage it measures on a sample of its text
+        # (tok.calibrate above): include/vibrato_hip.h, vbt_tokenizer_connid_reorder_info.  VBT_CONNID_REORDER=0: off (A/B).
         ri = tok.connid_reorder_info()
         reorder_info = ("internal" if ri["epoch"] else "off") if world > 1 else {"mode": "internal" if ri["epoch"] else "off", **ri}
     gathered_ok = None
@@ -338,6 +344,7 @@ def main():
             if user_csv is not None:
                 dvm.reset_user_lexicon_from_reader(user_csv)
             tokm = V.Tokenizer(dvm, devices=[local_rank] * k_dev).ignore_space(args.ignore_space).max_grouping_len(args.max_grouping_len)
+            tokm.calibrate(text=text, offsets=offs)
             h2h[f"one_call_device_list_0x{k_dev}"] = tokm.host_pipeline_benchmark(text, offs, threads=1, rounds=1)
             del tokm, dvm
 

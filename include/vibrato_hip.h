@@ -153,8 +153,10 @@ VBT_API uint32_t vbt_tokenizer_num_devices(const vbt_tokenizer* tok);
 /* Connection-id locality, built in (the reference's `reorder` + `map` workflow -- map/src/reorder.rs:34-63,
  * MatrixConnector::map_connection_ids matrix_connector.rs:99-116, Dictionary::map_connection_ids_from_iter dictionary.rs:245-259,
  * docs/map.md -- without a caller action): the first batch of at least VBT_CONNID_MIN_SENTENCES (2048) sentences a tokenizer sees
- * has its first VBT_CONNID_SAMPLE (16384) sentences swept once more with the connection-id counters on; the ids are sorted by
- * count and every later launch reads a device image whose matrix rows / columns and entry id pairs are renumbered hot ids first.
+ * has up to VBT_CONNID_SAMPLE (16384) of its sentences, spread evenly over the batch, copied aside by two small kernels on the call's
+ * stream -- the call itself stays asynchronous: nothing is allocated, synchronised or waited for on the caller's side -- and a
+ * background thread sweeps that sample once more with the connection-id counters on, sorts the ids by count and publishes a device
+ * image whose matrix rows / columns and entry id pairs are renumbered hot ids first; launches enqueued from then on read it.
  * Results are bit-identical (a pure permutation) and nothing visible is in device ids: Token::left_id / right_id, vbt_dict_conn_cost,
  * vbt_dict_write, the connection-id counters (vbt_workspace_connid_counts, vbt_worker_*connid*) all stay in the dictionary's
  * numbering, and a mapping applied with vbt_dict_map_connection_ids before the tokenizer was created is kept underneath.
@@ -162,6 +164,13 @@ VBT_API uint32_t vbt_tokenizer_num_devices(const vbt_tokenizer* tok);
  * state (0 waiting for a large batch, 1 running, 2 done, 3 off), sentences sampled, the minimum batch size, microseconds the
  * calibration took, left ids moved, right ids moved, 0}; of the tokenizer's first device. */
 VBT_API int vbt_tokenizer_connid_reorder_info(const vbt_tokenizer* tok, uint64_t out[8]);
+/* The same calibration up front and synchronously, from host text (`n` sentences, `offsets[n + 1]`; at most VBT_CONNID_SAMPLE of them,
+ * spread evenly, are used), on every device of the tokenizer: for callers who do not want the image to change under their first
+ * batches (map/src/reorder.rs:34-63 run as a step of its own).  A no-op once a calibration has happened or when it is switched off. */
+VBT_API int vbt_tokenizer_calibrate(const vbt_tokenizer* tok, const uint8_t* text, const uint64_t* offsets, uint64_t n);
+/* Returns once no calibration is running on any device of the tokenizer, or after timeout_ms (< 0: no limit); *idle = 1 when none
+ * is running.  (Benchmarks wait here behind their warm-up so that the counting sweep does not share the GPU with the timed region.) */
+VBT_API int vbt_tokenizer_connid_reorder_wait(const vbt_tokenizer* tok, int64_t timeout_ms, int* idle);
 VBT_API void vbt_tokenizer_free(vbt_tokenizer* tok);
 VBT_API const vbt_dict* vbt_tokenizer_dictionary(const vbt_tokenizer* tok); /* Tokenizer::dictionary, tokenizer.rs:77 */
 
@@ -232,9 +241,13 @@ VBT_API const vbt_token_rec* vbt_batch_records(const vbt_batch* b, uint64_t sent
 VBT_API int vbt_batch_arrays(const vbt_batch* b, const vbt_token_rec** tokens, const uint32_t** tok_off,
                              const uint32_t** tok_cnt);
 /* Byte-identical output of the `tokenize` CLI for the whole batch (tokenize/src/main.rs:83-127).
- * *out is malloc'ed; release with vbt_free.  Rendered by up to VBT_FORMAT_THREADS host threads (default: the host's cores, at
- * most 32) in two passes over chunks of sentences: exact sizes, then every chunk in place. */
+ * *out belongs to the library: release it ONLY with vbt_free (never free(): the pointer does not start a malloc block).  Rendered by up
+ * to VBT_FORMAT_THREADS host threads (default: the host's cores, at most 64) in two passes over chunks of sentences: exact sizes,
+ * then every chunk in place. */
 VBT_API int vbt_batch_format(const vbt_batch* b, int mode, char** out, size_t* len);
+/* Releases a buffer handed out by vbt_batch_format / vbt_dict_write.  A pointer that is not a live buffer of this library (freed
+ * already, or from somewhere else) is ignored.  Big buffers are kept for the next call (at most 4 / 512 MiB per process) until
+ * vbt_tokenizer_trim_pool or vbt_tokenizer_free. */
 VBT_API void vbt_free(void* p);
 
 /* ---- Device-resident API (zero-copy; what bench.py times) ------------------------ */
@@ -268,10 +281,12 @@ VBT_API int vbt_workspace_results(const vbt_workspace* ws, const vbt_token_rec**
 /* The final exchange of a multi-GPU job without copy kernels: every later vbt_tokenize_batch_device call of this workspace leaves
  * its results in ONE caller-owned device buffer laid out as a rank's slot of the gather (vibrato_amd/sharding.py; north_star:
  * "RCCL over xGMI only for the final gather"):
- *   [32-byte header {n_sentences u64, n_tokens u32, 0}] [tok_off u32 x max_sentences] [tok_cnt u32 x max_sentences] [vbt_token_rec x n_tokens]
+ *   [32-byte header {n_sentences u64, n_tokens u32, error flags u32, 0 x 16 bytes}] [tok_off u32 x max_sentences] [tok_cnt u32 x max_sentences] [vbt_token_rec x n_tokens]
  * -- tok_cnt written by the sweep, tok_off and the records by the packing kernel, the header with its total -- so the collective
  * (ncclSend / all-gather of the slot) starts from what the tokenizer wrote.  d_slot: 8-byte aligned device memory of slot_bytes >=
- * 32 + 8 max_sentences + 24 x (tokens of the largest batch); a batch whose tokens do not fit sets error flag 1.  d_slot = NULL:
+ * 32 + 8 max_sentences + 24 x (tokens of the largest batch); a batch whose tokens do not fit sets error flag 1 -- in the workspace's
+ * statistics AND in the header's flags word, whose n_tokens is then the number of records the slot holds (a consumer of gathered slots
+ * sees nothing else of the rank that wrote one).  d_slot = NULL:
  * back to the workspace's own buffers.  vbt_workspace_results then points into the slot.  The caller alternates two slots to
  * overlap the gather of batch k with the kernels of batch k + 1. */
 VBT_API int vbt_workspace_set_packed_output(vbt_workspace* ws, void* d_slot, uint64_t slot_bytes, uint64_t max_sentences);

@@ -251,8 +251,9 @@ def test_internal_connid_renumbering_is_invisible():
     st = torch.cuda.current_stream().cuda_stream
     ws.run(d_text.data_ptr(), d_offs.data_ptr(), 1000, int(offs[1000]), st)  # < 2048 sentences: image 0
     assert tok.connid_reorder_info()["epoch"] == 0
-    ws.run(d_text.data_ptr(), d_offs.data_ptr(), 4000, len(text), st)        # calibrates on its own first sentences, then runs on image 1
+    ws.run(d_text.data_ptr(), d_offs.data_ptr(), 4000, len(text), st)        # a sample of it is copied aside; a background thread renumbers
     torch.cuda.synchronize()
+    assert tok.wait_connid_reorder(60)
     info = tok.connid_reorder_info()
     assert info["epoch"] == 1 and info["state"] == "done" and info["sample_sentences"] == 4000
     assert info["moved_left"] > 0 and info["moved_right"] > 0
@@ -260,6 +261,9 @@ def test_internal_connid_renumbering_is_invisible():
     l1, r1 = _oracle_counts(do, True, text, offs, 0, 4000)
     glid, grid = ws.connid_counts()
     assert np.array_equal(glid, l0 + l1) and np.array_equal(grid, r0 + r1)
+    ws.run(d_text.data_ptr(), d_offs.data_ptr(), 1000, int(offs[1000]), st)  # image 1 now: the counters so far are folded first
+    glid, grid = ws.connid_counts()
+    assert np.array_equal(glid, 2 * l0 + l1) and np.array_equal(grid, 2 * r0 + r1)
     glid2, grid2 = ws.connid_counts(reset=True)  # reading twice does not fold twice
     assert np.array_equal(glid2, glid) and np.array_equal(grid2, grid)
     ws.run(d_text.data_ptr(), d_offs.data_ptr(), 1000, int(offs[1000]), st)
@@ -316,6 +320,7 @@ def test_internal_renumbering_off_and_on_top_of_a_callers_mapping(monkeypatch):
         ws.count_connids(True)
         ws.run(d_text.data_ptr(), d_offs.data_ptr(), 2500, len(text), torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
+        assert tok.wait_connid_reorder(60)
         info = tok.connid_reorder_info()
         assert (info["epoch"], info["state"]) == ((0, "off") if reorder == "0" else (1, "done"))
         glid, grid = ws.connid_counts()
@@ -349,7 +354,71 @@ def test_tie_heavy_dictionaries_under_the_internal_renumbering(seed, monkeypatch
             dv.reset_user_lexicon_from_reader(d["user"])
         tv = V.Tokenizer(dv).ignore_space(ignore_space).max_grouping_len(mgl)
         exp, exp_off = ora.Tokenizer(do, ignore_space, mgl).new_worker().tokenize_batch(text, offs)
-        for _ in range(2):  # the calibrating batch and one that starts on the renumbered image
+        for k in range(3):  # the batch that triggers the calibration, one that may run while it goes on, one on the renumbered image
             got, got_off = tv.tokenize_batch(text=text, offsets=offs).tokens_in_order()
             assert np.array_equal(got_off, exp_off) and all(np.array_equal(got[f], exp[f]) for f in V.TOKEN_DTYPE.names)
+            if k == 1:
+                assert tv.wait_connid_reorder(60)
         assert tv.connid_reorder_info()["state"] == "done"
+
+
+@pytest.mark.gpu
+def test_calibration_leaves_the_device_call_asynchronous_and_results_unchanged():
+    """vbt_tokenize_batch_device is enqueue-only, also on the batch that triggers the renumbering (round-5 advisor: it used to block
+    ~38 ms, allocate and synchronise the caller's stream): the call returns in well under a millisecond, the calibration runs on a
+    background thread and a stream of its own, and the records are the oracle's before, while and after the image is swapped.  The
+    up-front form (vbt_tokenizer_calibrate) does the same synchronously and leaves nothing for the first batch to do."""
+    import time
+    import torch
+    from vibrato_amd import sharding
+    sd = synth.SynthDict("small")
+    text, offs = sd.sentences(6000, "lognormal_40")
+    do = ora.Dictionary.from_sources_binmatrix(sd.lex, sd.matrix, sd.num_right, sd.num_left, sd.char_def, sd.unk)
+    exp, _ = ora.Tokenizer(do).new_worker().tokenize_batch(text, offs)
+    d_text = torch.from_numpy(text).cuda()
+    d_offs = torch.from_numpy(offs.astype(np.int64)).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+
+    def records(ws):
+        s = ws.stats()
+        assert s["error_flags"] == 0 and s["n_tokens"] == len(exp)
+        v = sharding.workspace_views(ws, 6000, s["n_tokens"])
+        got, _ = sharding.tokens_in_sentence_order(v["tok_off"].cpu().numpy().view(np.uint32), v["tok_cnt"].cpu().numpy().view(np.uint32),
+                                                   v["tokens"].cpu().numpy().view(V.TOKEN_DTYPE))
+        return got.tobytes()
+
+    enqueue_ms = []
+    for attempt in range(3):
+        dv = V.SystemDictionaryBuilder.from_readers_binmatrix(sd.lex, sd.matrix, sd.num_right, sd.num_left, sd.char_def, sd.unk)
+        tok = V.Tokenizer(dv)
+        ws = tok.workspace(6000, len(text))
+        ws.run(d_text.data_ptr(), d_offs.data_ptr(), 1000, int(offs[1000]), st)  # < 2048 sentences: loads the kernels, triggers nothing
+        torch.cuda.synchronize()
+        assert tok.connid_reorder_info()["state"] == "waiting"
+        t0 = time.perf_counter()
+        ws.run(d_text.data_ptr(), d_offs.data_ptr(), 6000, len(text), st)  # the triggering batch
+        enqueue_ms.append((time.perf_counter() - t0) * 1e3)
+        assert tok.connid_reorder_info()["state"] in ("running", "done")
+        seen = set()
+        for k in range(200):
+            assert records(ws) == exp.tobytes()
+            state = tok.connid_reorder_info()
+            seen.add((state["state"], state["epoch"]))
+            if state["state"] == "done" and k >= 3 and ("done", 1) in seen:
+                break
+            ws.run(d_text.data_ptr(), d_offs.data_ptr(), 6000, len(text), st)
+        assert tok.wait_connid_reorder(60) and tok.connid_reorder_info()["epoch"] == 1
+        ws.run(d_text.data_ptr(), d_offs.data_ptr(), 6000, len(text), st)
+        assert records(ws) == exp.tobytes()
+        if min(enqueue_ms) < 1.0:
+            break
+    assert min(enqueue_ms) < 1.0, enqueue_ms
+    # up front, from host text
+    dv = V.SystemDictionaryBuilder.from_readers_binmatrix(sd.lex, sd.matrix, sd.num_right, sd.num_left, sd.char_def, sd.unk)
+    tok = V.Tokenizer(dv)
+    info = tok.calibrate(text=text, offsets=offs)
+    assert info["state"] == "done" and info["epoch"] == 1 and info["sample_sentences"] == 6000
+    ws = tok.workspace(6000, len(text))
+    ws.run(d_text.data_ptr(), d_offs.data_ptr(), 6000, len(text), st)
+    assert records(ws) == exp.tobytes() and tok.connid_reorder_info()["epoch"] == 1
+    assert tok.calibrate(text=text, offsets=offs)["epoch"] == 1  # a second call is a no-op

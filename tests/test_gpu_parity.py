@@ -208,7 +208,7 @@ def test_config4_on_unidic_through_the_multi_device_tokenizer():
     to, tv = ora.Tokenizer(do), V.Tokenizer(dv, devices=[0, 0])
     text, offs = sd.sentences(1000000, "lognormal_40")
     _config4_checks(sd, to, tv, text, offs)
-    assert tv.num_devices() == 2 and tv.connid_reorder_info()["epoch"] == 1
+    assert tv.num_devices() == 2 and tv.wait_connid_reorder(120) and tv.connid_reorder_info()["epoch"] == 1
 
 
 def _config4_checks(sd, to, tv, text, offs):

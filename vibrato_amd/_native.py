@@ -68,6 +68,8 @@ SIGNATURES = {
     "vbt_tokenizer_new_multi": (_int, [_vp, _int, _u32, C.POINTER(C.c_int), _u32, _PP]),
     "vbt_tokenizer_num_devices": (_u32, [_vp]),
     "vbt_tokenizer_connid_reorder_info": (_int, [_vp, C.POINTER(_u64)]),
+    "vbt_tokenizer_calibrate": (_int, [_vp, _vp, _vp, _u64]),
+    "vbt_tokenizer_connid_reorder_wait": (_int, [_vp, C.c_int64, C.POINTER(C.c_int)]),
     "vbt_tokenizer_free": (None, [_vp]),
     "vbt_tokenizer_dictionary": (_vp, [_vp]),
     "vbt_tokenizer_trim_pool": (_int, [_vp]),

@@ -270,6 +270,26 @@ class Tokenizer:
         return {"epoch": int(out[0]), "state": ("waiting", "running", "done", "off")[min(int(out[1]), 3)], "sample_sentences": int(out[2]),
                 "min_sentences": int(out[3]), "ms": out[4] / 1e3, "moved_left": int(out[5]), "moved_right": int(out[6])}
 
+    def wait_connid_reorder(self, timeout_s=None):
+        """Blocks while a calibration of the internal renumbering is running (it runs on a background thread behind the tokenizer's
+        first large batch); True when none is running any more."""
+        idle = C.c_int(0)
+        N.check(N.lib().vbt_tokenizer_connid_reorder_wait(self._handle(), -1 if timeout_s is None else int(timeout_s * 1000), C.byref(idle)))
+        return bool(idle.value)
+
+    def calibrate(self, sentences=None, text=None, offsets=None):
+        """The internal renumbering of the connection ids done up front, synchronously, from host text (vbt_tokenizer_calibrate)."""
+        if sentences is not None:
+            enc = [_b(s) for s in sentences]
+            offsets = np.zeros(len(enc) + 1, dtype=np.uint64)
+            if enc:
+                offsets[1:] = np.cumsum([len(e) for e in enc])
+            text = np.frombuffer(b"".join(enc), dtype=np.uint8)
+        text = np.ascontiguousarray(text, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        N.check(N.lib().vbt_tokenizer_calibrate(self._handle(), text.ctypes.data if text.size else None, offsets.ctypes.data, len(offsets) - 1))
+        return self.connid_reorder_info()
+
     def dictionary(self):
         """Tokenizer::dictionary (tokenizer.rs:77-79)."""
         self._handle()

@@ -14,7 +14,10 @@
 #include <stdexcept>
 #include <string>
 #include <thread>
+#include <unordered_set>
 #include <vector>
+
+#include <unistd.h>
 
 #include <hsa/hsa.h>
 #include <hsa/hsa_ext_amd.h>
@@ -107,6 +110,7 @@ struct Sdma {
     static bool wait(std::vector<hsa_signal_t>& sigs) {
         bool good = true;
         for (hsa_signal_t sig : sigs) {
+            if (!sig.handle) continue;  // (waited for and destroyed already: the pipelined call lands its chunks one by one)
             while (hsa_signal_wait_scacquire(sig, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_ACTIVE) >= 1) {}
             if (hsa_signal_load_relaxed(sig) < 0) good = false;
             (void)hsa_signal_destroy(sig);
@@ -137,6 +141,8 @@ struct vbt_tokenizer {
     // instead of 877 k separately allocated std::strings (built at the first format call)
     struct FlatFeatures { std::vector<uint32_t> off; std::vector<char> blob; } flat[3];
     std::once_flag flat_once;
+    // tokens per KiB of text the batches so far produced at most (0: none yet): sizes the result block of a pipelined call up front
+    std::atomic<uint32_t> tok_per_kib{0};
     std::atomic<int> out_mode{-1};      // VBT_H2H_OUT: 0 = the packing kernel stores into the pinned block, 1 = SDMA copies (default); published with release once the replicas' Sdma exist
     ~vbt_tokenizer() { for (auto& r : reps) r->pool.clear(); }  // before the Tokenizers (workspaces reference them)
 };
@@ -406,44 +412,63 @@ void pool_give(vbt_tokenizer* tok, Replica& rep, std::unique_ptr<PooledWorkspace
 // front of the caller's pointer holds the capacity; the last few big ones are kept instead of freed: 100 MB of `tokenize` output per
 // batch would otherwise be mapped, faulted in page by page (the kernel zeroes every page first: that, not the copying, bounded the
 // formatter at ~10 GB/s on 64 threads) and unmapped again for every batch.
-struct OutHeader { uint64_t magic, cap; };
-constexpr uint64_t kOutMagic = 0x7662745F6F757462ull;
+// Only pointers this library handed out are ever touched: the live ones are registered, so a second vbt_free of the same pointer or
+// a pointer from somewhere else is IGNORED -- nothing in front of a foreign pointer is read, no block can enter the cache twice
+// (round-5 advisor).  The cache holds at most kOutCacheSlots buffers / kOutCacheMaxTotal bytes and is released by
+// vbt_tokenizer_trim_pool and vbt_tokenizer_free.
+struct OutHeader { uint64_t cap, pad; };
 constexpr size_t kOutCacheSlots = 4;
-constexpr uint64_t kOutCacheMinBytes = 1u << 20, kOutCacheMaxTotal = 2048ull << 20;
+constexpr uint64_t kOutCacheMinBytes = 1u << 20, kOutCacheMaxTotal = 512ull << 20;
 std::mutex g_out_mu;
-std::vector<OutHeader*> g_out_cache;
+std::vector<OutHeader*> g_out_cache;        // idle buffers
+std::unordered_set<const void*> g_out_live;  // the caller-side pointers of the buffers that are handed out
 
 void* out_alloc(size_t bytes) {
+    OutHeader* h = nullptr;
     if (bytes >= kOutCacheMinBytes) {
         std::lock_guard<std::mutex> g(g_out_mu);
         size_t best = g_out_cache.size();
         for (size_t i = 0; i < g_out_cache.size(); ++i)
             if (g_out_cache[i]->cap >= bytes && g_out_cache[i]->cap <= 2 * bytes + (1u << 20) && (best == g_out_cache.size() || g_out_cache[i]->cap < g_out_cache[best]->cap)) best = i;
         if (best != g_out_cache.size()) {
-            OutHeader* h = g_out_cache[best];
+            h = g_out_cache[best];
             g_out_cache.erase(g_out_cache.begin() + (long)best);
+            g_out_live.insert(h + 1);
             return h + 1;
         }
     }
     const size_t cap = bytes >= kOutCacheMinBytes ? bytes + bytes / 8 : (bytes ? bytes : 1);  // (head room: the next batch's output is about as long)
-    OutHeader* h = static_cast<OutHeader*>(std::malloc(sizeof(OutHeader) + cap));
+    h = static_cast<OutHeader*>(std::malloc(sizeof(OutHeader) + cap));
     if (!h) return nullptr;
-    h->magic = kOutMagic; h->cap = cap;
+    h->cap = cap; h->pad = 0;
+    std::lock_guard<std::mutex> g(g_out_mu);
+    g_out_live.insert(h + 1);
     return h + 1;
 }
 
 void out_free(void* p) {
     if (!p) return;
-    OutHeader* h = static_cast<OutHeader*>(p) - 1;
-    if (h->magic != kOutMagic) { std::free(p); return; }  // (not ours: a caller's own malloc -- be forgiving)
-    if (h->cap >= kOutCacheMinBytes) {
+    OutHeader* h = nullptr;
+    {
         std::lock_guard<std::mutex> g(g_out_mu);
-        uint64_t held = h->cap;
-        for (const OutHeader* q : g_out_cache) held += q->cap;
-        if (g_out_cache.size() < kOutCacheSlots && held <= kOutCacheMaxTotal) { g_out_cache.push_back(h); return; }
+        if (g_out_live.erase(p) == 0) return;  // not a live buffer of this library: freed already, or never ours
+        h = static_cast<OutHeader*>(p) - 1;
+        if (h->cap >= kOutCacheMinBytes) {
+            uint64_t held = h->cap;
+            for (const OutHeader* q : g_out_cache) held += q->cap;
+            if (g_out_cache.size() < kOutCacheSlots && held <= kOutCacheMaxTotal) { g_out_cache.push_back(h); return; }
+        }
     }
-    h->magic = 0;
     std::free(h);
+}
+
+void out_cache_trim() {
+    std::vector<OutHeader*> drop;
+    {
+        std::lock_guard<std::mutex> g(g_out_mu);
+        drop.swap(g_out_cache);
+    }
+    for (OutHeader* h : drop) std::free(h);
 }
 
 // Persistent host threads for the formatter (starting 63 threads per call cost 2-3 ms of a 10 ms call).  run(T, body): body(k) for
@@ -453,7 +478,16 @@ void out_free(void* p) {
 // at once gain nothing.
 class HostPool {
   public:
-    static HostPool& get() { static HostPool* p = new HostPool; return *p; }  // (leaked on purpose: parked threads at process exit)
+    // (leaked on purpose: parked threads at process exit.  One pool per PROCESS: a fork()ed child inherits the object with its thread
+    // count but none of the threads -- it would wait for workers that do not exist -- so the child gets a pool of its own.)
+    static HostPool& get() {
+        static std::mutex mu;
+        static HostPool* p = nullptr;
+        static pid_t owner = 0;
+        std::lock_guard<std::mutex> g(mu);
+        if (!p || owner != getpid()) { p = new HostPool; owner = getpid(); }
+        return *p;
+    }
     // reserves up to `want` workers (this thread included); returns the number granted; run() must follow with exactly that T
     unsigned begin(unsigned want) {
         job_mu_.lock();
@@ -464,9 +498,8 @@ class HostPool {
         }
         return std::min<unsigned>(want, threads_ + 1);
     }
-    template <typename F>
-    void run(unsigned T, F&& body) {
-        std::function<void(unsigned)> fn = body;
+    // (`fn` is built by the caller BEFORE begin(): nothing between begin() and the hand-over below can throw with job_mu_ held)
+    void run(unsigned T, std::function<void(unsigned)>& fn) {
         {
             std::lock_guard<std::mutex> g(mu_);
             fn_ = &fn; active_ = T; pending_ = T - 1; ++gen_;
@@ -688,11 +721,28 @@ int vbt_tokenizer_connid_reorder_info(const vbt_tokenizer* tok, uint64_t out[8])
     });
 }
 
+int vbt_tokenizer_calibrate(const vbt_tokenizer* tok, const uint8_t* text, const uint64_t* offsets, uint64_t n) {
+    return guarded([&] {
+        if (!tok || !offsets || (!text && n && offsets[n] != offsets[0])) throw Error(VBT_ERR_INVALID_ARGUMENT, "null argument");
+        for (auto& r : tok->reps) r->t->calibrate_host(text, offsets, n);
+    });
+}
+
+int vbt_tokenizer_connid_reorder_wait(const vbt_tokenizer* tok, int64_t timeout_ms, int* idle) {
+    return guarded([&] {
+        if (!tok) throw Error(VBT_ERR_INVALID_ARGUMENT, "null argument");
+        bool all = true;
+        for (auto& r : tok->reps) all = r->t->wait_calibration(timeout_ms) && all;
+        if (idle) *idle = all ? 1 : 0;
+    });
+}
+
 void vbt_tokenizer_free(vbt_tokenizer* tok) {
     if (!tok) return;
     for (auto& r : tok->reps) r->pool.clear();
     while (tok->reps.size() > 1) tok->reps.pop_back();  // the replicas that borrow the dictionary go first
     delete tok;
+    out_cache_trim();
 }
 
 const vbt_dict* vbt_tokenizer_dictionary(const vbt_tokenizer* tok) { return &tok->dict_view; }  // borrowed: do not free
@@ -968,24 +1018,43 @@ int vbt_tokenize_batch(const vbt_tokenizer* tok_, const uint8_t* text, const uin
             vbt_tokenizer* tok;
             std::unique_ptr<vbt_batch> b;
             std::vector<Shard> sh;
+            std::vector<hsa_signal_t> dma;                       // copies into out_blk still in flight (pipelined call)
+            std::vector<std::unique_ptr<PooledWorkspace>> pipe;  // the two chunk workspaces of a pipelined call (device of reps[0])
             ~Holder() {
+                (void)Sdma::wait(dma);  // nothing may still be writing into a block that goes back to the pool
+                for (auto& p : pipe)
+                    if (p) { (void)hipSetDevice(tok->reps[0]->t->device()); (void)hipStreamSynchronize(p->stream); pool_give(tok, *tok->reps[0], std::move(p)); }
                 for (size_t k = 0; k < sh.size(); ++k)
                     if (sh[k].p) { (void)hipSetDevice(tok->reps[k]->t->device()); (void)hipStreamSynchronize(sh[k].p->stream); pool_give(tok, *tok->reps[k], std::move(sh[k].p)); }
                 if (b) { host_give(tok, std::move(b->in_blk)); host_give(tok, std::move(b->out_blk)); }
             }
-        } h{tok, std::make_unique<vbt_batch>(), {}};
+        } h{tok, std::make_unique<vbt_batch>(), {}, {}, {}};
         vbt_batch& b = *h.b;
         b.tok = tok;
         b.n = n;
         // the batch's own copy of the input, in pinned memory: [n + 1 rebased offsets][text][8 bytes per shard: totals][per shard: its offsets rebased to the shard]
+        // One call, pipelined (single device, results by SDMA): the batch is cut into K chunks that alternate between two chunk-sized
+        // workspaces / streams -- the H2D copy and the host's preparation of chunk c + 1 and the D2H copy of chunk c - 1 run under the
+        // kernels of chunk c (tokenize/src/main.rs:76-95 is a single-threaded caller: without this, one call serialises copy in ->
+        // kernels -> copy out and reaches 20 M sentences/s where the kernels alone do 70).  VBT_H2H_CHUNKS (default 4; 1 = off);
+        // chunks of at least 2 MiB.  The result block has to exist before the first chunk's totals do: it is sized from the
+        // tokens per KiB the tokenizer's batches produced so far (the first batch runs unpipelined and sets it; a batch that
+        // outgrows the estimate is redone unpipelined).
+        uint32_t K = 1;
+        if (R == 1) {
+            static const uint32_t kmax = [] { const char* e = std::getenv("VBT_H2H_CHUNKS"); const int v = e && *e ? std::atoi(e) : 4; return (uint32_t)std::min(std::max(v, 1), 16); }();
+            K = (uint32_t)std::min<uint64_t>(kmax, std::max<uint64_t>(1, bytes >> 21));
+            if (n < 64ull * K || tok->tok_per_kib.load(std::memory_order_relaxed) == 0) K = 1;
+        }
+        const uint32_t parts = std::max(R, K);
         const size_t text_end = (n + 1) * 8 + ((bytes + 7) & ~(uint64_t)7);
-        b.in_blk = host_take(tok, text_end + 8 * R + (R > 1 ? (n + R) * 8 : 0) + 24);
+        b.in_blk = host_take(tok, text_end + 8 * parts + (parts > 1 ? (n + parts) * 8 : 0) + 24);
         uint64_t* offs = static_cast<uint64_t*>(b.in_blk->p);
         uint8_t* txt = reinterpret_cast<uint8_t*>(offs + n + 1);
         b.offsets = offs;
         b.text = txt;
         uint32_t* tails = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(b.in_blk->p) + text_end);  // per shard {n_tokens, error flags}
-        uint64_t* shard_offs = reinterpret_cast<uint64_t*>(tails + 2 * R);
+        uint64_t* shard_offs = reinterpret_cast<uint64_t*>(tails + 2 * parts);
         std::vector<uint64_t> bounds;
         shard_bounds(offsets, n, R, bounds);  // (on the caller's offsets: the rule only looks at differences)
         // How the results reach the host (VBT_H2H_OUT): 1 (default) = packed on the device, then copied by the GPU's SDMA engines
@@ -1005,6 +1074,113 @@ int vbt_tokenize_batch(const vbt_tokenizer* tok_, const uint8_t* text, const uin
             }
         }
         const bool use_sdma = tok->out_mode.load(std::memory_order_acquire) == 1;
+        auto note_ratio = [&](uint64_t total) {  // tokens per KiB, rounded up: the largest seen
+            if (!bytes) return;
+            const uint32_t r = (uint32_t)std::min<uint64_t>(0xFFFFFFu, (total * 1024 + bytes - 1) / bytes + 1);
+            uint32_t cur = tok->tok_per_kib.load(std::memory_order_relaxed);
+            while (r > cur && !tok->tok_per_kib.compare_exchange_weak(cur, r, std::memory_order_relaxed)) {}
+        };
+        if (K > 1 && use_sdma) {
+            struct Chunk { uint64_t s0, s1, b0, b1, tok_base = 0; uint32_t* tail; size_t first_sig = 0, n_sigs = 0; };
+            std::vector<uint64_t> cb;
+            shard_bounds(offsets, n, K, cb);
+            std::vector<Chunk> ch(K);
+            uint64_t max_s = 0, max_b = 0;
+            for (uint32_t c = 0; c < K; ++c) {
+                ch[c].s0 = cb[c]; ch[c].s1 = cb[c + 1];
+                ch[c].b0 = offsets[ch[c].s0] - lo; ch[c].b1 = offsets[ch[c].s1] - lo;
+                ch[c].tail = tails + 2 * c;
+                ch[c].tail[0] = ch[c].tail[1] = 0;
+                max_s = std::max(max_s, ch[c].s1 - ch[c].s0); max_b = std::max(max_b, ch[c].b1 - ch[c].b0);
+            }
+            Replica& rep = *tok->reps[0];
+            HIPX(hipSetDevice(rep.t->device()));
+            h.pipe.push_back(pool_take(tok, rep, max_s, max_b));
+            h.pipe.push_back(pool_take(tok, rep, max_s, max_b));
+            // the result block, from the estimate: 1/8 of head room + a token per sentence
+            const uint64_t cap_tokens = std::min<uint64_t>(bytes, (bytes * tok->tok_per_kib.load(std::memory_order_relaxed) / 1024) * 9 / 8 + n + 1024);
+            b.out_blk = host_take(tok, n * 8 + (size_t)cap_tokens * sizeof(vbt_token_rec) + 16);
+            uint32_t* o = static_cast<uint32_t*>(b.out_blk->p);
+            vbt_token_rec* otok = reinterpret_cast<vbt_token_rec*>(o + 2 * n);
+            uint64_t total = 0;
+            uint32_t error_flags = 0;
+            bool overflow = false;
+            std::vector<std::pair<size_t, size_t>> sig_range(K, {0, 0});
+            // chunk c's kernels are done: its totals are in; its results start their way to the host on the DMA engines
+            auto harvest = [&](uint32_t c) {
+                PooledWorkspace& p = *h.pipe[c & 1];
+                HIPX(hipStreamSynchronize(p.stream));
+                Chunk& q = ch[c];
+                error_flags |= q.tail[1];
+                q.tok_base = total;
+                if (q.tail[1] & kErrFatal) return;  // (a rejected batch: nothing to copy)
+                if (total + q.tail[0] > cap_tokens) { overflow = true; return; }
+                total += q.tail[0];
+                const uint64_t ns = q.s1 - q.s0;
+                const void* src[3] = {p.ws->d_tok_off, p.ws->d_tok_cnt, p.ws->d_tokens};
+                void* dst[3] = {o + q.s0, o + n + q.s0, otok + q.tok_base};
+                const size_t len[3] = {(size_t)ns * 4, (size_t)ns * 4, (size_t)q.tail[0] * sizeof(vbt_token_rec)};
+                sig_range[c].first = h.dma.size();
+                if (!rep.sdma->issue(src, dst, len, 3, h.dma)) throw Error(VBT_ERR_DEVICE, "device -> host copy of the results failed (hsa_amd_memory_async_copy)");
+                sig_range[c].second = h.dma.size();
+            };
+            // chunk c's copies have landed (before its workspace is used again, and at the end): rebase its token offsets to the batch
+            auto land = [&](uint32_t c) {
+                bool good = true;
+                for (size_t i = sig_range[c].first; i < sig_range[c].second; ++i) {
+                    hsa_signal_t sig = h.dma[i];
+                    if (!sig.handle) continue;
+                    while (hsa_signal_wait_scacquire(sig, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_ACTIVE) >= 1) {}
+                    if (hsa_signal_load_relaxed(sig) < 0) good = false;
+                    (void)hsa_signal_destroy(sig);
+                    h.dma[i].handle = 0;
+                }
+                if (!good) throw Error(VBT_ERR_DEVICE, "device -> host copy of the results failed (hsa_amd_memory_async_copy)");
+                if (ch[c].tok_base)
+                    for (uint64_t i = ch[c].s0; i < ch[c].s1; ++i) o[i] += (uint32_t)ch[c].tok_base;
+            };
+            for (uint32_t c = 0; c < K && !overflow; ++c) {
+                Chunk& q = ch[c];
+                const uint64_t ns = q.s1 - q.s0, nb = q.b1 - q.b0;
+                // the batch's own copy of this chunk's input, and its offsets rebased to the chunk
+                for (uint64_t i = q.s0; i < q.s1; ++i) offs[i] = offsets[i] - lo;
+                if (c + 1 == K) offs[n] = bytes;
+                if (nb) std::memcpy(txt + q.b0, text + lo + q.b0, nb);
+                uint64_t* so = shard_offs + q.s0 + c;
+                for (uint64_t i = 0; i <= ns; ++i) so[i] = offsets[q.s0 + i] - lo - q.b0;
+                if (c >= 2) land(c - 2);  // the workspace's previous results are out
+                PooledWorkspace& p = *h.pipe[c & 1];
+                if (ns) {
+                    if (nb) HIPX(hipMemcpyAsync(p.d_text, txt + q.b0, nb, hipMemcpyHostToDevice, p.stream));
+                    HIPX(hipMemcpyAsync(p.d_off, so, (ns + 1) * 8, hipMemcpyHostToDevice, p.stream));
+                    p.ws->run(static_cast<const uint8_t*>(p.d_text), p.d_off, ns, nb, p.stream, /*defer_pack=*/false);
+                    HIPX(hipMemcpyAsync(q.tail, p.ws->d_ctrl, 8, hipMemcpyDeviceToHost, p.stream));
+                }
+                if (c >= 1) harvest(c - 1);
+            }
+            if (!overflow) harvest(K - 1);
+            if (!overflow) {
+                for (uint32_t c = K >= 2 ? K - 2 : 0; c < K; ++c) land(c);
+                if (error_flags & kErrUtf8) {
+                    for (uint64_t i = 0; i < n; ++i)
+                        if (!valid_utf8(txt + offs[i], offs[i + 1] - offs[i])) throw Error(VBT_ERR_UTF8, "sentence " + std::to_string(i) + " is not valid UTF-8");
+                }
+                check_device_errors(error_flags);
+                b.n_tokens = total;
+                b.tok_off = o; b.tok_cnt = o + n; b.tokens = otok;
+                note_ratio(total);
+                for (auto& p : h.pipe) pool_give(tok, rep, std::move(p));
+                h.pipe.clear();
+                *out = h.b.release();
+                return;
+            }
+            // the estimate was too low for this text: drain, give everything back and run the batch unpipelined (exact sizing)
+            (void)Sdma::wait(h.dma);
+            for (auto& p : h.pipe) { HIPX(hipStreamSynchronize(p->stream)); pool_give(tok, rep, std::move(p)); }
+            h.pipe.clear();
+            host_give(tok, std::move(b.out_blk));
+            for (uint32_t c = 0; c < K; ++c) ch[c].tail[0] = ch[c].tail[1] = 0;
+        }
         h.sh.resize(R);
         // Every device is driven by ITS OWN host thread (a single-device tokenizer: the calling thread): the thread rebases its shard's
         // offsets, copies its shard of the text into the pinned block, enqueues the H2D copies and the launch sequence on its device
@@ -1069,6 +1245,7 @@ int vbt_tokenize_batch(const vbt_tokenizer* tok_, const uint8_t* text, const uin
         check_device_errors(error_flags);
         if (total >= 0xFFFFFFFFull) throw Error(VBT_ERR_INVALID_ARGUMENT, "batch too large (split it)");
         b.n_tokens = total;
+        note_ratio(total);
         b.out_blk = host_take(tok, n * 8 + (size_t)b.n_tokens * sizeof(vbt_token_rec) + 16);
         uint32_t* o = static_cast<uint32_t*>(b.out_blk->p);
         vbt_token_rec* otok = reinterpret_cast<vbt_token_rec*>(o + 2 * n);
@@ -1119,6 +1296,7 @@ int vbt_tokenizer_trim_pool(const vbt_tokenizer* tok_) {
             blocks.swap(tok->host_pool);
         }
         for (size_t k = 0; k < ws.size(); ++k) { HIPX(hipSetDevice(tok->reps[k]->t->device())); ws[k].clear(); }
+        out_cache_trim();  // the formatter's idle output buffers (process-wide)
     });
 }
 

@@ -174,8 +174,24 @@ Tokenizer::Tokenizer(const Dictionary* dict, bool ignore_space, uint32_t max_gro
     // internal renumbering of the connection ids by measured usage (maybe_calibrate): on unless VBT_CONNID_REORDER=0
     if (env_u32("VBT_CONNID_REORDER", 1) == 0) calib_state_.store(3);
     calib_min_ = std::max<uint32_t>(1, env_u32("VBT_CONNID_MIN_SENTENCES", 2048));
-    calib_sample_ = std::max<uint32_t>(1, env_u32("VBT_CONNID_SAMPLE", 16384));
+    calib_sample_ = std::min<uint32_t>(1u << 20, std::max<uint32_t>(1, env_u32("VBT_CONNID_SAMPLE", 16384)));
     info_.min_sentences = calib_min_;
+    if (calib_state_.load() == 0) {
+        // the sample buffers: 512 bytes per sample sentence (the mean Japanese sentence is ~140), between 1 and 32 MiB
+        try {
+            s_cap_bytes_ = std::min<uint64_t>(32ull << 20, std::max<uint64_t>(1ull << 20, 512 * calib_sample_));
+            HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&s_text_), s_cap_bytes_ + 16)); allocs_.push_back(s_text_);
+            HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&s_offs_), (calib_sample_ + 1) * 8)); allocs_.push_back(s_offs_);
+            HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&s_src_), calib_sample_ * 4 + 16)); allocs_.push_back(s_src_);
+            s_info_ = s_src_ + calib_sample_;
+            HIP_CHECK(hipEventCreateWithFlags(reinterpret_cast<hipEvent_t*>(&calib_event_), hipEventDisableTiming));
+            HIP_CHECK(hipStreamCreateWithFlags(reinterpret_cast<hipStream_t*>(&calib_stream_), hipStreamNonBlocking));
+        } catch (...) {
+            for (void* p : allocs_) (void)hipFree(p);
+            if (calib_event_) (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(calib_event_));
+            throw;
+        }
+    }
     cur_.store(img0.get(), std::memory_order_release);
     images_.push_back(std::move(img0));
 }
@@ -189,7 +205,10 @@ void Tokenizer::upload_lexicon(const Lexicon& lx, DevLexicon& out) {
 }
 
 Tokenizer::~Tokenizer() {
+    if (calib_thread_.joinable()) calib_thread_.join();  // (a calibration in flight reads the images and the sample buffers)
     (void)hipSetDevice(device_);
+    if (calib_event_) (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(calib_event_));
+    if (calib_stream_) (void)hipStreamDestroy(reinterpret_cast<hipStream_t>(calib_stream_));
     for (auto& im : images_)
         for (void* p : im->allocs) (void)hipFree(p);
     for (void* p : allocs_) (void)hipFree(p);
@@ -365,8 +384,9 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
     if (n > max_sentences || total_bytes > max_bytes) throw Error(VBT_ERR_INVALID_ARGUMENT, "batch exceeds the workspace capacity");
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     HIP_CHECK(hipSetDevice(tok.device()));
-    // the tokenizer's first large batch renumbers the connection ids of the device image by their measured usage (once)
-    if (!fused) tok.maybe_calibrate(d_text, d_offsets, n, stream_);
+    // the tokenizer's first large batch has a sample of itself copied aside (two small kernels on this stream); a background thread
+    // renumbers the connection ids of the device image by the usage it measures there and publishes the new image when it is ready
+    if (!fused) tok.maybe_calibrate(d_text, d_offsets, n, total_bytes, stream_);
     const DevImage& image = tok.image();  // one image for every launch of this batch
     if (count_connids && image.epoch != count_epoch) {  // the counters on the device are in another image's ids: fold them first
         if (has_run) fold_connid_counts();  // (not "last_stream != nullptr": the null stream is a stream)
@@ -650,39 +670,121 @@ void Workspace::reset_connid_counts() {
 
 // ------------------------------------------------------------------ connection ids by usage
 
-void Tokenizer::maybe_calibrate(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n, void* stream) const {
+void Tokenizer::finish_calibration(bool done, bool give_up) const {
+    {
+        std::lock_guard<std::mutex> g(calib_mu_);
+        // (a rejected sample -- error flags in its own run, an empty sample -- lets a later batch try again, three times at most)
+        if (!done && !give_up && ++calib_attempts_ >= 3) give_up = true;
+        calib_state_.store(done ? 2 : give_up ? 3 : 0, std::memory_order_release);
+    }
+    calib_cv_.notify_all();
+}
+
+bool Tokenizer::wait_calibration(int64_t timeout_ms) const {
+    std::unique_lock<std::mutex> g(calib_mu_);
+    auto idle = [&] { return calib_state_.load(std::memory_order_acquire) != 1; };
+    if (timeout_ms < 0) { calib_cv_.wait(g, idle); return true; }
+    return calib_cv_.wait_for(g, std::chrono::milliseconds(timeout_ms), idle);
+}
+
+void Tokenizer::maybe_calibrate(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n, uint64_t total_bytes, void* stream_) const {
     if (n < calib_min_ || calib_state_.load(std::memory_order_acquire) != 0) return;
-    int idle = 0;
-    if (!calib_state_.compare_exchange_strong(idle, 1)) return;  // another thread is at it: this batch runs on the current image
-    bool done = false;
+    {
+        std::lock_guard<std::mutex> g(calib_mu_);
+        int idle = 0;
+        if (!calib_state_.compare_exchange_strong(idle, 1)) return;  // another thread is at it: this batch runs on the current image
+        if (calib_thread_.joinable()) calib_thread_.join();  // (an earlier attempt whose sample was rejected: it has left the state at 0)
+    }
+    // everything the caller's stream gets: two small kernels and an event record -- no allocation, no synchronisation, no host wait
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    kern::sample_batch(stream, d_text, d_offsets, n, total_bytes, (uint32_t)calib_sample_, s_cap_bytes_, s_text_, s_offs_, s_src_, s_info_);
+    if (hipGetLastError() != hipSuccess || hipEventRecord(reinterpret_cast<hipEvent_t>(calib_event_), stream) != hipSuccess) {
+        finish_calibration(false, true);
+        return;
+    }
     try {
-        done = calibrate(d_text, d_offsets, n, stream);
-        calib_state_.store(done ? 2 : 0, std::memory_order_release);  // (not done: the sample was rejected -- a later batch tries again)
-    } catch (const std::exception& e) {
-        // an optimisation that cannot run (no memory for the sample's workspace, ...) must not fail the caller's batch: the image
-        // stays as it is, for good
-        if (std::getenv("VBT_DEBUG")) std::fprintf(stderr, "[vbt] connection-id renumbering given up: %s\n", e.what());
-        (void)hipGetLastError();
-        calib_state_.store(3, std::memory_order_release);
+        calib_thread_ = std::thread([this] { background_calibration(); });
+    } catch (const std::exception&) {
+        finish_calibration(false, true);  // out of threads: the image stays as it is
     }
 }
 
-bool Tokenizer::calibrate(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n, void* stream_) const {
+void Tokenizer::background_calibration() const {
+    bool done = false, give_up = false;
+    try {
+        HIP_CHECK(hipSetDevice(device_));
+        HIP_CHECK(hipEventSynchronize(reinterpret_cast<hipEvent_t>(calib_event_)));  // the sample is complete
+        hipStream_t cs = reinterpret_cast<hipStream_t>(calib_stream_);
+        uint32_t ns = 0;
+        HIP_CHECK(hipMemcpyAsync(&ns, s_info_, 4, hipMemcpyDeviceToHost, cs));
+        HIP_CHECK(hipStreamSynchronize(cs));
+        uint64_t bytes = 0;
+        if (ns) {
+            HIP_CHECK(hipMemcpyAsync(&bytes, s_offs_ + ns, 8, hipMemcpyDeviceToHost, cs));
+            HIP_CHECK(hipStreamSynchronize(cs));
+        }
+        done = ns != 0 && calibrate_sample(ns, bytes);
+    } catch (const std::exception& e) {
+        // an optimisation that cannot run (no memory for the sample's workspace, ...) must not fail anybody's batch: the image
+        // stays as it is, for good
+        if (std::getenv("VBT_DEBUG")) std::fprintf(stderr, "[vbt] connection-id renumbering given up: %s\n", e.what());
+        (void)hipGetLastError();
+        give_up = true;
+    }
+    finish_calibration(done, give_up);
+}
+
+void Tokenizer::calibrate_host(const uint8_t* text, const uint64_t* offsets, uint64_t n) const {
+    for (;;) {
+        const int st = calib_state_.load(std::memory_order_acquire);
+        if (st == 2 || st == 3 || n == 0) return;
+        if (st == 1) { wait_calibration(-1); continue; }
+        std::lock_guard<std::mutex> g(calib_mu_);
+        int idle = 0;
+        if (calib_state_.compare_exchange_strong(idle, 1)) { if (calib_thread_.joinable()) calib_thread_.join(); break; }
+    }
+    bool done = false, give_up = false;
+    try {
+        HIP_CHECK(hipSetDevice(device_));
+        // the sample, spread evenly over the caller's sentences (as sample_plan does it on the device), cut where the buffer ends
+        const uint64_t want = std::min<uint64_t>(n, calib_sample_);
+        std::vector<uint64_t> so(1, 0);
+        std::vector<uint8_t> st;
+        for (uint64_t j = 0; j < want; ++j) {
+            const uint64_t src = (uint64_t)(((unsigned __int128)j * n) / want);
+            if (offsets[src + 1] < offsets[src]) throw Error(VBT_ERR_INVALID_ARGUMENT, "offsets must be non-decreasing");
+            const uint64_t len = offsets[src + 1] - offsets[src];
+            if (so.back() + len > s_cap_bytes_) break;
+            st.insert(st.end(), text + offsets[src], text + offsets[src] + len);
+            so.push_back(so.back() + len);
+        }
+        const uint64_t ns = so.size() - 1;
+        if (ns) {
+            hipStream_t cs = reinterpret_cast<hipStream_t>(calib_stream_);
+            if (!st.empty()) HIP_CHECK(hipMemcpyAsync(s_text_, st.data(), st.size(), hipMemcpyHostToDevice, cs));
+            HIP_CHECK(hipMemcpyAsync(s_offs_, so.data(), so.size() * 8, hipMemcpyHostToDevice, cs));
+            HIP_CHECK(hipStreamSynchronize(cs));
+            done = calibrate_sample(ns, so.back());
+        }
+    } catch (const Error& e) {
+        finish_calibration(false, e.code != VBT_ERR_INVALID_ARGUMENT);
+        throw;
+    } catch (...) {
+        finish_calibration(false, true);
+        throw;
+    }
+    finish_calibration(done, give_up);
+}
+
+// The counting sweep over the sample (s_text_ / s_offs_, ns sentences) on the calibration stream, the sort, the renumbered image.
+bool Tokenizer::calibrate_sample(uint64_t ns, uint64_t bytes) const {
     const auto t0 = std::chrono::steady_clock::now();
-    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-    HIP_CHECK(hipSetDevice(device_));
-    HIP_CHECK(hipStreamSynchronize(stream));  // the caller's text and offsets are complete
-    const uint64_t ns = std::min<uint64_t>(n, calib_sample_);
-    uint64_t o0 = 0, o1 = 0;
-    HIP_CHECK(hipMemcpy(&o0, d_offsets, 8, hipMemcpyDeviceToHost));
-    HIP_CHECK(hipMemcpy(&o1, d_offsets + ns, 8, hipMemcpyDeviceToHost));
-    if (o1 < o0 || o1 - o0 >= 0xFFFFFFF0ull) return false;  // (the batch's own run reports what is wrong with it)
     const size_t nl = dict_->num_left, nr = dict_->num_right;
     std::vector<uint64_t> lid(nl), rid(nr);
     {
-        Workspace ws(*this, ns, o1 - o0);  // (its run() comes back here and finds the state "running")
+        Workspace ws(*this, ns, bytes);  // (its run() comes back to maybe_calibrate and finds the state "running")
         ws.enable_connid_counts(true);
-        ws.run(d_text, d_offsets, ns, o1 - o0, stream_);
+        ws.run(s_text_, s_offs_, ns, bytes, calib_stream_);
         vbt_call_stats st;
         ws.stats(&st);
         if (st.error_flags) return false;
@@ -702,7 +804,7 @@ bool Tokenizer::calibrate(const uint8_t* d_text, const uint64_t* d_offsets, uint
     const uint32_t ml = order(lid, pl), mr = order(rid, pr);
     std::unique_ptr<DevImage> im;
     if (ml || mr) {
-        im = renumbered_image(pl, pr, stream_);
+        im = renumbered_image(pl, pr, calib_stream_);
         im->epoch = 1;
     }
     std::lock_guard<std::mutex> g(img_mu_);

@@ -2,9 +2,11 @@
 // batch workspace and the kernel launch sequence.  See DESIGN.md for the layout.
 #pragma once
 #include <atomic>
+#include <condition_variable>
 #include <cstdint>
 #include <memory>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "dict.hpp"
@@ -146,16 +148,26 @@ class Tokenizer {
     const DevImage& image_of(uint32_t epoch) const;
     const DevDict& dev() const { return image().dev; }
     int device() const { return device_; }
-    // Called by Workspace::run in front of every batch: the first batch of >= min_sentences gets its first sentences (at most
-    // VBT_CONNID_SAMPLE, default 16384) swept once more with the connection-id counters on (the reorder tool's statistics,
-    // worker.rs:77-93, lattice.rs:170-183); the ids are sorted by count (mapper.rs:108-146) and a renumbered image -- permuted
-    // matrix, permuted id pairs in the entries -- replaces the current one for every later launch.  Synchronises `stream` once.
-    void maybe_calibrate(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n, void* stream) const;
+    // Called by Workspace::run in front of every batch.  The first batch of >= min_sentences triggers the renumbering of the device
+    // image's connection ids by measured usage -- WITHOUT blocking, allocating or synchronising anything on the caller's side: two small
+    // kernels on the caller's stream copy a sample (at most VBT_CONNID_SAMPLE = 16384 sentences, spread evenly over the batch) into
+    // buffers the tokenizer owns; a background host thread then sweeps the sample once more on a stream of its own with the
+    // connection-id counters on (the reorder tool's statistics, worker.rs:77-93, lattice.rs:170-183), sorts the ids by count
+    // (mapper.rs:108-146), builds the renumbered image -- permuted matrix, permuted id pairs in the entries -- and publishes it.
+    // Launches enqueued before that moment read the old image, later ones the new one; results do not depend on the image.
+    void maybe_calibrate(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n, uint64_t total_bytes, void* stream) const;
+    // The same from host buffers, synchronously (vbt_tokenizer_calibrate): for callers who want it done up front.  No-op when a
+    // calibration has already happened or is switched off; waits for one that is running.
+    void calibrate_host(const uint8_t* text, const uint64_t* offsets, uint64_t n) const;
+    // Returns once no calibration is running (state != 1), or after timeout_ms (< 0: no limit); true = not running.
+    bool wait_calibration(int64_t timeout_ms) const;
     ConnidReorderInfo reorder_info() const;
 
   private:
     void upload_lexicon(const Lexicon& lx, DevLexicon& out);
-    bool calibrate(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n, void* stream) const;
+    bool calibrate_sample(uint64_t ns, uint64_t bytes) const;  // counting sweep over the sample buffers + new image; false: sample rejected
+    void finish_calibration(bool done, bool give_up) const;
+    void background_calibration() const;
     std::unique_ptr<DevImage> renumbered_image(const std::vector<uint16_t>& perm_left, const std::vector<uint16_t>& perm_right, void* stream) const;
     const Dictionary* dict_;
     std::unique_ptr<Dictionary> owned_;
@@ -167,6 +179,17 @@ class Tokenizer {
     mutable std::atomic<int> calib_state_{0};
     mutable ConnidReorderInfo info_;
     uint64_t calib_min_ = 2048, calib_sample_ = 16384;
+    // the calibration sample (device memory owned by the tokenizer, allocated with the image when the renumbering is on), the event
+    // behind the kernels that fill it, the stream the counting sweep runs on, the thread that does it
+    uint8_t* s_text_ = nullptr;
+    uint64_t* s_offs_ = nullptr;
+    uint32_t *s_src_ = nullptr, *s_info_ = nullptr;
+    uint64_t s_cap_bytes_ = 0;
+    void *calib_event_ = nullptr, *calib_stream_ = nullptr;
+    mutable std::thread calib_thread_;
+    mutable std::mutex calib_mu_;
+    mutable std::condition_variable calib_cv_;
+    mutable int calib_attempts_ = 0;
 };
 
 class Workspace {

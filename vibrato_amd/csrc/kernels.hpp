@@ -48,5 +48,10 @@ void expand_connector_i32(dim3 grid, const DevConnector& c, int32_t* out, uint32
 // dst[l][r] = src[inv_left[l]][inv_right[r]] (i16 cells, or i32 when `wide`): the matrix under a renumbering of the connection ids
 void permute_matrix(hipStream_t stream, const void* src, void* dst, bool wide, const uint16_t* inv_left, const uint16_t* inv_right, uint32_t num_left, uint32_t num_right);
 
+// the calibration sample (Tokenizer::maybe_calibrate): up to `want` sentences spread evenly over the batch, copied into s_text / s_offs
+// (s_offs[0 .. k], k = info[0] = the sentences whose text fits cap_bytes; s_src: want words of scratch), on `stream`
+void sample_batch(hipStream_t stream, const uint8_t* text, const uint64_t* offsets, uint64_t n, uint64_t total_bytes, uint32_t want, uint64_t cap_bytes,
+                  uint8_t* s_text, uint64_t* s_offs, uint32_t* s_src, uint32_t* info);
+
 }  // namespace kern
 }  // namespace vbt

@@ -24,6 +24,16 @@ __device__ __forceinline__ uint32_t block_exscan(uint32_t v, uint32_t* warp_sums
     block_total = tot;
     return base + ex;
 }
+// Header of a packed result slot (Workspace::set_packed_output): {n_sentences u64, n_tokens u32, error flags u32, 0 x 4}.  A slot that
+// is too small for this batch reports the records it holds (never more than were written) and says so in the flags word -- a consumer
+// of the gathered slots on another rank sees nothing else of this rank's state (round-5 advisor).
+__device__ __forceinline__ void write_out_header(const BatchArgs& A, uint32_t all) {
+    if (!A.out_header) return;
+    const bool over = all > A.tok_cap;
+    A.out_header[0] = A.n; A.out_header[1] = 0u; A.out_header[2] = over ? A.tok_cap : all;
+    A.out_header[3] = A.ctrl[kError] | (over ? (uint32_t)kErrTokCap : 0u);
+    A.out_header[4] = 0u; A.out_header[5] = 0u; A.out_header[6] = 0u; A.out_header[7] = 0u;
+}
 __global__ void __launch_bounds__(1024) tok_tile_scan(BatchArgs A, uint32_t* tile_sums, uint32_t n_tiles) {
     __shared__ uint32_t ws[16];
     uint32_t running = 0;
@@ -37,7 +47,7 @@ __global__ void __launch_bounds__(1024) tok_tile_scan(BatchArgs A, uint32_t* til
     }
     if (threadIdx.x == 0) {
         A.ctrl[kTotal] = running;
-        if (A.out_header) { A.out_header[0] = A.n; A.out_header[1] = 0u; A.out_header[2] = running; A.out_header[3] = 0u; }
+        write_out_header(A, running);
     }
 }
 // kPackSplit (8) workgroups share a tile: each redoes the tile's (cheap) offset scan and copies every kPackSplit-th stripe of its
@@ -81,7 +91,7 @@ __global__ void __launch_bounds__(kScanBlock) compact_tokens(BatchArgs A, const 
         base = before;
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             A.ctrl[kTotal] = all;
-            if (A.out_header) { A.out_header[0] = A.n; A.out_header[1] = 0u; A.out_header[2] = all; A.out_header[3] = 0u; }  // {n_sentences u64, n_tokens u32, 0}
+            write_out_header(A, all);
         }
     }
     for (uint32_t i = 0; i < kScanItems; ++i) {
@@ -174,6 +184,58 @@ __global__ void __launch_bounds__(256) permute_matrix(const CellT* __restrict__ 
     dst[(size_t)l * num_right + r] = src[(size_t)inv_left[l] * num_right + inv_right[r]];
 }
 
+
+// The calibration sample of Tokenizer::maybe_calibrate (engine.hip): up to `want` sentences, spread evenly over the caller's batch
+// (sentence j of the sample = sentence floor(j n / ns) of the batch -- an ordered corpus, headlines first and body later, is sampled
+// over its whole length, not on its prefix), copied into the tokenizer's own buffers on the caller's stream: the counting sweep then
+// runs on a side stream from there, after the caller's buffers may be gone.  sample_plan (one workgroup): lengths, their prefix =
+// the sample's offsets, the number of sentences whose text fits `cap_bytes`; info = {sentences, bytes}.  Offsets that decrease or leave
+// the declared window give an empty sample (the batch's own run reports them).
+__global__ void __launch_bounds__(1024) sample_plan(const uint64_t* __restrict__ offsets, uint64_t n, uint64_t total_bytes, uint32_t want, uint64_t cap_bytes,
+                                                    uint64_t* __restrict__ s_offs, uint32_t* __restrict__ s_src, uint32_t* __restrict__ info) {
+    __shared__ uint32_t ws[16];
+    __shared__ uint32_t bad_any, unfit;  // unfit: the first sample sentence that does not fit any more
+    const uint64_t o0 = offsets[0], oN = offsets[n];
+    const uint32_t ns = (uint32_t)(n < want ? n : want);
+    if (threadIdx.x == 0) { bad_any = (oN < o0 || oN - o0 > total_bytes) ? 1u : 0u; unfit = ns; }
+    __syncthreads();
+    uint64_t running = 0;
+    for (uint32_t j0 = 0; j0 < ns; j0 += 1024) {
+        const uint32_t j = j0 + threadIdx.x;
+        uint32_t len = 0, src = 0;
+        bool huge = false;  // (a sentence of 4 MiB or more ends the sample; clipped, so that 1024 lengths add up in 32 bits)
+        if (j < ns) {
+            src = (uint32_t)(((unsigned __int128)j * n) / ns);
+            const uint64_t a = offsets[src], b = offsets[src + 1];
+            if (b < a || a < o0 || b > oN || b - a > 0xFFFFFFFFull) atomicOr(&bad_any, 1u);
+            else { huge = b - a > 0x3FFFFFull; len = huge ? 0x3FFFFFu : (uint32_t)(b - a); }
+            s_src[j] = src;
+        }
+        uint32_t tot;
+        const uint32_t ex = block_exscan(len, ws, tot);
+        if (j < ns) {
+            s_offs[j] = running + ex;
+            if (huge || running + ex + len > cap_bytes) atomicMin(&unfit, j);
+        }
+        running += tot;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t k = bad_any ? 0u : unfit;
+        info[0] = k;  // (s_offs[k] = start of the first sentence that does not fit = end of the last one that does)
+        if (k == ns) s_offs[ns] = running;
+    }
+}
+// one wavefront per sample sentence: its bytes into the sample text
+__global__ void __launch_bounds__(64) sample_copy(const uint8_t* __restrict__ text, const uint64_t* __restrict__ offsets, const uint64_t* __restrict__ s_offs,
+                                                  const uint32_t* __restrict__ s_src, const uint32_t* __restrict__ info, uint8_t* __restrict__ s_text) {
+    const uint32_t j = blockIdx.x;
+    if (j >= info[0]) return;
+    const uint32_t src = s_src[j];
+    const uint64_t a = offsets[src], len = offsets[src + 1] - a, to = s_offs[j];
+    for (uint64_t i = threadIdx.x; i < len; i += 64) s_text[to + i] = text[a + i];
+}
+
 }  // namespace
 
 namespace kern {
@@ -182,6 +244,12 @@ void permute_matrix(hipStream_t stream, const void* src, void* dst, bool wide, c
     const dim3 grid((num_right + 255) / 256, num_left);
     if (wide) hipLaunchKernelGGL(vbt::permute_matrix<int32_t>, grid, dim3(256), 0, stream, static_cast<const int32_t*>(src), static_cast<int32_t*>(dst), inv_left, inv_right, num_right);
     else hipLaunchKernelGGL(vbt::permute_matrix<int16_t>, grid, dim3(256), 0, stream, static_cast<const int16_t*>(src), static_cast<int16_t*>(dst), inv_left, inv_right, num_right);
+}
+
+void sample_batch(hipStream_t stream, const uint8_t* text, const uint64_t* offsets, uint64_t n, uint64_t total_bytes, uint32_t want, uint64_t cap_bytes,
+                  uint8_t* s_text, uint64_t* s_offs, uint32_t* s_src, uint32_t* info) {
+    hipLaunchKernelGGL(vbt::sample_plan, dim3(1), dim3(1024), 0, stream, offsets, n, total_bytes, want, cap_bytes, s_offs, s_src, info);
+    hipLaunchKernelGGL(vbt::sample_copy, dim3(want), dim3(64), 0, stream, text, offsets, s_offs, s_src, info, s_text);
 }
 
 uint32_t pack_split() { return kPackSplit; }

@@ -61,13 +61,13 @@ def packed_bytes(max_sentences, max_tokens):
 
 def pack_results(out, n_sentences, n_tokens, total_dev, tok_off, tok_cnt, tokens, max_sentences):
     """Lays one rank's results out in `out` (uint8 tensor of packed_bytes(...) bytes, 8-byte aligned):
-    header {n_sentences u64, n_tokens u32 (copied from the device counter `total_dev`), 0}, tok_off[u32 x
+    header {n_sentences u64, n_tokens u32 (copied from the device counter `total_dev`), error flags u32 = 0, 0 x 16 bytes}, tok_off[u32 x
     max_sentences], tok_cnt[u32 x max_sentences], then the first `n_tokens` token records.  tok_off / tok_cnt /
     tokens / total_dev are uint8 views of the workspace's result buffers (device_view); only device-side copies and
     fills are issued, on the current stream -- nothing passes through host memory."""
     import torch
     out[:8].view(torch.int64).fill_(int(n_sentences))
-    out[8:16].zero_()
+    out[8:_HEADER].zero_()
     out[8:12].copy_(total_dev[:4], non_blocking=True)
     base = _HEADER
     out[base:base + 4 * n_sentences].copy_(tok_off[:4 * n_sentences], non_blocking=True)
@@ -114,10 +114,14 @@ def gather_to_root(send, root_out=None, root=0, group=None, async_op=False):
 
 
 def unpack_results(slot, max_sentences):
-    """Host view of one rank's slot: (n_sentences, n_tokens, tok_off, tok_cnt, tokens[structured])."""
+    """Host view of one rank's slot: (n_sentences, n_tokens, tok_off, tok_cnt, tokens[structured]).  Raises if the rank that wrote
+    the slot flagged it (header word 3: device error flags, e.g. 1 = the slot was too small for the rank's tokens)."""
     from .api import TOKEN_DTYPE
     raw = slot.cpu().numpy()
     n_s, n_t = int(raw[:8].view(np.int64)[0]), int(raw[8:12].view(np.uint32)[0])
+    flags = int(raw[12:16].view(np.uint32)[0])
+    if flags:
+        raise RuntimeError(f"packed result slot carries device error flags {flags} (1 = slot too small for the batch's tokens)")
     base = _HEADER
     off = raw[base:base + 4 * n_s].view(np.uint32)
     base += 4 * max_sentences
