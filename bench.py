@@ -247,7 +247,8 @@ def main():
         to_all = args.gather == "all"
         gather = {"send": [torch.empty(slot, dtype=torch.uint8, device="cuda") for _ in range(2)],
                   "out": [torch.empty(world * slot, dtype=torch.uint8, device="cuda") if (to_all or rank == 0) else None for _ in range(2)],
-                  "work": [None, None], "comm": torch.cuda.Stream(), "slot": slot, "max_s": max_s, "k": 0}
+                  "work": [None, None], "comm": torch.cuda.Stream(), "slot": slot, "max_s": max_s, "k": 0,
+                  "ev": [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(2)]}
 
     def step():
         if gather is None:
@@ -264,10 +265,12 @@ def main():
         ready.record()
         with torch.cuda.stream(gather["comm"]):
             gather["comm"].wait_event(ready)
+            gather["ev"][b][0].record()  # (the collective of this step, timed on the communication stream: per_rank.gather_ms)
             if to_all:
                 _, gather["work"][b] = sharding.gather_packed(gather["send"][b], gather["out"][b], async_op=True)
             else:
                 _, gather["work"][b] = sharding.gather_to_root(gather["send"][b], gather["out"][b], root=0, async_op=True)
+            gather["ev"][b][1].record()
 
     def drain():
         if gather is not None:
@@ -295,7 +298,24 @@ def main():
         ri = tok.connid_reorder_info()
         reorder_info = ("internal" if ri["epoch"] else "off") if world > 1 else {"mode": "internal" if ri["epoch"] else "off", **ri}
     gathered_ok = None
+    per_rank = None
     if world > 1:
+        # what every rank did, so that the first run on real GPUs explains itself: its own wall time per step (the job's is the
+        # maximum), the kernels of its last step (hipEvents on the launch stream), the gather of its last step on the communication
+        # stream (under RCCL an asynchronous collective is "done" for a non-root rank once its send is), and its share of the corpus
+        lastb = (gather["k"] - 1) & 1
+        torch.cuda.synchronize()
+        g_ms = gather["ev"][lastb][0].elapsed_time(gather["ev"][lastb][1])
+        mine = torch.tensor([elapsed / args.steps * 1e3, st["ms_tier0"], st["ms_tier12"], st["ms_pack"], g_ms, float(n), float(nbytes), float(total_tokens)],
+                            dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        rows = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(rows, mine)
+        per_rank = [{"rank": r, "ms_per_step": round(float(x[0]), 4), "gen_ms": round(float(x[1]), 4), "lattice_ms": round(float(x[2]), 4),
+                     "pack_ms": round(float(x[3]), 4), "gather_ms": round(float(x[4]), 4), "sentences": int(x[5]), "bytes": int(x[6]), "tokens": int(x[7])}
+                    for r, x in enumerate(rows)]
+        slowest = max(p_["ms_per_step"] for p_ in per_rank)
+        for p_ in per_rank:
+            p_["idle_ms_per_step"] = round(slowest - p_["ms_per_step"], 4)  # what the rank waits for the slowest one at the closing barrier
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -334,7 +354,7 @@ def main():
     # point pays -- the copy of the text into the batch, H2D, kernels, D2H of the token records into host memory
     h2h = None
     if not args.no_host_pipeline and world == 1:
-        h2h = {"one_call": tok.host_pipeline_benchmark(text, offs, threads=1, rounds=1),
+        h2h = {"one_call": tok.host_pipeline_benchmark(text, offs, threads=1, rounds=1, repeats=6),
                "pipelined": tok.host_pipeline_benchmark(text, offs, threads=4, rounds=4),
                "pipelined_8_threads": tok.host_pipeline_benchmark(text, offs, threads=8, rounds=4)}
         # one tokenizer over several replicas of the image (vbt_tokenizer_new_multi; this box has one GPU, so device 0 is listed 4 and 8
@@ -496,9 +516,10 @@ def main():
         # ---- the output stage: text in -> MeCab-format text out (tokenize/src/main.rs:78-95), never `value` ----
         fmt = None
         if not args.no_host_pipeline and world == 1:
-            bt = tok.tokenize_batch(text=text, offsets=offs)  # warm: pooled workspace and pinned blocks exist
-            bt.format_bytes("mecab")
-            del bt
+            for _ in range(3):  # warm: pooled workspaces and pinned blocks exist, and the calls just before this leg (several host
+                bt = tok.tokenize_batch(text=text, offsets=offs)  # threads at once) no longer count as "concurrent callers": a lone call is pipelined
+                bt.format_bytes("mecab")
+                del bt
             t_e = time.perf_counter()
             bt = tok.tokenize_batch(text=text, offsets=offs)
             t_tok = time.perf_counter() - t_e
@@ -580,11 +601,20 @@ def main():
             "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
             "dtype": "i32 costs / i16 matrix / u32 ids",
             "data": "synthetic", "input_MB_per_s": round(total_bytes_all * args.steps / elapsed / 1e6, 2),
+            # what a drop-in's single-threaded caller sees (tokenize/src/main.rs:76-95): ONE vbt_tokenize_batch call, one host thread,
+            # host text in -> token records in host memory (H2D, kernels and D2H pipelined in chunks inside the call); never `value`
+            "value_host_to_host": (h2h["one_call"]["sentences_per_s"] if h2h else None),
+            "value_text_in_to_mecab_text_out": (fmt["text_in_to_text_out_sentences_per_s"] if fmt else None),
             "config": {"workload": workload,
+                       "value_is": "device-resident: text and offsets in HBM when the timed region starts, token records left in HBM (the PCIe-inclusive "
+                                   "rates are value_host_to_host / host_to_host / format)",
                        "baseline_config": 4 if world > 1 else (5 if args.ignore_space and args.user_lexicon else 3 if args.dict == "unidic" else None),
                        "ignore_space": args.ignore_space, "max_grouping_len": args.max_grouping_len, "user_lexicon_words": args.user_lexicon,
                        "connection_ids_reordered": reorder_info, "parallelism": par},
             "parity_vs_oracle_sample": parity, "tokens_per_step": total_tokens,
+            "parity_gate": "this run compared a 5 000-sentence sample of the timed batch (3 000 per suite leg) and the formatter's bytes with the oracle; the "
+                           "full-size comparisons (configs 2, 3, 5 and the dense law: every record of 100 000 sentences) are tests/test_gpu_parity.py",
+            "per_rank": per_rank,
             "gather": ({"bytes_per_rank_slot": gather["slot"], "collective": "all_gather_into_tensor" if args.gather == "all" else "gather to rank 0 (grouped send/recv)", "device_resident": True,
                         "delivered_all_shards": bool(gathered_ok)} if world > 1 else None),
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all,

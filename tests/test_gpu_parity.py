@@ -800,3 +800,38 @@ print("OK")
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, VBT_H2H_OUT="0"), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-2000:]
+
+
+def test_one_call_pipelined_in_chunks_matches_oracle_and_survives_a_wrong_estimate():
+    """vbt_tokenize_batch on a single device cuts a batch of >= 4 MiB into chunks that alternate between two workspaces (copy in,
+    kernels and copy out of neighbouring chunks overlap; tokenize/src/main.rs:76-95 is a single-threaded caller).  The result block
+    is sized from the tokens per KiB seen so far: the tokenizer's first batch runs unpipelined, the second one in chunks -- same
+    records, offsets ascending over the chunk borders, empty sentences at the borders -- and a text that yields five times the
+    tokens per byte (single letters between spaces) outgrows the estimate and is redone unpipelined, again with the oracle's records."""
+    sd = synth.SynthDict("small")
+    to, tv = _oracle_and_product(sd)
+    text, offs = sd.sentences(45000, "lognormal_40")
+    assert len(text) > (4 << 20)
+    # empty sentences where the chunk borders will fall (the bounds are cut by bytes)
+    mid = int(np.searchsorted(offs, offs[-1] // 2))
+    offs = np.concatenate([offs[:mid + 1], offs[mid:mid + 1], offs[mid:mid + 1], offs[mid + 1:]]).astype(np.uint64)
+    created0 = tv.pool_stats()[0]
+    _assert_batch_equal(to, tv, text, offs)  # unpipelined: one workspace
+    assert tv.pool_stats()[0] == created0 + 1
+    batch, _ = _assert_batch_equal(to, tv, text, offs)  # in chunks, over two workspaces: the idle one and a new one
+    assert tv.pool_stats()[0] == created0 + 2
+    toks, off, cnt = batch.arrays()
+    live = cnt > 0
+    assert np.all(np.diff(off[live].astype(np.int64)) == cnt[live][:-1])  # packed in sentence order across the chunk borders
+    _assert_batch_equal(to, tv, text, offs)
+    assert tv.pool_stats()[0] == created0 + 2  # steady state: nothing new
+    dense = ("a " * 100).encode()
+    enc = [dense] * 24000
+    o2 = np.zeros(len(enc) + 1, dtype=np.uint64)
+    o2[1:] = np.cumsum([len(e) for e in enc])
+    t2 = np.frombuffer(b"".join(enc), dtype=np.uint8)
+    assert len(t2) > (4 << 20)
+    _, ntok = _assert_batch_equal(to, tv, t2, o2)  # estimate too low: redone unpipelined
+    assert ntok > 4 * 24000 * 40
+    _assert_batch_equal(to, tv, t2, o2)  # and now the estimate holds
+    _assert_batch_equal(to, tv, text, offs)

@@ -17,6 +17,8 @@
 #include <unordered_set>
 #include <vector>
 
+#include <pthread.h>
+#include <sched.h>
 #include <unistd.h>
 
 #include <hsa/hsa.h>
@@ -39,9 +41,11 @@ struct PooledWorkspace {
     void* d_text = nullptr;
     uint64_t* d_off = nullptr;
     hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;  // behind the last command of a chunk (pipelined host call)
     uint64_t cap_sentences = 0, cap_bytes = 0;
     ~PooledWorkspace() {
         ws.reset();
+        if (done) (void)hipEventDestroy(done);
         (void)hipFree(d_text);
         (void)hipFree(d_off);
         if (stream) (void)hipStreamDestroy(stream);
@@ -90,7 +94,48 @@ struct Sdma {
         hsa_agent_t near{};
         if (hsa_agent_get_info(gpu, static_cast<hsa_agent_info_t>(HSA_AMD_AGENT_INFO_NEAREST_CPU), &near) == HSA_STATUS_SUCCESS && near.handle) cpu = near;
         ok = true;
+        // Which SDMA engine carries the results.  Left to the runtime (hsa_amd_memory_async_copy) the choice depends on what else the
+        // process has done with the device: inside an application that had used torch's copies before, the default landed on an engine
+        // that moved the 68 MB of a headline batch at 29 GB/s instead of 52 -- one host call 28 M instead of 40 M sentences/s, and the
+        // unexplained 18 vs 27 M box-to-box spread of round 5's text -> text leg.  So the engines are timed once, here (a 4 MiB copy,
+        // best of two, on each of the first four engines the device -> host direction offers and on the default entry point), and the
+        // fastest is used from then on.  VBT_SDMA_ENGINE=<bit index> picks one, -1 = the default entry point.
+        uint32_t mask = 0;
+        const bool have = hsa_amd_memory_copy_engine_status(cpu, gpu, &mask) == HSA_STATUS_SUCCESS;
+        if (const char* e = std::getenv("VBT_SDMA_ENGINE")) {
+            const int want = std::atoi(e);
+            if (want >= 0 && want < 16 && have && (mask >> want & 1u)) engine = 1u << want;
+        } else if (have && mask) {
+            constexpr size_t kProbe = 4u << 20;
+            void *d = nullptr, *hst = nullptr;
+            if (hipMalloc(&d, kProbe) == hipSuccess && hipHostMalloc(&hst, kProbe, hipHostMallocPortable) == hipSuccess) {
+                double best = 1e30;
+                uint32_t best_engine = 0;
+                for (int cand = -1; cand < 4; ++cand) {
+                    if (cand >= 0 && !(mask >> cand & 1u)) continue;
+                    engine = cand < 0 ? 0u : 1u << cand;
+                    double t_min = 1e30;
+                    for (int rep = 0; rep < 3; ++rep) {
+                        std::vector<hsa_signal_t> sigs;
+                        const void* src[1] = {d};
+                        void* dst[1] = {hst};
+                        const size_t len[1] = {kProbe};
+                        const auto t0 = std::chrono::steady_clock::now();
+                        const bool good = issue(src, dst, len, 1, sigs) && wait(sigs);
+                        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                        if (!good) { t_min = 1e30; break; }
+                        if (rep) t_min = std::min(t_min, dt);  // (the first copy on an engine sets its queue up)
+                    }
+                    if (t_min < best * 0.97) { best = t_min; best_engine = engine; }  // (the default entry point wins ties)
+                }
+                engine = best_engine;
+                if (std::getenv("VBT_DEBUG")) std::fprintf(stderr, "[vbt] SDMA engine for results: %s%u (%.1f GB/s on the probe)\n", engine ? "bit mask " : "runtime's choice ", engine, kProbe / best / 1e9);
+            }
+            if (hst) (void)hipHostFree(hst);
+            if (d) (void)hipFree(d);
+        }
     }
+    uint32_t engine = 0;  // hsa_amd_sdma_engine_id_t of the device -> host copies (0: hsa_amd_memory_async_copy picks)
     // dst[k] (pinned host) <- src[k] (device), bytes[k].  issue() starts the copies and appends one completion signal per copy
     // (initial value 1: what rocprofv3's memory-copy tracing expects of a caller, it aborts on a shared, counted signal); wait()
     // returns when all have landed.  Split in two so that the copies of several devices run side by side.
@@ -99,12 +144,29 @@ struct Sdma {
             if (!bytes[k]) continue;
             hsa_signal_t sig;
             if (hsa_signal_create(1, 0, nullptr, &sig) != HSA_STATUS_SUCCESS) return false;
-            if (hsa_amd_memory_async_copy(dst[k], cpu, src[k], gpu, bytes[k], 0, nullptr, sig) != HSA_STATUS_SUCCESS) {
+            const hsa_status_t st = engine ? hsa_amd_memory_async_copy_on_engine(dst[k], cpu, src[k], gpu, bytes[k], 0, nullptr, sig, static_cast<hsa_amd_sdma_engine_id_t>(engine), false)
+                                           : hsa_amd_memory_async_copy(dst[k], cpu, src[k], gpu, bytes[k], 0, nullptr, sig);
+            if (st != HSA_STATUS_SUCCESS) {
                 (void)hsa_signal_destroy(sig);
                 return false;
             }
             sigs.push_back(sig);
         }
+        return true;
+    }
+    // dst (device) <- src (pinned host): the way in, next to the HIP runtime as well -- a copy the runtime enqueues on a stream waits for
+    // everything in front of it in the stream's HARDWARE queue, and with the runtime's default of four hardware queues (an application
+    // that initialised HIP before this library: GPU_MAX_HW_QUEUES can no longer be raised) the streams of a pipelined call's chunks
+    // share queues: chunk c + 1's text then waited for chunk c's kernels and a pipelined call was slower than an unpipelined one
+    bool issue_h2d(const void* src, void* dst, size_t bytes, std::vector<hsa_signal_t>& sigs) const {
+        if (!bytes) return true;
+        hsa_signal_t sig;
+        if (hsa_signal_create(1, 0, nullptr, &sig) != HSA_STATUS_SUCCESS) return false;
+        if (hsa_amd_memory_async_copy(dst, gpu, src, cpu, bytes, 0, nullptr, sig) != HSA_STATUS_SUCCESS) {
+            (void)hsa_signal_destroy(sig);
+            return false;
+        }
+        sigs.push_back(sig);
         return true;
     }
     static bool wait(std::vector<hsa_signal_t>& sigs) {
@@ -121,7 +183,36 @@ struct Sdma {
 };
 
 // One device of a tokenizer: the dictionary's device image, the idle workspaces of that device and its DMA engines.
+// The CPUs of the NUMA node a device hangs off (sysfs: /sys/bus/pci/devices/<domain:bus:device.function>/numa_node, then
+// /sys/devices/system/node/node<N>/cpulist); empty when the platform does not say.  The host thread that drives a device of a
+// multi-device call is pinned there: it copies the shard's text into pinned memory and polls the device's signals.
+static std::vector<int> cpus_near_device(int device) {
+    std::vector<int> cpus;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return cpus;
+    char path[128];
+    std::snprintf(path, sizeof(path), "/sys/bus/pci/devices/%04x:%02x:%02x.0/numa_node", prop.pciDomainID, prop.pciBusID, prop.pciDeviceID);
+    int node = -1;
+    if (FILE* f = std::fopen(path, "r")) { if (std::fscanf(f, "%d", &node) != 1) node = -1; std::fclose(f); }
+    if (node < 0) return cpus;
+    std::snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+    FILE* f = std::fopen(path, "r");
+    if (!f) return cpus;
+    int a = 0, b = 0;
+    for (;;) {  // "0-63,128-191"
+        if (std::fscanf(f, "%d", &a) != 1) break;
+        b = a;
+        int c = std::fgetc(f);
+        if (c == '-') { if (std::fscanf(f, "%d", &b) != 1) break; c = std::fgetc(f); }
+        for (int i = a; i <= b && i < CPU_SETSIZE; ++i) cpus.push_back(i);
+        if (c != ',') break;
+    }
+    std::fclose(f);
+    return cpus;
+}
+
 struct Replica {
+    std::vector<int> near_cpus;                          // CPUs of the device's NUMA node (empty: unknown)
     std::unique_ptr<Tokenizer> t;
     std::vector<std::unique_ptr<PooledWorkspace>> pool;  // idle workspaces (guarded by the tokenizer's pool_mu)
     std::unique_ptr<Sdma> sdma;                          // device -> pinned-host copies on the DMA engines (created at the first host batch)
@@ -143,6 +234,11 @@ struct vbt_tokenizer {
     std::once_flag flat_once;
     // tokens per KiB of text the batches so far produced at most (0: none yet): sizes the result block of a pipelined call up front
     std::atomic<uint32_t> tok_per_kib{0};
+    // vbt_tokenize_batch calls running right now, calls started so far, and the last call that saw another one in flight: only a
+    // caller that has been alone for a while gets its batch pipelined in chunks (host threads that stream batches side by side
+    // overlap each other's copies and kernels already; a chunked call in their midst is slower for everybody)
+    std::atomic<int> calls_in_flight{0};
+    std::atomic<uint64_t> call_seq{0}, last_concurrent{0};
     std::atomic<int> out_mode{-1};      // VBT_H2H_OUT: 0 = the packing kernel stores into the pinned block, 1 = SDMA copies (default); published with release once the replicas' Sdma exist
     ~vbt_tokenizer() { for (auto& r : reps) r->pool.clear(); }  // before the Tokenizers (workspaces reference them)
 };
@@ -318,6 +414,7 @@ std::unique_ptr<PooledWorkspace> pool_take(vbt_tokenizer* tok, Replica& rep, uin
     HIPX(hipMalloc(&p->d_text, p->cap_bytes));
     HIPX(hipMalloc(reinterpret_cast<void**>(&p->d_off), (p->cap_sentences + 1) * 8));
     HIPX(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+    HIPX(hipEventCreateWithFlags(&p->done, hipEventDisableTiming));
     return p;
 }
 
@@ -694,6 +791,7 @@ int vbt_tokenizer_new_multi(vbt_dict* dict, int ignore_space, uint32_t max_group
             auto rep = std::make_unique<Replica>();
             rep->t = std::make_unique<Tokenizer>(dict->d, ignore_space != 0, max_grouping_len, devices[k]);  // (leaves that device current)
             rep->dev_budget = device_pool_budget();
+            rep->near_cpus = cpus_near_device(rep->t->device());
             h->reps.push_back(std::move(rep));
         }
         h->reps[0]->t->adopt(std::unique_ptr<Dictionary>(dict->d));  // the other replicas borrow it: reps[0] is destroyed last
@@ -1018,9 +1116,12 @@ int vbt_tokenize_batch(const vbt_tokenizer* tok_, const uint8_t* text, const uin
             vbt_tokenizer* tok;
             std::unique_ptr<vbt_batch> b;
             std::vector<Shard> sh;
+            int alone = 0;                                       // calls in flight on this tokenizer, this one included, when it started
+            uint64_t seq = 0;                                    // this call's number
             std::vector<hsa_signal_t> dma;                       // copies into out_blk still in flight (pipelined call)
-            std::vector<std::unique_ptr<PooledWorkspace>> pipe;  // the two chunk workspaces of a pipelined call (device of reps[0])
+            std::vector<std::unique_ptr<PooledWorkspace>> pipe;  // the chunk workspaces of a pipelined call (device of reps[0])
             ~Holder() {
+                if (tok->calls_in_flight.fetch_sub(1, std::memory_order_relaxed) > 1) tok->last_concurrent.store(tok->call_seq.load(std::memory_order_relaxed), std::memory_order_relaxed);
                 (void)Sdma::wait(dma);  // nothing may still be writing into a block that goes back to the pool
                 for (auto& p : pipe)
                     if (p) { (void)hipSetDevice(tok->reps[0]->t->device()); (void)hipStreamSynchronize(p->stream); pool_give(tok, *tok->reps[0], std::move(p)); }
@@ -1028,7 +1129,8 @@ int vbt_tokenize_batch(const vbt_tokenizer* tok_, const uint8_t* text, const uin
                     if (sh[k].p) { (void)hipSetDevice(tok->reps[k]->t->device()); (void)hipStreamSynchronize(sh[k].p->stream); pool_give(tok, *tok->reps[k], std::move(sh[k].p)); }
                 if (b) { host_give(tok, std::move(b->in_blk)); host_give(tok, std::move(b->out_blk)); }
             }
-        } h{tok, std::make_unique<vbt_batch>(), {}, {}, {}};
+        } h{tok, std::make_unique<vbt_batch>(), {}, tok->calls_in_flight.fetch_add(1, std::memory_order_relaxed) + 1, tok->call_seq.fetch_add(1, std::memory_order_relaxed) + 1, {}, {}};
+        if (h.alone > 1) tok->last_concurrent.store(h.seq, std::memory_order_relaxed);
         vbt_batch& b = *h.b;
         b.tok = tok;
         b.n = n;
@@ -1036,15 +1138,19 @@ int vbt_tokenize_batch(const vbt_tokenizer* tok_, const uint8_t* text, const uin
         // One call, pipelined (single device, results by SDMA): the batch is cut into K chunks that alternate between two chunk-sized
         // workspaces / streams -- the H2D copy and the host's preparation of chunk c + 1 and the D2H copy of chunk c - 1 run under the
         // kernels of chunk c (tokenize/src/main.rs:76-95 is a single-threaded caller: without this, one call serialises copy in ->
-        // kernels -> copy out and reaches 20 M sentences/s where the kernels alone do 70).  VBT_H2H_CHUNKS (default 4; 1 = off);
+        // kernels -> copy out and reaches 20 M sentences/s where the kernels alone do 70).  VBT_H2H_CHUNKS (default 5; 1 = off);
         // chunks of at least 2 MiB.  The result block has to exist before the first chunk's totals do: it is sized from the
         // tokens per KiB the tokenizer's batches produced so far (the first batch runs unpipelined and sets it; a batch that
         // outgrows the estimate is redone unpipelined).
         uint32_t K = 1;
         if (R == 1) {
-            static const uint32_t kmax = [] { const char* e = std::getenv("VBT_H2H_CHUNKS"); const int v = e && *e ? std::atoi(e) : 4; return (uint32_t)std::min(std::max(v, 1), 16); }();
+            static const uint32_t kmax = [] { const char* e = std::getenv("VBT_H2H_CHUNKS"); const int v = e && *e ? std::atoi(e) : 5; return (uint32_t)std::min(std::max(v, 1), 16); }();
             K = (uint32_t)std::min<uint64_t>(kmax, std::max<uint64_t>(1, bytes >> 21));
             if (n < 64ull * K || tok->tok_per_kib.load(std::memory_order_relaxed) == 0) K = 1;
+            // several host threads streaming batches overlap each other's copies and kernels already (4 threads: 58-62 M sentences/s
+            // whole batches, 51 M with every call cut into chunks): only a lone call is cut
+            const uint64_t lc = tok->last_concurrent.load(std::memory_order_relaxed);
+            if (h.alone > 1 || (lc && h.seq - lc <= 2)) K = 1;
         }
         const uint32_t parts = std::max(R, K);
         const size_t text_end = (n + 1) * 8 + ((bytes + 7) & ~(uint64_t)7);
@@ -1082,8 +1188,20 @@ int vbt_tokenize_batch(const vbt_tokenizer* tok_, const uint8_t* text, const uin
         };
         if (K > 1 && use_sdma) {
             struct Chunk { uint64_t s0, s1, b0, b1, tok_base = 0; uint32_t* tail; size_t first_sig = 0, n_sigs = 0; };
-            std::vector<uint64_t> cb;
-            shard_bounds(offsets, n, K, cb);
+            // chunk borders by bytes, at sentence borders; the first and the last chunk half as long as the others: the head of the call
+            // (copying the first chunk together, its H2D) and its tail (the last chunk's D2H) are what nothing overlaps
+            std::vector<uint64_t> cb(K + 1, n);
+            cb[0] = 0;
+            {
+                const uint32_t wt = K >= 3 ? 2 * (K - 1) : K;
+                uint32_t acc = 0;
+                for (uint32_t c = 1; c < K; ++c) {
+                    acc += K >= 3 ? (c == 1 ? 1u : 2u) : 1u;
+                    const uint64_t target = lo + (uint64_t)(((unsigned __int128)bytes * acc) / wt);
+                    cb[c] = std::min<uint64_t>(n, (uint64_t)(std::lower_bound(offsets, offsets + n + 1, target) - offsets));
+                    if (cb[c] < cb[c - 1]) cb[c] = cb[c - 1];
+                }
+            }
             std::vector<Chunk> ch(K);
             uint64_t max_s = 0, max_b = 0;
             for (uint32_t c = 0; c < K; ++c) {
@@ -1095,8 +1213,10 @@ int vbt_tokenize_batch(const vbt_tokenizer* tok_, const uint8_t* text, const uin
             }
             Replica& rep = *tok->reps[0];
             HIPX(hipSetDevice(rep.t->device()));
-            h.pipe.push_back(pool_take(tok, rep, max_s, max_b));
-            h.pipe.push_back(pool_take(tok, rep, max_s, max_b));
+            // three chunk workspaces in rotation: chunk c + 1 is enqueued while c runs and c - 1 is on its way out (with two, the
+            // enqueue of chunk c waited for the copy of c - 2 to land and the GPU idled in between: traced)
+            const uint32_t W = std::min<uint32_t>(3, K);
+            for (uint32_t w = 0; w < W; ++w) h.pipe.push_back(pool_take(tok, rep, max_s, max_b));
             // the result block, from the estimate: 1/8 of head room + a token per sentence
             const uint64_t cap_tokens = std::min<uint64_t>(bytes, (bytes * tok->tok_per_kib.load(std::memory_order_relaxed) / 1024) * 9 / 8 + n + 1024);
             b.out_blk = host_take(tok, n * 8 + (size_t)cap_tokens * sizeof(vbt_token_rec) + 16);
@@ -1107,9 +1227,15 @@ int vbt_tokenize_batch(const vbt_tokenizer* tok_, const uint8_t* text, const uin
             bool overflow = false;
             std::vector<std::pair<size_t, size_t>> sig_range(K, {0, 0});
             // chunk c's kernels are done: its totals are in; its results start their way to the host on the DMA engines
+            // The kernels of all chunks go to ONE stream, in chunk order, every chunk followed by an event: how many hardware queues the
+            // process has (HIP's default is four, shared by every stream of the application) and which streams share one is then
+            // irrelevant -- on streams of their own the chunks of a pipelined call ran 25 % slower than an unpipelined call inside a
+            // process that had initialised HIP before this library.  VBT_H2H_ONE_STREAM=0: a stream per workspace (A/B).
+            static const bool one_stream = [] { const char* e = std::getenv("VBT_H2H_ONE_STREAM"); return !(e && *e == '0'); }();
+            auto stream_of = [&](uint32_t c) { return one_stream ? h.pipe[0]->stream : h.pipe[c % W]->stream; };
             auto harvest = [&](uint32_t c) {
-                PooledWorkspace& p = *h.pipe[c & 1];
-                HIPX(hipStreamSynchronize(p.stream));
+                PooledWorkspace& p = *h.pipe[c % W];
+                HIPX(hipEventSynchronize(p.done));
                 Chunk& q = ch[c];
                 error_flags |= q.tail[1];
                 q.tok_base = total;
@@ -1139,7 +1265,12 @@ int vbt_tokenize_batch(const vbt_tokenizer* tok_, const uint8_t* text, const uin
                 if (ch[c].tok_base)
                     for (uint64_t i = ch[c].s0; i < ch[c].s1; ++i) o[i] += (uint32_t)ch[c].tok_base;
             };
-            for (uint32_t c = 0; c < K && !overflow; ++c) {
+            static const bool trace = std::getenv("VBT_H2H_TRACE") != nullptr;  // developer aid: where a pipelined call's time goes (us since its start)
+            const auto t_start = std::chrono::steady_clock::now();
+            auto stamp = [&](const char* what, uint32_t c) {
+                if (trace) std::fprintf(stderr, "[vbt h2h] %-8s chunk %u at %7.1f us\n", what, c, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_start).count());
+            };
+            auto prep_enqueue = [&](uint32_t c) {
                 Chunk& q = ch[c];
                 const uint64_t ns = q.s1 - q.s0, nb = q.b1 - q.b0;
                 // the batch's own copy of this chunk's input, and its offsets rebased to the chunk
@@ -1148,19 +1279,32 @@ int vbt_tokenize_batch(const vbt_tokenizer* tok_, const uint8_t* text, const uin
                 if (nb) std::memcpy(txt + q.b0, text + lo + q.b0, nb);
                 uint64_t* so = shard_offs + q.s0 + c;
                 for (uint64_t i = 0; i <= ns; ++i) so[i] = offsets[q.s0 + i] - lo - q.b0;
-                if (c >= 2) land(c - 2);  // the workspace's previous results are out
-                PooledWorkspace& p = *h.pipe[c & 1];
+                stamp("prepared", c);
+                if (c >= W) { land(c - W); stamp("landed", c - W); }  // the workspace's previous results are out
+                PooledWorkspace& p = *h.pipe[c % W];
                 if (ns) {
-                    if (nb) HIPX(hipMemcpyAsync(p.d_text, txt + q.b0, nb, hipMemcpyHostToDevice, p.stream));
-                    HIPX(hipMemcpyAsync(p.d_off, so, (ns + 1) * 8, hipMemcpyHostToDevice, p.stream));
-                    p.ws->run(static_cast<const uint8_t*>(p.d_text), p.d_off, ns, nb, p.stream, /*defer_pack=*/false);
-                    HIPX(hipMemcpyAsync(q.tail, p.ws->d_ctrl, 8, hipMemcpyDeviceToHost, p.stream));
+                    // the way in on the DMA engines too (Sdma::issue_h2d: why); the kernels are enqueued once the chunk's input has landed --
+                    // the host is W chunks ahead of the device, this wait costs the call nothing
+                    std::vector<hsa_signal_t> in;
+                    bool ok = rep.sdma->issue_h2d(txt + q.b0, p.d_text, nb, in);
+                    ok = rep.sdma->issue_h2d(so, p.d_off, (ns + 1) * 8, in) && ok;
+                    ok = Sdma::wait(in) && ok;
+                    if (!ok) throw Error(VBT_ERR_DEVICE, "host -> device copy of a chunk failed (hsa_amd_memory_async_copy)");
+                    p.ws->run(static_cast<const uint8_t*>(p.d_text), p.d_off, ns, nb, stream_of(c), /*defer_pack=*/false);
+                    HIPX(hipMemcpyAsync(q.tail, p.ws->d_ctrl, 8, hipMemcpyDeviceToHost, stream_of(c)));
                 }
-                if (c >= 1) harvest(c - 1);
+                HIPX(hipEventRecord(p.done, stream_of(c)));
+                stamp("enqueued", c);
+            };
+            // The host runs ahead of the device by as many chunks as there are workspaces: it prepares and enqueues chunk c + W - 1 before
+            // it blocks for the totals of chunk c (blocking first left the GPU idle while the next chunk was being copied together).
+            for (uint32_t enq = 0, har = 0; har < K && !overflow; ++har) {
+                while (enq < K && enq < har + W) prep_enqueue(enq++);
+                harvest(har);
+                stamp("harvest", har);
             }
-            if (!overflow) harvest(K - 1);
             if (!overflow) {
-                for (uint32_t c = K >= 2 ? K - 2 : 0; c < K; ++c) land(c);
+                for (uint32_t c = K - W; c < K; ++c) { land(c); stamp("landed", c); }
                 if (error_flags & kErrUtf8) {
                     for (uint64_t i = 0; i < n; ++i)
                         if (!valid_utf8(txt + offs[i], offs[i + 1] - offs[i])) throw Error(VBT_ERR_UTF8, "sentence " + std::to_string(i) + " is not valid UTF-8");
@@ -1190,10 +1334,23 @@ int vbt_tokenize_batch(const vbt_tokenizer* tok_, const uint8_t* text, const uin
             std::vector<std::exception_ptr> errs(R);
             std::vector<std::thread> th;
             auto run = [&](uint32_t k) { try { body(k); } catch (...) { errs[k] = std::current_exception(); } };
+            // the thread of device k runs on the CPUs of that device's NUMA node (VBT_NUMA_PIN=0: wherever the OS puts it); the calling
+            // thread, which takes device 0, stays where its owner put it
+            static const bool pin = [] { const char* e = std::getenv("VBT_NUMA_PIN"); return !(e && *e == '0'); }();
+            auto run_pinned = [&](uint32_t k) {
+                const std::vector<int>& cpus = tok->reps[k]->near_cpus;
+                if (pin && !cpus.empty()) {
+                    cpu_set_t set;
+                    CPU_ZERO(&set);
+                    for (int c : cpus) CPU_SET(c, &set);
+                    (void)pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
+                }
+                run(k);
+            };
             uint32_t started = 1;
             try {
                 th.reserve(R);
-                for (; started < R; ++started) th.emplace_back(run, started);
+                for (; started < R; ++started) th.emplace_back(run_pinned, started);
             } catch (const std::exception&) {}  // (out of threads: the rest runs here)
             run(0);
             for (uint32_t k = started; k < R; ++k) run(k);

@@ -344,14 +344,12 @@ Workspace::Workspace(const Tokenizer& t, uint64_t max_s, uint64_t max_b) : tok(t
         pipe.g_cand = static_cast<uint4*>(alloc((size_t)pipe.node_factor * slots * 16));
         pipe.g_hits = static_cast<uint4*>(alloc((size_t)pipe.node_factor * slots * 16));
         pipe.s_tier = static_cast<uint8_t*>(alloc(ns));
-        for (size_t t = 0; t < tiers.size(); ++t) {
-            hipStream_t st;
-            HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-            streams.push_back(st);
-            hipEvent_t e;
-            HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            tier_events.push_back(e);
-        }
+        // (the side streams of the LDS tiers are created when a launch sequence first needs one -- run(): only tier sets with several
+        // tiers below the segment tier do.  Created here, every workspace took four streams, and with the HIP runtime's default of four
+        // hardware queues the streams of the workspaces a pipelined host call alternates between all landed on ONE queue: their
+        // kernels ran strictly one after the other, with a full drain at every switch.)
+        streams.assign(tiers.size(), nullptr);
+        tier_events.assign(tiers.size(), nullptr);
         HIP_CHECK(hipEventCreateWithFlags(reinterpret_cast<hipEvent_t*>(&ev_fork2), hipEventDisableTiming));
 
         kern::gen_set_max_lds(163840);
@@ -370,11 +368,11 @@ void Workspace::release() {
     for (void* p : pipe_allocs) (void)hipFree(p);
     pipe_allocs.clear();
     for (auto& e : ev) if (e) { (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(e)); e = nullptr; }
-    for (void* e : tier_events) (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(e));
+    for (void* e : tier_events) if (e) (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(e));
     tier_events.clear();
     if (ev_fork2) (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(ev_fork2));
     ev_fork2 = nullptr;
-    for (void* st : streams) (void)hipStreamDestroy(reinterpret_cast<hipStream_t>(st));
+    for (void* st : streams) if (st) (void)hipStreamDestroy(reinterpret_cast<hipStream_t>(st));
     streams.clear();
 }
 
@@ -499,6 +497,14 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
         for (size_t i = 0; i < n_conc; ++i) {
             const size_t t = n_conc - 1 - i;
             const bool on_main = main_seg && t == a.seg_tier;
+            if (!on_main && !streams[t]) {
+                hipStream_t new_stream;
+                HIP_CHECK(hipStreamCreateWithFlags(&new_stream, hipStreamNonBlocking));
+                streams[t] = new_stream;
+                hipEvent_t new_event;
+                HIP_CHECK(hipEventCreateWithFlags(&new_event, hipEventDisableTiming));
+                tier_events[t] = new_event;
+            }
             hipStream_t side = on_main ? stream : reinterpret_cast<hipStream_t>(streams[t]);
             if (!on_main) HIP_CHECK(hipStreamWaitEvent(side, reinterpret_cast<hipEvent_t>(ev_fork2), 0));
             // one workgroup per list entry: the lists are built on the device, so the grid covers the whole batch and the
