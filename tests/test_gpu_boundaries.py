@@ -279,11 +279,11 @@ def test_the_boundaries_with_the_cpp_sweep_loop():
 
 def test_drawn_scheduling_knobs_and_sentence_shapes_agree_with_the_oracle():
     """hypothesis draws (length law, sentence count, space density, ignore_space, max_grouping_len, dictionary density, VBT_TIERS,
-    VBT_SEG_BYTES, VBT_GEN_LDS, VBT_GEN_LEVELS, VBT_GEN_WAVES) together -- the hand-picked points of test_gpu_parity.py cover
+    VBT_SEG_BYTES, VBT_GEN_LDS, VBT_GEN_LEVELS, VBT_GEN_WAVES, VBT_LEAN) together -- the hand-picked points of test_gpu_parity.py cover
     each knob alone -- with a fixed example budget and a fixed seed (derandomize): every record equals the oracle's."""
     from hypothesis import given, settings, strategies as st, HealthCheck
 
-    tier_sets = ["10240,49152,163840", "2048,8192", "1024", "4096,6144,8192,12288,16384,65536", "1536,163840", "3072", "2048,4096,32768,163840",
+    tier_sets = ["8192,10240,49152,163840", "10240,49152,163840", "2048,8192", "1024", "4096,6144,8192,12288,16384,65536", "1536,163840", "3072", "2048,4096,32768,163840",
                  "65536", "8192,12288,16384,24576,32768,49152,65536,163840", "512,163840"]
     level_sets = ["16384,32768,163840", "4096,8192,163840", "8192,65536,131072"]
     dicts = {}
@@ -294,17 +294,18 @@ def test_drawn_scheduling_knobs_and_sentence_shapes_agree_with_the_oracle():
             dicts[shape] = (sd, ora.Dictionary.from_sources_binmatrix(sd.lex, sd.matrix, sd.num_right, sd.num_left, sd.char_def, sd.unk))
         return dicts[shape]
 
-    saved = {k: os.environ.get(k) for k in ("VBT_TIERS", "VBT_SEG_BYTES", "VBT_GEN_LDS", "VBT_GEN_LEVELS", "VBT_GEN_WAVES", "VBT_GEN_WAVES1")}
+    saved = {k: os.environ.get(k) for k in ("VBT_TIERS", "VBT_SEG_BYTES", "VBT_GEN_LDS", "VBT_GEN_LEVELS", "VBT_GEN_WAVES", "VBT_GEN_WAVES1", "VBT_LEAN")}
 
     @settings(max_examples=30, derandomize=True, deadline=None, suppress_health_check=list(HealthCheck))
     @given(shape=st.sampled_from(["small", "small-dense", "tiny"]), law=st.sampled_from(["uniform_5_20", "lognormal_40", "mixed"]),
            n=st.integers(1, 1200), space_p=st.sampled_from([0.0, 0.03, 0.1, 0.3]), ignore_space=st.booleans(), mgl=st.sampled_from([0, 1, 3, 24]),
            tiers=st.sampled_from(tier_sets), seg=st.sampled_from(["default", "0", "first", "last"]), gen_lds=st.sampled_from([1024, 2048, 3072, 4096, 8192]),
-           levels=st.sampled_from(level_sets), waves=st.sampled_from([1, 2, 4, 8]), seed=st.integers(1, 1 << 30))
-    def run(shape, law, n, space_p, ignore_space, mgl, tiers, seg, gen_lds, levels, waves, seed):
+           levels=st.sampled_from(level_sets), waves=st.sampled_from([1, 2, 4, 8]), lean=st.booleans(), seed=st.integers(1, 1 << 30))
+    def run(shape, law, n, space_p, ignore_space, mgl, tiers, seg, gen_lds, levels, waves, lean, seed):
         sd, do = dictionary(shape)
         sizes = tiers.split(",")
-        env = {"VBT_TIERS": tiers, "VBT_GEN_LDS": str(gen_lds), "VBT_GEN_LEVELS": levels, "VBT_GEN_WAVES": str(waves), "VBT_GEN_WAVES1": str(waves)}
+        env = {"VBT_TIERS": tiers, "VBT_GEN_LDS": str(gen_lds), "VBT_GEN_LEVELS": levels, "VBT_GEN_WAVES": str(waves), "VBT_GEN_WAVES1": str(waves),
+               "VBT_LEAN": "1" if lean else "0"}
         if seg != "default":
             env["VBT_SEG_BYTES"] = "0" if seg == "0" else sizes[0] if seg == "first" else sizes[-1]
         for k in saved:

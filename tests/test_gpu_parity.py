@@ -126,12 +126,14 @@ def test_all_tiers_agree(tiers, fused, monkeypatch):
                                  {"VBT_SEG_BYTES": "0"}, {"VBT_SEG_BYTES": "8192"}, {"VBT_TIERS": "4096,16384", "VBT_SEG_BYTES": "4096"},
                                  {"VBT_TIERS": "3072", "VBT_SEG_BYTES": "2048"},
                                  {"VBT_TIERS": "1536,163840", "VBT_SEG_BYTES": "1536"}, {"VBT_TIERS": "2048", "VBT_SEG_BYTES": "2048", "VBT_GEN_LDS": "1024", "VBT_GEN_LEVELS": "4096,8192,163840"},
-                                 {"VBT_PACK_SCAN": "1"}, {"VBT_FB_WGS": "3", "VBT_TIERS": "1024"}])
+                                 {"VBT_PACK_SCAN": "1"}, {"VBT_FB_WGS": "3", "VBT_TIERS": "1024"},
+                                 {"VBT_LEAN": "0"}, {"VBT_TIERS": "3072,5120,10240,163840"}, {"VBT_TIERS": "6144,8192", "VBT_SEG_BYTES": "8192", "VBT_LEAN": "0"}])
 def test_generator_scheduling_variants_agree(env, monkeypatch):
     """A tiny bulk-generator LDS (most sentences then go through gen_long, the multi-wavefront generator, with 1 / 2 / 4 / 8
     wavefronts per workgroup and through its small levels), the segmented sweep of sentences that do not fit the segment tier
     (cut anywhere, the window of open end lists handed over; down to segments of 8 positions), the tile-prefix kernel in front
-    of the packing and a fallback launch of three waves must not change a single token."""
+    of the packing, a fallback launch of three waves, and the lean instance of the sweep (lattice_lean: the tiers in front of the segment
+    tier, whole sentences with the generator's pass records) switched off or spread over two small tiers must not change a single token."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     sd = synth.SynthDict("small")

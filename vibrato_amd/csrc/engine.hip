@@ -289,7 +289,11 @@ Workspace::Workspace(const Tokenizer& t, uint64_t max_s, uint64_t max_b) : tok(t
     {
         const char* e = std::getenv("VBT_TIERS");
         // (default: ONE 10 KiB tier that is also the segment tier -- 16 waves per CU, 4 per SIMD: lattice_lds is built for 128 VGPRs -- + two escape tiers)
-        std::string spec = e && *e ? e : (fused ? "16384,32768,65536" : env_u32("VBT_SEG_BYTES", kSegTierBytes) ? "10240,49152,163840" : "8192,12288,16384,24576,32768,49152,65536,163840");
+        // (+ in front of it, where the build has the lean instance of the sweep, an 8 KiB tier for it -- five waves per SIMD -- for the whole
+        // sentences that arrive with the generator's pass records; VBT_LEAN=0: without.  A second lean tier just under the segment tier's
+        // size for the whole sentences of 8-10 KiB bought nothing: sweep 0.683 vs 0.682 ms, and every further tier costs the step ~0.015 ms)
+        const bool lean_default = kern::lattice_has_lean() && env_u32("VBT_LEAN", 1) != 0;
+        std::string spec = e && *e ? e : (fused ? "16384,32768,65536" : env_u32("VBT_SEG_BYTES", kSegTierBytes) ? (lean_default ? "8192,10240,49152,163840" : "10240,49152,163840") : "8192,12288,16384,24576,32768,49152,65536,163840");
         size_t pos = 0;
         while (pos < spec.size()) {
             size_t c = spec.find(',', pos);
@@ -426,6 +430,16 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
                 if (tiers[t] >= seg_bytes) { a.seg_tier = (uint32_t)t; break; }
     }
     a.sid0 = 0; a.cctrl = d_cctrl; a.list_off = 0;
+    last_seg_tier = a.seg_tier;
+    // The tiers in front of the segment tier go to the lean instance of the sweep (whole sentences with the generator's records; everything
+    // else -- segmented, counted, i32 cells -- is routed to the tiers behind them): VBT_LEAN=0 / VBT_LAT_PERSIST=1 keep the general
+    // instance everywhere.  Without a segment tier only the first tier is lean.
+    a.n_lean = 0;
+    if (kern::lattice_has_lean() && env_u32("VBT_LEAN", 1) != 0 && !env_u32("VBT_LAT_PERSIST", 0) && !fused && T >= 2 && a.seg_tier != 0 && !count_connids && !image.dev.matrix_wide) {
+        a.n_lean = a.seg_tier < T ? a.seg_tier : 1u;
+        for (uint32_t t = 0; t < a.n_lean; ++t)
+            if (tiers[t] > 65536u) { a.n_lean = t; break; }
+    }
     a.lid_count = count_connids ? d_connid : nullptr;
     a.rid_count = count_connids ? d_connid + tok.dict().num_left : nullptr;
     a.s_counted = count_connids ? d_counted : nullptr;
@@ -510,7 +524,8 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
             // one workgroup per list entry: the lists are built on the device, so the grid covers the whole batch and the
             // workgroups beyond a list's length exit at once (VBT_LAT_PERSIST=1: persistent waves with a work cursor)
             const uint32_t grid = !persist ? cn : (t < tier_waves.size() && tier_waves[t]) ? std::min<uint32_t>(tier_waves[t], waves_for(tiers[t], cn)) : waves_for(tiers[t], cn);
-            launch_lattice(a, dim3(grid), tiers[t], side, (uint32_t)t, persist);
+            if (t < a.n_lean) kern::lattice_lean(cn, tiers[t], side, D, a, (uint32_t)t);
+            else launch_lattice(a, dim3(grid), tiers[t], side, (uint32_t)t, persist);
             if (t == a.seg_tier)
                 for (size_t x = t + 1; x < T; ++x)
                     launch_lattice(a, dim3(waves_for(tiers[x], std::min<uint32_t>(cn, 4096))), tiers[x], side, (uint32_t)x, 1u);
@@ -549,7 +564,7 @@ void Workspace::serve(const uint8_t* h_text_dev, uint8_t* d_text, uint64_t* d_of
     a.scratch = d_scratch; a.scratch_bytes = scratch_bytes;
     a.prof = nullptr;
     a.lists = d_over; a.list_stride = (uint32_t)(2 * std::max<uint64_t>(max_sentences, 1)); a.n_tiers = 1;
-    a.tier_prio = 0; a.seg_tier = 0; a.sid0 = 0; a.cctrl = d_cctrl; a.list_off = 0; a.direct_push = 0;
+    a.tier_prio = 0; a.seg_tier = 0; a.n_lean = 0; a.sid0 = 0; a.cctrl = d_cctrl; a.list_off = 0; a.direct_push = 0;
     a.lid_count = nullptr; a.rid_count = nullptr; a.s_counted = nullptr;
     constexpr uint32_t kOneLds = 65536;  // generator arrays (~26 B per character), then the lattice (whole up to ~400 characters, in segments beyond)
     a.tier_bytes[0] = kOneLds;
@@ -592,9 +607,11 @@ void Workspace::stats(vbt_call_stats* out) {
         out->n_tier2 = cc[2 * (T - 1)];
         out->n_tier1 = last_n - out->n_tier0 - out->n_tier2;
     } else {
-        out->n_tier0 = cc[0];
+        // n_tier0: the tiers sentences are routed to up front (up to the segment tier; without one: the first tier), n_tier1: the tiers
+        // behind them (escape tiers: what a sweep passed on), n_tier2: the global-memory kernel
+        const size_t front = last_seg_tier < T ? last_seg_tier + 1 : 1;
+        for (size_t t = 0; t < T; ++t) (t < front ? out->n_tier0 : out->n_tier1) += cc[2 * t];
         out->n_tier2 = cc[2 * T];
-        for (size_t t = 1; t < T; ++t) out->n_tier1 += cc[2 * t];
     }
     out->n_tokens = ctrl[kTotal];
     out->error_flags = ctrl[kError];

@@ -80,6 +80,7 @@ struct BatchArgs {
     uint32_t list_stride;
     uint32_t n_tiers;
     uint32_t seg_tier;     // LDS tier that sweeps longer sentences in segments (>= n_tiers: none)
+    uint32_t n_lean;       // the first n_lean LDS tiers are swept by the lean instance (lattice_lean: whole sentences with the generator's pass records ONLY)
     uint32_t direct_push;  // gen_one appends to the work lists directly instead of routing through s_tier (no build_lists behind it)
     uint32_t tier_prio;  // the top `tier_prio` LDS tiers run at raised wave priority (0 = off)
     // a launch covers sentences [sid0, sid0 + n); cctrl = the list counters it works with (cctrl[2t] = entries of
@@ -241,6 +242,7 @@ class Workspace {
     char* d_scratch = nullptr;
     uint64_t scratch_bytes = 0;
     std::vector<uint32_t> tiers;  // LDS bytes per wave of each LDS tier
+    uint32_t last_seg_tier = 0xFFFFFFFFu;  // of the last run(): what stats() counts as "routed up front" (tiers <= it) and as escape tiers
     std::vector<uint32_t> tier_waves;  // lattice grid per tier (empty = fill the machine per tier)
     bool timing = false, profile = false;
     void read_profile(uint64_t* out, bool reset);  // kProfWords values

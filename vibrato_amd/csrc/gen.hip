@@ -390,7 +390,7 @@ __device__ __forceinline__ void gen_long(const DevDict& D, const BatchArgs& A, u
     const uint64_t fixed = lattice_fixed_bytes(C, n, eo(n + 1), passes);
     uint32_t tier = fallback;
     for (uint32_t t = 0; t < A.n_tiers; ++t)
-        if (fixed <= A.tier_bytes[t]) { tier = t; break; }
+        if (t >= A.n_lean && fixed <= A.tier_bytes[t]) { tier = t; break; }
     if (A.seg_tier < A.n_tiers && tier > A.seg_tier) tier = A.seg_tier;
     if (tid == 0) A.s_hdr[sid] = make_uint4(n | (nb << 16), C | (tier << 16), passes, (uint32_t)(b0 - uniform64(A.offsets[0])));
     route(tier);

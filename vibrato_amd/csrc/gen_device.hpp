@@ -38,7 +38,35 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
     const uint8_t* __restrict__ txt = A.text + b0;
     const size_t slot0 = sentence_slot(A, b0, sid);
 
-    const uint32_t n = count_chars(txt, nb);
+    // The text comes in as ONE unaligned 32-bit load per lane and 64-byte chunk -- byte bi and the three behind it, what a lead byte
+    // needs to decode its character -- four chunks (256 bytes: 85 % of the headline's sentences whole) requested together and, for a
+    // sentence of at most 256 bytes, kept in registers from the character count to the decode.  (Round 5 loaded single bytes chunk by
+    // chunk, once to count the characters and once more to decode them, fetched the continuation bytes from the neighbouring lanes
+    // through the LDS crossbar -- six ds_bpermute per chunk -- and waited for every chunk's chr2inf / mapper gathers before it looked at
+    // the next chunk: 6-7 dependent round trips for the mean sentence where there are two, text and gathers.)
+    constexpr uint32_t kGroup = 4;  // chunks per group
+    auto bytes4 = [&](uint32_t bi) -> uint32_t {  // bytes bi .. bi + 3 of the sentence, 0 behind its end; 0x80 (no lead byte) for bi >= nb
+        if (bi >= nb) return 0x80u;
+        if (nb >= 4) {
+            const uint32_t a = bi + 4 <= nb ? bi : nb - 4;  // never reads outside [0, nb)
+            uint32_t v;
+            __builtin_memcpy(&v, txt + a, 4);
+            return v >> (8u * (bi - a));
+        }
+        uint32_t v = txt[bi];
+        if (bi + 1 < nb) v |= (uint32_t)txt[bi + 1] << 8;
+        if (bi + 2 < nb) v |= (uint32_t)txt[bi + 2] << 16;
+        return v;
+    };
+    uint32_t w0[kGroup];
+    const bool one_group = nb <= 64 * kGroup;
+    uint32_t n = 0;
+    if (one_group) {
+#pragma unroll
+        for (uint32_t q = 0; q < kGroup; ++q) w0[q] = bytes4(q * 64 + ln);
+#pragma unroll
+        for (uint32_t q = 0; q < kGroup; ++q) n += (uint32_t)__popcll(__ballot((w0[q] & 0xC0u) != 0x80u));
+    } else n = count_chars(txt, nb);
     if (n == 0) {
         init();
         if (ln == 0) A.tok_cnt[sid] = 0;
@@ -66,39 +94,42 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
     uint32_t* const hcount = L.hcount;  // hits staged so far
     for (uint32_t i = ln; i < n + 1; i += 64) endc[i] = i == 0 ? 1u : 0u;  // BOS ends at 0
 
-    // decode (Sentence::compute_basic / compute_categories, sentence.rs:40-55); the 3 bytes after a
-    // lead byte come from neighbouring lanes (or the look-ahead chunk), not from memory again
+    // decode (Sentence::compute_basic / compute_categories, sentence.rs:40-55): per group of four chunks the characters, then ALL their
+    // chr2inf / mapper gathers, then the stores
     {
         uint16_t* c2b = A.g_c2b + slot0;
         uint32_t cb = 0;
-        uint32_t cur = ln < nb ? txt[ln] : 0x80u;
-        for (uint32_t c0 = 0; c0 < nb; c0 += 64) {
-            const uint32_t bi = c0 + ln;
-            const uint32_t nxt = bi + 64 < nb ? txt[bi + 64] : 0x80u;
-            const uint32_t b = cur;
-            uint32_t t[3];
+        for (uint32_t g0 = 0; g0 < nb; g0 += 64 * kGroup) {
+            uint32_t w[kGroup], cp[kGroup], idx[kGroup];
 #pragma unroll
-            for (int k = 1; k <= 3; ++k) {
-                const uint32_t src = (ln + k) & 63u;
-                const uint32_t a = __shfl(cur, src), c = __shfl(nxt, src);
-                t[k - 1] = ((ln + k < 64) ? a : c) & 0x3Fu;
+            for (uint32_t q = 0; q < kGroup; ++q) w[q] = one_group ? w0[q] : bytes4(g0 + q * 64 + ln);
+#pragma unroll
+            for (uint32_t q = 0; q < kGroup; ++q) {
+                const uint32_t b = w[q] & 0xFFu, t0 = (w[q] >> 8) & 0x3Fu, t1 = (w[q] >> 16) & 0x3Fu, t2 = (w[q] >> 24) & 0x3Fu;
+                const bool lead = (b & 0xC0u) != 0x80u;
+                const uint64_t m = __ballot(lead);
+                idx[q] = lead ? cb + (uint32_t)__popcll(m & lt_mask) : 0xFFFFFFFFu;
+                cp[q] = b < 0x80 ? b : b < 0xE0 ? ((b & 0x1F) << 6) | t0 : b < 0xF0 ? ((b & 0x0F) << 12) | (t0 << 6) | t1 : ((b & 0x07) << 18) | (t0 << 12) | (t1 << 6) | t2;
+                cb += (uint32_t)__popcll(m);
             }
-            const bool lead = bi < nb && (b & 0xC0) != 0x80;
-            const uint64_t m = __ballot(lead);
-            if (lead) {
-                const uint32_t idx = cb + (uint32_t)__popcll(m & lt_mask);
-                uint32_t cp;
-                if (b < 0x80) cp = b;
-                else if (b < 0xE0) cp = ((b & 0x1F) << 6) | t[0];
-                else if (b < 0xF0) cp = ((b & 0x0F) << 12) | (t[0] << 6) | t[1];
-                else cp = ((b & 0x07) << 18) | (t[0] << 12) | (t[1] << 6) | t[2];
-                ci[idx] = D.chr2inf[cp < 65536u ? cp : 0u];  // character.rs:112-116
-                code[idx] = cp < D.sys.mapper_len ? D.sys.mapper[cp] : (uint16_t)0;
-                if (D.has_user) ucode[idx] = cp < D.user.mapper_len ? D.user.mapper[cp] : (uint16_t)0;
-                c2b[idx] = (uint16_t)bi;
+            uint32_t civ[kGroup], cov[kGroup], ucv[kGroup];
+#pragma unroll
+            for (uint32_t q = 0; q < kGroup; ++q) {
+                const bool lead = idx[q] != 0xFFFFFFFFu;
+                const uint32_t c = lead ? cp[q] : 0u;
+                civ[q] = D.chr2inf[c < 65536u ? c : 0u];  // character.rs:112-116
+                cov[q] = c < D.sys.mapper_len ? D.sys.mapper[c] : (uint16_t)0;
+                ucv[q] = D.has_user && c < D.user.mapper_len ? D.user.mapper[c] : (uint16_t)0;
             }
-            cb += (uint32_t)__popcll(m);
-            cur = nxt;
+#pragma unroll
+            for (uint32_t q = 0; q < kGroup; ++q) {
+                if (idx[q] != 0xFFFFFFFFu) {
+                    ci[idx[q]] = civ[q];
+                    code[idx[q]] = (uint16_t)cov[q];
+                    if (D.has_user) ucode[idx[q]] = (uint16_t)ucv[q];
+                    c2b[idx[q]] = (uint16_t)(g0 + q * 64 + ln);
+                }
+            }
         }
         if (ln == 0) c2b[n] = (uint16_t)nb;
     }
@@ -436,7 +467,7 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
         // smallest tier whose LDS holds the lattice arrays (connection costs are never staged)
         const uint64_t fixed = lattice_fixed_bytes(C, n, eo(n + 1), passes);
         for (uint32_t t = 0; t < A.n_tiers; ++t)
-            if (fixed <= A.tier_bytes[t]) { tier = t; break; }
+            if (t >= A.n_lean && fixed <= A.tier_bytes[t]) { tier = t; break; }  // (the lean instance only takes sentences with records)
         // longer sentences are swept in segments inside the segment tier instead of one huge LDS block (lattice_lds cuts anywhere;
         // what it cannot sweep there -- a window of end lists wider than the tier -- it hands to the escape tiers itself)
         if (A.seg_tier < A.n_tiers && tier > A.seg_tier) tier = A.seg_tier;

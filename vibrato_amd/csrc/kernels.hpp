@@ -29,6 +29,9 @@ void gen_set_max_lds(int bytes);  // hipFuncAttributeMaxDynamicSharedMemorySize 
 // ---- lattice.hip: the sweep (one instance per {ignore_space, i32 matrix cells}) and the resident Worker kernel
 void lattice_lds(uint32_t workgroups, uint32_t lds_bytes, hipStream_t stream, const DevDict& D, const BatchArgs& a, uint32_t tier, uint32_t persistent);
 void lattice_set_max_lds(int bytes);
+// the lean instance for whole sentences that arrive with the generator's pass records (built for 5 waves per SIMD); the common build only
+bool lattice_has_lean();
+void lattice_lean(uint32_t workgroups, uint32_t lds_bytes, hipStream_t stream, const DevDict& D, const BatchArgs& a, uint32_t tier);
 void tokenize_serve(uint32_t lds_bytes, hipStream_t stream, const DevDict& D, const BatchArgs& a, const uint8_t* h_text, uint32_t* ctl, uint32_t last_seq,
                     uint32_t idle_polls, uint32_t max_served);
 

@@ -858,6 +858,131 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
     return 0;
 }
 
+#if VBT_ASM_LOOP && VBT_LDS_REC && VBT_GEN_RECORDS && VBT_C2B_LDS
+#define VBT_HAS_LEAN 1
+// The lean instance of the sweep: a sentence that fits its tier WHOLE and arrives with the generator's pass records (header word 2,
+// bit 31: gen_device.hpp) -- four sentences in five on running text.  Nothing of lattice_sentence's machinery for the rest is here
+// (segments, hand-over, the pre-pass, the C++ loop, connection-id counting, retries): header -> candidates, records and byte offsets
+// into LDS -> the assembly loop (sweep_asm.hpp) -> back-trace -> token records.  Same LDS layout, same records, same results; what
+// differs is what the compiler has to keep alive around the loop: this instance is built for FIVE waves per SIMD (96 VGPRs) with an
+// 8 KiB tier -- the loop is bound by VALU issue at 74 % utilisation with four, a fifth wave fills the gaps -- where the general
+// instance needs 128 VGPRs (round 5 ran the general instance at five waves: 18 VGPRs spilled, and lost).
+// Returns 0, or a reason for the caller to hand the sentence to the fused kernel (cannot happen: the generator sized it exactly).
+template <bool kSpaceMode>
+__device__ __forceinline__ uint32_t lattice_whole(const DevDict& D, const BatchArgs& A, uint32_t lds_bytes, uint32_t sid, uint4 h) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const uint32_t ln = threadIdx.x;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)g_smem;
+    const uint32_t n = h.x & 0xFFFFu, C = h.y & 0xFFFFu, SL = h.z & 0x7FFFFFFFu;  // characters, candidates, passes (exact)
+    const size_t slot0 = (size_t)h.w + (size_t)kSentenceSlack * sid;
+    const size_t node0 = (size_t)A.node_factor * slot0;
+    const uint4* __restrict__ ndg = A.g_cand + node0;
+    const uint2* __restrict__ grec = reinterpret_cast<const uint2*>(A.g_hits + node0);
+    const uint16_t* __restrict__ c2bg = A.g_c2b + slot0;
+    const uint32_t E = C + 1u;       // end-list slots: one per candidate + BOS (slot 0); slot E is the EOS node's
+    const uint32_t kBosSeq = C + 1u;
+    if (!(h.z >> 31) || E >= 8190u || lds0 + lds_bytes > 65536u) return 26;
+    Arena ar{g_smem, lds_bytes, 0, true};
+    uint2* const e_rec = ar.take<uint2>(E + 2);
+    uint2* const cnd = ar.take<uint2>(C + 2);
+    uint16_t* const path = ar.take<uint16_t>(n + 4);
+    uint16_t* const c2bl = ar.take<uint16_t>(n + 4);
+    uint2* const vhead = ar.take<uint2>(SL + 10u);
+    if (!ar.ok) return 26;
+    const uint32_t offK = lds0, offC = lds0 + (uint32_t)(reinterpret_cast<char*>(cnd) - g_smem);
+    // everything the sentence needs from global memory is requested up front: the first two candidate records, pass records and
+    // byte offsets per lane; what is left follows in rounds of 64
+    uint4 r0 = ndg[ln < C ? ln : 0u], r1 = ndg[64 + ln < C ? 64 + ln : 0u];
+    uint2 p0 = grec[ln < SL ? ln : 0u], p1 = grec[64 + ln < SL ? 64 + ln : 0u];
+    uint32_t cb0 = c2bg[ln <= n ? ln : n], cb1 = c2bg[64 + ln <= n ? 64 + ln : n];
+    auto put_cand = [&](uint32_t c, const uint4& r) {
+        const uint32_t es = r.y >> 16;
+        e_rec[es] = make_uint2((((0xFFFEu - c) & 0xFFFFu) << 16) | (r.w >> 16), kDeadHi);
+        cnd[c] = make_uint2(r.x, (es << 3) | (r.y << 16));
+    };
+    if (ln == 0) {
+        e_rec[0] = make_uint2(((0xFFFEu - kBosSeq) & 0xFFFFu) << 16, 0x80000000u);  // BOS: cost 0, right id 0 (lattice.rs:72-83)
+        cnd[C] = make_uint2(0u, E << 3);                                              // EOS: left id 0, word cost 0 (lattice.rs:85-101)
+        e_rec[E] = make_uint2(((0xFFFEu - C) & 0xFFFFu) << 16, kDeadHi);
+    }
+    if (ln < C) put_cand(ln, r0);
+    if (64 + ln < C) put_cand(64 + ln, r1);
+    for (uint32_t c = 128 + ln; c < C; c += 64) put_cand(c, ndg[c]);
+    if (ln < SL) vhead[ln] = make_uint2(p0.x + lds0, p0.y + lds0);
+    if (64 + ln < SL) vhead[64 + ln] = make_uint2(p1.x + lds0, p1.y + lds0);
+    for (uint32_t P = 128 + ln; P < SL; P += 64) { const uint2 r = grec[P]; vhead[P] = make_uint2(r.x + lds0, r.y + lds0); }
+    if (ln < 10) vhead[SL + ln] = make_uint2(offK, offC);  // the empty passes behind the last one (records are read up to SL + 7)
+    if (ln <= n) c2bl[ln] = (uint16_t)cb0;
+    if (64 + ln <= n) c2bl[64 + ln] = (uint16_t)cb1;
+    for (uint32_t i = 128 + ln; i <= n; i += 64) c2bl[i] = c2bg[i];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    {   // ---- fused gather + cost recurrence: the assembly loop (matrix_connector.rs:79-85, lattice.rs:103-151) ----
+        const uint64_t mb = (uint64_t)reinterpret_cast<uintptr_t>(D.matrix);
+        u32x4 rsrc;
+        rsrc.x = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)mb);
+        rsrc.y = ((uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(mb >> 32)) & 0xFFFFu) | (2u << 16);
+        rsrc.z = (uint32_t)__builtin_amdgcn_readfirstlane(D.matrix_bytes);
+        rsrc.w = 0x00020000u;
+        const uint32_t sl_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)SL);
+        const uint32_t hd_v = lds0 + (uint32_t)(reinterpret_cast<char*>(vhead) - g_smem);
+        asm volatile(VBT_SWEEP_TEXT :: [rp] "v"(hd_v), [sl] "s"(sl_s), [rs] "s"(rsrc), [ln] "v"(ln), [offk] "v"(offK) : VBT_SWEEP_CLOBBERS);
+    }
+    // ---- back-trace + token records (append_top_nodes lattice.rs:159-168, token.rs:21-92) ----
+    auto node_cost = [&](uint32_t c) { return e_rec[(cnd[c].y & 0xFFFFu) >> 3].y ^ 0x80000000u; };
+    auto node_pred = [&](uint32_t c) { return 0xFFFEu - (cnd[c].x & 0xFFFFu); };
+    uint32_t T = 0;
+    if (ln == 0) {
+        uint32_t seq = node_pred(C);
+        while (seq != kBosSeq && T < n) { path[T++] = (uint16_t)seq; seq = node_pred(seq); }
+    }
+    T = (uint32_t)__builtin_amdgcn_readfirstlane((int)T);
+    __syncthreads();
+    if (ln == 0) { A.tok_cnt[sid] = T; if (T) atomicAdd(&A.tile_sums[sid / kScanTile], T); }
+    const uint4* __restrict__ pcg = A.g_pc + slot0;
+    for (uint32_t t = ln; t < T; t += 64) {
+        const uint32_t c = path[T - 1 - t];
+        const uint4 r = ndg[c];
+        uint32_t stp = t ? ndg[path[T - t]].w & 0xFFFFu : 0u;  // a token starts where its predecessor on the path ends ...
+        if constexpr (kSpaceMode) {
+            if (stp < n) {
+                const uint4 rp = pcg[stp];
+                if (rp.y >> 31) stp += rp.z;  // ... behind the space run there (tokenizer.rs:113-125)
+            }
+        }
+        const uint32_t en = r.w & 0xFFFFu;
+        vbt_token_rec o;
+        o.start_char = stp; o.end_char = en;
+        o.start_byte = c2bl[stp]; o.end_byte = c2bl[en];
+        o.word_idx = r.z;
+        o.total_cost = (int32_t)node_cost(c);
+        A.tok_stage[slot0 + t] = o;
+    }
+    return 0;
+}
+
+#ifndef VBT_LEAN_WAVES
+#define VBT_LEAN_WAVES 5
+#endif
+template <bool kSpaceMode>
+__global__ void __launch_bounds__(64, VBT_LEAN_WAVES) lattice_lean(DevDict D, BatchArgs A, uint32_t tier) {
+    const uint32_t* list = A.lists + (size_t)tier * A.list_stride + A.list_off;
+    const uint32_t count = A.cctrl[2 * tier];
+    const uint32_t item = blockIdx.x;  // one list entry per workgroup (the grid covers the batch), newest entries first: see lattice_lds
+    if (item >= count) return;
+    const uint32_t sid = __builtin_amdgcn_readfirstlane(list[count - 1 - item]);
+    const uint4 hq = A.s_hdr[sid];
+    const uint4 h = make_uint4(__builtin_amdgcn_readfirstlane(hq.x), __builtin_amdgcn_readfirstlane(hq.y), __builtin_amdgcn_readfirstlane(hq.z), __builtin_amdgcn_readfirstlane(hq.w));
+    const uint32_t fail = lattice_whole<kSpaceMode>(D, A, A.tier_bytes[tier], sid, h);
+    if (fail) {
+        if (threadIdx.x == 0) atomicAdd(&A.ctrl[fail < 32 ? fail : 28], 1u);
+        list_push_fb(A, sid);
+    }
+}
+#else
+#define VBT_HAS_LEAN 0
+#endif
+
 template <bool kSpaceMode, bool kWide>
 __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, BatchArgs A, uint32_t tier, uint32_t persistent) {
     const uint32_t ln = threadIdx.x;
@@ -1010,6 +1135,15 @@ namespace kern {
 void lattice_lds(uint32_t workgroups, uint32_t lds_bytes, hipStream_t stream, const DevDict& D, const BatchArgs& a, uint32_t tier, uint32_t persistent) {
     auto k = pick(D, [](auto s, auto w) { return &vbt::lattice_lds<decltype(s)::value, decltype(w)::value>; });
     hipLaunchKernelGGL(k, dim3(workgroups), dim3(64), lds_bytes, stream, D, a, tier, persistent);
+}
+bool lattice_has_lean() { return VBT_HAS_LEAN != 0; }
+void lattice_lean(uint32_t workgroups, uint32_t lds_bytes, hipStream_t stream, const DevDict& D, const BatchArgs& a, uint32_t tier) {
+#if VBT_HAS_LEAN
+    if (D.space_cateset) hipLaunchKernelGGL(vbt::lattice_lean<true>, dim3(workgroups), dim3(64), lds_bytes, stream, D, a, tier);
+    else hipLaunchKernelGGL(vbt::lattice_lean<false>, dim3(workgroups), dim3(64), lds_bytes, stream, D, a, tier);
+#else
+    (void)workgroups; (void)lds_bytes; (void)stream; (void)D; (void)a; (void)tier;
+#endif
 }
 void lattice_set_max_lds(int bytes) {
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(vbt::lattice_lds<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
