@@ -367,6 +367,9 @@ def main():
             tokm.calibrate(text=text, offsets=offs)
             h2h[f"one_call_device_list_0x{k_dev}"] = tokm.host_pipeline_benchmark(text, offs, threads=1, rounds=1)
             del tokm, dvm
+        # what one more device costs a call on the host side (one host thread per device; both lists are replicas on ONE physical GPU, so
+        # the kernels' time is the same and the difference is launches, copies' fixed costs and thread hand-offs): (T(x8) - T(x4)) / 4
+        h2h["fixed_ms_per_additional_device"] = round((h2h["one_call_device_list_0x8"]["ms_per_batch"] - h2h["one_call_device_list_0x4"]["ms_per_batch"]) / 4, 4)
 
     result = None
     if rank == 0:
@@ -415,16 +418,27 @@ def main():
         ins = (tr or {}).get("wave_insts_by_kernel", {})
         sqk = (tr or {}).get("sq_by_kernel", {})
 
+        SWEEP = ("lattice_lds", "lattice_lean")  # the sweep's two instances: one launch each per step, side by side
+
+        def merged(table, kernels):
+            """Sum of a per-kernel table of the committed PMC summary over several kernels."""
+            out = {}
+            for kname in kernels:
+                for key, v in (table.get(kname) or {}).items():
+                    out[key] = out.get(key, 0) + v
+            return out or None
+
         def issue(kernel, ms):
             """Instruction-issue view of a kernel from the committed PMC pass: the VALU-only busy time (SALU has its own pipe) at
             VALU_CYCLES issue cycles per wave64 instruction on 1024 SIMDs, and where the waves' cycles went (SQ counters)."""
-            k = ins.get(kernel)
+            kernels = kernel if isinstance(kernel, tuple) else (kernel,)
+            k = merged(ins, kernels)
             if not k or ms <= 0:
                 return None
             floor_ms = k["valu"] * VALU_CYCLES / (N_SIMD * CLOCK_HZ) * 1e3
             out = {"wave_insts": k, "cycles_per_wave64_valu_assumed": VALU_CYCLES, "valu_busy_ms": round(floor_ms, 4),
                    "valu_busy_frac_of_kernel_time": round(floor_ms / ms, 4)}
-            q = sqk.get(kernel)
+            q = merged(sqk, kernels)
             if q and q.get("wave_cycles"):
                 out["sq_wave_cycle_shares"] = {"wait_any": round(q.get("wait_any", 0) / q["wave_cycles"], 4),
                                                "wait_inst_any": round(q.get("wait_inst_any", 0) / q["wave_cycles"], 4),
@@ -435,17 +449,19 @@ def main():
             return out
 
         roofline = {"bound": "hbm",
-                    "kernel": "lattice_lds (the per-tier launches of one step run concurrently on side streams; duration = hipEvents on "
-                              "the launch stream from the fork behind the bulk generator to the join of every sweep, the long sentences' "
-                              "side streams included; the fallback launch and the packing behind the join are pack_ms)",
+                    "kernel": "lattice_lean + lattice_lds: the sweep, two instances of one loop launched side by side (lean: whole sentences that "
+                              "arrive with the generator's pass records, 8 KiB tier, 5 waves per SIMD; general: everything else, 10 KiB tier); both span the "
+                              "same interval of a step (rocprofv3: either kernel's duration = this span).  duration = hipEvents on the launch stream from "
+                              "the fork behind the generators to the join of every sweep; the fallback launch and the packing behind the join are pack_ms",
                     "achieved": round(achieved / 1e9, 3), "peak": HBM_PEAK_BPS / 1e9, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_BPS, 6),
-                    "traffic": trk.get("lattice_lds"), "traffic_source": tr["source"] if tr else None,
+                    "traffic": (sum(trk.get(kname, 0) for kname in SWEEP) or None), "traffic_source": tr["source"] if tr else None,
+                    "traffic_from_committed_profile": True,  # (not measured in this run: separate rocprofv3 --pmc passes of the same command, tools/profile_round.sh)
                     "algorithmic_bytes_per_launch": int(b_lat), "kernel_ms": round(ms_lat, 4),
                     "pairs_per_launch": {"dedup_cells_in_the_numerator": int(cnt["n_pairs_dedup"] * scale), "reference_pairs_gathered_by_the_kernel": int(cnt["n_pairs_ref"] * scale),
                                          "note": "the kernel gathers one cell per (candidate, predecessor) pair of the reference's search_min_node; the "
                                                  "numerator counts one per distinct (start node, left id, predecessor)"},
-                    "issue": issue("lattice_lds", ms_lat),
+                    "issue": issue(SWEEP, ms_lat),
                     "gen_candidates": {"achieved": round(b_gen / (ms_gen * 1e-3) / 1e9, 3) if ms_gen > 0 else None,
                                        "frac": round(b_gen / (ms_gen * 1e-3) / HBM_PEAK_BPS, 6) if ms_gen > 0 else None,
                                        "algorithmic_bytes_per_launch": int(b_gen), "kernel_ms": round(ms_gen, 4),

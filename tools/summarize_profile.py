@@ -36,7 +36,7 @@ if trace:
     spans = []
     for a, b in zip(starts, starts[1:] + [len(rows)]):
         step = [r for r in rows[a:b] if int(r["Grid_Size_X"]) > 0]
-        lat = [r for r in step if name(r) == "lattice_lds"]
+        lat = [r for r in step if name(r) in ("lattice_lds", "lattice_lean")]  # the sweep's two instances run side by side
         if len(step) < 3 or not lat:
             continue
         t0 = int(step[0]["Start_Timestamp"])
@@ -50,7 +50,7 @@ if trace:
         avg = lambda k: sum(s_[k] for s_ in spans) / len(spans)
         lines += ["## Per-step wall spans from the same kernel trace (the per-tier `lattice_lds` launches of a step run concurrently, so the",
                   "   per-launch average above is not a wall time; bench.py times the same span with hipEvents on the launch stream)\n",
-                  f"| steps | whole step us | gen_candidates(+large) us | lattice_lds span (first start -> last end) us |\n|---|---|---|---|",
+                  f"| steps | whole step us | gen_candidates(+large) us | sweep span: lattice_lean + lattice_lds (first start -> last end) us |\n|---|---|---|---|",
                   f"| {len(spans)} full-batch steps | {avg('step_us'):.1f} | {avg('gen_us'):.1f} | {avg('lattice_span_us'):.1f} |\n"]
 pm = collections.OrderedDict()
 for f in sorted(glob.glob(f"{src}/pmc*/**/*counter_collection.csv", recursive=True)):

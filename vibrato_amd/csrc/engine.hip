@@ -376,6 +376,8 @@ void Workspace::release() {
     tier_events.clear();
     if (ev_fork2) (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(ev_fork2));
     ev_fork2 = nullptr;
+    if (ev_fork_early) (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(ev_fork_early));
+    ev_fork_early = nullptr;
     for (void* st : streams) if (st) (void)hipStreamDestroy(reinterpret_cast<hipStream_t>(st));
     streams.clear();
 }
@@ -488,6 +490,42 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
         // (s_tier[] = 0xFF, "nothing routed yet", is written by validate_batch: one launch less per batch)
         kern::gen_candidates(cn, gen_lds, stream, D, a);
         kern::build_lists(lb, stream, a, -1);
+        const size_t n_conc = a.seg_tier < T ? a.seg_tier + 1 : T;  // the tiers sentences are routed to up front: one launch each, side by side
+        // The segment tier (the critical path: the longest sentences, then the escape tiers behind it) is launched on the launch
+        // stream itself -- no event round trip before it starts nor before what follows it (VBT_MAIN_SEG=0: every tier on a side stream).
+        const bool main_seg = env_u32("VBT_MAIN_SEG", 1) != 0 && a.seg_tier < T;
+        auto launch_tier = [&](size_t t, hipEvent_t after) {
+            const bool on_main = main_seg && t == a.seg_tier;
+            if (!on_main && !streams[t]) {
+                hipStream_t new_stream;
+                HIP_CHECK(hipStreamCreateWithFlags(&new_stream, hipStreamNonBlocking));
+                streams[t] = new_stream;
+                hipEvent_t new_event;
+                HIP_CHECK(hipEventCreateWithFlags(&new_event, hipEventDisableTiming));
+                tier_events[t] = new_event;
+            }
+            hipStream_t side = on_main ? stream : reinterpret_cast<hipStream_t>(streams[t]);
+            if (!on_main) HIP_CHECK(hipStreamWaitEvent(side, after, 0));
+            // one workgroup per list entry: the lists are built on the device, so the grid covers the whole batch and the
+            // workgroups beyond a list's length exit at once (VBT_LAT_PERSIST=1: persistent waves with a work cursor)
+            const uint32_t grid = !persist ? cn : (t < tier_waves.size() && tier_waves[t]) ? std::min<uint32_t>(tier_waves[t], waves_for(tiers[t], cn)) : waves_for(tiers[t], cn);
+            if (t < a.n_lean) kern::lattice_lean(cn, tiers[t], side, D, a, (uint32_t)t);
+            else launch_lattice(a, dim3(grid), tiers[t], side, (uint32_t)t, persist);
+            if (t == a.seg_tier)
+                for (size_t x = t + 1; x < T; ++x)
+                    launch_lattice(a, dim3(waves_for(tiers[x], std::min<uint32_t>(cn, 4096))), tiers[x], side, (uint32_t)x, 1u);
+            if (!on_main) HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(tier_events[t]), side));
+        };
+        // (VBT_LEAN_EARLY=1, a measured negative result kept as a knob: the lean tiers' lists are complete behind build_lists -- gen_long
+        // files nothing there -- so their sweep could start here, next to the gen_long levels, in whose tail the machine idles for 55 us
+        // of the headline step.  It does start, and its 100 k one-wave workgroups keep gen_long's 16-32 KiB workgroups off the CUs until
+        // they have drained: headline 1.339 -> 1.348 ms, config 5 3.590 -> 3.575 ms.  Round 3 saw the same from the other side.)
+        const bool lean_early = a.n_lean > 0 && env_u32("VBT_LEAN_EARLY", 0) != 0;
+        if (lean_early) {
+            if (!ev_fork_early) HIP_CHECK(hipEventCreateWithFlags(reinterpret_cast<hipEvent_t*>(&ev_fork_early), hipEventDisableTiming));
+            HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_fork_early), stream));
+            for (size_t t = 0; t < a.n_lean && t < n_conc; ++t) launch_tier(t, reinterpret_cast<hipEvent_t>(ev_fork_early));
+        }
         // gen_one files every sentence that outgrows it at the smallest level of gen_long that holds it; the levels run one after
         // the other on the launch stream: workgroups of 4 wavefronts (16 at the last level, which has a CU to itself), as many as
         // a CU's LDS and its 32 wave slots admit.  (Next to the bulk generator, on side streams, their 16-160 KiB workgroups do not
@@ -501,35 +539,13 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
         }
         rec(1);
         HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(ev_fork2), stream));
-        // One lattice_lds launch per LDS tier up to the segment tier (default: a single tier).  The tiers above it are escape
-        // tiers: nothing is routed to them up front, they take what the tier before them could not sweep (a window of end lists
-        // wider than its LDS), so they are launched on the segment tier's stream, behind it.
-        const size_t n_conc = a.seg_tier < T ? a.seg_tier + 1 : T;
-        // The segment tier (the critical path: the longest sentences, then the escape tiers behind it) is launched on the launch
-        // stream itself -- no event round trip before it starts nor before what follows it (VBT_MAIN_SEG=0: every tier on a side stream).
-        const bool main_seg = env_u32("VBT_MAIN_SEG", 1) != 0 && a.seg_tier < T;
+        // One launch per LDS tier up to the segment tier (the lean tiers in front of it may be running already).  The tiers above it
+        // are escape tiers: nothing is routed to them up front, they take what the tier before them could not sweep (a window of end
+        // lists wider than its LDS), so they are launched on the segment tier's stream, behind it.
         for (size_t i = 0; i < n_conc; ++i) {
             const size_t t = n_conc - 1 - i;
-            const bool on_main = main_seg && t == a.seg_tier;
-            if (!on_main && !streams[t]) {
-                hipStream_t new_stream;
-                HIP_CHECK(hipStreamCreateWithFlags(&new_stream, hipStreamNonBlocking));
-                streams[t] = new_stream;
-                hipEvent_t new_event;
-                HIP_CHECK(hipEventCreateWithFlags(&new_event, hipEventDisableTiming));
-                tier_events[t] = new_event;
-            }
-            hipStream_t side = on_main ? stream : reinterpret_cast<hipStream_t>(streams[t]);
-            if (!on_main) HIP_CHECK(hipStreamWaitEvent(side, reinterpret_cast<hipEvent_t>(ev_fork2), 0));
-            // one workgroup per list entry: the lists are built on the device, so the grid covers the whole batch and the
-            // workgroups beyond a list's length exit at once (VBT_LAT_PERSIST=1: persistent waves with a work cursor)
-            const uint32_t grid = !persist ? cn : (t < tier_waves.size() && tier_waves[t]) ? std::min<uint32_t>(tier_waves[t], waves_for(tiers[t], cn)) : waves_for(tiers[t], cn);
-            if (t < a.n_lean) kern::lattice_lean(cn, tiers[t], side, D, a, (uint32_t)t);
-            else launch_lattice(a, dim3(grid), tiers[t], side, (uint32_t)t, persist);
-            if (t == a.seg_tier)
-                for (size_t x = t + 1; x < T; ++x)
-                    launch_lattice(a, dim3(waves_for(tiers[x], std::min<uint32_t>(cn, 4096))), tiers[x], side, (uint32_t)x, 1u);
-            if (!on_main) HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(tier_events[t]), side));
+            if (lean_early && t < a.n_lean) continue;
+            launch_tier(t, reinterpret_cast<hipEvent_t>(ev_fork2));
         }
         for (size_t t = 0; t < n_conc; ++t)
             if (!(main_seg && t == a.seg_tier)) HIP_CHECK(hipStreamWaitEvent(stream, reinterpret_cast<hipEvent_t>(tier_events[t]), 0));

@@ -228,6 +228,7 @@ class Workspace {
     std::vector<void*> streams;      // one side stream per LDS tier
     std::vector<void*> tier_events;
     void* ev_fork2 = nullptr;
+    void* ev_fork_early = nullptr;  // behind build_lists: where the lean tiers' sweeps fork off (created at first use)
     bool fused = false;              // VBT_FUSED=1: the single fused kernel per sentence (A/B reference)
     unsigned long long* d_connid = nullptr;  // [num_left + num_right] usage counters (DEVICE ids of image `count_epoch`), allocated on first use
     uint32_t* d_counted = nullptr;           // per-sentence watermark of the counted steps
