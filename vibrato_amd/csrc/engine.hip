@@ -509,7 +509,11 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
             // one workgroup per list entry: the lists are built on the device, so the grid covers the whole batch and the
             // workgroups beyond a list's length exit at once (VBT_LAT_PERSIST=1: persistent waves with a work cursor)
             const uint32_t grid = !persist ? cn : (t < tier_waves.size() && tier_waves[t]) ? std::min<uint32_t>(tier_waves[t], waves_for(tiers[t], cn)) : waves_for(tiers[t], cn);
+            // (where the lean instance runs -- the default build on i16 cells, no counting -- the segment tier gets the slim instance of the
+            // general sweep: the same code without its C++ loop, `exact` mode and counting phase; VBT_SLIM=0: the general instance)
+            static const bool slim_on = env_u32("VBT_SLIM", 1) != 0;
             if (t < a.n_lean) kern::lattice_lean(cn, tiers[t], side, D, a, (uint32_t)t);
+            else if (slim_on && a.n_lean > 0 && !persist && tiers[t] <= 65536u) kern::lattice_slim(cn, tiers[t], side, D, a, (uint32_t)t);
             else launch_lattice(a, dim3(grid), tiers[t], side, (uint32_t)t, persist);
             if (t == a.seg_tier)
                 for (size_t x = t + 1; x < T; ++x)

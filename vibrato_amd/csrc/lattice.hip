@@ -42,13 +42,19 @@ namespace {
 #else
 #define SEG_TRACE(...) do { } while (0)
 #endif
-template <bool kSpaceMode, bool kWide>
+// kSlim: the instance for what the default build routes to the segment tier on running text -- i16 cells, sentences short enough for
+// the dead-predecessor sentinel, an LDS tier the records' 16-bit addresses reach, no connection-id counting: the assembly loop is the
+// only loop, and the C++ loop, the `exact` instance and the counting phase are not compiled in (anything else: return 34, the caller
+// hands the sentence to the general instance's escape tier).
+template <bool kSpaceMode, bool kWide, bool kSlim = false>
 __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const BatchArgs& A, uint32_t tier, uint32_t sid, uint4 h) {
     typedef __attribute__((address_space(3))) const uint64_t lds_cu64;
     typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     const uint32_t ln = threadIdx.x;
     const uint32_t lds_bytes = A.tier_bytes[tier];
+    unsigned long long* const lid_count_ = kSlim ? nullptr : A.lid_count;  // (slim: neither counting nor profiling is compiled in)
+    unsigned long long* const prof_ = kSlim ? nullptr : A.prof;
     constexpr uint32_t kD = VBT_DEPTH;  // passes whose gathers are in flight
     constexpr uint32_t kSh = kWide ? 2u : 1u;  // log2 of the matrix cell size
     // absolute LDS address of the dynamic shared memory (records hold absolute addresses: no base add per access)
@@ -59,9 +65,9 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
     };
     {
         // profiling adds straight into the spread counters: nothing but the last time stamp lives between marks
-        uint64_t prof_t = A.prof ? clock64() : 0;
-        unsigned long long* const pr_ = A.prof ? A.prof + (size_t)(sid & (kProfSlots - 1)) * kProfWords : nullptr;
-#define PROF_MARK(i) do { if (A.prof) { const uint64_t t_ = clock64(); if (ln == 0) atomicAdd(&pr_[i], (unsigned long long)(t_ - prof_t)); prof_t = t_; } } while (0)
+        uint64_t prof_t = prof_ ? clock64() : 0;
+        unsigned long long* const pr_ = prof_ ? prof_ + (size_t)(sid & (kProfSlots - 1)) * kProfWords : nullptr;
+#define PROF_MARK(i) do { if (prof_) { const uint64_t t_ = clock64(); if (ln == 0) atomicAdd(&pr_[i], (unsigned long long)(t_ - prof_t)); prof_t = t_; } } while (0)
         const uint32_t nT = h.x & 0xFFFFu, CT = h.y & 0xFFFFu, passesT = h.z & 0x7FFFFFFFu;
         const size_t slot0 = (size_t)h.w + (size_t)kSentenceSlack * sid;  // (sentence_slot: the header holds the byte offset relative to the batch)
         const size_t node0 = (size_t)A.node_factor * slot0;
@@ -74,10 +80,11 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
         const uint32_t nbT = h.x >> 16;
         const uint32_t half_bytes = 8u * A.node_factor * (nbT + kSentenceSlack);
         // where a dead predecessor's sentinel cost could meet a live cost, every predecessor's own field is tested instead (kDeadHi)
-        const bool exact = kWide || nT >= 8000u;
+        const bool exact = !kSlim && (kWide || nT >= 8000u);
+        if (kSlim && (nT >= 8000u || lds0 + lds_bytes > 65536u)) return 34;
         // the common build sweeps in assembly (sweep_asm.hpp) over 8-byte records (16-bit LDS addresses) -- in the sentence's LDS, or
         // (VBT_LDS_REC=0) vector-fetched from the region below; the 64-byte scalar records (LPass) feed the C++ loop of the other builds
-        const bool vrec_mode = VBT_ASM_LOOP && !kWide && !exact && kD == 2 && !A.lid_count && lds0 + lds_bytes <= 65536u;
+        const bool vrec_mode = kSlim ? true : (VBT_ASM_LOOP && !kWide && !exact && kD == 2 && !lid_count_ && lds0 + lds_bytes <= 65536u);
         constexpr bool kLdsRec = VBT_LDS_REC != 0;
         const bool lds_rec = kLdsRec && vrec_mode;  // the pass records live in LDS: nothing bounds them but the tier
         // (a sentence that is swept whole dumps nothing: its records take the whole region)
@@ -92,7 +99,7 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
         uint2* const vrec = reinterpret_cast<uint2*>(rec);
         uint32_t seg_a = 0, seg_c = 0, seg_p = 0, sb = 0, m_in = 1, fail = 0;
         bool multi = false, done = false;
-        uint32_t counted = A.lid_count ? __builtin_amdgcn_readfirstlane(A.s_counted[sid]) : 0u;
+        uint32_t counted = lid_count_ ? __builtin_amdgcn_readfirstlane(A.s_counted[sid]) : 0u;
         uint32_t prof_S = 0, prof_SL = 0;
         uint32_t budget = lds_bytes;  // what a segment may be estimated at; shrinks when an estimate turns out too low
         // reachability state of the position sweep (tokenizer.rs:106-138), carried from segment to segment
@@ -257,7 +264,7 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
 #if !VBT_LOOP_PROF
         PROF_MARK(3);
 #else
-        if (A.prof) prof_t = clock64();  // (slot 3 is the loop's LDS wait in these builds)
+        if (prof_) prof_t = clock64();  // (slot 3 is the loop's LDS wait in these builds)
 #endif
 
         // ---- structural pre-pass (tokenizer.rs:106-138, control flow only) + pass records ----
@@ -452,7 +459,7 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
 #if !VBT_LOOP_PROF
         PROF_MARK(3);  // (the candidates' way into LDS counts as load time wherever it happens)
 #else
-        if (A.prof) prof_t = clock64();
+        if (prof_) prof_t = clock64();
 #endif
 
         // ---- fused gather + cost recurrence (matrix_connector.rs:79-85, lattice.rs:103-151) ----
@@ -544,7 +551,7 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
                     asm volatile(VBT_SWEEP_TEXT
                                  :: VBT_REC_OPERANDS, [sl] "s"(sl_s), [rs] "s"(rsrc), [ln] "v"(ln), [offk] "v"(offk_v), [plds] "v"(plds)
                                  : VBT_SWEEP_CLOBBERS);
-                    if (A.prof && ln == 0) {
+                    if (prof_ && ln == 0) {
                         const uint64_t* q = reinterpret_cast<const uint64_t*>(path);
                         atomicAdd(&pr_[5], (unsigned long long)q[0]); atomicAdd(&pr_[3], (unsigned long long)q[1]);
                         if (VBT_LOOP_PROF == 2) {  // (whole iterations by kind: slots 5 / 3 = cycles of the common / the other iterations, 0 / 1 = their counts)
@@ -704,7 +711,7 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
             uint2* __restrict__ nb = reinterpret_cast<uint2*>(A.g_hits + node0) + seg_c;
             for (uint32_t c = ln; c < C; c += 64) nb[c] = make_uint2(node_cost(c), node_pred(c));
         }
-        if (A.lid_count) {
+        if (lid_count_) {
             // Lattice::add_connid_counts (lattice.rs:170-183): for every inserted node r and every node l in
             // ends[r.start_node]: lid_count[r.left_id] += 1, rid_count[l.right_id] += 1; then the same for EOS
             // (left_id 0) against ends[len_char].  Only inserted ("live") nodes exist in the reference's lists.
@@ -728,8 +735,8 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
                     live += (uint32_t)__popcll(__ballot(alive));
                     if (alive) atomicAdd(&A.rid_count[er.x & 0xFFFFu], (unsigned long long)nc);
                 }
-                if (eos_step) { if (ln == 0) atomicAdd(&A.lid_count[0], (unsigned long long)live); }
-                else for (uint32_t c = c_beg + ln; c < c_beg + nc; c += 64) atomicAdd(&A.lid_count[nd[c].x / D.num_right], (unsigned long long)live);
+                if (eos_step) { if (ln == 0) atomicAdd(&lid_count_[0], (unsigned long long)live); }
+                else for (uint32_t c = c_beg + ln; c < c_beg + nc; c += 64) atomicAdd(&lid_count_[nd[c].x / D.num_right], (unsigned long long)live);
             }
             const uint32_t upto = last_seg ? nT + 1 : seg_b;
             if (upto > counted) { counted = upto; if (ln == 0) A.s_counted[sid] = counted; }
@@ -848,7 +855,7 @@ __device__ __forceinline__ uint32_t lattice_sentence(const DevDict& D, const Bat
         }  // segments
         if (fail) return fail;
         PROF_MARK(7);
-        if (A.prof && ln == 0) {
+        if (prof_ && ln == 0) {
             atomicAdd(&pr_[kProfPhases + 1], (unsigned long long)prof_S);
             atomicAdd(&pr_[kProfPhases + 2], (unsigned long long)prof_SL);
             atomicAdd(&pr_[kProfPhases + 3], (unsigned long long)CT);
@@ -1026,6 +1033,30 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
     }
 }
 
+#if VBT_HAS_LEAN
+#ifndef VBT_SLIM_WAVES
+#define VBT_SLIM_WAVES 4
+#endif
+// The segment tier's launch of the default build on i16 cells without counting: lattice_sentence<.., kSlim> (see there).
+template <bool kSpaceMode>
+__global__ void __launch_bounds__(64, VBT_SLIM_WAVES) lattice_slim(DevDict D, BatchArgs A, uint32_t tier) {
+    if (A.tier_prio) __builtin_amdgcn_s_setprio(2);
+    const uint32_t* list = A.lists + (size_t)tier * A.list_stride + A.list_off;
+    const uint32_t count = A.cctrl[2 * tier];
+    const uint32_t item = blockIdx.x;
+    if (item >= count) return;
+    const uint32_t sid = __builtin_amdgcn_readfirstlane(list[count - 1 - item]);
+    const uint4 hq = A.s_hdr[sid];
+    const uint4 h = make_uint4(__builtin_amdgcn_readfirstlane(hq.x), __builtin_amdgcn_readfirstlane(hq.y), __builtin_amdgcn_readfirstlane(hq.z), __builtin_amdgcn_readfirstlane(hq.w));
+    const uint32_t fail = lattice_sentence<kSpaceMode, false, true>(D, A, tier, sid, h);
+    if (fail) {
+        const bool escape = tier + 1 < A.n_tiers && fail != 27;
+        if (threadIdx.x == 0 && !escape) atomicAdd(&A.ctrl[fail < 32 ? fail : 28], 1u);
+        if (escape) list_push(A, tier + 1, sid); else list_push_fb(A, sid);
+    }
+}
+#endif
+
 // Worker::tokenize() latency path (worker.rs:49-55; the 3-call loop of tokenize/src/main.rs:78-82): one wavefront, one sentence at
 // a time, and NO launch per sentence: the kernel stays resident and serves the worker's calls out of its pinned host block.
 //   written by the kernel: ctl[0] status = the sequence number of the last sentence served (written last, system-scope release: the
@@ -1137,6 +1168,14 @@ void lattice_lds(uint32_t workgroups, uint32_t lds_bytes, hipStream_t stream, co
     hipLaunchKernelGGL(k, dim3(workgroups), dim3(64), lds_bytes, stream, D, a, tier, persistent);
 }
 bool lattice_has_lean() { return VBT_HAS_LEAN != 0; }
+void lattice_slim(uint32_t workgroups, uint32_t lds_bytes, hipStream_t stream, const DevDict& D, const BatchArgs& a, uint32_t tier) {
+#if VBT_HAS_LEAN
+    if (D.space_cateset) hipLaunchKernelGGL(vbt::lattice_slim<true>, dim3(workgroups), dim3(64), lds_bytes, stream, D, a, tier);
+    else hipLaunchKernelGGL(vbt::lattice_slim<false>, dim3(workgroups), dim3(64), lds_bytes, stream, D, a, tier);
+#else
+    (void)workgroups; (void)lds_bytes; (void)stream; (void)D; (void)a; (void)tier;
+#endif
+}
 void lattice_lean(uint32_t workgroups, uint32_t lds_bytes, hipStream_t stream, const DevDict& D, const BatchArgs& a, uint32_t tier) {
 #if VBT_HAS_LEAN
     if (D.space_cateset) hipLaunchKernelGGL(vbt::lattice_lean<true>, dim3(workgroups), dim3(64), lds_bytes, stream, D, a, tier);
