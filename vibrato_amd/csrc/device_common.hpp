@@ -228,9 +228,6 @@ __device__ __forceinline__ void unk_spans(uint32_t cinfo, uint32_t g, uint32_t i
 #ifndef VBT_GEN_RECORDS
 #define VBT_GEN_RECORDS 1  // the bulk generator lays out the sweep's pass records for the sentences lattice_lds sweeps whole (gen_device.hpp)
 #endif
-#ifndef VBT_GEN_SEGMENTS
-#define VBT_GEN_SEGMENTS 1  // the bulk generator also cuts the sentences that do not fit the lean tier whole and lays out their segments' pass records (gen_device.hpp)
-#endif
 #ifndef VBT_GENLONG_PROF
 #define VBT_GENLONG_PROF 0  // developer aid (tools/dbg/genlong_profile.py on a variant build): gen_long's wall cycles between its barriers
 #endif
@@ -294,18 +291,6 @@ __host__ __device__ __forceinline__ uint32_t step_passes(uint32_t nc, uint32_t n
 __host__ __device__ __forceinline__ uint64_t lattice_fixed_bytes(uint32_t C, uint32_t n, uint32_t E, uint32_t passes) {
     return 8ull * (E + 2ull) + 8ull * (C + 2ull) + (VBT_C2B_LDS ? 4ull : 2ull) * (n + 4ull) + 48  // (+ alignment; VBT_LDS_REC=0: the first three pass records of the assembly loop)
            + (VBT_LDS_REC ? 8ull * (passes + 10ull) : 0ull) + (VBT_GUARD ? 72ull : 0ull);
-}
-// A sentence that does not fit the lean tier whole is cut into segments by the GENERATOR (gen_device.hpp: the cuts, the pass records of
-// every segment and a table of segment headers in the upper half of the sentence's hit-staging region), and lattice_lean sweeps it
-// segment by segment.  Layout of that upper half, in 8-byte words: [2 words per segment header x (kMaxSegs + 1)] [pass records];
-// header k = {a | b << 16, first candidate | candidates << 16}, {first slot | window slots << 16, first pass record}; header S
-// (behind the last segment) holds the total of the records in its last word.
-constexpr uint32_t kMaxSegs = 32;
-constexpr uint32_t kSegTableWords = 2u * (kMaxSegs + 1u);
-constexpr uint32_t kLeanBackWindow = 256;  // back pointers lattice_lean's back-trace holds in LDS at least (next to the token path: 2 bytes per character)
-// LDS of one segment in lattice_lean: slot records, candidate records, pass records (+ the empty ones behind the last)
-__host__ __device__ __forceinline__ uint64_t lean_seg_bytes(uint32_t C, uint32_t E, uint32_t passes) {
-    return 8ull * (E + 2ull) + 8ull * (C + 2ull) + 8ull * (passes + 10ull) + 32;
 }
 // Cost word of a slot whose node was never inserted (its start position is never visited).  Biased cost 0xC0000000 = +2^30: with
 // 16-bit connection and word costs a sentence of < 8000 characters keeps every live cost inside +-2^29, so such a predecessor

@@ -299,22 +299,16 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
         const uint32_t t_max = A.seg_tier < A.n_tiers ? A.seg_tier : A.n_tiers - 1u;
         if (lattice_fixed_bytes(C, n, eo(n + 1), 1u) > A.tier_bytes[t_max]) pre.on = false;
     }
-    // (p_beg / c_beg: slot / candidate index relative to the arena of the (segment of the) sentence; offC: where its candidate records begin)
-    // (the sentences that do not fit whole are cut further down, for the lean instance of the sweep: then the window end of every position is kept)
-    const bool seg_ok = (VBT_GEN_SEGMENTS != 0) && kSweepTakesRecords && !A.lid_count && !A.direct_push && !D.matrix_wide && n < 8000u && A.n_lean > 0 && A.tier_bytes[A.n_lean - 1u] <= 65536u;
-    auto put_rec = [&](uint32_t P, uint32_t p_beg, uint32_t np, uint32_t c_beg, uint32_t nc, uint32_t k, uint32_t r, uint32_t rounds, uint32_t offC) {
+    auto put_rec = [&](uint32_t P, uint32_t p_beg, uint32_t np, uint32_t c_beg, uint32_t nc, uint32_t k, uint32_t r, uint32_t rounds) {
         const uint32_t np_r = np - kRoundPreds * r < kRoundPreds ? np - kRoundPreds * r : kRoundPreds;
         const uint32_t nc_r = nc - kRoundCands * k < kRoundCands ? nc - kRoundCands * k : kRoundCands;
         const uint32_t nu = (np_r + 3u) >> 2;
         const uint32_t fl = nu | (r == 0 ? 8u : 0u) | (r + 1 == rounds ? 16u : 0u);
         pre.recs[P] = make_uint2(((p_beg + kRoundPreds * r) << 3) | ((np < 4u ? np : 4u) << 16) | (nc_r << 24),
-                                 (offC + ((c_beg + kRoundCands * k) << 3)) | (fl << 16) | (np_r << 24));
+                                 (pre.offC + ((c_beg + kRoundCands * k) << 3)) | (fl << 16) | (np_r << 24));
     };
-    // (lm, space, co_i, nc, eo_i, np: what the record loop below holds of position i anyway; sbv / scv / offCv: first slot, first candidate
-    // and candidate-record offset of the segment position i lies in -- 0, 0, pre.offC for a sentence that is swept whole; ex_out: the
-    // pass records laid out in front of this lane's)
-    auto pre_chunk = [&](auto space_c, uint32_t c0, uint64_t lm, uint32_t space, uint32_t co_i, uint32_t nc_i, uint32_t eo_i, uint32_t np_i,
-                         uint32_t sbv, uint32_t scv, uint32_t offCv, uint32_t& ex_out) {
+    // (lm, space, co_i, nc, eo_i, np: what the record loop below holds of position i anyway)
+    auto pre_chunk = [&](auto space_c, uint32_t c0, uint64_t lm, uint32_t space, uint32_t co_i, uint32_t nc_i, uint32_t eo_i, uint32_t np_i) {
         constexpr bool kSp = decltype(space_c)::value;
         const uint32_t i = c0 + ln;
         const bool in = i < n;
@@ -377,18 +371,16 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
         }
         uint32_t tot;
         const uint32_t ex = wave_exscan(nsl, tot);
-        ex_out = pre.SL + ex;
         if (pre.SL + tot + 64u > pre.cap) { pre.on = false; return; }  // (wave-uniform; the region is 16 bytes per candidate slot: never in practice)
         for (uint32_t q = 0, k = 0, r = 0; q < nsl; ++q) {
-            put_rec(pre.SL + ex + q, p_beg - sbv, np, c_beg - scv, nc, k, r, rounds, offCv);
+            put_rec(pre.SL + ex + q, p_beg, np, c_beg, nc, k, r, rounds);
             if (++r == rounds) { r = 0; ++k; }
         }
         pre.SL += tot;
     };
 #else
-    struct { bool on; uint32_t stop; uint32_t offC; } pre{false, 0, 0};
-    constexpr bool seg_ok = false;
-    auto pre_chunk = [&](auto, uint32_t, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t&) {};
+    struct { bool on; uint32_t stop; } pre{false, 0};
+    auto pre_chunk = [&](auto, uint32_t, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t) {};
 #endif
     {   // per-character records for the lattice kernel:
         // {cand_off | end-list offset << 16, pass bound of the position's step | window end << 14 | space << 31,
@@ -425,16 +417,14 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
                 nc_i = nc;
             }
             if (pre.on && !pre.stop) {
-                uint32_t ex_unused;
-                if (D.space_cateset) pre_chunk(std::true_type{}, c0, lm, space, co_i, nc_i, eo_i, cnt, 0u, 0u, pre.offC, ex_unused);
-                else pre_chunk(std::false_type{}, c0, lm, space, co_i, nc_i, eo_i, cnt, 0u, 0u, pre.offC, ex_unused);
+                if (D.space_cateset) pre_chunk(std::true_type{}, c0, lm, space, co_i, nc_i, eo_i, cnt);
+                else pre_chunk(std::false_type{}, c0, lm, space, co_i, nc_i, eo_i, cnt);
             }
             uint32_t m = e;  // inclusive prefix maximum over the lanes
             m = wave_inscan_max_dpp(m);
             if (i < n) {
                 const uint32_t upto = m > far ? m : far;  // furthest end of any candidate of the positions <= i (<= n)
                 const uint64_t third = space ? (uint64_t)grp[i] : lm;
-                if (seg_ok) code[i] = (uint16_t)eo(upto + 1);  // (the trie codes are dead: the window end of the position, for the cuts below)
                 const uint32_t yw = (nsl < 0x3FFFu ? nsl : 0x3FFFu) | (eo(upto + 1) << 14) | space;
                 pc[i] = make_uint4(co_i | (eo_i << 16), yw, (uint32_t)third, (uint32_t)(third >> 32));
             }
@@ -468,111 +458,10 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
         for (uint32_t t = 0; t < A.n_tiers; ++t)
             if (fixed_x <= A.tier_bytes[t]) { tx = t; break; }
         if (pre.SL + nsl + 64u <= pre.cap && tx < A.n_tiers && (A.seg_tier >= A.n_tiers || tx <= A.seg_tier) && A.tier_bytes[tx] <= 65536u) {
-            for (uint32_t q = ln; q < nsl; q += 64) put_rec(pre.SL + q, y0, np, C, 1u, 0u, q, nsl, pre.offC);
+            for (uint32_t q = ln; q < nsl; q += 64) put_rec(pre.SL + q, y0, np, C, 1u, 0u, q, nsl);
             tier = tx; passes = exact; pre_flag = 0x80000000u;
         }
     }
-#if VBT_GEN_SEGMENTS
-    // ---- A sentence that does not fit a tier whole, cut HERE for the lean instance of the sweep (lattice_lean) ----
-    // The cuts (any position that does not follow a space: a visited space run and the word it hands its visit to stay together), the
-    // pass records of every segment -- LDS addresses relative to the segment's arena: slot records of its window [eo(a), window end(b))
-    // at 0, its candidate records behind them -- and a table of segment headers go to the upper half of the sentence's hit-staging
-    // region (device_common.hpp: kSegTableWords); the header's third word becomes 1 << 30 | segments.  The sweep then needs neither
-    // the per-character records nor a pre-pass nor a search for cuts: candidates and records in, loop, nodes out, hand-over.
-    // Same state machine as above (second pass over the positions: the cuts need the window ends of the positions behind them).
-    // (they go to the LAST lean tier: with two of them the cut sentences -- the longest ones -- get a launch of their own, in front of the whole ones')
-    if (!pre_flag && seg_ok && 2u * (n + 2u) + 2u * kLeanBackWindow + 64u <= A.tier_bytes[A.n_lean - 1u]) {  // (the back-trace's arena: token path + a window of back pointers)
-        const uint32_t lds_lean = A.tier_bytes[A.n_lean - 1u];
-        uint2* const up = reinterpret_cast<uint2*>(A.g_hits + base) + region;  // the upper half (the lower one takes the nodes of finished segments)
-        pre.recs = up + kSegTableWords;
-        pre.cap = region > kSegTableWords + 128u ? (uint32_t)(region - kSegTableWords - 64u) : 0u;
-        pre.on = pre.cap != 0; pre.windowed = true; pre.stop = 0; pre.cur = 1; pre.pend = 0; pre.sn_eos = n; pre.SL = 0; pre.w = 0;
-        const uint32_t eos_bound = step_passes(1u, maxcnt);
-        // the furthest end b of a segment that starts at a and fits the lean tier (0: none does)
-        auto choose_cut = [&](uint32_t a) -> uint32_t {
-            const uint32_t sb = eo(a), c_a = get_co(a);
-            uint32_t best = 0, run = 0;
-            for (uint32_t w0 = 0; w0 < 256 && a + w0 < n; w0 += 64) {
-                const uint32_t b = a + w0 + ln + 1;
-                uint32_t nsl = 0;
-                bool sp = false;
-                if (b <= n) {
-                    const uint32_t i = b - 1;
-                    sp = D.space_cateset && (ci[i] & D.space_cateset);
-                    uint32_t nc = get_co(i + 1) - get_co(i);
-                    if (sp) { const uint32_t sw = i + grp[i]; nc = sw < n ? get_co(sw + 1) - get_co(sw) : 0u; }
-                    nsl = step_passes(nc, eo(i + 1) - eo(i));
-                }
-                uint32_t tot;
-                const uint32_t incl = wave_exscan(nsl, tot) + nsl + run;
-                bool fits = false;
-                if (b <= n) {
-                    const uint32_t Ck = get_co(b) - c_a, Ek = (b == n ? eo(n + 1) : (uint32_t)code[b - 1]) - sb;
-                    fits = Ek < 8190u && lean_seg_bytes(Ck, Ek, incl + eos_bound) <= lds_lean;  // (+ the EOS step: the segment may turn out to be the last)
-                }
-                const uint64_t m = __ballot(fits && (b == n || !sp));
-                if (m) best = a + w0 + 64u - (uint32_t)__builtin_clzll(m);
-                run += tot;
-                if (__ballot(fits) == 0) break;
-            }
-            return best;
-        };
-        uint32_t n_seg = 0, next_a = 0;
-        uint32_t sbv = 0, scv = 0, offCv = 0, hdv = 0, startv = 0xFFFFFFFFu, segv = 0, Cv = 0;  // of the segment this lane's position lies in
-        uint32_t e_sb = 0, e_sc = 0, e_offC = 0, e_C = 0, e_seg = 0, e_hd = 0, e_start = 0xFFFFFFFFu;  // of the newest segment; in the end: of the EOS step's
-        bool ok = pre.on;
-        for (uint32_t c0 = 0; c0 < n && ok && !pre.stop; c0 += 64) {
-            // a position in front of the chunk's first new segment lies in the newest segment so far
-            sbv = e_sb; scv = e_sc; offCv = e_offC; hdv = e_hd; startv = e_start; segv = e_seg; Cv = e_C;
-            while (next_a < n && next_a < c0 + 64) {  // the segments that start inside this chunk
-                const uint32_t b = n_seg < kMaxSegs ? choose_cut(next_a) : 0u;
-                if (!b) { ok = false; break; }
-                const uint32_t sb = eo(next_a), sc = get_co(next_a), Ck = get_co(b) - sc, Ek = (b == n ? eo(n + 1) : (uint32_t)code[b - 1]) - sb;
-                if (ln == 0) up[2 * n_seg] = make_uint2(next_a | (b << 16), sc | (Ck << 16));
-                const bool mine = c0 + ln >= next_a;
-                sbv = mine ? sb : sbv; scv = mine ? sc : scv; offCv = mine ? 8u * (Ek + 2u) : offCv; hdv = mine ? (sb | (Ek << 16)) : hdv;
-                startv = mine ? next_a : startv; segv = mine ? n_seg : segv; Cv = mine ? Ck : Cv;
-                e_sb = sb; e_sc = sc; e_offC = 8u * (Ek + 2u); e_C = Ck; e_seg = n_seg; e_hd = sb | (Ek << 16); e_start = next_a;
-                ++n_seg; next_a = b;
-            }
-            if (!ok) break;
-            const uint32_t i = c0 + ln;
-            uint32_t space = 0, co_i = 0, nc_i = 0, eo_i = 0, cnt = 0;
-            uint64_t lm = 0;
-            if (i < n) {
-                space = (D.space_cateset && (ci[i] & D.space_cateset)) ? 0x80000000u : 0u;
-                lm = get_lens(i);
-                co_i = get_co(i);
-                nc_i = get_co(i + 1) - co_i;
-                eo_i = eo(i);
-                if (space) { const uint32_t sw = i + grp[i]; nc_i = sw < n ? get_co(sw + 1) - get_co(sw) : 0u; }
-                cnt = eo(i + 1) - eo_i;
-            }
-            uint32_t ex = 0;
-            if (D.space_cateset) pre_chunk(std::true_type{}, c0, lm, space, co_i, nc_i, eo_i, cnt, sbv, scv, offCv, ex);
-            else pre_chunk(std::false_type{}, c0, lm, space, co_i, nc_i, eo_i, cnt, sbv, scv, offCv, ex);
-            if (!pre.on || !pre.windowed) { ok = false; break; }
-            if (i == startv) up[2 * segv + 1] = make_uint2(hdv, ex);  // the segment's first pass record: what was laid out in front of its first position
-            if (pre.stop) {  // only spaces are left behind position sn_eos: its segment is the last one (what lies behind is never visited)
-                const uint32_t l = pre.sn_eos - c0;
-                e_sb = (uint32_t)__builtin_amdgcn_readlane((int)sbv, (int)l); e_sc = (uint32_t)__builtin_amdgcn_readlane((int)scv, (int)l);
-                e_offC = (uint32_t)__builtin_amdgcn_readlane((int)offCv, (int)l); e_seg = (uint32_t)__builtin_amdgcn_readlane((int)segv, (int)l);
-                e_C = (uint32_t)__builtin_amdgcn_readlane((int)Cv, (int)l);
-            }
-        }
-        if (ok) {
-            // + the EOS step (insert_eos(start_node), tokenizer.rs:138): predecessors = ends[sn_eos], the one candidate behind its segment's
-            const uint32_t y0 = eo(pre.sn_eos), y1 = pre.sn_eos < n ? eo(pre.sn_eos + 1) : eo(n + 1);
-            const uint32_t np = y1 - y0, nsl = (np + kRoundPreds - 1) / kRoundPreds;
-            const uint32_t S = e_seg + 1u;
-            if (pre.SL + nsl + 64u <= pre.cap && lean_seg_bytes(e_C, (e_offC >> 3) - 2u, 0u) <= lds_lean) {
-                for (uint32_t q = ln; q < nsl; q += 64) put_rec(pre.SL + q, y0 - e_sb, np, e_C, 1u, 0u, q, nsl, e_offC);
-                if (ln == 0) up[2 * S + 1] = make_uint2(0u, pre.SL + nsl);  // behind the last segment: where its records end
-                tier = A.n_lean - 1u; passes = S; pre_flag = 0x40000000u;
-            }
-        }
-    }
-#endif
 #endif
     if (!pre_flag) {
         // smallest tier whose LDS holds the lattice arrays (connection costs are never staged)

@@ -968,146 +968,6 @@ __device__ __forceinline__ uint32_t lattice_whole(const DevDict& D, const BatchA
     return 0;
 }
 
-// ... and a sentence that does not fit: cut by the generator (gen_device.hpp: segment headers and per-segment pass records in the upper
-// half of the sentence's hit-staging region), swept here segment by segment.  Per segment: its candidates and records into LDS (the
-// slot window's front holds the nodes the previous segment handed over), the assembly loop, (total cost, back pointer) of its nodes
-// out to the region's lower half, the slots behind the cut moved to the front.  Then the windowed back-trace of lattice_sentence.
-template <bool kSpaceMode>
-__device__ __forceinline__ uint32_t lattice_segments(const DevDict& D, const BatchArgs& A, uint32_t lds_bytes, uint32_t sid, uint4 h) {
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    const uint32_t ln = threadIdx.x;
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)g_smem;
-    const uint32_t nT = h.x & 0xFFFFu, nbT = h.x >> 16, CT = h.y & 0xFFFFu, S = h.z & 0xFFFFu;
-    const size_t slot0 = (size_t)h.w + (size_t)kSentenceSlack * sid;
-    const size_t node0 = (size_t)A.node_factor * slot0;
-    const uint32_t region = A.node_factor * (nbT + kSentenceSlack);
-    const uint4* __restrict__ ndg = A.g_cand + node0;
-    uint2* const nbuf = reinterpret_cast<uint2*>(A.g_hits + node0);            // lower half: (total cost, back pointer) per node
-    const uint2* __restrict__ up = nbuf + region;                              // upper half: segment headers, then the pass records
-    const uint2* __restrict__ grec = up + kSegTableWords;
-    const uint32_t kBosSeq = CT + 1u;
-    if (S == 0 || S > kMaxSegs || lds0 + lds_bytes > 65536u) return 26;
-    uint2* const e_rec = reinterpret_cast<uint2*>(g_smem);  // the slot records sit at the start of the arena in every segment
-    if (ln == 0) e_rec[0] = make_uint2(((0xFFFEu - kBosSeq) & 0xFFFFu) << 16, 0x80000000u);  // BOS (lattice.rs:72-83)
-    const uint64_t mb = (uint64_t)reinterpret_cast<uintptr_t>(D.matrix);
-    u32x4 rsrc;
-    rsrc.x = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)mb);
-    rsrc.y = ((uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(mb >> 32)) & 0xFFFFu) | (2u << 16);
-    rsrc.z = (uint32_t)__builtin_amdgcn_readfirstlane(D.matrix_bytes);
-    rsrc.w = 0x00020000u;
-    uint32_t back_eos = kBosSeq;
-    uint2 hd0 = up[0], hd1 = up[1];
-    for (uint32_t k = 0; k < S; ++k) {
-        const uint2 nx0 = up[2 * k + 2], nx1 = up[2 * k + 3];  // the next segment's header (behind the last one: the end of the records)
-        const uint32_t w0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)hd0.y), w1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)hd1.x);
-        const uint32_t r0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)hd1.y), r1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)nx1.y);
-        const uint32_t seg_c = w0 & 0xFFFFu, C = w0 >> 16, sb = w1 & 0xFFFFu, E = w1 >> 16, SL = r1 - r0;
-        const bool last = k + 1 == S;
-        Arena ar{g_smem, lds_bytes, 0, true};
-        (void)ar.take<uint2>(E + 2);
-        uint2* const cnd = ar.take<uint2>(C + 2);
-        uint2* const vhead = ar.take<uint2>(SL + 10u);
-        if (!ar.ok || E >= 8190u || r1 < r0) return 26;
-        const uint32_t offK = lds0, offC = lds0 + (uint32_t)(reinterpret_cast<char*>(cnd) - g_smem);
-        const uint4* __restrict__ nd = ndg + seg_c;
-        const uint2* __restrict__ gr = grec + r0;
-        const uint32_t fld0 = 0xFFFEu - seg_c;
-        uint4 c0r = nd[ln < C ? ln : 0u], c1r = nd[64 + ln < C ? 64 + ln : 0u];
-        uint2 p0 = gr[ln < SL ? ln : 0u], p1 = gr[64 + ln < SL ? 64 + ln : 0u];
-        auto put_cand = [&](uint32_t c, const uint4& r) {
-            const uint32_t es = (r.y >> 16) - sb;
-            e_rec[es] = make_uint2((((fld0 - c) & 0xFFFFu) << 16) | (r.w >> 16), kDeadHi);
-            cnd[c] = make_uint2(r.x, (es << 3) | (r.y << 16));
-        };
-        if (last && ln == 0) {
-            cnd[C] = make_uint2(0u, E << 3);  // EOS pseudo candidate (insert_eos, lattice.rs:85-101): left id 0, word cost 0
-            e_rec[E] = make_uint2(((fld0 - C) & 0xFFFFu) << 16, kDeadHi);
-        }
-        if (ln < C) put_cand(ln, c0r);
-        if (64 + ln < C) put_cand(64 + ln, c1r);
-        for (uint32_t c = 128 + ln; c < C; c += 64) put_cand(c, nd[c]);
-        if (ln < SL) vhead[ln] = make_uint2(p0.x + lds0, p0.y + lds0);
-        if (64 + ln < SL) vhead[64 + ln] = make_uint2(p1.x + lds0, p1.y + lds0);
-        for (uint32_t P = 128 + ln; P < SL; P += 64) { const uint2 r = gr[P]; vhead[P] = make_uint2(r.x + lds0, r.y + lds0); }
-        if (ln < 10) vhead[SL + ln] = make_uint2(offK, offC);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        {
-            const uint32_t sl_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)SL);
-            const uint32_t hd_v = lds0 + (uint32_t)(reinterpret_cast<char*>(vhead) - g_smem);
-            asm volatile(VBT_SWEEP_TEXT :: [rp] "v"(hd_v), [sl] "s"(sl_s), [rs] "s"(rsrc), [ln] "v"(ln), [offk] "v"(offK) : VBT_SWEEP_CLOBBERS);
-        }
-        // (total cost, back pointer) of the segment's nodes
-        for (uint32_t c = ln; c < C; c += 64) {
-            const uint2 q = cnd[c];
-            nbuf[seg_c + c] = make_uint2(e_rec[(q.y & 0xFFFFu) >> 3].y ^ 0x80000000u, 0xFFFEu - (q.x & 0xFFFFu));
-        }
-        if (last) back_eos = 0xFFFEu - (cnd[C].x & 0xFFFFu);
-        else {
-            // hand-over: the slots behind the cut -- final nodes that start in front of it, and the untouched slots of later candidates
-            // among them -- move to the front of the window, 64 records at a time, ascending
-            const uint32_t i0 = ((uint32_t)__builtin_amdgcn_readfirstlane((int)nx1.x) & 0xFFFFu) - sb, m_out = E - i0;
-            for (uint32_t q0 = 0; q0 < m_out; q0 += 64) {
-                const uint32_t q = q0 + ln;
-                const uint2 r = e_rec[i0 + (q < m_out ? q : 0u)];
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                if (q < m_out) e_rec[q] = r;
-            }
-            __syncthreads();
-        }
-        hd0 = nx0; hd1 = nx1;
-    }
-    // ---- back-trace over the nodes left in global memory, window by window + token records (as lattice_sentence) ----
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's own dumps: stores complete
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    Arena a2{g_smem, lds_bytes, 0, true};
-    uint16_t* const path = a2.take<uint16_t>(nT + 1);
-    uint16_t* const back = a2.take<uint16_t>(0);
-    const uint32_t W = a2.ok && lds_bytes > a2.used + 64 ? (uint32_t)((lds_bytes - a2.used - 64) / 2) : 0u;
-    if (W < kLeanBackWindow) return 33;  // (the generator cuts only sentences whose token path leaves this window: gen_device.hpp)
-    uint32_t T = 0, seq = back_eos, win_lo = CT + 2;
-    seq = __builtin_amdgcn_readfirstlane(seq);
-    while (seq != kBosSeq && T < nT) {
-        if (seq < win_lo) {
-            const uint32_t hi = seq + 1, lo = hi > W ? hi - W : 0u;
-            __syncthreads();
-            for (uint32_t c = lo + ln; c < hi; c += 64) back[c - lo] = (uint16_t)nbuf[c].y;
-            __syncthreads();
-            win_lo = lo;
-        }
-        if (ln == 0) {
-            while (seq != kBosSeq && seq >= win_lo && T < nT) { path[T++] = (uint16_t)seq; seq = back[seq - win_lo]; }
-        }
-        seq = __builtin_amdgcn_readfirstlane(seq);
-        T = __builtin_amdgcn_readfirstlane(T);
-    }
-    __syncthreads();
-    if (ln == 0) { A.tok_cnt[sid] = T; if (T) atomicAdd(&A.tile_sums[sid / kScanTile], T); }
-    const uint4* __restrict__ pcg = A.g_pc + slot0;
-    const uint16_t* __restrict__ c2b = A.g_c2b + slot0;
-    for (uint32_t t = ln; t < T; t += 64) {
-        const uint32_t c = path[T - 1 - t];
-        const uint4 r = ndg[c];
-        uint32_t stp = t ? ndg[path[T - t]].w & 0xFFFFu : 0u;
-        if constexpr (kSpaceMode) {
-            if (stp < nT) {
-                const uint4 rp = pcg[stp];
-                if (rp.y >> 31) stp += rp.z;
-            }
-        }
-        const uint32_t en = r.w & 0xFFFFu;
-        vbt_token_rec o;
-        o.start_char = stp; o.end_char = en;
-        o.start_byte = c2b[stp]; o.end_byte = c2b[en];
-        o.word_idx = r.z;
-        o.total_cost = (int32_t)nbuf[c].x;
-        A.tok_stage[slot0 + t] = o;
-    }
-    return 0;
-}
-
 #ifndef VBT_LEAN_WAVES
 #define VBT_LEAN_WAVES 5
 #endif
@@ -1120,7 +980,7 @@ __global__ void __launch_bounds__(64, VBT_LEAN_WAVES) lattice_lean(DevDict D, Ba
     const uint32_t sid = __builtin_amdgcn_readfirstlane(list[count - 1 - item]);
     const uint4 hq = A.s_hdr[sid];
     const uint4 h = make_uint4(__builtin_amdgcn_readfirstlane(hq.x), __builtin_amdgcn_readfirstlane(hq.y), __builtin_amdgcn_readfirstlane(hq.z), __builtin_amdgcn_readfirstlane(hq.w));
-    const uint32_t fail = (h.z >> 30) == 1u ? lattice_segments<kSpaceMode>(D, A, A.tier_bytes[tier], sid, h) : lattice_whole<kSpaceMode>(D, A, A.tier_bytes[tier], sid, h);
+    const uint32_t fail = lattice_whole<kSpaceMode>(D, A, A.tier_bytes[tier], sid, h);
     if (fail) {
         if (threadIdx.x == 0) atomicAdd(&A.ctrl[fail < 32 ? fail : 28], 1u);
         list_push_fb(A, sid);
