@@ -418,7 +418,7 @@ def main():
         ins = (tr or {}).get("wave_insts_by_kernel", {})
         sqk = (tr or {}).get("sq_by_kernel", {})
 
-        SWEEP = ("lattice_lds", "lattice_lean")  # the sweep's two instances: one launch each per step, side by side
+        SWEEP = ("lattice_lds", "lattice_slim", "lattice_lean")  # the sweep's instances: general (escape tiers), slim (segment tier), lean -- launched side by side
 
         def merged(table, kernels):
             """Sum of a per-kernel table of the committed PMC summary over several kernels."""
@@ -449,8 +449,8 @@ def main():
             return out
 
         roofline = {"bound": "hbm",
-                    "kernel": "lattice_lean + lattice_lds: the sweep, two instances of one loop launched side by side (lean: whole sentences that "
-                              "arrive with the generator's pass records, 8 KiB tier, 5 waves per SIMD; general: everything else, 10 KiB tier); both span the "
+                    "kernel": "lattice_lean + lattice_slim: the sweep, two instances of one loop launched side by side (lean: whole sentences that "
+                              "arrive with the generator's pass records, 8 KiB tier, 5 waves per SIMD; slim: everything else, 10 KiB segment tier); both span the "
                               "same interval of a step (rocprofv3: either kernel's duration = this span).  duration = hipEvents on the launch stream from "
                               "the fork behind the generators to the join of every sweep; the fallback launch and the packing behind the join are pack_ms",
                     "achieved": round(achieved / 1e9, 3), "peak": HBM_PEAK_BPS / 1e9, "unit": "GB/s",

@@ -219,9 +219,16 @@ VBT_API int vbt_connid_probs(const uint64_t* counts, size_t n, uint32_t* ids, do
  * text[offsets[s] .. offsets[s+1]). Copies text to the device, runs the kernels,
  * copies token records back (the GPU's SDMA engines, into a pinned block sized to the result). The batch keeps its own copy of the text.
  * Every sentence must be valid UTF-8 (a Rust `str`): otherwise VBT_ERR_UTF8 and no batch.
- * Thread-safe per tokenizer: each call takes a workspace (device scratch + staging + stream) from the tokenizer's
- * pool and returns it, so steady-state calls do no device allocation (vbt_tokenizer_pool_stats); batches pushed from
- * several host threads overlap their copies with each other's kernels (6-8 threads reach the kernel-bound rate).
+ * ONE call is a pipeline (tokenize/src/main.rs:76-95 is a single-threaded caller): on a single-device tokenizer a lone caller's batch of
+ * 4 MiB or more is cut at sentence borders into VBT_H2H_CHUNKS (default 5, 1 = off) chunks that rotate through three chunk-sized
+ * workspaces -- the copy in and the copy out of neighbouring chunks run on the SDMA engines next to the kernels of the chunk in
+ * between, into ONE result block (40 M sentences/s for one call from one thread on the headline workload; 20 M unpipelined).  The
+ * tokenizer's first batch runs unpipelined (it sets the tokens-per-KiB estimate the result block of a pipelined call is sized by; a
+ * batch that outgrows the estimate is redone unpipelined).  Results are the same arrays either way.
+ * Thread-safe per tokenizer: each call takes workspaces (device scratch + staging + stream) from the tokenizer's
+ * pool and returns them, so steady-state calls do no device allocation (vbt_tokenizer_pool_stats); batches pushed from
+ * several host threads overlap their copies with each other's kernels (4-8 threads reach 62-66 M sentences/s; such calls are not
+ * cut into chunks: only a caller that has been alone for its last two calls is).
  * The pools keep idle workspaces (~400 B of device memory per byte of text of the batch they were sized for) and pinned
  * blocks for reuse, at most VBT_POOL_MAX_MB=<device MB>[,<pinned MB>] of each (default: a quarter of the GPU's memory -- 72 GiB on
  * an MI355X -- and 8192 MB of pinned memory; what would exceed it is released instead of pooled, and a caller whose workspace

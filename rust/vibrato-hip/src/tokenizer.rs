@@ -166,6 +166,34 @@ impl Tokenizer {
         LineBatches { tokenizer: self, lines: lines.into_iter(), batch_bytes: batch_bytes.max(1), batch_lines: batch_lines.max(1), current: None, next: 0, failed: false }
     }
 
+    /// The internal renumbering of the connection ids by measured usage (the reference's `reorder` + `map` workflow,
+    /// `map/src/reorder.rs:34-63`, applied to the DEVICE image only: nothing visible changes), done up front and synchronously on a
+    /// sample of `lines` (at most 16 384 of them, spread evenly).  Without this call the tokenizer does the same in the background behind
+    /// its first batch of 2048 or more sentences; a second call is a no-op.
+    pub fn calibrate<I, S>(&self, lines: I) -> Result<()>
+    where
+        I: IntoIterator<Item = S>,
+        S: AsRef<str>,
+    {
+        let mut text: Vec<u8> = Vec::new();
+        let mut offsets: Vec<u64> = vec![0];
+        for l in lines {
+            text.extend_from_slice(l.as_ref().as_bytes());
+            offsets.push(text.len() as u64);
+        }
+        let tok = self.raw()?;
+        // Safety: `text` / `offsets` outlive the call; the library copies what it samples.
+        check(unsafe { sys::vbt_tokenizer_calibrate(tok, text.as_ptr(), offsets.as_ptr(), (offsets.len() - 1) as u64) })
+    }
+
+    /// Blocks while a background calibration is running (`timeout_ms < 0`: no limit); `Ok(true)` when none is running any more.
+    pub fn wait_for_calibration(&self, timeout_ms: i64) -> Result<bool> {
+        let tok = self.raw()?;
+        let mut idle: i32 = 0;
+        check(unsafe { sys::vbt_tokenizer_connid_reorder_wait(tok, timeout_ms, &mut idle) })?;
+        Ok(idle != 0)
+    }
+
     /// Releases the idle device workspaces and pinned blocks `tokenize_batch` keeps for reuse (about 400 bytes of device memory per
     /// byte of text of every batch that was in flight at once; at most a quarter of the GPU's memory, `VBT_POOL_MAX_MB`). They are
     /// created again on demand. Thread-safe; a no-op before the first batch.

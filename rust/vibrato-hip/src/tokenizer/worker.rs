@@ -13,10 +13,12 @@ use crate::tokenizer::Tokenizer;
 /// `(connection id, probability)` pairs in descending order of probability, id 0 left out (`dictionary/mapper.rs:84`).
 pub type ConnIdProbs = Vec<(usize, f64)>;
 
-/// Holds one sentence and, after `tokenize()`, its tokens.  Every `tokenize()` call is ONE kernel launch (the library reads the
-/// text from the worker's pinned host block and writes the token records back into it): ~45 us for a 49-character sentence on an
-/// MI355X, against ~12 us on one CPU core for the reference -- the reference's calling pattern keeps working, but the throughput
-/// path is [`Tokenizer::tokenize_batch`] (three orders of magnitude above this loop).
+/// Holds one sentence and, after `tokenize()`, its tokens.  `tokenize()` costs NO kernel launch in steady state: the worker's first
+/// call starts a resident one-wavefront kernel that polls a doorbell in the worker's pinned host block, reads the text out of it
+/// and writes the token records back into it (it leaves after ~2 ms without a call, or after 4096 sentences, and the next call
+/// starts it again).  ~39 us for a 47-character sentence on an MI355X (21 us up to 13 characters), against ~12.5 us on one CPU
+/// core for the reference -- the reference's calling pattern keeps working, but it is 3x SLOWER than the CPU here; the throughput
+/// path is [`Tokenizer::tokenize_batch`] / [`Tokenizer::tokenize_lines`] (three orders of magnitude above this loop).
 pub struct Worker<'t> {
     raw: *mut sys::vbt_worker,
     tokenizer: &'t Tokenizer,

@@ -36,7 +36,7 @@ if trace:
     spans = []
     for a, b in zip(starts, starts[1:] + [len(rows)]):
         step = [r for r in rows[a:b] if int(r["Grid_Size_X"]) > 0]
-        lat = [r for r in step if name(r) in ("lattice_lds", "lattice_lean")]  # the sweep's two instances run side by side
+        lat = [r for r in step if name(r) in ("lattice_lds", "lattice_slim", "lattice_lean")]  # the sweep's two instances run side by side
         if len(step) < 3 or not lat:
             continue
         t0 = int(step[0]["Start_Timestamp"])
