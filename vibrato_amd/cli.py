@@ -86,24 +86,34 @@ def main(argv=None, stdin=None, stdout=None):
             while batches.get() is not None:
                 pass
 
-    stages = [threading.Thread(target=tokenize_stage), threading.Thread(target=output_stage)]
+    # (daemon threads, and the sentinel is posted whatever happens to the reader -- an I/O error on stdin, a KeyboardInterrupt: the stages
+    # then finish what is queued and the reader's exception is raised behind the join instead of an interpreter that hangs at exit)
+    stages = [threading.Thread(target=tokenize_stage, daemon=True), threading.Thread(target=output_stage, daemon=True)]
     for t in stages:
         t.start()
-    block = []
-    for raw in stdin:
-        if raw.endswith(b"\n"):
-            raw = raw[:-1]
-            if raw.endswith(b"\r"):
+    reader_error = None
+    try:
+        block = []
+        for raw in stdin:
+            if raw.endswith(b"\n"):
                 raw = raw[:-1]
-        block.append(raw)
-        if len(block) >= args.block:
+                if raw.endswith(b"\r"):
+                    raw = raw[:-1]
+            block.append(raw)
+            if len(block) >= args.block:
+                blocks.put(block)
+                block = []
+        if block:
             blocks.put(block)
-            block = []
-    if block:
-        blocks.put(block)
-    blocks.put(None)
-    for t in stages:
-        t.join()
+    except BaseException as e:  # noqa: BLE001 -- re-raised below, behind the join
+        reader_error = e
+        failure.append(e)  # (the stages skip what is still queued)
+    finally:
+        blocks.put(None)
+        for t in stages:
+            t.join()
+    if reader_error is not None:
+        raise reader_error
     if failure:
         raise failure[0]
     stdout.flush()
