@@ -177,6 +177,35 @@ def test_tokenizer_fails_loudly_without_gpu(fixture_sources):
     assert d.num_words(0) == 46  # the dictionary handle survives a failed Tokenizer::new
 
 
+def test_vbt_free_ignores_what_is_not_a_live_buffer_of_the_library(fixture_sources):
+    """vbt_free releases only pointers the library handed out and that are still live (round-5 advisor: a 16-byte header in front of
+    the pointer used to be trusted -- a second free put one block into the output cache twice, a foreign pointer had the bytes in front
+    of it read and was then freed): a second vbt_free of the same buffer and a pointer from somewhere else are ignored, a big buffer
+    goes through the cache and comes back for the next request, and the cache is released with the tokenizer's pools."""
+    import ctypes as C
+    from vibrato_amd import _native as N
+    s = fixture_sources
+    d = V.SystemDictionaryBuilder.from_readers(s["lex.csv"], s["matrix.def"], s["char.def"], s["unk.def"])
+    L = N.lib()
+    out, n = C.c_void_p(), C.c_size_t()
+    N.check(L.vbt_dict_write(d._handle(), -1, C.byref(out), C.byref(n)))
+    assert n.value > 1000 and C.string_at(out.value, 21) == b"VibratoTokenizer 0.5\n"
+    L.vbt_free.argtypes = [C.c_void_p]
+    L.vbt_free(out)
+    L.vbt_free(out)            # again: ignored (it is not live any more)
+    foreign = C.create_string_buffer(b"x" * 64)
+    L.vbt_free(C.cast(C.byref(foreign, 32), C.c_void_p))  # never ours: ignored, nothing in front of it is read or freed
+    assert foreign.raw[:64] == b"x" * 64
+    L.vbt_free(None)
+    # the library still hands out good buffers afterwards
+    a, b = C.c_void_p(), C.c_void_p()
+    N.check(L.vbt_dict_write(d._handle(), -1, C.byref(a), C.byref(n)))
+    N.check(L.vbt_dict_write(d._handle(), -1, C.byref(b), C.byref(n)))
+    assert a.value != b.value and C.string_at(a.value, n.value) == C.string_at(b.value, n.value)
+    L.vbt_free(a)
+    L.vbt_free(b)
+
+
 def test_utf8_validity_matches_python_strict_decoder():
     """vbt_utf8_valid == Rust `str` validity == Python's strict 'utf-8' codec, on hand-picked and random byte strings."""
     from vibrato_amd.api import utf8_valid

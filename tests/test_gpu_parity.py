@@ -837,3 +837,58 @@ def test_one_call_pipelined_in_chunks_matches_oracle_and_survives_a_wrong_estima
     assert ntok > 4 * 24000 * 40
     _assert_batch_equal(to, tv, t2, o2)  # and now the estimate holds
     _assert_batch_equal(to, tv, text, offs)
+
+
+def test_a_packed_result_slot_that_is_too_small_says_so_in_its_header():
+    """vbt_workspace_set_packed_output: a consumer of gathered slots on another rank sees nothing of the writing rank but the slot.  A
+    slot that holds the batch carries flags 0 and the batch's token total; one that is too small carries the records that were written
+    (never more), error flag 1 in its header -- and in the workspace's statistics -- and sharding.unpack_results refuses it (round-5 advisor:
+    the header used to report the full total over a truncated slot, bytes 16..31 were never written)."""
+    import torch
+    from vibrato_amd import sharding
+    sd = synth.SynthDict("small")
+    to, tv = _oracle_and_product(sd)
+    text, offs = sd.sentences(3000, "lognormal_40")
+    exp, exp_off = to.new_worker().tokenize_batch(text, offs)
+    n, ntok = 3000, len(exp)
+    d_text = torch.from_numpy(text).cuda()
+    d_offs = torch.from_numpy(offs.astype(np.int64)).cuda()
+    ws = tv.workspace(n, len(text))
+    stream = torch.cuda.current_stream().cuda_stream
+    for cap, ok in ((ntok + 10, True), (ntok // 2, False), (ntok, True)):
+        slot = torch.full((sharding.packed_bytes(n, cap),), 0xAB, dtype=torch.uint8, device="cuda")
+        ws.set_packed_output(slot.data_ptr(), slot.numel(), n)
+        ws.run(d_text.data_ptr(), d_offs.data_ptr(), n, len(text), stream)
+        st = ws.stats()
+        head = slot[:32].cpu().numpy()
+        assert int(head[:8].view(np.int64)[0]) == n and not head[16:].any()  # all 32 header bytes are written
+        if ok:
+            assert st["error_flags"] == 0 and int(head[12:16].view(np.uint32)[0]) == 0 and int(head[8:12].view(np.uint32)[0]) == ntok
+            n_s, n_t, off, cnt, tk = sharding.unpack_results(slot, n)
+            got, _ = sharding.tokens_in_sentence_order(off, cnt, tk)
+            assert got.tobytes() == exp.tobytes()
+        else:
+            assert st["error_flags"] & 1 and int(head[12:16].view(np.uint32)[0]) & 1 and int(head[8:12].view(np.uint32)[0]) == cap
+            with pytest.raises(RuntimeError):
+                sharding.unpack_results(slot, n)
+    ws.set_packed_output(None, 0, 0)
+
+
+def test_large_batches_from_several_threads_and_from_one_give_the_same_records():
+    """Batches big enough to be pipelined in chunks (>= 4 MiB), pushed by three host threads at once (calls that see each other run
+    unpipelined), then by one thread alone (pipelined again after two quiet calls): every result equals the oracle's."""
+    from concurrent.futures import ThreadPoolExecutor
+    sd = synth.SynthDict("small")
+    to, tv = _oracle_and_product(sd)
+    text, offs = sd.sentences(40000, "lognormal_40")
+    assert len(text) > (4 << 20)
+    exp, exp_off = to.new_worker().tokenize_batch(text, offs)
+
+    def one(_):
+        got, got_off = tv.tokenize_batch(text=text, offsets=offs).tokens_in_order()
+        return np.array_equal(got_off, exp_off) and got.tobytes() == exp.tobytes()
+
+    assert one(0)  # the first batch: unpipelined, sets the estimate
+    with ThreadPoolExecutor(3) as ex:
+        assert all(ex.map(one, range(9)))
+    assert all(one(k) for k in range(5))
