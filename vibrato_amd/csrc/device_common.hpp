@@ -228,6 +228,9 @@ __device__ __forceinline__ void unk_spans(uint32_t cinfo, uint32_t g, uint32_t i
 #ifndef VBT_GEN_RECORDS
 #define VBT_GEN_RECORDS 1  // the bulk generator lays out the sweep's pass records for the sentences lattice_lds sweeps whole (gen_device.hpp)
 #endif
+#ifndef VBT_CPINFO
+#define VBT_CPINFO 1  // the generators read character class and trie codes of a code point in one 8-byte load (DevDict::cpinfo); 0: separate tables (A/B)
+#endif
 #ifndef VBT_GENLONG_PROF
 #define VBT_GENLONG_PROF 0  // developer aid (tools/dbg/genlong_profile.py on a variant build): gen_long's wall cycles between its barriers
 #endif

@@ -165,6 +165,18 @@ Tokenizer::Tokenizer(const Dictionary* dict, bool ignore_space, uint32_t max_gro
         }
         dev_.num_right = dict_->num_right;
         dev_.chr2inf = dev_upload(dict_->chr2inf, allocs_);
+        {   // per code point: character class + trie codes in one 8-byte entry
+            const size_t ms = dict_->system.mapper.size(), mu = dict_->has_user ? dict_->user.mapper.size() : 0;
+            const size_t len = std::max<size_t>(65536, std::max(ms, mu));
+            std::vector<uint2> cp(len + 1);
+            for (size_t c = 0; c <= len; ++c) {
+                const uint32_t info = dict_->chr2inf[c < 65536 && c < len ? c : 0];
+                const uint32_t sc = c < len && c < ms ? dict_->system.mapper[c] : 0u, uc = c < len && c < mu ? dict_->user.mapper[c] : 0u;
+                cp[c] = make_uint2(info, sc | (uc << 16));
+            }
+            dev_.cpinfo = dev_upload(cp, allocs_);
+            dev_.cpinfo_len = (uint32_t)len;
+        }
         dev_.unk_off = dev_upload(dict_->unk_offsets, allocs_);
         dev_.unk_entries = dev_upload(dict_->unk_entries, allocs_);
     } catch (...) {

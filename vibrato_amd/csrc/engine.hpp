@@ -31,6 +31,11 @@ struct DevDict {
     uint32_t matrix_bytes;        // bytes of the matrix (< 2^32: checked at upload)
     uint32_t matrix_wide;
     const uint32_t* chr2inf;      // 65536 packed CharInfo
+    // what the generators read per character, in ONE 8-byte load: {chr2inf[cp] (character.rs:112-116: cp >= 65536 -> entry 0), code of the
+    // system trie | code of the user trie << 16}; cpinfo_len entries for the code points below it + one for everything beyond (round 5:
+    // two gathers per character -- 94 of a sentence's ~520 line requests in a kernel that is bound by their number)
+    const uint2* cpinfo;
+    uint32_t cpinfo_len;
     const uint32_t* unk_off;      // n_categories + 1
     const Entry* unk_entries;
     uint32_t space_cateset;       // 0 when ignore_space is off (tokenizer.rs:16,50)

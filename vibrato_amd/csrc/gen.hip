@@ -170,9 +170,10 @@ __device__ __forceinline__ void gen_long(const DevDict& D, const BatchArgs& A, u
                 else if (b < 0xE0) cp = ((b & 0x1F) << 6) | t[0];
                 else if (b < 0xF0) cp = ((b & 0x0F) << 12) | (t[0] << 6) | t[1];
                 else cp = ((b & 0x07) << 18) | (t[0] << 12) | (t[1] << 6) | t[2];
-                ci[idx] = D.chr2inf[cp < 65536u ? cp : 0u];  // character.rs:112-116
-                code[idx] = cp < D.sys.mapper_len ? D.sys.mapper[cp] : (uint16_t)0;
-                if (D.has_user) ucode[idx] = cp < D.user.mapper_len ? D.user.mapper[cp] : (uint16_t)0;
+                const uint2 e = D.cpinfo[cp < D.cpinfo_len ? cp : D.cpinfo_len];  // {character class (character.rs:112-116), trie codes}: one load
+                ci[idx] = e.x;
+                code[idx] = (uint16_t)(e.y & 0xFFFFu);
+                if (D.has_user) ucode[idx] = (uint16_t)(e.y >> 16);
                 c2b[idx] = (uint16_t)bi;
             }
         }

@@ -112,21 +112,24 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
                 cp[q] = b < 0x80 ? b : b < 0xE0 ? ((b & 0x1F) << 6) | t0 : b < 0xF0 ? ((b & 0x0F) << 12) | (t0 << 6) | t1 : ((b & 0x07) << 18) | (t0 << 12) | (t1 << 6) | t2;
                 cb += (uint32_t)__popcll(m);
             }
-            uint32_t civ[kGroup], cov[kGroup], ucv[kGroup];
+            uint2 cpv[kGroup];  // {character class, system code | user code << 16}: one load per character (DevDict::cpinfo)
 #pragma unroll
             for (uint32_t q = 0; q < kGroup; ++q) {
                 const bool lead = idx[q] != 0xFFFFFFFFu;
                 const uint32_t c = lead ? cp[q] : 0u;
-                civ[q] = D.chr2inf[c < 65536u ? c : 0u];  // character.rs:112-116
-                cov[q] = c < D.sys.mapper_len ? D.sys.mapper[c] : (uint16_t)0;
-                ucv[q] = D.has_user && c < D.user.mapper_len ? D.user.mapper[c] : (uint16_t)0;
+#if VBT_CPINFO
+                cpv[q] = D.cpinfo[c < D.cpinfo_len ? c : D.cpinfo_len];  // character.rs:112-116 (code points beyond the table: entry 0's class, no code)
+#else  // (A/B: round 5's two or three gathers per character)
+                cpv[q].x = D.chr2inf[c < 65536u ? c : 0u];
+                cpv[q].y = (c < D.sys.mapper_len ? D.sys.mapper[c] : 0u) | ((D.has_user && c < D.user.mapper_len ? D.user.mapper[c] : 0u) << 16);
+#endif
             }
 #pragma unroll
             for (uint32_t q = 0; q < kGroup; ++q) {
                 if (idx[q] != 0xFFFFFFFFu) {
-                    ci[idx[q]] = civ[q];
-                    code[idx[q]] = (uint16_t)cov[q];
-                    if (D.has_user) ucode[idx[q]] = (uint16_t)ucv[q];
+                    ci[idx[q]] = cpv[q].x;
+                    code[idx[q]] = (uint16_t)(cpv[q].y & 0xFFFFu);
+                    if (D.has_user) ucode[idx[q]] = (uint16_t)(cpv[q].y >> 16);
                     c2b[idx[q]] = (uint16_t)(g0 + q * 64 + ln);
                 }
             }
