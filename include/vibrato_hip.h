@@ -297,9 +297,10 @@ VBT_API int vbt_workspace_results(const vbt_workspace* ws, const vbt_token_rec**
  * back to the workspace's own buffers.  vbt_workspace_results then points into the slot.  The caller alternates two slots to
  * overlap the gather of batch k with the kernels of batch k + 1. */
 VBT_API int vbt_workspace_set_packed_output(vbt_workspace* ws, void* d_slot, uint64_t slot_bytes, uint64_t max_sentences);
-/* Per-call statistics (synchronizes the stream of the last call): how many sentences were routed
- * to the smallest LDS tier of the lattice kernel (n_tier0), to the larger LDS tiers (n_tier1) and to
- * the global-memory fallback kernel (n_tier2; a re-routed sentence is counted twice), tokens
+/* Per-call statistics (synchronizes the stream of the last call): how many sentences were filed
+ * in the LDS tiers sentences are routed to up front -- the lean tier and the segment tier (n_tier0) --, in the escape tiers behind
+ * them (n_tier1: what a sweep passed on) and in the list of the global-memory fallback kernel (n_tier2; a re-routed sentence is
+ * counted in every list it was filed in), tokens
  * written, device error flags (1 = token buffer full, 2 = scratch exhausted, 4 = sentence too
  * long, 8 = bad offsets, 16 = invalid UTF-8) and, with timing enabled, the hipEvent-measured durations (ms, on the launch stream) of the
  * input check and the candidate generators (ms_tier0: validate_batch, gen_candidates, build_lists, the gen_long levels), of the
