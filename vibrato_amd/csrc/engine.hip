@@ -53,6 +53,13 @@ T* dev_upload(const std::vector<T>& v, std::vector<void*>& allocs) {
     return p;
 }
 
+// hipMemset returns before the fill has run, and the fill is a null-stream operation: nothing orders it against kernels of the
+// non-blocking streams every batch runs on.  Whatever is zeroed for a later launch is zeroed and waited for.
+void zero_now(void* p, size_t bytes) {
+    HIP_CHECK(hipMemsetAsync(p, 0, bytes, nullptr));
+    HIP_CHECK(hipStreamSynchronize(nullptr));
+}
+
 uint32_t env_u32(const char* name, uint32_t dflt) {
     const char* s = std::getenv(name);
     return s && *s ? (uint32_t)std::strtoul(s, nullptr, 10) : dflt;
@@ -114,7 +121,7 @@ Tokenizer::Tokenizer(const Dictionary* dict, bool ignore_space, uint32_t max_gro
                 uint32_t* flag = nullptr;
                 HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&flag), 16));
                 tmp.push_back(flag);
-                HIP_CHECK(hipMemset(flag, 0, 16));
+                zero_now(flag, 16);
                 DevConnector c{};
                 c.bases = dev_upload(sc.bases, tmp); c.checks = dev_upload(sc.checks, tmp); c.costs = dev_upload(sc.costs, tmp);
                 c.n_bases = (uint32_t)sc.bases.size(); c.n_checks = (uint32_t)sc.checks.size();
@@ -131,7 +138,7 @@ Tokenizer::Tokenizer(const Dictionary* dict, bool ignore_space, uint32_t max_gro
                 int16_t* m = nullptr;
                 HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&m), (cells + 1) * 2));
                 tmp.push_back(m);
-                HIP_CHECK(hipMemset(m + cells, 0, 2));
+                zero_now(m + cells, 2);
                 kern::expand_connector_i16(grid, c, m, dict_->num_right, dict_->num_left, flag);
                 uint32_t out_of_range = 0;
                 HIP_CHECK(hipMemcpy(&out_of_range, flag, 4, hipMemcpyDeviceToHost));
@@ -147,7 +154,7 @@ Tokenizer::Tokenizer(const Dictionary* dict, bool ignore_space, uint32_t max_gro
                     int32_t* w = nullptr;
                     HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&w), (cells + 1) * 4));
                     tmp.push_back(w);
-                    HIP_CHECK(hipMemset(w + cells, 0, 4));
+                    zero_now(w + cells, 4);
                     kern::expand_connector_i32(grid, c, w, dict_->num_right, dict_->num_left, flag);
                     HIP_CHECK(hipDeviceSynchronize());
                     tmp.pop_back();
@@ -274,7 +281,7 @@ std::unique_ptr<DevImage> Tokenizer::renumbered_image(const std::vector<uint16_t
             void* m = nullptr;
             HIP_CHECK(hipMalloc(&m, (cells + 1) * cell));
             im->allocs.push_back(m);
-            HIP_CHECK(hipMemset(static_cast<char*>(m) + cells * cell, 0, cell));
+            zero_now(static_cast<char*>(m) + cells * cell, cell);
             kern::permute_matrix(stream, base.dev.matrix, m, base.dev.matrix_wide != 0, d_il, d_ir, dict_->num_left, dict_->num_right);
             HIP_CHECK(hipStreamSynchronize(stream));  // (not the device: a resident Worker kernel of another thread must not hold this up)
             im->dev.matrix = static_cast<const int16_t*>(m);
@@ -343,7 +350,7 @@ Workspace::Workspace(const Tokenizer& t, uint64_t max_s, uint64_t max_b) : tok(t
         }
     }
     d_prof = static_cast<unsigned long long*>(alloc(2 * kProfSlots * kProfWords * 8));  // (second half: gen_long's phases in a VBT_GENLONG_PROF build)
-    HIP_CHECK(hipMemset(d_prof, 0, 2 * kProfSlots * kProfWords * 8));
+    zero_now(d_prof, 2 * kProfSlots * kProfWords * 8);
     const uint64_t mb = env_u32("VBT_SCRATCH_MB", 0);
     // (fused fallback only: rare sentences; a one-sentence Worker must not pin 256 MiB)
     scratch_bytes = mb ? mb << 20 : std::max<uint64_t>(std::min<uint64_t>(256ull << 20, (16ull << 20) + 512 * nbts), 64 * nbts);
@@ -669,7 +676,7 @@ void Workspace::enable_connid_counts(bool on) {
         HIP_CHECK(hipMalloc(&p, std::max<size_t>(words * 8, 16)));
         pipe_allocs.push_back(p);
         d_connid = static_cast<unsigned long long*>(p);
-        HIP_CHECK(hipMemset(d_connid, 0, words * 8));
+        zero_now(d_connid, words * 8);
         void* q = nullptr;
         HIP_CHECK(hipMalloc(&q, std::max<size_t>(max_sentences * 4, 16)));
         pipe_allocs.push_back(q);
@@ -692,7 +699,7 @@ void Workspace::fold_connid_counts() {
     std::vector<uint64_t> dl(nl), dr(nr);
     HIP_CHECK(hipMemcpy(dl.data(), d_connid, nl * 8, hipMemcpyDeviceToHost));
     HIP_CHECK(hipMemcpy(dr.data(), d_connid + nl, nr * 8, hipMemcpyDeviceToHost));
-    HIP_CHECK(hipMemset(d_connid, 0, (nl + nr) * 8));
+    zero_now(d_connid, (nl + nr) * 8);
     acc_lid.resize(nl, 0); acc_rid.resize(nr, 0);
     add_unmapped(tok.image_of(count_epoch), dl, dr, acc_lid.data(), acc_rid.data());
 }
@@ -710,7 +717,7 @@ void Workspace::read_connid_counts(uint64_t* lid, uint64_t* rid, bool reset) {
     for (size_t i = 0; i < nr; ++i) rid[i] = i < acc_rid.size() ? acc_rid[i] : 0;
     add_unmapped(tok.image_of(count_epoch), dl, dr, lid, rid);
     if (reset) {
-        HIP_CHECK(hipMemset(d_connid, 0, (nl + nr) * 8));
+        zero_now(d_connid, (nl + nr) * 8);
         acc_lid.clear(); acc_rid.clear();
     }
 }
@@ -719,7 +726,7 @@ void Workspace::reset_connid_counts() {
     HIP_CHECK(hipSetDevice(tok.device()));
     if (!d_connid) return;
     if (has_run) HIP_CHECK(hipStreamSynchronize(reinterpret_cast<hipStream_t>(last_stream)));
-    HIP_CHECK(hipMemset(d_connid, 0, ((size_t)tok.dict().num_left + tok.dict().num_right) * 8));
+    zero_now(d_connid, ((size_t)tok.dict().num_left + tok.dict().num_right) * 8);
     acc_lid.clear(); acc_rid.clear();
 }
 
@@ -844,6 +851,13 @@ bool Tokenizer::calibrate_sample(uint64_t ns, uint64_t bytes) const {
         ws.stats(&st);
         if (st.error_flags) return false;
         ws.read_connid_counts(lid.data(), rid.data(), false);
+        if (std::getenv("VBT_DEBUG")) {
+            uint64_t sl = 0, sr = 0;
+            for (uint64_t v : lid) sl += v;
+            for (uint64_t v : rid) sr += v;
+            std::fprintf(stderr, "[vbt] calibration sample: %llu sentences, %llu bytes, %llu tokens, counted pairs %llu / %llu\n", (unsigned long long)ns,
+                         (unsigned long long)bytes, (unsigned long long)st.n_tokens, (unsigned long long)sl, (unsigned long long)sr);
+        }
     }
     // ids by descending count, then ascending id (ConnIdCounter::compute_probs, mapper.rs:108-146); id 0 (BOS / EOS) stays
     auto order = [](const std::vector<uint64_t>& cnt, std::vector<uint16_t>& perm) {
@@ -883,7 +897,7 @@ void Workspace::read_profile(uint64_t* out, bool reset) {
     for (int i = 0; i < kProfWords; ++i) out[i] = 0;
     for (int k = 0; k < kProfSlots; ++k)
         for (int i = 0; i < kProfWords; ++i) out[i] += h[(size_t)k * kProfWords + i];
-    if (reset) HIP_CHECK(hipMemset(half, 0, h.size() * 8));
+    if (reset) zero_now(half, h.size() * 8);
 }
 
 }  // namespace vbt
