@@ -127,13 +127,15 @@ def test_all_tiers_agree(tiers, fused, monkeypatch):
                                  {"VBT_TIERS": "3072", "VBT_SEG_BYTES": "2048"},
                                  {"VBT_TIERS": "1536,163840", "VBT_SEG_BYTES": "1536"}, {"VBT_TIERS": "2048", "VBT_SEG_BYTES": "2048", "VBT_GEN_LDS": "1024", "VBT_GEN_LEVELS": "4096,8192,163840"},
                                  {"VBT_PACK_SCAN": "1"}, {"VBT_FB_WGS": "3", "VBT_TIERS": "1024"},
-                                 {"VBT_LEAN": "0"}, {"VBT_TIERS": "3072,5120,10240,163840"}, {"VBT_TIERS": "6144,8192", "VBT_SEG_BYTES": "8192", "VBT_LEAN": "0"}])
+                                 {"VBT_LEAN": "0"}, {"VBT_TIERS": "3072,5120,10240,163840"}, {"VBT_TIERS": "6144,8192", "VBT_SEG_BYTES": "8192", "VBT_LEAN": "0"},
+                                 {"VBT_GEN_SWEEP": "1"}, {"VBT_GEN_SWEEP": "1", "VBT_TIERS": "3072,10240,163840"}])
 def test_generator_scheduling_variants_agree(env, monkeypatch):
     """A tiny bulk-generator LDS (most sentences then go through gen_long, the multi-wavefront generator, with 1 / 2 / 4 / 8
     wavefronts per workgroup and through its small levels), the segmented sweep of sentences that do not fit the segment tier
     (cut anywhere, the window of open end lists handed over; down to segments of 8 positions), the tile-prefix kernel in front
     of the packing, a fallback launch of three waves, and the lean instance of the sweep (lattice_lean: the tiers in front of the segment
-    tier, whole sentences with the generator's pass records) switched off or spread over two small tiers must not change a single token."""
+    tier, whole sentences with the generator's pass records) switched off or spread over two small tiers, and the generator's wave sweeping
+    its own sentence (VBT_GEN_SWEEP=1, a measured negative result kept as a knob) must not change a single token."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     sd = synth.SynthDict("small")
@@ -693,16 +695,17 @@ def test_tokenize_lines_batches_behind_an_iterator():
     exp_tok, exp_off = to.new_worker().tokenize_batch(text, offs)
     buf = text.tobytes()
     lines = [buf[int(offs[i]):int(offs[i + 1])].decode("utf-8") for i in range(len(offs) - 1)]
-    seen, batches = 0, set()
+    seen, batches, last = 0, 0, None
     for s, (b, i) in enumerate(tv.tokenize_lines(iter(lines), batch_bytes=int(offs[300]), batch_lines=250)):
-        batches.add(id(b))
+        batches += b is not last  # (not a set of id(b): a freed batch's address is free for the next but one -- seen once in ~15 runs)
+        last = b
         e = exp_tok[int(exp_off[s]):int(exp_off[s + 1])]
         assert b.num_tokens(i) == len(e)
         r = b.records(i)
         for f in V.TOKEN_DTYPE.names:
             assert np.array_equal(r[f], e[f]), (s, f)
         seen += 1
-    assert seen == len(lines) and len(batches) >= 3
+    assert seen == len(lines) and batches >= 3
 
 
 def test_worker_resident_kernel_handshake_under_pauses():

@@ -29,6 +29,7 @@ namespace {
 
 constexpr uint64_t kNoFit = ~0ull;
 constexpr uint8_t kRouteDone = 0xFC;  // s_tier value of a sentence that already sits in a work list
+constexpr uint8_t kRouteInline = 0xFB;  // ... of a sentence the generator's own wave swept (gen_sweep): in no list
 
 // Cache policy of the three random-access streams (A/B knobs): non-temporal loads
 // do not allocate in the per-CU vector L1, whose in-order tag pipeline stalls on hit-under-miss.

@@ -500,14 +500,19 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
                 for (int q = 0; q < 3; ++q) gen_level_lds[q] = v[q];
         }
         const uint32_t cn = (uint32_t)n, lb = (cn + 1023) / 1024;
-        a.sid0 = 0; a.n = cn; a.cctrl = d_cctrl; a.list_off = 0; a.direct_push = 0;
+        a.sid0 = 0; a.n = cn; a.cctrl = d_cctrl; a.list_off = 0; a.direct_push = 0; a.inline_lean = 0;
         for (int q = 0; q < kGenLevels; ++q) a.gen_level_bytes[q] = gen_level_lds[q] - 16;
         const uint32_t persist = env_u32("VBT_LAT_PERSIST", 0);
         auto launch_lattice = [&](const BatchArgs& a_, dim3 grid_, uint32_t lds_, hipStream_t st_, uint32_t tier_, uint32_t persistent_) {
             kern::lattice_lds(grid_.x, lds_, st_, D, a_, tier_, persistent_);
         };
         // (s_tier[] = 0xFF, "nothing routed yet", is written by validate_batch: one launch less per batch)
-        kern::gen_candidates(cn, gen_lds, stream, D, a);
+        // (VBT_GEN_SWEEP=1, experiment: the generator's wave sweeps its own sentence when it routed it to the lean tier)
+        const bool gen_sweep = a.n_lean == 1 && env_u32("VBT_GEN_SWEEP", 0) != 0;
+        a.inline_lean = gen_sweep ? 1u : 0u;
+        last_inline = gen_sweep;
+        if (gen_sweep) kern::gen_sweep(cn, tiers[0], stream, D, a);
+        else kern::gen_candidates(cn, gen_lds, stream, D, a);
         kern::build_lists(lb, stream, a, -1);
         const size_t n_conc = a.seg_tier < T ? a.seg_tier + 1 : T;  // the tiers sentences are routed to up front: one launch each, side by side
         // The segment tier (the critical path: the longest sentences, then the escape tiers behind it) is launched on the launch
@@ -603,7 +608,7 @@ void Workspace::serve(const uint8_t* h_text_dev, uint8_t* d_text, uint64_t* d_of
     a.scratch = d_scratch; a.scratch_bytes = scratch_bytes;
     a.prof = nullptr;
     a.lists = d_over; a.list_stride = (uint32_t)(2 * std::max<uint64_t>(max_sentences, 1)); a.n_tiers = 1;
-    a.tier_prio = 0; a.seg_tier = 0; a.n_lean = 0; a.sid0 = 0; a.cctrl = d_cctrl; a.list_off = 0; a.direct_push = 0;
+    a.tier_prio = 0; a.seg_tier = 0; a.n_lean = 0; a.sid0 = 0; a.cctrl = d_cctrl; a.list_off = 0; a.direct_push = 0; a.inline_lean = 0;
     a.lid_count = nullptr; a.rid_count = nullptr; a.s_counted = nullptr;
     constexpr uint32_t kOneLds = 65536;  // generator arrays (~26 B per character), then the lattice (whole up to ~400 characters, in segments beyond)
     a.tier_bytes[0] = kOneLds;
@@ -651,6 +656,7 @@ void Workspace::stats(vbt_call_stats* out) {
         const size_t front = last_seg_tier < T ? last_seg_tier + 1 : 1;
         for (size_t t = 0; t < T; ++t) (t < front ? out->n_tier0 : out->n_tier1) += cc[2 * t];
         out->n_tier2 = cc[2 * T];
+        if (last_inline) out->n_tier0 += cc[1];  // (gen_sweep: swept by the generator's own wave, counted by build_lists)
     }
     out->n_tokens = ctrl[kTotal];
     out->error_flags = ctrl[kError];

@@ -86,6 +86,7 @@ struct BatchArgs {
     uint32_t n_tiers;
     uint32_t seg_tier;     // LDS tier that sweeps longer sentences in segments (>= n_tiers: none)
     uint32_t n_lean;       // the first n_lean LDS tiers are swept by the lean instance (lattice_lean: whole sentences with the generator's pass records ONLY)
+    uint32_t inline_lean;  // gen_sweep: the generator's wave sweeps its sentence itself when it routed it to a lean tier (nothing is filed for it)
     uint32_t direct_push;  // gen_one appends to the work lists directly instead of routing through s_tier (no build_lists behind it)
     uint32_t tier_prio;  // the top `tier_prio` LDS tiers run at raised wave priority (0 = off)
     // a launch covers sentences [sid0, sid0 + n); cctrl = the list counters it works with (cctrl[2t] = entries of
@@ -229,6 +230,7 @@ class Workspace {
     uint32_t* d_tile_sums = nullptr;
     uint32_t *d_tok_off = nullptr, *d_tok_cnt = nullptr, *d_ctrl = nullptr, *d_over = nullptr, *d_cctrl = nullptr;
     std::vector<void*> pipe_allocs;  // buffers of the two-kernel pipeline
+    bool last_inline = false;        // the last run used gen_sweep (stats: its sentences are counted in the first tier's cursor word)
     BatchArgs pipe{};                // device pointers of those buffers
     std::vector<void*> streams;      // one side stream per LDS tier
     std::vector<void*> tier_events;

@@ -424,6 +424,10 @@ __global__ void __launch_bounds__(1024) build_lists(BatchArgs A, int only_list) 
         if (lane == 0) w_cnt[wave][l] = (uint32_t)__popcll(m);
         if (mine) my_rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
     }
+    {   // sentences the generator's own wave swept (gen_sweep) are in no list: counted in the first tier's cursor word (unused: lean tiers have no cursor)
+        const uint64_t m = __ballot(t == kRouteInline && only_list < 0);
+        if (lane == 0 && m) atomicAdd(&A.cctrl[1], (uint32_t)__popcll(m));
+    }
     __syncthreads();
     if (threadIdx.x < n_lists) {
         uint32_t tot = 0;

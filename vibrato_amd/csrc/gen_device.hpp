@@ -13,7 +13,8 @@ namespace {
 // search_min_node's result depends only on that pair (lattice.rs:129-151), so the lattice kernel
 // evaluates one row per group instead of one per candidate.
 // (Sentences that outgrow this wavefront's LDS -- ~26 bytes per character -- are handed to gen_long: one workgroup per sentence.)
-__device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, uint32_t sid, uint32_t lds_bytes) {
+// Returns the sentence's header as written to s_hdr (tier 0xFF: nothing to sweep here -- empty, or filed for gen_long / the fallback).
+__device__ __forceinline__ uint4 gen_one(const DevDict& D, const BatchArgs& A, uint32_t sid, uint32_t lds_bytes) {
     const uint32_t ln = threadIdx.x;
     const uint64_t lt_mask = (1ull << ln) - 1ull;
     uint64_t prof_t = A.prof ? clock64() : 0, prof_acc[3] = {};
@@ -28,12 +29,13 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
     };
     // (header with tier 0xFF: nothing for lattice_lds -- the final header is written with the routing decision, by gen_long for what is filed there)
     auto init = [&]() { if (ln == 0) { A.s_hdr[sid] = make_uint4(0u, 0xFFu << 16, 0u, 0u); A.s_tier[sid] = 0xFF; } };
+    const uint4 none = make_uint4(0u, 0xFFu << 16, 0u, 0u);
     if (nb64 == 0) {
         init();
         if (ln == 0) A.tok_cnt[sid] = 0;
-        return;
+        return none;
     }
-    if (nb64 >= 65535) { init(); route(fallback); return; }  // positions are u16 in the LDS lattice
+    if (nb64 >= 65535) { init(); route(fallback); return none; }  // positions are u16 in the LDS lattice
     const uint32_t nb = (uint32_t)nb64;
     const uint8_t* __restrict__ txt = A.text + b0;
     const size_t slot0 = sentence_slot(A, b0, sid);
@@ -70,14 +72,14 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
     if (n == 0) {
         init();
         if (ln == 0) A.tok_cnt[sid] = 0;
-        return;
+        return none;
     }
     const GenOneLds L = carve_gen_one(g_smem, lds_bytes, n, D.has_user != 0);
     if (!L.ok) {
         // Outgrows this wavefront: gen_long, one workgroup per sentence.
         init();
         route(A.n_tiers + 1 + gen_long_level(A, n, nb, D.has_user != 0));
-        return;
+        return none;
     }
     init();
     uint64_t* const lens = L.lens;
@@ -211,7 +213,7 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
     }
     any_global = __ballot(any_global) != 0;  // (wave-uniform from here on)
     // words > 64 chars need the generic pre-pass, > 65531 nodes need u32 indices: fused kernel
-    if (C >= 65532 || any_long) { route(fallback); return; }
+    if (C >= 65532 || any_long) { route(fallback); return none; }
     if (ln == 0) set_co(n, C);
     // End lists (`ends[e]` of lattice.rs:39-43) are laid out here once and for all: node slots are numbered by end
     // position (BOS is slot 0, the only node ending at 0), so the lattice kernel reads every candidate with its slot
@@ -230,7 +232,7 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
         }
     }
     __syncthreads();
-    if (C > region) { route(fallback); return; }  // denser than the region: fused path
+    if (C > region) { route(fallback); return none; }  // denser than the region: fused path
     // The staged hits are read back by this wave only: its stores have to be complete (workgroup scope:
     // s_waitcnt vmcnt(0); the vector L1 is write-through and never held these lines).  An agent-scope
     // release would write the whole L2 back (buffer_wbl2) once per sentence.
@@ -475,8 +477,10 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
         // what it cannot sweep there -- a window of end lists wider than the tier -- it hands to the escape tiers itself)
         if (A.seg_tier < A.n_tiers && tier > A.seg_tier) tier = A.seg_tier;
     }
-    if (ln == 0) A.s_hdr[sid] = make_uint4(n | (nb << 16), C | (tier << 16), passes | pre_flag, (uint32_t)(b0 - uniform64(A.offsets[0])));
-    route(tier);
+    const uint4 hdr = make_uint4(n | (nb << 16), C | (tier << 16), passes | pre_flag, (uint32_t)(b0 - uniform64(A.offsets[0])));
+    if (ln == 0) A.s_hdr[sid] = hdr;
+    if (A.inline_lean && pre_flag && tier < A.n_lean) { if (ln == 0) A.s_tier[sid] = kRouteInline; }  // the caller sweeps it now
+    else route(tier);
     PROF_MARK(2);
     if (A.prof && ln == 0) {
         unsigned long long* pr_ = A.prof + (size_t)(sid & (kProfSlots - 1)) * kProfWords;
@@ -484,6 +488,7 @@ __device__ __forceinline__ void gen_one(const DevDict& D, const BatchArgs& A, ui
         atomicAdd(&pr_[kProfPhases], 1ull);
     }
 #undef PROF_MARK
+    return hdr;
 }
 
 }  // namespace

@@ -31,6 +31,7 @@ void lattice_lds(uint32_t workgroups, uint32_t lds_bytes, hipStream_t stream, co
 void lattice_set_max_lds(int bytes);
 // the lean instance for whole sentences that arrive with the generator's pass records (built for 5 waves per SIMD); the common build only
 bool lattice_has_lean();
+void gen_sweep(uint32_t n, uint32_t lds_bytes, hipStream_t stream, const DevDict& D, const BatchArgs& a);  // generator + lean sweep in one wave (needs lattice_has_lean())
 void lattice_lean(uint32_t workgroups, uint32_t lds_bytes, hipStream_t stream, const DevDict& D, const BatchArgs& a, uint32_t tier);
 // the segment tier's instance without the C++ loop, the `exact` mode and connection-id counting (i16 cells, < 8000 characters, tier <= 64 KiB)
 void lattice_slim(uint32_t workgroups, uint32_t lds_bytes, hipStream_t stream, const DevDict& D, const BatchArgs& a, uint32_t tier);

@@ -986,6 +986,28 @@ __global__ void __launch_bounds__(64, VBT_LEAN_WAVES) lattice_lean(DevDict D, Ba
         list_push_fb(A, sid);
     }
 }
+
+// Generator and lean sweep in ONE wave: gen_one, and when it routed its sentence to a lean tier (whole, with pass records) the same wave
+// sweeps it at once -- what gen_one left in global memory is read back by the wave that wrote it (L2 hits; a workgroup-scope fence is
+// all it takes, as in tokenize_serve) -- so at any moment some of a CU's waves wait for memory (generator) while others issue VALU
+// (sweep).  Everything else is filed as by gen_candidates.
+template <bool kSpaceMode>
+__global__ void __launch_bounds__(64, VBT_LEAN_WAVES) gen_sweep(DevDict D, BatchArgs A, uint32_t lds_bytes) {
+    if (batch_rejected(A)) return;
+    const uint32_t sid = A.sid0 + blockIdx.x;
+    const uint4 hq = gen_one(D, A, sid, lds_bytes);
+    const uint4 h = make_uint4(__builtin_amdgcn_readfirstlane(hq.x), __builtin_amdgcn_readfirstlane(hq.y), __builtin_amdgcn_readfirstlane(hq.z), __builtin_amdgcn_readfirstlane(hq.w));
+    const uint32_t tier = (h.y >> 16) & 0xFFu;
+    if (!(tier < A.n_lean && (h.z >> 31))) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const uint32_t fail = lattice_whole<kSpaceMode>(D, A, A.tier_bytes[tier], sid, h);
+    if (fail) {
+        if (threadIdx.x == 0) atomicAdd(&A.ctrl[fail < 32 ? fail : 28], 1u);
+        list_push_fb(A, sid);
+    }
+}
 #else
 #define VBT_HAS_LEAN 0
 #endif
@@ -1174,6 +1196,14 @@ void lattice_slim(uint32_t workgroups, uint32_t lds_bytes, hipStream_t stream, c
     else hipLaunchKernelGGL(vbt::lattice_slim<false>, dim3(workgroups), dim3(64), lds_bytes, stream, D, a, tier);
 #else
     (void)workgroups; (void)lds_bytes; (void)stream; (void)D; (void)a; (void)tier;
+#endif
+}
+void gen_sweep(uint32_t n, uint32_t lds_bytes, hipStream_t stream, const DevDict& D, const BatchArgs& a) {
+#if VBT_HAS_LEAN
+    if (D.space_cateset) hipLaunchKernelGGL(vbt::gen_sweep<true>, dim3(n), dim3(64), lds_bytes, stream, D, a, lds_bytes);
+    else hipLaunchKernelGGL(vbt::gen_sweep<false>, dim3(n), dim3(64), lds_bytes, stream, D, a, lds_bytes);
+#else
+    (void)n; (void)lds_bytes; (void)stream; (void)D; (void)a;
 #endif
 }
 void lattice_lean(uint32_t workgroups, uint32_t lds_bytes, hipStream_t stream, const DevDict& D, const BatchArgs& a, uint32_t tier) {
