@@ -229,6 +229,11 @@ __device__ __forceinline__ void unk_spans(uint32_t cinfo, uint32_t g, uint32_t i
 #ifndef VBT_GEN_RECORDS
 #define VBT_GEN_RECORDS 1  // the bulk generator lays out the sweep's pass records for the sentences lattice_lds sweeps whole (gen_device.hpp)
 #endif
+// gen_one's expansion of the staged hits: rounds of 64 hits whose first entries are requested together, ahead of the first store (1 = round by round).
+// Measured (round 6, tools/dbg/fill_ab.sh): 2 rounds neutral (0.559-0.565 vs 0.554-0.557 ms), 4 rounds 0.62-0.63 ms -- the expansion is not waiting for its own stores.
+#ifndef VBT_FILL_ROUNDS
+#define VBT_FILL_ROUNDS 1
+#endif
 #ifndef VBT_CPINFO
 #define VBT_CPINFO 1  // the generators read character class and trie codes of a code point in one 8-byte load (DevDict::cpinfo); 0: separate tables (A/B)
 #endif

@@ -250,6 +250,51 @@ __device__ __forceinline__ uint4 gen_one(const DevDict& D, const BatchArgs& A, u
     // cost 5 % more; the sweep's load phase does not notice the wider record)
     const uint32_t H = *hcount;  // <= C <= region
     const uint32_t row_cells = D.num_right;  // a left id's row of the connection matrix starts at cell left_id * num_right
+#if VBT_FILL_ROUNDS > 1
+    // (VBT_FILL_ROUNDS rounds of 64 hits at a time: all their hits and first entries are requested before the first candidate is stored,
+    // so a round's entry loads do not queue up behind the previous round's stores in the in-order vmcnt)
+    constexpr uint32_t kR = VBT_FILL_ROUNDS;
+    for (uint32_t h0 = 0; h0 < H; h0 += 64 * kR) {
+        uint4 hr[kR];
+        Entry e0[kR];
+#pragma unroll
+        for (uint32_t r = 0; r < kR; ++r) {
+            const uint32_t h = h0 + 64 * r + ln;
+            hr[r] = make_uint4(0, 0, 0, 0);
+            if (h < H) {
+                const uint2 q = h < lcap ? lhits[h] : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+                hr[r] = q.y != 0xFFFFFFFFu ? unpack_hit(q) : hits[h];
+            }
+        }
+#pragma unroll
+        for (uint32_t r = 0; r < kR; ++r) {
+            const uint32_t lex = hr[r].y >> 16;
+            const Entry* __restrict__ ent = lex == 0 ? D.sys.entries : lex == 1 ? D.user.entries : D.unk_entries;
+            e0[r] = ent[(hr[r].y & 0xFFFFu) ? hr[r].x : 0u];
+        }
+#pragma unroll
+        for (uint32_t r = 0; r < kR; ++r) {
+            const uint32_t c = hr[r].y & 0xFFFFu, lex = hr[r].y >> 16, end = hr[r].z & 0xFFFFu, pos = hr[r].z >> 16;
+            if (c) {
+                const Entry* __restrict__ ent = lex == 0 ? D.sys.entries : lex == 1 ? D.user.entries : D.unk_entries;
+                const uint32_t dest = get_co(pos) + hr[r].w;
+                const uint32_t slot0 = atomicAdd(&endc[end], c);  // the hit's run of slots in ends[end]
+                A.g_cand[base + dest] = make_uint4((e0[r].left_right & 0xFFFFu) * row_cells, (e0[r].cost & 0xFFFFu) | (slot0 << 16),
+                                                   (lex << 30) | e0[r].word_id, end | (e0[r].left_right & 0xFFFF0000u));
+                for (uint32_t t0 = 1; t0 < c; t0 += 4) {  // (homographs: the rest of the run, four entries at a time)
+                    Entry e[4];
+#pragma unroll
+                    for (uint32_t q = 0; q < 4; ++q) e[q] = ent[hr[r].x + (t0 + q < c ? t0 + q : t0)];
+#pragma unroll
+                    for (uint32_t q = 0; q < 4; ++q)
+                        if (t0 + q < c)
+                            A.g_cand[base + dest + t0 + q] = make_uint4((e[q].left_right & 0xFFFFu) * row_cells, (e[q].cost & 0xFFFFu) | ((slot0 + t0 + q) << 16),
+                                                                        (lex << 30) | e[q].word_id, end | (e[q].left_right & 0xFFFF0000u));
+                }
+            }
+        }
+    }
+#else
     for (uint32_t h0 = 0; h0 < H; h0 += 64) {
         const uint32_t h = h0 + ln;
         uint4 hr = make_uint4(0, 0, 0, 0);
@@ -277,6 +322,7 @@ __device__ __forceinline__ uint4 gen_one(const DevDict& D, const BatchArgs& A, u
             }
         }
     }
+#endif
     __syncthreads();
     // exclusive end-list offset of position p (0 .. n + 1): the cursors now hold the inclusive prefix
     auto eo = [&](uint32_t p) { return p == 0 ? 0u : p == 1 ? 1u : endc[p - 1]; };
