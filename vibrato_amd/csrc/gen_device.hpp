@@ -310,10 +310,27 @@ __device__ __forceinline__ uint4 gen_one(const DevDict& D, const BatchArgs& A, u
             for (uint32_t t0 = 0; t0 < c; t0 += 4) {
                 Entry e[4];
 #pragma unroll
-                for (uint32_t q = 0; q < 4; ++q) e[q] = ent[hr.x + (t0 + q < c ? t0 + q : t0)];
+                for (uint32_t q = 0; q < 4; ++q) {
+#if VBT_ABLATE == 2  // (timing probe: no entry loads)
+                    e[q].word_id = hr.x + q; e[q].left_right = hr.x & 0x00FF00FFu; e[q].cost = hr.x & 0xFFu;
+#else
+                    e[q] = ent[hr.x + (t0 + q < c ? t0 + q : t0)];
+#endif
+                }
 #pragma unroll
                 for (uint32_t q = 0; q < 4; ++q) {
+#if VBT_ABLATE == 1  // (timing probe: the entry loads stay, no candidate is stored)
+                    if (t0 + q < c && e[q].cost == 0x7FFFFFF0u + dest) {
+#elif VBT_ABLATE == 3  // (timing probe: every candidate store goes to the sentence's first slots -- 64 lanes, 64 neighbouring slots)
                     if (t0 + q < c) {
+                        const uint32_t k = ln + 0 * dest;
+                        A.g_cand[base + k] = make_uint4((e[q].left_right & 0xFFFFu) * row_cells, (e[q].cost & 0xFFFFu) | ((slot0 + t0 + q) << 16),
+                                                        (lex << 30) | e[q].word_id, end | (e[q].left_right & 0xFFFF0000u));
+                    }
+                    if (false) {
+#else
+                    if (t0 + q < c) {
+#endif
                         const uint32_t k = dest + t0 + q;
                         A.g_cand[base + k] = make_uint4((e[q].left_right & 0xFFFFu) * row_cells, (e[q].cost & 0xFFFFu) | ((slot0 + t0 + q) << 16),
                                                         (lex << 30) | e[q].word_id, end | (e[q].left_right & 0xFFFF0000u));
