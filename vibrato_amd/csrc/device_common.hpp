@@ -237,6 +237,9 @@ __device__ __forceinline__ void unk_spans(uint32_t cinfo, uint32_t g, uint32_t i
 #ifndef VBT_ABLATE  // timing probes of gen_one's expansion (results are wrong: run with VBT_SKIP_SWEEP=1); tools/dbg/gen_ablate.sh
 #define VBT_ABLATE 0
 #endif
+#ifndef VBT_ABLATE_LEAN  // timing probes of lattice_whole (lattice.hip); tools/dbg/lean_ablate.py
+#define VBT_ABLATE_LEAN 0
+#endif
 #ifndef VBT_CPINFO
 #define VBT_CPINFO 1  // the generators read character class and trie codes of a code point in one 8-byte load (DevDict::cpinfo); 0: separate tables (A/B)
 #endif

@@ -570,15 +570,21 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
         // One launch per LDS tier up to the segment tier (the lean tiers in front of it may be running already).  The tiers above it
         // are escape tiers: nothing is routed to them up front, they take what the tier before them could not sweep (a window of end
         // lists wider than its LDS), so they are launched on the segment tier's stream, behind it.
-        static const bool skip_sweep = env_u32("VBT_SKIP_SWEEP", 0) != 0;  // (timing probes of the generator: tools/dbg/gen_ablate.sh)
+        static const uint32_t skip_env = env_u32("VBT_SKIP_SWEEP", 0);
+        const uint32_t skip_mode = count_connids ? 0u : skip_env;  // (the calibration's counting run stays whole: the probes time the renumbered image)  // (timing probes, results wrong: 1 = no sweep at all (tools/dbg/gen_ablate.py), 2 = the lean tiers only, 3 = all but the lean tiers)
+        const bool skip_sweep = skip_mode == 1;
         for (size_t i = 0; i < n_conc; ++i) {
             const size_t t = n_conc - 1 - i;
             if (skip_sweep) break;
+            if ((skip_mode == 2 && t >= a.n_lean) || (skip_mode == 3 && t < a.n_lean)) {  // (the join below still finds the tier's event recorded)
+                if (!(main_seg && t == a.seg_tier) && tier_events[t]) HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(tier_events[t]), stream));
+                continue;
+            }
             if (lean_early && t < a.n_lean) continue;
             launch_tier(t, reinterpret_cast<hipEvent_t>(ev_fork2));
         }
         for (size_t t = 0; t < n_conc && !skip_sweep; ++t)
-            if (!(main_seg && t == a.seg_tier)) HIP_CHECK(hipStreamWaitEvent(stream, reinterpret_cast<hipEvent_t>(tier_events[t]), 0));
+            if (!(main_seg && t == a.seg_tier) && tier_events[t]) HIP_CHECK(hipStreamWaitEvent(stream, reinterpret_cast<hipEvent_t>(tier_events[t]), 0));
         rec(3);
         // whatever the pipeline could not take: fused kernel, global-memory lattice (persistent waves with a work cursor; the list is
         // empty or a handful of sentences, and the kernel uses scratch memory: launching 1024 of them cost 15 us, 128 cost 6)

@@ -933,8 +933,16 @@ __device__ __forceinline__ uint32_t lattice_whole(const DevDict& D, const BatchA
         rsrc.w = 0x00020000u;
         const uint32_t sl_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)SL);
         const uint32_t hd_v = lds0 + (uint32_t)(reinterpret_cast<char*>(vhead) - g_smem);
+#if VBT_ABLATE_LEAN != 1 && VBT_ABLATE_LEAN != 4  // (timing probes of the lean instance, results wrong: 1 = no loop, no back-trace, no records; 2 = loop, nothing behind it; 3 = no records; 4 = the loop skipped only)
         asm volatile(VBT_SWEEP_TEXT :: [rp] "v"(hd_v), [sl] "s"(sl_s), [rs] "s"(rsrc), [ln] "v"(ln), [offk] "v"(offK) : VBT_SWEEP_CLOBBERS);
+#else
+        asm volatile("" :: "v"(hd_v), "s"(sl_s), "s"(rsrc), "v"(ln), "v"(offK) : "memory");
+#endif
     }
+#if VBT_ABLATE_LEAN == 1 || VBT_ABLATE_LEAN == 2
+    if (ln == 0) A.tok_cnt[sid] = e_rec[1].y & 0u;
+    return 0;
+#endif
     // ---- back-trace + token records (append_top_nodes lattice.rs:159-168, token.rs:21-92) ----
     auto node_cost = [&](uint32_t c) { return e_rec[(cnd[c].y & 0xFFFFu) >> 3].y ^ 0x80000000u; };
     auto node_pred = [&](uint32_t c) { return 0xFFFEu - (cnd[c].x & 0xFFFFu); };
@@ -945,6 +953,10 @@ __device__ __forceinline__ uint32_t lattice_whole(const DevDict& D, const BatchA
     }
     T = (uint32_t)__builtin_amdgcn_readfirstlane((int)T);
     __syncthreads();
+#if VBT_ABLATE_LEAN == 3 || VBT_ABLATE_LEAN == 4
+    if (ln == 0) A.tok_cnt[sid] = T & 0u;
+    return 0;
+#endif
     if (ln == 0) { A.tok_cnt[sid] = T; if (T) atomicAdd(&A.tile_sums[sid / kScanTile], T); }
     const uint4* __restrict__ pcg = A.g_pc + slot0;
     for (uint32_t t = ln; t < T; t += 64) {
