@@ -899,7 +899,13 @@ __device__ __forceinline__ uint32_t lattice_whole(const DevDict& D, const BatchA
     const uint32_t offK = lds0, offC = lds0 + (uint32_t)(reinterpret_cast<char*>(cnd) - g_smem);
     // everything the sentence needs from global memory is requested up front: the first two candidate records, pass records and
     // byte offsets per lane; what is left follows in rounds of 64
+#if VBT_ABLATE_LEAN == 5  // (timing probe: the load phase alone with 8 instead of 16 bytes per candidate -- wrong data, half the traffic)
+    const uint2* __restrict__ nd8 = reinterpret_cast<const uint2*>(ndg);
+    auto ld8 = [&](uint32_t c) { const uint2 q = nd8[c]; return make_uint4(q.x, q.y & 0x00FFFFFFu, q.x, q.y); };
+    uint4 r0 = ld8(ln < C ? ln : 0u), r1 = ld8(64 + ln < C ? 64 + ln : 0u);
+#else
     uint4 r0 = ndg[ln < C ? ln : 0u], r1 = ndg[64 + ln < C ? 64 + ln : 0u];
+#endif
     uint2 p0 = grec[ln < SL ? ln : 0u], p1 = grec[64 + ln < SL ? 64 + ln : 0u];
     uint32_t cb0 = c2bg[ln <= n ? ln : n], cb1 = c2bg[64 + ln <= n ? 64 + ln : n];
     auto put_cand = [&](uint32_t c, const uint4& r) {
@@ -914,7 +920,11 @@ __device__ __forceinline__ uint32_t lattice_whole(const DevDict& D, const BatchA
     }
     if (ln < C) put_cand(ln, r0);
     if (64 + ln < C) put_cand(64 + ln, r1);
+#if VBT_ABLATE_LEAN == 5
+    for (uint32_t c = 128 + ln; c < C; c += 64) put_cand(c, ld8(c));
+#else
     for (uint32_t c = 128 + ln; c < C; c += 64) put_cand(c, ndg[c]);
+#endif
     if (ln < SL) vhead[ln] = make_uint2(p0.x + lds0, p0.y + lds0);
     if (64 + ln < SL) vhead[64 + ln] = make_uint2(p1.x + lds0, p1.y + lds0);
     for (uint32_t P = 128 + ln; P < SL; P += 64) { const uint2 r = grec[P]; vhead[P] = make_uint2(r.x + lds0, r.y + lds0); }
@@ -933,13 +943,13 @@ __device__ __forceinline__ uint32_t lattice_whole(const DevDict& D, const BatchA
         rsrc.w = 0x00020000u;
         const uint32_t sl_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)SL);
         const uint32_t hd_v = lds0 + (uint32_t)(reinterpret_cast<char*>(vhead) - g_smem);
-#if VBT_ABLATE_LEAN != 1 && VBT_ABLATE_LEAN != 4  // (timing probes of the lean instance, results wrong: 1 = no loop, no back-trace, no records; 2 = loop, nothing behind it; 3 = no records; 4 = the loop skipped only)
+#if VBT_ABLATE_LEAN != 1 && VBT_ABLATE_LEAN != 4 && VBT_ABLATE_LEAN != 5  // (timing probes of the lean instance, results wrong: 1 = no loop, no back-trace, no records; 2 = loop, nothing behind it; 3 = no records; 4 = the loop skipped only)
         asm volatile(VBT_SWEEP_TEXT :: [rp] "v"(hd_v), [sl] "s"(sl_s), [rs] "s"(rsrc), [ln] "v"(ln), [offk] "v"(offK) : VBT_SWEEP_CLOBBERS);
 #else
         asm volatile("" :: "v"(hd_v), "s"(sl_s), "s"(rsrc), "v"(ln), "v"(offK) : "memory");
 #endif
     }
-#if VBT_ABLATE_LEAN == 1 || VBT_ABLATE_LEAN == 2
+#if VBT_ABLATE_LEAN == 1 || VBT_ABLATE_LEAN == 2 || VBT_ABLATE_LEAN == 5
     if (ln == 0) A.tok_cnt[sid] = e_rec[1].y & 0u;
     return 0;
 #endif
@@ -985,6 +995,9 @@ __device__ __forceinline__ uint32_t lattice_whole(const DevDict& D, const BatchA
 #endif
 template <bool kSpaceMode>
 __global__ void __launch_bounds__(64, VBT_LEAN_WAVES) lattice_lean(DevDict D, BatchArgs A, uint32_t tier) {
+#if VBT_ABLATE_LEAN == 7  // (timing probe: the launch alone)
+    if (A.n != 0xFFFFFFFFu) return;
+#endif
     const uint32_t* list = A.lists + (size_t)tier * A.list_stride + A.list_off;
     const uint32_t count = A.cctrl[2 * tier];
     const uint32_t item = blockIdx.x;  // one list entry per workgroup (the grid covers the batch), newest entries first: see lattice_lds
@@ -992,6 +1005,10 @@ __global__ void __launch_bounds__(64, VBT_LEAN_WAVES) lattice_lean(DevDict D, Ba
     const uint32_t sid = __builtin_amdgcn_readfirstlane(list[count - 1 - item]);
     const uint4 hq = A.s_hdr[sid];
     const uint4 h = make_uint4(__builtin_amdgcn_readfirstlane(hq.x), __builtin_amdgcn_readfirstlane(hq.y), __builtin_amdgcn_readfirstlane(hq.z), __builtin_amdgcn_readfirstlane(hq.w));
+#if VBT_ABLATE_LEAN == 6  // (timing probe: launch, list entry and header)
+    if (threadIdx.x == 0 && h.x == 0xFFFFFFFFu) A.tok_cnt[sid] = 0;
+    return;
+#endif
     const uint32_t fail = lattice_whole<kSpaceMode>(D, A, A.tier_bytes[tier], sid, h);
     if (fail) {
         if (threadIdx.x == 0) atomicAdd(&A.ctrl[fail < 32 ? fail : 28], 1u);
