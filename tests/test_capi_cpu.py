@@ -234,7 +234,7 @@ def test_gather_ring_registers_are_untouched_in_the_compiled_isa():
     import sys
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_ring_isa.py")], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert r.stdout.count(" 0 violations") == 12, r.stdout  # lattice_lds x 4, lattice_lean x 2, lattice_slim x 2, tokenize_serve x 4
+    assert r.stdout.count(" 0 violations") == 14, r.stdout  # lattice_lds x 4, lattice_lean x 2, lattice_slim x 2, gen_sweep x 2, tokenize_serve x 4
 
 
 def test_ring_checker_flags_seeded_violations():

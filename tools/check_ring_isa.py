@@ -25,7 +25,7 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNELS = ("lattice_lds", "lattice_lean", "lattice_slim", "tokenize_serve")
+KERNELS = ("lattice_lds", "lattice_lean", "lattice_slim", "gen_sweep", "tokenize_serve")
 
 
 def mentions(text, reg):

@@ -312,6 +312,7 @@ Workspace::Workspace(const Tokenizer& t, uint64_t max_s, uint64_t max_b) : tok(t
         // sentences that arrive with the generator's pass records; VBT_LEAN=0: without.  A second lean tier just under the segment tier's
         // size for the whole sentences of 8-10 KiB bought nothing: sweep 0.683 vs 0.682 ms, and every further tier costs the step ~0.015 ms)
         const bool lean_default = kern::lattice_has_lean() && env_u32("VBT_LEAN", 1) != 0;
+        lean_tier_default = !(e && *e) && !fused && lean_default && env_u32("VBT_SEG_BYTES", kSegTierBytes) != 0;
         std::string spec = e && *e ? e : (fused ? "16384,32768,65536" : env_u32("VBT_SEG_BYTES", kSegTierBytes) ? (lean_default ? "8192,10240,49152,163840" : "10240,49152,163840") : "8192,12288,16384,24576,32768,49152,65536,163840");
         size_t pos = 0;
         while (pos < spec.size()) {
@@ -424,6 +425,12 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
         if (packed_slot) HIP_CHECK(hipMemsetAsync(packed_slot, 0, 32, stream));  // header of an empty result
         return;
     }
+    // this batch's tiers: the workspace's, except that a batch of short sentences (at most 96 bytes on average: nearly every lattice fits)
+    // gets a 6.5 KiB lean tier -- 24 of them on a CU, the lean instance's six waves per SIMD (80 VGPRs) -- instead of the 8 KiB one (20):
+    // sentences of 5-20 characters 164 -> 170 M sentences/s; at the headline's 140 bytes per sentence the two are equal, and with both
+    // tiers in the set the generator is slower by what the sweep gains (round 6, tools/dbg/tiers6_ab.sh).  VBT_TIERS set: as given.
+    std::vector<uint32_t> tiers = this->tiers;
+    if (lean_tier_default && n && total_bytes <= 96 * n && tiers.size() >= 2 && tiers[0] == 8192u) tiers[0] = 6656u;
     const size_t T = tiers.size();
     const size_t stride = 2 * std::max<uint64_t>(max_sentences, 1);
     BatchArgs a = pipe;

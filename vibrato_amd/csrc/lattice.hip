@@ -991,7 +991,7 @@ __device__ __forceinline__ uint32_t lattice_whole(const DevDict& D, const BatchA
 }
 
 #ifndef VBT_LEAN_WAVES
-#define VBT_LEAN_WAVES 5
+#define VBT_LEAN_WAVES 6
 #endif
 template <bool kSpaceMode>
 __global__ void __launch_bounds__(64, VBT_LEAN_WAVES) lattice_lean(DevDict D, BatchArgs A, uint32_t tier) {

@@ -18,10 +18,12 @@
 //   * what is left to wait for per iteration: vmcnt at the top (loads issued three iterations ago), then the iteration's LDS reads.
 //
 // Software pipeline: the gathers of a pass are issued 3 iterations before it is consumed (part of them miss L2: two iterations of
-// lead left ~165 cycles per iteration parked at the top), its record is requested 6 ahead, iterations are unrolled by six
-// (gather slot = iteration mod 3, record slot = record mod 6).  Iteration si consumes pass si, issues the gathers of pass si + 3
-// from record si + 3 and requests record si + 6 -- the request in front of the gathers, so that whatever waits for the gathers of
-// an iteration has waited for its record request too.
+// lead left ~165 cycles per iteration parked at the top); iterations are unrolled by six (gather slot = iteration mod 3).  Iteration si
+// consumes pass si and issues the gathers of pass si + 3 from record si + 3.  The records: with VBT_LDS_REC (the default build: 8-byte
+// records in the sentence's LDS) record r sits in register slot r mod 3 and iteration si requests record si + 5 -- a broadcast ds_read
+// behind the iteration's own LDS wait, landed at the next iteration's, first touched two iterations on; with the records in global
+// memory (VBT_LDS_REC=0, round 4) the request is a vector load six passes ahead into one of six slots, in front of the gathers, so
+// that whatever waits for the gathers of an iteration has waited for its record request too.
 //
 // Gathers: a NARROW pass (one unit) issues one load, a wide pass four (a unit without lanes runs under EXEC = 0: it moves nothing
 // but takes its place in vmcnt, tools/calib/exec0_vmcnt.hip).  Loads return in order, so everything issued up to the gathers of
@@ -36,16 +38,17 @@
 // The common pass -- at most 4 predecessors, at most 16 candidates, one step: 62 % of the passes of running text -- is a straight
 // line without a taken branch; every other shape (more units, rounds of a step, empty passes behind the last) branches out of line.
 //
-// Registers (fixed, declared as clobbers; inputs are operands):
-//   v24 zero   v25 cl   v26..v29 k, k + 4, k + 8, k + 12   v30 8 k   v31 8 cl
+// Registers (fixed, declared as clobbers; inputs are operands).  Default build (records in LDS): v24-v79 -- with the compiler's own
+// that is 80 VGPRs, six waves per SIMD for the lean instance (round 5's layout, kept for VBT_LDS_REC=0, ran to v87):
+//   v24 node cost (VBT_LDS_REC=0: zero)   v25 cl   v26..v29 k, k + 4, k + 8, k + 12   v30 8 k   v31 8 cl
 //   v32-35 / v36-39 / v40-43  gather slot 0 / 1 / 2: connection costs of units 0..3 of the pass in flight
 //   v44 v45 v46 / v47 v48 v49 / v50 v51 v52  slot 0 / 1 / 2: this lane's predecessor address, candidate record address, meta of the
 //            pass in the slot (predecessors of the round << 8 | phases << 16 | candidates << 24)
 //   v53 candidate record address of the pass being issued   v54 first cell of its matrix row   v55-58 right ids / cell indices of its units
 //   v60-67  slot records {field | right id, cost} of units 0..3 of the pass in hand     v68 its candidate's {slot offset | word cost << 16}
-//   v69 v70 minimum cost / field of the winner   v71 v72 slot address, node cost   v73 scratch
+//   v69 v70 minimum cost / field of the winner (v70 first holds the masked cost the minimum is taken of)   v71 slot address
 //   v74:75  the lane's running minimum (field | right id, cost) across units and rounds of a step; all ones between steps
-//   v[76:77] .. v[86:87]  record slots 0..5
+//   v[76:77] v[78:79] v[72:73]  record slots 0..2        (VBT_LDS_REC=0: v72 node cost, v73 scratch, v[76:77] .. v[86:87] record slots 0..5)
 //   s[36:37] / s[38:39] / s[40:41]  slot 0 / 1 / 2: lanes of unit 0 of the pass in the slot     s42 / s43 / s44 its flags
 //   s45-s57 scratch (record word, flags, masks)   s58 byte selector of meta   s59 passes left
 //   v59 LDS address of the record of the trip's first pass (VBT_LDS_REC=0: s[60:61], its address in global memory)
@@ -75,7 +78,7 @@
 #define VBT_GATHERS_N 0
 #define VBT_GATHERS_W 0
 #elif VBT_NO_GATHER == 2  /* every lane gathers cell 0: the loads are issued and waited for, but they all hit one line */
-#define VBT_GLOAD(W, IDX) "buffer_load_sshort " W ", v24, %[rs], 0 idxen\n\t"
+#define VBT_GLOAD(W, IDX) "buffer_load_sshort " W ", off, %[rs], 0\n\t"
 #define VBT_GATHERS_N 1
 #define VBT_GATHERS_W 4
 #else
@@ -154,22 +157,31 @@
 // VM = lanes that saw a predecessor (and write).  Minimum cost over the quad, then the smallest field among the lanes that hold it
 // (the last inserted predecessor, lattice.rs:141-146); + word cost (lattice.rs:125); cost -> the slot record, field -> the low half
 // of the candidate record (the back pointer).  FILL1/FILL2: two independent instructions for the DPP wait states.
+// (VBT_VT: the masked cost while the quad minimum is taken -- dead before the field goes into v70, so with the records in LDS it IS v70;
+// VBT_VNC: the node's cost.  Register layout of the build with the records in LDS: v24-v79, see VBT_SWEEP_CLOBBERS.)
+#if VBT_LDS_REC
+#define VBT_VT "v70"
+#define VBT_VNC "v24"
+#else
+#define VBT_VT "v73"
+#define VBT_VNC "v72"
+#endif
 #define VBT_FINISH(KLO, KHI, VM, CA, FILL1, FILL2)                                                   \
-    "v_cndmask_b32_e64 v73, -1, " KHI ", " VM "\n\t"                                                 \
+    "v_cndmask_b32_e64 " VBT_VT ", -1, " KHI ", " VM "\n\t"                                          \
     FILL1 FILL2                                                                                       \
-    "v_min_u32_dpp v69, v73, v73" VBT_DPP1                                                            \
+    "v_min_u32_dpp v69, " VBT_VT ", " VBT_VT VBT_DPP1                                                 \
     "v_add_u32_sdwa v71, v68, %[offk]" VBT_SDWA_LO                                                    \
     "s_nop 0\n\t"                                                                                     \
     "v_min_u32_dpp v69, v69, v69" VBT_DPP2                                                            \
-    "v_cmp_eq_u32_e32 vcc, v73, v69\n\t"                                                              \
-    "v_add_u32_sdwa v72, v69, sext(v68)" VBT_SDWA_SEXT_HI                                             \
+    "v_cmp_eq_u32_e32 vcc, " VBT_VT ", v69\n\t"                                                       \
+    "v_add_u32_sdwa " VBT_VNC ", v69, sext(v68)" VBT_SDWA_SEXT_HI                                     \
     "v_cndmask_b32_e32 v70, -1, " KLO ", vcc\n\t"                                                     \
     "s_nop 1\n\t"                                                                                     \
     "v_min_u32_dpp v70, v70, v70" VBT_DPP1                                                            \
     "s_nop 1\n\t"                                                                                     \
     "v_min_u32_dpp v70, v70, v70" VBT_DPP2                                                            \
     "s_mov_b64 exec, " VM "\n\t"                                                                      \
-    "ds_write_b32 v71, v72 offset:4\n\t"                                                              \
+    "ds_write_b32 v71, " VBT_VNC " offset:4\n\t"                                                      \
     "ds_write_b16_d16_hi " CA ", v70\n\t"
 
 // one unit of a general pass: (cost + connection cost, field) of predecessor 4 i + k against the running minimum; MASK = "" (a unit
@@ -321,12 +333,26 @@
 #define VBT_G0 "v32", "v33", "v34", "v35", "v44", "v45", "v46", "s[36:37]", "s42"
 #define VBT_G1 "v36", "v37", "v38", "v39", "v47", "v48", "v49", "s[38:39]", "s43"
 #define VBT_G2 "v40", "v41", "v42", "v43", "v50", "v51", "v52", "s[40:41]", "s44"
+#if VBT_LDS_REC
+// records in LDS: three slots, record r in slot r mod 3 -- the same index as its pass's gather slot.  Iteration si issues from record
+// si + 3 and requests record si + 5 into the slot of record si + 2 (dead since the issue of pass si + 2, an iteration ago): a request
+// sits behind its iteration's LDS wait and has landed at the next iteration's, so it is first touched two iterations on.  (Round 5
+// requested six ahead into six slots -- what the records needed when they were vector loads from global memory; three slots and
+// v73 / v72 folded away bring the block from v24-v87 to v24-v79: 80 VGPRs, six waves per SIMD for the lean instance.)
+#define VBT_R0 "v76", "v77"
+#define VBT_R1 "v78", "v79"
+#define VBT_R2 "v72", "v73"
+#define VBT_R0P "v[76:77]"
+#define VBT_R1P "v[78:79]"
+#define VBT_R2P "v[72:73]"
+#else
 #define VBT_R0 "v76", "v77"
 #define VBT_R1 "v78", "v79"
 #define VBT_R2 "v80", "v81"
 #define VBT_R3 "v82", "v83"
 #define VBT_R4 "v84", "v85"
 #define VBT_R5 "v86", "v87"
+#endif
 // behind iterations 1 and 3: two passes done -- out if none are left; behind iteration 5 the records move on by six
 #define VBT_HALF(NEXTLABEL)                                                                          \
     "s_sub_i32 s59, s59, 2\n\t"                                                                       \
@@ -350,6 +376,38 @@
     "s_branch .LBBvbt_x_%=\n"
 
 #define VBT_EXPAND(M, ...) M(__VA_ARGS__)
+#if VBT_LDS_REC
+// iteration U: gather slot and record slot U mod 3; requests record U + 5 of the trip (byte offset 8 (U + 5)) into slot (U + 2) mod 3
+#define VBT_IT0(M, V, VMC, TN, TW) VBT_EXPAND(M, "0", V, VMC, VBT_G0, VBT_R0, VBT_R2P, "40", TN, TW)
+#define VBT_IT1(M, V, VMC, TN, TW) VBT_EXPAND(M, "1", V, VMC, VBT_G1, VBT_R1, VBT_R0P, "48", TN, TW)
+#define VBT_IT2(M, V, VMC, TN, TW) VBT_EXPAND(M, "2", V, VMC, VBT_G2, VBT_R2, VBT_R1P, "56", TN, TW)
+#define VBT_IT3(M, V, VMC, TN, TW) VBT_EXPAND(M, "3", V, VMC, VBT_G0, VBT_R0, VBT_R2P, "64", TN, TW)
+#define VBT_IT4(M, V, VMC, TN, TW) VBT_EXPAND(M, "4", V, VMC, VBT_G1, VBT_R1, VBT_R0P, "72", TN, TW)
+#define VBT_IT5(M, V, VMC, TN, TW) VBT_EXPAND(M, "5", V, VMC, VBT_G2, VBT_R2, VBT_R1P, "80", TN, TW)
+
+// the prologue's issue of pass P (record slot P, gather slot P); the record of pass P + 3 is requested into the same slot behind it
+#define VBT_PRO(P, W0, W1, W2, W3, PA, CA, META, M, FL, R0, R1)                                      \
+    VBT_ISSUE_HEAD(PA, CA, R0, R1, FL)                                                                \
+    "s_cbranch_scc0 .LBBvbt_pn" P "_%=\n\t"                                                           \
+    VBT_WIDE_READS(PA)                                                                                \
+    "\n.LBBvbt_pn" P "_%=:\n\t"                                                                       \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                        \
+    "v_add_u32_sdwa v55, v55, v54" VBT_SDWA_LO                                                        \
+    VBT_META(META, R0, R1)                                                                            \
+    "s_mov_b64 " M ", s[48:49]\n\t"                                                                   \
+    "s_mov_b64 exec, s[48:49]\n\t"                                                                    \
+    VBT_GLOAD(W0, "v55")                                                                            \
+    "s_mov_b64 exec, -1\n\t"                                                                          \
+    "s_cmp_lg_u32 s46, 0\n\t"
+#define VBT_PRO0 VBT_EXPAND(VBT_PRO, "0", VBT_G0, VBT_R0)
+#define VBT_PRO1 VBT_EXPAND(VBT_PRO, "1", VBT_G1, VBT_R1)
+#define VBT_PRO2 VBT_EXPAND(VBT_PRO, "2", VBT_G2, VBT_R2)
+#define VBT_PRO_REC0 VBT_RECLOAD(VBT_R0P, "24")
+#define VBT_PRO_REC1 VBT_RECLOAD(VBT_R1P, "32")
+#define VBT_HEAD_R0 VBT_R0P
+#define VBT_HEAD_R1 VBT_R1P
+#define VBT_HEAD_R2 VBT_R2P
+#else
 // iteration U: gather slot U mod 3, issues from record slot (U + 3) mod 6, requests into record slot U
 #define VBT_IT0(M, V, VMC, TN, TW) VBT_EXPAND(M, "0", V, VMC, VBT_G0, VBT_R3, "v[76:77]", "48", TN, TW)
 #define VBT_IT1(M, V, VMC, TN, TW) VBT_EXPAND(M, "1", V, VMC, VBT_G1, VBT_R4, "v[78:79]", "56", TN, TW)
@@ -359,7 +417,7 @@
 #define VBT_IT5(M, V, VMC, TN, TW) VBT_EXPAND(M, "5", V, VMC, VBT_G2, VBT_R2, "v[86:87]", "88", TN, TW)
 
 // the prologue's issue of pass P (record slot P, gather slot P): the record of pass P + 3 is requested first
-#define VBT_PRO(P, W0, W1, W2, W3, PA, CA, META, M, FL, R0, R1, RLOAD, OFF)                          \
+#define VBT_PRO_(P, W0, W1, W2, W3, PA, CA, META, M, FL, R0, R1, RLOAD, OFF)                         \
     VBT_RECLOAD(RLOAD, OFF)                                                                           \
     VBT_ISSUE_HEAD(PA, CA, R0, R1, FL)                                                                \
     "s_cbranch_scc0 .LBBvbt_pn" P "_%=\n\t"                                                           \
@@ -373,16 +431,24 @@
     VBT_GLOAD(W0, "v55")                                                                            \
     "s_mov_b64 exec, -1\n\t"                                                                          \
     "s_cmp_lg_u32 s46, 0\n\t"
-#define VBT_PRO0 VBT_EXPAND(VBT_PRO, "0", VBT_G0, VBT_R0, "v[82:83]", "24")
-#define VBT_PRO1 VBT_EXPAND(VBT_PRO, "1", VBT_G1, VBT_R1, "v[84:85]", "32")
-#define VBT_PRO2 VBT_EXPAND(VBT_PRO, "2", VBT_G2, VBT_R2, "v[86:87]", "40")
+#define VBT_PRO0 VBT_EXPAND(VBT_PRO_, "0", VBT_G0, VBT_R0, "v[82:83]", "24")
+#define VBT_PRO1 VBT_EXPAND(VBT_PRO_, "1", VBT_G1, VBT_R1, "v[84:85]", "32")
+#define VBT_PRO2 VBT_EXPAND(VBT_PRO_, "2", VBT_G2, VBT_R2, "v[86:87]", "40")
+#define VBT_PRO_REC0
+#define VBT_PRO_REC1
+#define VBT_HEAD_R0 "v[76:77]"
+#define VBT_HEAD_R1 "v[78:79]"
+#define VBT_HEAD_R2 "v[80:81]"
+#endif
 
 #if VBT_LDS_REC
 #define VBT_REC_BASE "v_mov_b32 v59, %[rp]\n\t"
 #define VBT_REC_HEAD "v59"
+#define VBT_ZERO_INIT
 #else
 #define VBT_REC_BASE "s_mov_b64 s[60:61], %[rp]\n\t"
 #define VBT_REC_HEAD "%[hd]"
+#define VBT_ZERO_INIT "v_mov_b32 v24, 0\n\t"
 #endif
 #define VBT_SWEEP_TEXT                                                                               \
     /* Nothing the compiler issued may still be in flight: a load whose result no lane went on to use (the candidate records */ \
@@ -390,7 +456,7 @@
     /* and its destination may be one of the registers this block owns -- it would land in the middle of the loop.  (Round 4  */ \
     /* had this wait by accident: the drain of the record stores.  Found in round 5 as wrong tokens in one build variant.)   */ \
     "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"                                                               \
-    "v_mov_b32 v24, 0\n\t"                                                                            \
+    VBT_ZERO_INIT                                                                                     \
     "v_lshrrev_b32 v25, 2, %[ln]\n\t"                                                                 \
     "v_and_b32 v26, 3, %[ln]\n\t"                                                                     \
     "v_add_u32 v27, 4, v26\n\t"                                                                       \
@@ -405,22 +471,24 @@
     "s_mov_b32 s58, 0x07060302\n\t"                                                                   \
     VBT_PROF_INIT                                                                                     \
     /* the first three records out of LDS (global records: the builder left a copy there, no round trip at the start) */ \
-    "ds_read_b64 v[76:77], " VBT_REC_HEAD "\n\t"                                                      \
-    "ds_read_b64 v[78:79], " VBT_REC_HEAD " offset:8\n\t"                                             \
-    "ds_read_b64 v[80:81], " VBT_REC_HEAD " offset:16\n\t"                                            \
+    "ds_read_b64 " VBT_HEAD_R0 ", " VBT_REC_HEAD "\n\t"                                               \
+    "ds_read_b64 " VBT_HEAD_R1 ", " VBT_REC_HEAD " offset:8\n\t"                                      \
+    "ds_read_b64 " VBT_HEAD_R2 ", " VBT_REC_HEAD " offset:16\n\t"                                     \
     "s_waitcnt lgkmcnt(0)\n\t"                                                                        \
-    /* prologue: the gathers of passes 0, 1 and 2 (behind the requests for the records of passes 3, 4 and 5) */ \
+    /* prologue: the gathers of passes 0, 1 and 2 (and the requests for the records of the passes behind them) */ \
     VBT_PRO0                                                                                          \
     "s_cbranch_scc0 .LBBvbt_p0_%=\n\t"                                                                \
-    VBT_WIDE("v33", "v34", "v35", "v76", "v77")                                                       \
+    VBT_EXPAND(VBT_WIDE, "v33", "v34", "v35", VBT_R0)                                                 \
     "\n.LBBvbt_p0_%=:\n\t"                                                                            \
+    VBT_PRO_REC0                                                                                      \
     VBT_PRO1                                                                                          \
     "s_cbranch_scc0 .LBBvbt_p1_%=\n\t"                                                                \
-    VBT_WIDE("v37", "v38", "v39", "v78", "v79")                                                       \
+    VBT_EXPAND(VBT_WIDE, "v37", "v38", "v39", VBT_R1)                                                 \
     "\n.LBBvbt_p1_%=:\n\t"                                                                            \
+    VBT_PRO_REC1                                                                                      \
     VBT_PRO2                                                                                          \
     "s_cbranch_scc0 .LBBvbt_i0N_%=\n\t"                                                               \
-    VBT_WIDE("v41", "v42", "v43", "v80", "v81")                                                       \
+    VBT_EXPAND(VBT_WIDE, "v41", "v42", "v43", VBT_R2)                                                 \
     "s_branch .LBBvbt_i0W_%=\n"                                                                       \
     /* the loop: the narrow variants in line */                                                       \
     VBT_IT0(VBT_ITER, "N", VBT_VMC_N, "", "")                                                               \
@@ -453,10 +521,15 @@
     VBT_PROF_OUT                                                                                      \
     "s_mov_b64 exec, -1"
 
+#if VBT_LDS_REC
+#define VBT_CLOBBERS_HI
+#else
+#define VBT_CLOBBERS_HI "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87",
+#endif
 #define VBT_SWEEP_CLOBBERS                                                                           \
     "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39",                \
     "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57",   \
     "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75",          \
-    "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87",                                             \
+    "v76", "v77", "v78", "v79", VBT_CLOBBERS_HI                                                                                    \
     "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51",               \
     "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", VBT_PROF_CLOBBERS "vcc", "scc", "memory"
