@@ -171,6 +171,11 @@ VBT_API int vbt_tokenizer_calibrate(const vbt_tokenizer* tok, const uint8_t* tex
 /* Returns once no calibration is running on any device of the tokenizer, or after timeout_ms (< 0: no limit); *idle = 1 when none
  * is running.  (Benchmarks wait here behind their warm-up so that the counting sweep does not share the GPU with the timed region.) */
 VBT_API int vbt_tokenizer_connid_reorder_wait(const vbt_tokenizer* tok, int64_t timeout_ms, int* idle);
+/* Lattice density of the text the tokenizer has been seeing: candidates (lattice nodes before the sweep) per input byte of the last batch
+ * that reported, on the tokenizer's first device; 0 = no batch yet.  ~2.0 on running Japanese text over a unidic-sized lexicon, 4.4 on the
+ * dense synthetic law.  The library picks the LDS tiers of the sweep by it (> 3 = 10 KiB segments, else 8 KiB ones and
+ * one more wave per SIMD); exposed for observability.  No reference counterpart.  VBT_TIER_ADAPT=0: not measured, always 0. */
+VBT_API int vbt_tokenizer_lattice_density(const vbt_tokenizer* tok, double* candidates_per_byte);
 VBT_API void vbt_tokenizer_free(vbt_tokenizer* tok);
 VBT_API const vbt_dict* vbt_tokenizer_dictionary(const vbt_tokenizer* tok); /* Tokenizer::dictionary, tokenizer.rs:77 */
 

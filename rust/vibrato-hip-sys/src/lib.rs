@@ -112,6 +112,7 @@ extern "C" {
     pub fn vbt_tokenizer_connid_reorder_info(tok: *const vbt_tokenizer, out: *mut u64) -> c_int;
     pub fn vbt_tokenizer_calibrate(tok: *const vbt_tokenizer, text: *const u8, offsets: *const u64, n: u64) -> c_int;
     pub fn vbt_tokenizer_connid_reorder_wait(tok: *const vbt_tokenizer, timeout_ms: i64, idle: *mut c_int) -> c_int;
+    pub fn vbt_tokenizer_lattice_density(tok: *const vbt_tokenizer, candidates_per_byte: *mut f64) -> c_int;
     pub fn vbt_tokenizer_free(tok: *mut vbt_tokenizer);
     pub fn vbt_tokenizer_dictionary(tok: *const vbt_tokenizer) -> *const vbt_dict;
 

@@ -194,6 +194,15 @@ impl Tokenizer {
         Ok(idle != 0)
     }
 
+    /// Candidates (lattice nodes) per input byte of the last batch that reported: what the library picks the sweep's LDS tiers by
+    /// (`vbt_tokenizer_lattice_density`); 0.0 before the first batch.
+    pub fn lattice_density(&self) -> Result<f64> {
+        let tok = self.raw()?;
+        let mut d: f64 = 0.0;
+        check(unsafe { sys::vbt_tokenizer_lattice_density(tok, &mut d) })?;
+        Ok(d)
+    }
+
     /// Releases the idle device workspaces and pinned blocks `tokenize_batch` keeps for reuse (about 400 bytes of device memory per
     /// byte of text of every batch that was in flight at once; at most a quarter of the GPU's memory, `VBT_POOL_MAX_MB`). They are
     /// created again on demand. Thread-safe; a no-op before the first batch.

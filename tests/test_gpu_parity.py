@@ -686,6 +686,41 @@ def test_worker_loop_benchmark_counts_tokens():
         assert r["tokens"] == 2 * len(exp_tok) and r["us_per_call"] > 0
 
 
+def test_tier_set_follows_the_measured_lattice_density(monkeypatch):
+    """The sweep's default tier set is chosen per batch from the lattice density the tokenizer measured on the batches before it
+    (vbt_tokenizer_lattice_density: candidates per input byte, reported by build_lists into pinned memory): running text gets 8 KiB
+    segments behind a 7.5 KiB (short sentences: 6 KiB) lean tier, dense lattices the 8 / 10 KiB set.  The density is what the oracle
+    counts for the same sentences, and no choice changes a record: dense and ordinary dictionaries, first batch (nothing measured yet)
+    and later ones, adaptation on and off."""
+    import torch
+    for shape, law in (("small", "lognormal_40"), ("small-dense", "lognormal_40"), ("small", "uniform_5_20")):
+        sd = synth.SynthDict(shape)
+        do = ora.Dictionary.from_sources_binmatrix(sd.lex, sd.matrix, sd.num_right, sd.num_left, sd.char_def, sd.unk)
+        to = ora.Tokenizer(do)
+        text, offs = sd.sentences(3000, law)
+        w = to.new_worker()
+        w.reset_counters()
+        w.tokenize_batch(text, offs, counted=True, want_tokens=False)
+        cnt = w.counters()
+        want = cnt["n_nodes"] / len(text)  # the oracle's lattice nodes: every candidate of a visited start position
+        for adapt in ("1", "0"):
+            monkeypatch.setenv("VBT_TIER_ADAPT", adapt)
+            dv = V.SystemDictionaryBuilder.from_readers_binmatrix(sd.lex, sd.matrix, sd.num_right, sd.num_left, sd.char_def, sd.unk)
+            tv = V.Tokenizer(dv)
+            assert tv.lattice_density() == 0.0
+            for _ in range(3):  # the first batch runs before anything is known, the next ones behind its report
+                _assert_batch_equal(to, tv, text, offs)
+                torch.cuda.synchronize()
+            d = tv.lattice_density()
+            if adapt == "0":
+                assert d == 0.0
+                continue
+            # (the generator lists the candidates of every position, the oracle counts the nodes of the visited ones: the device's figure
+            # is the larger one, by the positions no path reaches)
+            assert (d > 3.0) == (shape == "small-dense"), (shape, law, d, want)
+            assert want * 0.95 <= d <= want * 1.6, (shape, law, d, want)
+
+
 def test_tokenize_lines_batches_behind_an_iterator():
     """Tokenizer.tokenize_lines: the per-line loop over an iterable, batched behind the scenes (three batches here: the line limit, the
     byte limit, the rest) -- every sentence comes back in input order with the oracle's records."""

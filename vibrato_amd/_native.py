@@ -70,6 +70,7 @@ SIGNATURES = {
     "vbt_tokenizer_connid_reorder_info": (_int, [_vp, C.POINTER(_u64)]),
     "vbt_tokenizer_calibrate": (_int, [_vp, _vp, _vp, _u64]),
     "vbt_tokenizer_connid_reorder_wait": (_int, [_vp, C.c_int64, C.POINTER(C.c_int)]),
+    "vbt_tokenizer_lattice_density": (_int, [_vp, C.POINTER(C.c_double)]),
     "vbt_tokenizer_free": (None, [_vp]),
     "vbt_tokenizer_dictionary": (_vp, [_vp]),
     "vbt_tokenizer_trim_pool": (_int, [_vp]),

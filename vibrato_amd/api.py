@@ -277,6 +277,12 @@ class Tokenizer:
         N.check(N.lib().vbt_tokenizer_connid_reorder_wait(self._handle(), -1 if timeout_s is None else int(timeout_s * 1000), C.byref(idle)))
         return bool(idle.value)
 
+    def lattice_density(self):
+        """Candidates per input byte of the last batch that reported (vbt_tokenizer_lattice_density); 0.0 before the first."""
+        d = C.c_double(0.0)
+        N.check(N.lib().vbt_tokenizer_lattice_density(self._handle(), C.byref(d)))
+        return float(d.value)
+
     def calibrate(self, sentences=None, text=None, offsets=None):
         """The internal renumbering of the connection ids done up front, synchronously, from host text (vbt_tokenizer_calibrate)."""
         if sentences is not None:

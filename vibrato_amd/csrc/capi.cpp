@@ -835,6 +835,13 @@ int vbt_tokenizer_connid_reorder_wait(const vbt_tokenizer* tok, int64_t timeout_
     });
 }
 
+int vbt_tokenizer_lattice_density(const vbt_tokenizer* tok, double* candidates_per_byte) {
+    return guarded([&] {
+        if (!tok || !candidates_per_byte) throw Error(VBT_ERR_INVALID_ARGUMENT, "null argument");
+        *candidates_per_byte = tok->reps[0]->t->candidates_per_byte();
+    });
+}
+
 void vbt_tokenizer_free(vbt_tokenizer* tok) {
     if (!tok) return;
     for (auto& r : tok->reps) r->pool.clear();

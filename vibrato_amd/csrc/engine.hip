@@ -80,6 +80,15 @@ Tokenizer::Tokenizer(const Dictionary* dict, bool ignore_space, uint32_t max_gro
     if (device >= count) throw Error(VBT_ERR_INVALID_ARGUMENT, "device: index out of range");
     HIP_CHECK(hipSetDevice(device));
     device_ = device;
+    {
+        void* h = nullptr;
+        HIP_CHECK(hipHostMalloc(&h, 64, hipHostMallocDefault));
+        std::memset(h, 0, 64);
+        density_host_ = static_cast<unsigned long long*>(h);
+        void* d = nullptr;
+        HIP_CHECK(hipHostGetDevicePointer(&d, h, 0));
+        density_dev_ = static_cast<unsigned long long*>(d);
+    }
     auto img0 = std::make_unique<DevImage>();
     DevDict& dev_ = img0->dev;  // image 0: the dictionary's own connection ids
     hipDeviceProp_t prop;
@@ -231,6 +240,14 @@ Tokenizer::~Tokenizer() {
     for (auto& im : images_)
         for (void* p : im->allocs) (void)hipFree(p);
     for (void* p : allocs_) (void)hipFree(p);
+    if (density_host_) (void)hipHostFree(density_host_);
+}
+
+double Tokenizer::candidates_per_byte() const {
+    if (!density_host_) return 0.0;
+    // (two separate 8-byte words written by one device thread, read without a lock: a torn pair is a slightly wrong ratio once)
+    const unsigned long long c = __atomic_load_n(&density_host_[0], __ATOMIC_RELAXED), b = __atomic_load_n(&density_host_[1], __ATOMIC_RELAXED);
+    return b ? (double)c / (double)b : 0.0;
 }
 
 const DevImage& Tokenizer::image_of(uint32_t epoch) const {
@@ -430,7 +447,22 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
     // sentences of 5-20 characters 164 -> 170 M sentences/s; at the headline's 140 bytes per sentence the two are equal, and with both
     // tiers in the set the generator is slower by what the sweep gains (round 6, tools/dbg/tiers6_ab.sh).  VBT_TIERS set: as given.
     std::vector<uint32_t> tiers = this->tiers;
-    if (lean_tier_default && n && total_bytes <= 96 * n && tiers.size() >= 2 && tiers[0] == 8192u) tiers[0] = 6656u;
+    uint32_t seg_bytes_default = kSegTierBytes;
+    if (lean_tier_default && n && tiers.size() >= 2 && tiers[0] == 8192u && tiers[1] == kSegTierBytes) {
+        // The default set {8 KiB lean, 10 KiB segments} is what DENSE lattices want (13 nodes per character: an 8 KiB segment holds too
+        // few positions, dense law 31.3 -> 28.3 M sentences/s).  Everything else is swept faster with 8 KiB segments -- 20 instead of 16
+        // of them on a CU, the slim instance's fifth wave per SIMD (96 VGPRs) -- behind a 7.5 KiB lean tier: headline 76.3 -> 79-80 M,
+        // config 5 28.6 -> 29.2 M (tools/dbg/slim5_ab.sh, slim5_scan.sh).  Which it is the tokenizer knows from the batches before this
+        // one (candidates_per_byte: 2.0 on running text, 4.4 on the dense law); the first batch is taken for running text.
+        // VBT_TIERS / VBT_SEG_BYTES / VBT_TIER_ADAPT=0: the set as given.
+        static const bool adapt = env_u32("VBT_TIER_ADAPT", 1) != 0;
+        const bool dense = tok.candidates_per_byte() > 3.0;
+        if (adapt && !dense) {
+            tiers[0] = total_bytes <= 96 * n ? 6144u : 7680u;
+            tiers[1] = 8192u;
+            seg_bytes_default = 8192u;
+        }
+    }
     const size_t T = tiers.size();
     const size_t stride = 2 * std::max<uint64_t>(max_sentences, 1);
     BatchArgs a = pipe;
@@ -451,7 +483,7 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
     a.lists = d_over; a.list_stride = (uint32_t)stride; a.n_tiers = (uint32_t)T;
     a.tier_prio = env_u32("VBT_TIER_PRIO", 3);
     {   // tier whose waves sweep longer sentences segment by segment (VBT_SEG_BYTES=0: off, sentences use the big tiers)
-        const uint32_t seg_bytes = env_u32("VBT_SEG_BYTES", kSegTierBytes);
+        const uint32_t seg_bytes = env_u32("VBT_SEG_BYTES", seg_bytes_default);
         a.seg_tier = 0xFFFFFFFFu;
         if (seg_bytes)
             for (size_t t = 0; t < T; ++t)
@@ -468,6 +500,7 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
         for (uint32_t t = 0; t < a.n_lean; ++t)
             if (tiers[t] > 65536u) { a.n_lean = t; break; }
     }
+    a.density_out = fused || !lean_tier_default || env_u32("VBT_TIER_ADAPT", 1) == 0 ? nullptr : tok.density_slot_dev();  // (reported only where it is used)
     a.lid_count = count_connids ? d_connid : nullptr;
     a.rid_count = count_connids ? d_connid + tok.dict().num_left : nullptr;
     a.s_counted = count_connids ? d_counted : nullptr;
@@ -624,7 +657,7 @@ void Workspace::serve(const uint8_t* h_text_dev, uint8_t* d_text, uint64_t* d_of
     a.prof = nullptr;
     a.lists = d_over; a.list_stride = (uint32_t)(2 * std::max<uint64_t>(max_sentences, 1)); a.n_tiers = 1;
     a.tier_prio = 0; a.seg_tier = 0; a.n_lean = 0; a.sid0 = 0; a.cctrl = d_cctrl; a.list_off = 0; a.direct_push = 0; a.inline_lean = 0;
-    a.lid_count = nullptr; a.rid_count = nullptr; a.s_counted = nullptr;
+    a.lid_count = nullptr; a.rid_count = nullptr; a.s_counted = nullptr; a.density_out = nullptr;
     constexpr uint32_t kOneLds = 65536;  // generator arrays (~26 B per character), then the lattice (whole up to ~400 characters, in segments beyond)
     a.tier_bytes[0] = kOneLds;
     const DevDict& D = tok.dev();  // (the image of the moment: a kernel that is started later may use a newer one)

@@ -86,6 +86,7 @@ struct BatchArgs {
     uint32_t n_tiers;
     uint32_t seg_tier;     // LDS tier that sweeps longer sentences in segments (>= n_tiers: none)
     uint32_t n_lean;       // the first n_lean LDS tiers are swept by the lean instance (lattice_lean: whole sentences with the generator's pass records ONLY)
+    unsigned long long* density_out;  // pinned host memory (device address), {candidates, bytes} of this batch's bulk-generated sentences: written once by build_lists; nullptr = not wanted
     uint32_t inline_lean;  // gen_sweep: the generator's wave sweeps its sentence itself when it routed it to a lean tier (nothing is filed for it)
     uint32_t direct_push;  // gen_one appends to the work lists directly instead of routing through s_tier (no build_lists behind it)
     uint32_t tier_prio;  // the top `tier_prio` LDS tiers run at raised wave priority (0 = off)
@@ -105,7 +106,9 @@ struct BatchArgs {
 // ctrl[kTotal] total tokens; ctrl[kError] DevError flags; ctrl[kBump..+1] u64 scratch bump pointer;
 // ctrl[kTierCtrl + 2t] = number of sentences tier t passed on, ctrl[kTierCtrl + 2t + 1] = work cursor of tier t
 // ctrl[kNodeCursor] bump pointer of the candidate arrays
-enum CtrlSlot { kTotal = 0, kError = 1, kBump = 2, kNodeCursor = 4, kTierCtrl = 6, kCtrlWords = 32 };
+// ctrl[kDensCand..+1] / ctrl[kDensBytes..+1] u64: candidates / bytes of the sentences the bulk generator took, ctrl[kDensDone] workgroups of
+// build_lists that have added theirs (the last one reports the two sums to the tokenizer's pinned slot: BatchArgs::density_out)
+enum CtrlSlot { kTotal = 0, kError = 1, kBump = 2, kNodeCursor = 4, kTierCtrl = 6, kDensCand = 8, kDensBytes = 10, kDensDone = 12, kCtrlWords = 32 };
 constexpr int kMaxTiers = 8;
 constexpr uint32_t kSegTierBytes = 10240;  // default LDS of the sweep's one tier: 16 wavefronts per CU (4 per SIMD, 128 VGPRs each) x 10 KiB = the CU's 160 KiB
 constexpr uint32_t kScanBlock = 256, kScanTile = 256;  // token packing: sentences per tile (small tiles: the copy needs the parallelism)
@@ -169,6 +172,11 @@ class Tokenizer {
     // Returns once no calibration is running (state != 1), or after timeout_ms (< 0: no limit); true = not running.
     bool wait_calibration(int64_t timeout_ms) const;
     ConnidReorderInfo reorder_info() const;
+    // Lattice density of the text this tokenizer has been seeing: candidates per input byte of the bulk-generated sentences of the last
+    // batch that reported (a device kernel stores the two sums into pinned host memory; nothing is ever waited for).  0 = nothing yet.
+    // Workspace::run picks the sweep's tier set by it: dense lattices want 10 KiB segments, everything else 8 KiB ones and a fifth wave.
+    double candidates_per_byte() const;
+    unsigned long long* density_slot_dev() const { return density_dev_; }
 
   private:
     void upload_lexicon(const Lexicon& lx, DevLexicon& out);
@@ -197,6 +205,8 @@ class Tokenizer {
     mutable std::mutex calib_mu_;
     mutable std::condition_variable calib_cv_;
     mutable int calib_attempts_ = 0;
+    unsigned long long* density_host_ = nullptr;  // {candidates, bytes}, pinned
+    unsigned long long* density_dev_ = nullptr;   // the same, as the device sees it
 };
 
 class Workspace {

@@ -424,6 +424,36 @@ __global__ void __launch_bounds__(1024) build_lists(BatchArgs A, int only_list) 
         if (lane == 0) w_cnt[wave][l] = (uint32_t)__popcll(m);
         if (mine) my_rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
     }
+    if (A.density_out && only_list < 0) {
+        // lattice density of the batch, for the tokenizer's choice of tiers for the batches behind this one (Tokenizer::candidates_per_byte):
+        // candidates and bytes of the sentences the bulk generator took (their headers are final), one pair of atomics per workgroup; the
+        // last workgroup stores the sums into the tokenizer's pinned slot
+        __shared__ uint32_t d_c[16], d_b[16];
+        uint32_t c = 0, b = 0;
+        if (rel < A.n) {
+            const uint4 hq = A.s_hdr[sid];
+            if (((hq.y >> 16) & 0xFFu) != 0xFFu) { c = hq.y & 0xFFFFu; b = hq.x >> 16; }
+        }
+        c = wave_sum(c); b = wave_sum(b);
+        if (lane == 0) { d_c[wave] = c; d_b[wave] = b; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long cs = 0, bs = 0;
+            for (uint32_t w = 0; w < 16; ++w) { cs += d_c[w]; bs += d_b[w]; }
+            unsigned long long* acc_c = reinterpret_cast<unsigned long long*>(&A.ctrl[kDensCand]);
+            unsigned long long* acc_b = reinterpret_cast<unsigned long long*>(&A.ctrl[kDensBytes]);
+            atomicAdd(acc_c, cs); atomicAdd(acc_b, bs);
+            __threadfence();
+            if (atomicAdd(&A.ctrl[kDensDone], 1u) == gridDim.x - 1) {
+                const unsigned long long tc = atomicAdd(acc_c, 0ull), tb = atomicAdd(acc_b, 0ull);
+                if (tb) {
+                    __hip_atomic_store(&A.density_out[0], tc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(&A.density_out[1], tb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
+        }
+        __syncthreads();
+    }
     {   // sentences the generator's own wave swept (gen_sweep) are in no list: counted in the first tier's cursor word (unused: lean tiers have no cursor)
         const uint64_t m = __ballot(t == kRouteInline && only_list < 0);
         if (lane == 0 && m) atomicAdd(&A.cctrl[1], (uint32_t)__popcll(m));

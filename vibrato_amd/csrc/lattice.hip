@@ -1086,7 +1086,7 @@ __global__ void __launch_bounds__(64, VBT_LAT_WAVES) lattice_lds(DevDict D, Batc
 
 #if VBT_HAS_LEAN
 #ifndef VBT_SLIM_WAVES
-#define VBT_SLIM_WAVES 4
+#define VBT_SLIM_WAVES 5
 #endif
 // The segment tier's launch of the default build on i16 cells without counting: lattice_sentence<.., kSlim> (see there).
 template <bool kSpaceMode>
