@@ -906,6 +906,11 @@ __device__ __forceinline__ uint32_t lattice_whole(const DevDict& D, const BatchA
 #else
     uint4 r0 = ndg[ln < C ? ln : 0u], r1 = ndg[64 + ln < C ? 64 + ln : 0u];
 #endif
+#if VBT_LEAN_UPFRONT > 2  // (candidates 128 .. 64 VBT_LEAN_UPFRONT - 1 requested with the first two rounds instead of round by round behind them)
+    uint4 rx[VBT_LEAN_UPFRONT - 2];
+#pragma unroll
+    for (uint32_t q = 0; q < VBT_LEAN_UPFRONT - 2; ++q) rx[q] = ndg[128 + 64 * q + ln < C ? 128 + 64 * q + ln : 0u];
+#endif
     uint2 p0 = grec[ln < SL ? ln : 0u], p1 = grec[64 + ln < SL ? 64 + ln : 0u];
     uint32_t cb0 = c2bg[ln <= n ? ln : n], cb1 = c2bg[64 + ln <= n ? 64 + ln : n];
     auto put_cand = [&](uint32_t c, const uint4& r) {
@@ -922,6 +927,11 @@ __device__ __forceinline__ uint32_t lattice_whole(const DevDict& D, const BatchA
     if (64 + ln < C) put_cand(64 + ln, r1);
 #if VBT_ABLATE_LEAN == 5
     for (uint32_t c = 128 + ln; c < C; c += 64) put_cand(c, ld8(c));
+#elif VBT_LEAN_UPFRONT > 2
+#pragma unroll
+    for (uint32_t q = 0; q < VBT_LEAN_UPFRONT - 2; ++q)
+        if (128 + 64 * q + ln < C) put_cand(128 + 64 * q + ln, rx[q]);
+    for (uint32_t c = 64 * VBT_LEAN_UPFRONT + ln; c < C; c += 64) put_cand(c, ndg[c]);
 #else
     for (uint32_t c = 128 + ln; c < C; c += 64) put_cand(c, ndg[c]);
 #endif
