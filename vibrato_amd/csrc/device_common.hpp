@@ -240,6 +240,9 @@ __device__ __forceinline__ void unk_spans(uint32_t cinfo, uint32_t g, uint32_t i
 #ifndef VBT_LEAN_UPFRONT  // lattice_whole: rounds of 64 candidate records requested before the first is used (2: the first form; 4 / 5: sweep 0.643-0.645 -> 0.629-0.634 ms)
 #define VBT_LEAN_UPFRONT 5
 #endif
+#ifndef VBT_LEAN_REG_TRACE  // lattice_whole: the back-trace over registers (v_readlane) instead of dependent LDS reads -- measured slower (sweep 0.627-0.637 -> 0.646-0.659 ms): off
+#define VBT_LEAN_REG_TRACE 0
+#endif
 #ifndef VBT_ABLATE_LEAN  // timing probes of lattice_whole (lattice.hip); tools/dbg/lean_ablate.py
 #define VBT_ABLATE_LEAN 0
 #endif

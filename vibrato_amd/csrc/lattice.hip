@@ -967,6 +967,32 @@ __device__ __forceinline__ uint32_t lattice_whole(const DevDict& D, const BatchA
     auto node_cost = [&](uint32_t c) { return e_rec[(cnd[c].y & 0xFFFFu) >> 3].y ^ 0x80000000u; };
     auto node_pred = [&](uint32_t c) { return 0xFFFEu - (cnd[c].x & 0xFFFFu); };
     uint32_t T = 0;
+#if VBT_LEAN_REG_TRACE
+    // The walk from EOS over registers instead of LDS: every lane holds the back pointers of candidates ln, ln + 64, ... (one round of LDS
+    // reads for all of them), and a step of the walk is a v_readlane -- a few cycles where a dependent ds_read_u16 takes an LDS round trip
+    // (~28 steps per sentence; 6 % of the kernel's time as LDS reads: profiles/EXPERIMENTS.md, the ablation probes).
+    if (C < 64u * 5u) {
+        uint32_t pr[5];
+#pragma unroll
+        for (uint32_t q = 0; q < 5; ++q) pr[q] = 64 * q + ln <= C ? node_pred(64 * q + ln) : kBosSeq;
+        uint32_t seq = C;  // (wave-uniform from here)
+        for (;;) {
+            const uint32_t q = seq >> 6, l = seq & 63u;
+            uint32_t nx;
+            switch (q) {
+                case 0: nx = (uint32_t)__builtin_amdgcn_readlane((int)pr[0], (int)l); break;
+                case 1: nx = (uint32_t)__builtin_amdgcn_readlane((int)pr[1], (int)l); break;
+                case 2: nx = (uint32_t)__builtin_amdgcn_readlane((int)pr[2], (int)l); break;
+                case 3: nx = (uint32_t)__builtin_amdgcn_readlane((int)pr[3], (int)l); break;
+                default: nx = (uint32_t)__builtin_amdgcn_readlane((int)pr[4], (int)l); break;
+            }
+            seq = nx;
+            if (seq == kBosSeq || T >= n || seq > C) break;  // (seq > C cannot happen: back pointers point at inserted candidates)
+            if (ln == 0) path[T] = (uint16_t)seq;
+            ++T;
+        }
+    } else
+#endif
     if (ln == 0) {
         uint32_t seq = node_pred(C);
         while (seq != kBosSeq && T < n) { path[T++] = (uint16_t)seq; seq = node_pred(seq); }
