@@ -450,7 +450,8 @@ def main():
 
         roofline = {"bound": "hbm",
                     "kernel": "lattice_lean + lattice_slim: the sweep, two instances of one loop launched side by side (lean: whole sentences that "
-                              "arrive with the generator's pass records, 8 KiB tier, 5 waves per SIMD; slim: everything else, 10 KiB segment tier); both span the "
+                              "arrive with the generator's pass records, 7.5 KiB tier, 80 VGPRs; slim: everything else, 8 KiB segments, 5 waves per SIMD -- "
+                              "batches of dense lattices: 8 / 10 KiB, by the density the tokenizer measured on the batches before); both span the "
                               "same interval of a step (rocprofv3: either kernel's duration = this span).  duration = hipEvents on the launch stream from "
                               "the fork behind the generators to the join of every sweep; the fallback launch and the packing behind the join are pack_ms",
                     "achieved": round(achieved / 1e9, 3), "peak": HBM_PEAK_BPS / 1e9, "unit": "GB/s",
@@ -627,7 +628,7 @@ def main():
                        "baseline_config": 4 if world > 1 else (5 if args.ignore_space and args.user_lexicon else 3 if args.dict == "unidic" else None),
                        "ignore_space": args.ignore_space, "max_grouping_len": args.max_grouping_len, "user_lexicon_words": args.user_lexicon,
                        "connection_ids_reordered": reorder_info, "parallelism": par},
-            "parity_vs_oracle_sample": parity, "tokens_per_step": total_tokens,
+            "parity_vs_oracle_sample": parity, "tokens_per_step": total_tokens, "lattice_density_candidates_per_byte": round(tok.lattice_density(), 3),
             "parity_gate": "this run compared a 5 000-sentence sample of the timed batch (3 000 per suite leg) and the formatter's bytes with the oracle; the "
                            "full-size comparisons (configs 2, 3, 5 and the dense law: every record of 100 000 sentences) are tests/test_gpu_parity.py",
             "per_rank": per_rank,
