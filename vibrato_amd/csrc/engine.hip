@@ -354,7 +354,7 @@ Workspace::Workspace(const Tokenizer& t, uint64_t max_s, uint64_t max_b) : tok(t
     d_tile_sums = static_cast<uint32_t*>(alloc(((ns + kScanTile - 1) / kScanTile + 1) * 4));
     d_tok_off = static_cast<uint32_t*>(alloc(ns * 4));
     d_tok_cnt = static_cast<uint32_t*>(alloc(ns * 4));
-    d_over = static_cast<uint32_t*>(alloc(2 * ns * 4 * (tiers.size() + kListsBehindTiers)));  // two regions per list: the launch stream's and (VBT_EARLY_LONG=1) the long sentences' side streams'
+    d_over = static_cast<uint32_t*>(alloc(2 * ns * 4 * (tiers.size() + 1 + kListsBehindTiers)));  // (+ 1: run() may put one more lean tier in front)  // two regions per list: the launch stream's and (VBT_EARLY_LONG=1) the long sentences' side streams'
     d_ctrl = static_cast<uint32_t*>(alloc((kCtrlWords + (size_t)kBlockCtrlWords) * 4));  // one block: cleared by one memset per batch
     d_cctrl = d_ctrl + kCtrlWords;
     if (const char* e = std::getenv("VBT_TIER_WAVES")) {  // experiment: fixed lattice grid per tier
@@ -389,8 +389,8 @@ Workspace::Workspace(const Tokenizer& t, uint64_t max_s, uint64_t max_b) : tok(t
         // tiers below the segment tier do.  Created here, every workspace took four streams, and with the HIP runtime's default of four
         // hardware queues the streams of the workspaces a pipelined host call alternates between all landed on ONE queue: their
         // kernels ran strictly one after the other, with a full drain at every switch.)
-        streams.assign(tiers.size(), nullptr);
-        tier_events.assign(tiers.size(), nullptr);
+        streams.assign(tiers.size() + 1, nullptr);
+        tier_events.assign(tiers.size() + 1, nullptr);
         HIP_CHECK(hipEventCreateWithFlags(reinterpret_cast<hipEvent_t*>(&ev_fork2), hipEventDisableTiming));
 
         kern::gen_set_max_lds(163840);
@@ -458,11 +458,17 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
         static const bool adapt = env_u32("VBT_TIER_ADAPT", 1) != 0;
         const bool dense = tok.candidates_per_byte() > 3.0;
         if (adapt && !dense) {
-            tiers[0] = total_bytes <= 96 * n ? 6144u : 7680u;
+            // (two lean tiers, 6 and 7.5 KiB, where the sentences are long enough to fill both; their launches share one side stream:
+            // headline 80.6-80.9 -> 81.6-82.4 M sentences/s, sweep 0.628-0.632 -> 0.607-0.612 ms; tools/dbg/tiers7_ab.sh, tiers8_ab.sh)
+            // (batches of more than 256 bytes per sentence -- config 5: 330 -- are mostly long sentences in segments: one 7.5 KiB lean tier)
+            const bool longs = total_bytes > 256 * n, shorts = total_bytes <= 96 * n;
+            tiers[0] = longs ? 7680u : 6144u;
             tiers[1] = 8192u;
+            if (!longs && !shorts && tiers.size() + 1 <= (size_t)kMaxTiers) tiers.insert(tiers.begin() + 1, 7680u);
             seg_bytes_default = 8192u;
         }
     }
+    last_T = (uint32_t)tiers.size();
     const size_t T = tiers.size();
     const size_t stride = 2 * std::max<uint64_t>(max_sentences, 1);
     BatchArgs a = pipe;
@@ -558,17 +564,22 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
         // The segment tier (the critical path: the longest sentences, then the escape tiers behind it) is launched on the launch
         // stream itself -- no event round trip before it starts nor before what follows it (VBT_MAIN_SEG=0: every tier on a side stream).
         const bool main_seg = env_u32("VBT_MAIN_SEG", 1) != 0 && a.seg_tier < T;
-        auto launch_tier = [&](size_t t, hipEvent_t after) {
+        // (every side stream costs the step a fork and a join across queues, ~0.02-0.03 ms: several lean tiers share ONE side stream, one
+        // launch behind the other -- VBT_LEAN_ONE_STREAM=0: a stream each)
+        static const bool lean_one = env_u32("VBT_LEAN_ONE_STREAM", 1) != 0;
+        auto slot_of = [&](size_t t) { return lean_one && t < a.n_lean ? (size_t)0 : t; };
+        auto launch_tier = [&](size_t t_, hipEvent_t after) {
+            const size_t t = t_, si = slot_of(t_);
             const bool on_main = main_seg && t == a.seg_tier;
-            if (!on_main && !streams[t]) {
+            if (!on_main && !streams[si]) {
                 hipStream_t new_stream;
                 HIP_CHECK(hipStreamCreateWithFlags(&new_stream, hipStreamNonBlocking));
-                streams[t] = new_stream;
+                streams[si] = new_stream;
                 hipEvent_t new_event;
                 HIP_CHECK(hipEventCreateWithFlags(&new_event, hipEventDisableTiming));
-                tier_events[t] = new_event;
+                tier_events[si] = new_event;
             }
-            hipStream_t side = on_main ? stream : reinterpret_cast<hipStream_t>(streams[t]);
+            hipStream_t side = on_main ? stream : reinterpret_cast<hipStream_t>(streams[si]);
             if (!on_main) HIP_CHECK(hipStreamWaitEvent(side, after, 0));
             // one workgroup per list entry: the lists are built on the device, so the grid covers the whole batch and the
             // workgroups beyond a list's length exit at once (VBT_LAT_PERSIST=1: persistent waves with a work cursor)
@@ -582,7 +593,7 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
             if (t == a.seg_tier)
                 for (size_t x = t + 1; x < T; ++x)
                     launch_lattice(a, dim3(waves_for(tiers[x], std::min<uint32_t>(cn, 4096))), tiers[x], side, (uint32_t)x, 1u);
-            if (!on_main) HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(tier_events[t]), side));
+            if (!on_main) HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(tier_events[si]), side));
         };
         // (VBT_LEAN_EARLY=1, a measured negative result kept as a knob: the lean tiers' lists are complete behind build_lists -- gen_long
         // files nothing there -- so their sweep could start here, next to the gen_long levels, in whose tail the machine idles for 55 us
@@ -624,7 +635,7 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
             launch_tier(t, reinterpret_cast<hipEvent_t>(ev_fork2));
         }
         for (size_t t = 0; t < n_conc && !skip_sweep; ++t)
-            if (!(main_seg && t == a.seg_tier) && tier_events[t]) HIP_CHECK(hipStreamWaitEvent(stream, reinterpret_cast<hipEvent_t>(tier_events[t]), 0));
+            if (!(main_seg && t == a.seg_tier) && slot_of(t) == t && tier_events[t]) HIP_CHECK(hipStreamWaitEvent(stream, reinterpret_cast<hipEvent_t>(tier_events[t]), 0));
         rec(3);
         // whatever the pipeline could not take: fused kernel, global-memory lattice (persistent waves with a work cursor; the list is
         // empty or a handful of sentences, and the kernel uses scratch memory: launching 1024 of them cost 15 us, 128 cost 6)
@@ -692,7 +703,7 @@ void Workspace::stats(vbt_call_stats* out) {
     HIP_CHECK(hipMemcpy(ctrl, d_ctrl, sizeof(ctrl), hipMemcpyDeviceToHost));
     HIP_CHECK(hipMemcpy(cc.data(), d_cctrl, cc.size() * 4, hipMemcpyDeviceToHost));
     std::memset(out, 0, sizeof(*out));
-    const size_t T = tiers.size();
+    const size_t T = last_T ? last_T : tiers.size();  // (the tiers of the last run: its default set may have had one tier more)
     out->n_sentences = last_n;
     if (fused) {
         out->n_tier0 = last_n - cc[0];

@@ -241,6 +241,7 @@ class Workspace {
     uint32_t *d_tok_off = nullptr, *d_tok_cnt = nullptr, *d_ctrl = nullptr, *d_over = nullptr, *d_cctrl = nullptr;
     std::vector<void*> pipe_allocs;  // buffers of the two-kernel pipeline
     bool lean_tier_default = false;  // the default tier set with the lean tier in front (run() may shrink that tier for a batch of short sentences)
+    uint32_t last_T = 0;             // LDS tiers of the last run()
     bool last_inline = false;        // the last run used gen_sweep (stats: its sentences are counted in the first tier's cursor word)
     BatchArgs pipe{};                // device pointers of those buffers
     std::vector<void*> streams;      // one side stream per LDS tier
