@@ -568,9 +568,11 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
         // launch behind the other -- VBT_LEAN_ONE_STREAM=0: a stream each)
         static const bool lean_one = env_u32("VBT_LEAN_ONE_STREAM", 1) != 0;
         auto slot_of = [&](size_t t) { return lean_one && t < a.n_lean ? (size_t)0 : t; };
+        // (the lean tiers on the launch stream and the segment tier on the side stream instead: sweep 0.604-0.614 -> 0.654-0.659 ms -- the long sentences' chain has to start first)
+        auto is_main = [&](size_t t) { return main_seg && t == a.seg_tier; };
         auto launch_tier = [&](size_t t_, hipEvent_t after) {
             const size_t t = t_, si = slot_of(t_);
-            const bool on_main = main_seg && t == a.seg_tier;
+            const bool on_main = is_main(t);
             if (!on_main && !streams[si]) {
                 hipStream_t new_stream;
                 HIP_CHECK(hipStreamCreateWithFlags(&new_stream, hipStreamNonBlocking));
@@ -628,14 +630,14 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
             const size_t t = n_conc - 1 - i;
             if (skip_sweep) break;
             if ((skip_mode == 2 && t >= a.n_lean) || (skip_mode == 3 && t < a.n_lean)) {  // (the join below still finds the tier's event recorded)
-                if (!(main_seg && t == a.seg_tier) && tier_events[t]) HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(tier_events[t]), stream));
+                if (!is_main(t) && tier_events[t]) HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(tier_events[t]), stream));
                 continue;
             }
             if (lean_early && t < a.n_lean) continue;
             launch_tier(t, reinterpret_cast<hipEvent_t>(ev_fork2));
         }
         for (size_t t = 0; t < n_conc && !skip_sweep; ++t)
-            if (!(main_seg && t == a.seg_tier) && slot_of(t) == t && tier_events[t]) HIP_CHECK(hipStreamWaitEvent(stream, reinterpret_cast<hipEvent_t>(tier_events[t]), 0));
+            if (!is_main(t) && slot_of(t) == t && tier_events[t]) HIP_CHECK(hipStreamWaitEvent(stream, reinterpret_cast<hipEvent_t>(tier_events[t]), 0));
         rec(3);
         // whatever the pipeline could not take: fused kernel, global-memory lattice (persistent waves with a work cursor; the list is
         // empty or a handful of sentences, and the kernel uses scratch memory: launching 1024 of them cost 15 us, 128 cost 6)
