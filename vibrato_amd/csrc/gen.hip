@@ -235,7 +235,8 @@ __device__ __forceinline__ void gen_long(const DevDict& D, const BatchArgs& A, u
     }
     __syncthreads();
     GL_MARK(3);
-    if (wv == 0) {  // candidates before a position (CSR offsets), then the end-list offsets
+    // candidates before a position (CSR offsets) and the end-list offsets: two independent prefix sums, one wave each
+    if (wv == 0) {
         uint32_t running = 0;
         for (uint32_t c0 = 0; c0 < n; c0 += 64) {
             const uint32_t i = c0 + ln;
@@ -247,6 +248,8 @@ __device__ __forceinline__ void gen_long(const DevDict& D, const BatchArgs& A, u
             if (running >= 65532u) { running = 65532u; break; }  // (wave-uniform) too many nodes for u16 indices: fused kernel, see below
         }
         if (ln == 0) { red[kC] = running; if (running < 65532u) co[n] = (uint16_t)running; }
+    }
+    if (wv == (nw > 1 ? 1u : 0u)) {
         uint32_t run2 = 0;
         for (uint32_t c0 = 0; c0 < n + 1; c0 += 64) {
             const uint32_t p = c0 + ln;
