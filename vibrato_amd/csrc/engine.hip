@@ -537,8 +537,10 @@ void Workspace::run(const uint8_t* d_text, const uint64_t* d_offsets, uint64_t n
         // Stream plan.  The launch stream runs gen_candidates -> build_lists -> gen_candidates_large (gen_long: the sentences
         // that outgrew the bulk generator's LDS, one workgroup of several wavefronts each) and then forks one lattice_lds launch
         // per LDS tier onto the tier streams and joins them.
-        // (the bulk generator keeps ~26 bytes of LDS per character: 4 KiB hold ~155 characters and 32+ waves per CU)
-        const uint32_t gen_lds = env_u32("VBT_GEN_LDS", 4096);
+        // (the bulk generator keeps ~26 bytes of LDS per character: 5 KiB hold ~195 characters at 32 waves per CU)
+        // (5 KiB: 32 waves x 5 KiB = the CU's 160 KiB; ~195 characters per sentence and room for ~130 more staged hits than 4 KiB -- config 5's
+        // generator 1.46-1.51 -> 1.38-1.45 ms, the headline's 0.564 -> 0.557-0.562; 6 / 8 KiB cost occupancy: slower)
+        const uint32_t gen_lds = env_u32("VBT_GEN_LDS", 5120);
         uint32_t gen_level_lds[kGenLevels] = {16384, 32768, 163840};  // the levels of gen_long (VBT_GEN_LEVELS=a,b,c): ~16 bytes per character
         if (const char* e = std::getenv("VBT_GEN_LEVELS")) {
             unsigned v[3];
